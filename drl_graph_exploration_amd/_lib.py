@@ -1,0 +1,94 @@
+"""ctypes loader for libdrlgx.so (the C ABI of include/drlgx.h).  Fails loudly when the HIP library
+has not been built — there is no Python or CPU fallback."""
+import ctypes as C
+import os
+
+from .config import DrlgxConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "libdrlgx.so")
+_lib = None
+
+N_TIMERS = 8
+
+
+class DrlgxError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _PATH
+
+
+# every symbol declared in include/drlgx.h
+SYMBOLS = [
+    "drlgx_create", "drlgx_destroy", "drlgx_set_stream", "drlgx_synchronize", "drlgx_strerror", "drlgx_last_error",
+    "drlgx_status_host", "drlgx_reset_host", "drlgx_step", "drlgx_utility", "drlgx_uncertainty_em", "drlgx_explored",
+    "drlgx_line_plan", "drlgx_lookahead", "drlgx_graph_capacity", "drlgx_graph", "drlgx_get_counts_host",
+    "drlgx_get_poses_host", "drlgx_get_landmarks_host", "drlgx_get_cov_traces_host", "drlgx_vm_shape",
+    "drlgx_get_virtual_map_host", "drlgx_get_ground_truth_host", "drlgx_get_adjacency_host", "drlgx_get_factors_host",
+    "drlgx_get_landmark_order_host", "drlgx_snapshot", "drlgx_restore", "drlgx_timing_enable",
+    "drlgx_timing_read_host", "drlgx_gcn_workspace_bytes", "drlgx_gcn_forward", "drlgx_gcn_backward",
+]
+
+
+def lib():
+    """Load libdrlgx.so and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_PATH):
+        raise DrlgxError(
+            "libdrlgx.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback." % _PATH)
+    L = C.CDLL(_PATH)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    L.drlgx_create.argtypes = [C.POINTER(DrlgxConfig), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.drlgx_destroy.argtypes = [vp]
+    L.drlgx_set_stream.argtypes = [vp, vp]
+    L.drlgx_synchronize.argtypes = [vp]
+    L.drlgx_strerror.restype = C.c_char_p
+    L.drlgx_strerror.argtypes = [C.c_int]
+    L.drlgx_last_error.restype = C.c_char_p
+    L.drlgx_last_error.argtypes = [vp]
+    L.drlgx_status_host.argtypes = [vp]
+    L.drlgx_reset_host.argtypes = [vp, C.c_int, ip, C.POINTER(C.c_uint32), dp]
+    L.drlgx_step.argtypes = [vp, vp, vp]
+    L.drlgx_utility.argtypes = [vp, vp, vp]
+    L.drlgx_uncertainty_em.argtypes = [vp, C.c_int, vp]
+    L.drlgx_explored.argtypes = [vp, vp]
+    L.drlgx_line_plan.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.drlgx_lookahead.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.drlgx_graph_capacity.argtypes = [vp, ip, ip, ip]
+    L.drlgx_graph.argtypes = [vp] + [vp] * 8
+    L.drlgx_get_counts_host.argtypes = [vp, C.c_int, ip]
+    L.drlgx_get_poses_host.argtypes = [vp, C.c_int, dp, dp]
+    L.drlgx_get_landmarks_host.argtypes = [vp, C.c_int, ip, dp, dp]
+    L.drlgx_get_cov_traces_host.argtypes = [vp, C.c_int, dp, dp]
+    L.drlgx_vm_shape.argtypes = [vp, ip, ip]
+    L.drlgx_get_virtual_map_host.argtypes = [vp, C.c_int, dp, dp, dp, C.POINTER(C.c_uint8)]
+    L.drlgx_get_ground_truth_host.argtypes = [vp, C.c_int, dp, dp]
+    L.drlgx_get_adjacency_host.argtypes = [vp, C.c_int, dp, dp]
+    L.drlgx_get_factors_host.argtypes = [vp, C.c_int, ip, ip, dp, dp]
+    L.drlgx_get_landmark_order_host.argtypes = [vp, ip]
+    L.drlgx_snapshot.argtypes = [vp, C.c_int]
+    L.drlgx_restore.argtypes = [vp, C.c_int]
+    L.drlgx_timing_enable.argtypes = [vp, C.c_int]
+    L.drlgx_timing_read_host.argtypes = [vp, dp, C.POINTER(C.c_int64)]
+    L.drlgx_gcn_workspace_bytes.restype = C.c_size_t
+    L.drlgx_gcn_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.drlgx_gcn_forward.argtypes = [vp] + [C.c_int] * 5 + [vp] * 12
+    L.drlgx_gcn_backward.argtypes = [vp] + [C.c_int] * 5 + [vp] * 15
+    _lib = L
+    return L
+
+
+def check(rc, handle=None):
+    if rc != 0:
+        L = lib()
+        msg = L.drlgx_strerror(rc).decode()
+        if handle is not None:
+            extra = L.drlgx_last_error(handle).decode()
+            if extra:
+                msg += " (" + extra + ")"
+        raise DrlgxError("drlgx error %d: %s" % (rc, msg))

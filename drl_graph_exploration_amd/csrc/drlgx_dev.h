@@ -1,0 +1,357 @@
+// drlgx device-side common definitions: HBM state layout, Pose2 algebra, small SPD solves,
+// mt19937 / normal_distribution streams.  gfx950 only.
+//
+// Reference semantics (paths under /root/reference): gtsam Pose2/Rot2 (third-party, absent —
+// SURVEY.md App. A.1), include/em_exploration/RNG.h:47-126 (libstdc++ mt19937 +
+// uniform_real_distribution + ONE shared normal_distribution), include/em_exploration/Utils.h:29-33.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/drlgx.h"
+
+#define DRLGX_MT_N 624
+#define DRLGX_MT_STRIDE 626  // 624 state words + gen index + cons index
+#define DRLGX_CNT_STRIDE 8
+#define DRLGX_RED_STRIDE 8
+#define DRLGX_PRIOR_STRIDE 16
+
+// cnt[] slots
+enum { C_P = 0, C_L = 1, C_M = 2, C_STEP = 3, C_ISAM = 4, C_NEWP = 5, C_NEWL = 6, C_FLAG = 7 };
+// red[] slots (outputs of the map kernel)
+enum { R_UTR = 0, R_KNOWN = 1, R_EXPL = 2, R_UDET = 3, R_UWTR = 4, R_DIST = 5 };
+
+// All per-instance arrays live in ONE HBM allocation; instance-major, contiguous per instance so a
+// workgroup streams its own slice with coalesced accesses.
+struct DrlgxState {
+  drlgx_config cfg;
+  int n_envs, n_inst, n_roll;  // instances: [0,n_envs) live, [n_envs, 2 n_envs) look-ahead bases, then rollouts
+  int P_max, L_max, M_max, LG, V, Vu, rows, cols, A_max;  // Vu = V rounded up to 4 (byte plane stride)
+  int win;  // (win x win) candidate window of cells around a pose = ceil(2*max_range/res)+1
+  int count_explored;
+  double lo_free, lo_occ, lo_min, lo_max, occ_thresh;  // log-odds constants computed on the HOST (bit-exact ladder)
+  int n_sweep;                                         // bbox sweep table length
+  const double *sweep_b;                               // [n_sweep] b values of OccupancyMap.cpp:86
+  const int *lm_order;                                 // [LG] libstdc++ unordered_map iteration order of GT keys
+  // --- simulator
+  double *gt_pose;    // [n_inst][4] x,y,c,s
+  double *gt_lm;      // [n_envs][LG][2]
+  int *parent;        // [n_inst] env that owns the ground-truth landmarks
+  uint32_t *mt;       // [n_inst][2][MT_STRIDE]  0 = sensor stream, 1 = control stream
+  double *nrm_saved;  // [n_inst][2]
+  int *nrm_has;       // [n_inst][2]
+  // --- isam (linearisation point, delta, factors)
+  int *cnt;          // [n_inst][CNT_STRIDE]
+  double *th_pose;   // [n_inst][P_max][4]
+  double *d_pose;    // [n_inst][P_max][3]
+  double *th_lm;     // [n_inst][L_max][2]
+  double *d_lm;      // [n_inst][L_max][2]
+  int *lm_key;       // [n_inst][L_max]
+  int *key_slot;     // [n_inst][LG]
+  double *prior;     // [n_inst][16]: pose(4) + information(9)
+  double *odo;       // [n_inst][P_max][4] measured odometry between pose i and i+1 (x,y,c,s)
+  int *meas_pose;    // [n_inst][M_max]
+  int *meas_lm;      // [n_inst][M_max]
+  double *meas_br;   // [n_inst][M_max][2]
+  // --- results of the last optimise (SLAM2D::result_ and Map)
+  double *est_pose;   // [n_inst][P_max][4]
+  double *est_lm;     // [n_inst][L_max][2]
+  double *pose_info;  // [n_inst][P_max][6]  symmetric 3x3: xx xy xt yy yt tt
+  double *lm_info;    // [n_inst][L_max][3]  symmetric 2x2: xx xy yy
+  double *pose_tr;    // [n_inst][P_max]  trace of marginal covariance
+  double *lm_tr;      // [n_inst][L_max]
+  // --- virtual map
+  double *vm_prob;  // [n_inst][V]
+  double *vm_info;  // [n_inst][3][V]  planes xx, xy, yy
+  uint8_t *vm_upd;  // [n_inst][Vu]
+  double *vm_tr;    // [n_inst][V]  trace of covariance per cell (VirtualMap::toCovTrace)
+  double *red;      // [n_inst][RED_STRIDE]
+  // --- scratch
+  double *slam_ws;  // [n_inst][slam_ws_stride] dense Schur system when it does not fit LDS
+  size_t slam_ws_stride;
+  int *slam_iws;  // [n_inst][slam_iws_stride] observation table + per-pose factor ranges
+  size_t slam_iws_stride;
+  int *status;  // [1]
+};
+
+struct LaunchSel {
+  int base;                // first instance
+  int n;                   // number of instances (= grid size)
+  const uint8_t *active;   // [n] or null
+  const int32_t *n_act;    // [n] or null: instance active iff act_idx < n_act[i]
+  int act_idx;
+  __device__ __forceinline__ bool on(int i) const {
+    if (active && !active[i]) return false;
+    if (n_act && act_idx >= n_act[i]) return false;
+    return true;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Pose2 algebra (x, y, cos, sin)
+// ------------------------------------------------------------------------------------------------
+struct Pose {
+  double x, y, c, s;
+};
+struct P2 {
+  double x, y;
+};
+
+__device__ __forceinline__ void rot_from_cos_sin(double c, double s, double &oc, double &os) {
+  if (fabs(c * c + s * s - 1.0) > 1e-9) {
+    double n = sqrt(c * c + s * s);
+    c /= n;
+    s /= n;
+  }
+  oc = c;
+  os = s;
+}
+__device__ __forceinline__ Pose make_pose(double x, double y, double th) { return Pose{x, y, cos(th), sin(th)}; }
+__device__ __forceinline__ double theta_of(const Pose &p) { return atan2(p.s, p.c); }
+__device__ __forceinline__ Pose compose(const Pose &a, const Pose &b) {
+  Pose r;
+  rot_from_cos_sin(a.c * b.c - a.s * b.s, a.s * b.c + a.c * b.s, r.c, r.s);
+  r.x = a.x + (a.c * b.x - a.s * b.y);
+  r.y = a.y + (a.s * b.x + a.c * b.y);
+  return r;
+}
+__device__ __forceinline__ Pose between(const Pose &p1, const Pose &p2, double *H1) {
+  double c = p1.c * p2.c + p1.s * p2.s, s = -p1.s * p2.c + p1.c * p2.s;
+  Pose r;
+  rot_from_cos_sin(c, s, r.c, r.s);
+  double dx = p2.x - p1.x, dy = p2.y - p1.y;
+  r.x = p1.c * dx + p1.s * dy;
+  r.y = -p1.s * dx + p1.c * dy;
+  if (H1) {
+    double dt1 = -p2.s * dx + p2.c * dy;
+    double dt2 = -p2.c * dx - p2.s * dy;
+    H1[0] = -r.c; H1[1] = -r.s; H1[2] = dt1;
+    H1[3] = r.s;  H1[4] = -r.c; H1[5] = dt2;
+    H1[6] = 0;    H1[7] = 0;    H1[8] = -1;
+  }
+  return r;
+}
+__device__ __forceinline__ P2 transform_to(const Pose &p, const P2 &pt) {
+  double dx = pt.x - p.x, dy = pt.y - p.y;
+  return P2{p.c * dx + p.s * dy, -p.s * dx + p.c * dy};
+}
+__device__ __forceinline__ P2 transform_from(const Pose &p, const P2 &q) {
+  return P2{p.c * q.x - p.s * q.y + p.x, p.s * q.x + p.c * q.y + p.y};
+}
+template <bool JAC>
+__device__ __forceinline__ double bearing_of(const Pose &p, const P2 &pt, double *Hx, double *Hl) {
+  P2 d = transform_to(p, pt);
+  double d2 = d.x * d.x + d.y * d.y, n = sqrt(d2);
+  if (fabs(n) > 1e-5) {
+    if (JAC) {
+      double a = -d.y / d2, b = d.x / d2;
+      Hx[0] = a * -1.0;
+      Hx[1] = b * -1.0;
+      Hx[2] = a * d.y + b * -d.x;
+      Hl[0] = a * p.c + b * -p.s;
+      Hl[1] = a * p.s + b * p.c;
+    }
+    double c, s;
+    rot_from_cos_sin(d.x / n, d.y / n, c, s);
+    return atan2(s, c);
+  }
+  if (JAC) {
+    Hx[0] = Hx[1] = Hx[2] = 0;
+    Hl[0] = Hl[1] = 0;
+  }
+  return 0.0;
+}
+template <bool JAC>
+__device__ __forceinline__ double range_of(const Pose &p, const P2 &pt, double *Hx, double *Hl) {
+  double dx = pt.x - p.x, dy = pt.y - p.y;
+  double r = sqrt(dx * dx + dy * dy);
+  if (JAC) {
+    double ux = dx / r, uy = dy / r;
+    Hx[0] = ux * -p.c + uy * -p.s;
+    Hx[1] = ux * p.s + uy * -p.c;
+    Hx[2] = 0;
+    Hl[0] = ux;
+    Hl[1] = uy;
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small SPD helpers — symmetric storage: 3x3 = (a00,a01,a02,a11,a12,a22); 2x2 = (a00,a01,a11)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double det2s(double a, double b, double d) { return a * d - b * b; }
+__device__ __forceinline__ void inv2_llt_s(double a, double b, double d, double &oa, double &ob, double &od) {
+  // m.llt().solve(I) for symmetric [[a,b],[b,d]]
+  double l00 = sqrt(a), l10 = b / l00, l11 = sqrt(d - l10 * l10);
+  // column 0
+  double y0 = 1.0 / l00, y1 = (0.0 - l10 * y0) / l11;
+  double x1 = y1 / l11, x0 = (y0 - l10 * x1) / l00;
+  oa = x0;
+  ob = x1;
+  // column 1
+  y0 = 0.0 / l00;
+  y1 = (1.0 - l10 * y0) / l11;
+  x1 = y1 / l11;
+  od = x1;
+}
+struct LLT3 {
+  double l00, l10, l11, l20, l21, l22;
+  __device__ __forceinline__ LLT3(double a00, double a01, double a02, double a11, double a12, double a22) {
+    l00 = sqrt(a00);
+    l10 = a01 / l00;
+    l20 = a02 / l00;
+    l11 = sqrt(a11 - l10 * l10);
+    l21 = (a12 - l20 * l10) / l11;
+    l22 = sqrt(a22 - l20 * l20 - l21 * l21);
+  }
+  __device__ __forceinline__ void solve(double b0, double b1, double b2, double &x0, double &x1, double &x2) const {
+    double y0 = b0 / l00, y1 = (b1 - l10 * y0) / l11, y2 = (b2 - l20 * y0 - l21 * y1) / l22;
+    x2 = y2 / l22;
+    x1 = (y1 - l21 * x2) / l11;
+    x0 = (y0 - l10 * x1 - l20 * x2) / l00;
+  }
+};
+__device__ __forceinline__ double det3s(double a00, double a01, double a02, double a11, double a12, double a22) {
+  return a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02);
+}
+
+// ------------------------------------------------------------------------------------------------
+// mt19937 stream held in LDS by ONE wave: state[624] + gen (how far the lazy recurrence has been
+// applied) + cons (next word to hand out).  The recurrence is applied 64 words at a time by the
+// whole wave; consumption is wave-uniform (every lane computes the same scalars).
+// Identical output sequence to libstdc++ std::mt19937 (bits/random.tcc).
+// ------------------------------------------------------------------------------------------------
+struct MtStream {
+  uint32_t *st;        // LDS, 624 state words (+2 words used only for load/store of gen/cons)
+  uint32_t gen, cons;  // wave-uniform registers: words generated / consumed so far (monotonic)
+};
+
+// one-wave barrier that also orders LDS accesses
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+
+// load a stream from HBM into LDS (64 lanes) and back
+__device__ inline MtStream mt_load(uint32_t *lds, const uint32_t *g, int lane) {
+  for (int i = lane; i < DRLGX_MT_STRIDE; i += 64) lds[i] = g[i];
+  wave_sync();
+  MtStream s;
+  s.st = lds;
+  s.gen = lds[DRLGX_MT_N];
+  s.cons = lds[DRLGX_MT_N + 1];
+  return s;
+}
+__device__ inline void mt_store(const MtStream &s, uint32_t *g, int lane) {
+  wave_sync();
+  for (int i = lane; i < DRLGX_MT_N; i += 64) g[i] = s.st[i];
+  if (lane == 0) {
+    g[DRLGX_MT_N] = s.gen;
+    g[DRLGX_MT_N + 1] = s.cons;
+  }
+}
+// std::mt19937(seed) state (bits/random.tcc seed()); gen = cons = 0 <=> libstdc++'s _M_p = 624
+__device__ inline MtStream mt_seed(uint32_t *lds, uint32_t seed, int lane) {
+  if (lane == 0) {
+    uint32_t x = seed;
+    lds[0] = x;
+    for (int i = 1; i < DRLGX_MT_N; ++i) {
+      x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+      lds[i] = x;
+    }
+  }
+  wave_sync();
+  MtStream s;
+  s.st = lds;
+  s.gen = 0;
+  s.cons = 0;
+  return s;
+}
+// advance the lazy recurrence by up to 64 words (all 64 lanes).  Word i (<623) needs the OLD word
+// i+1 and word 623 the NEW word 0, so a batch never straddles the wrap (the last batch of a round is
+// short) and every lane reads before any lane writes.  Word (i+397)%624 is old for i<227 and was
+// renewed >= 227 words ago otherwise — never inside the same batch.
+__device__ inline void mt_refill(MtStream &s, int lane) {
+  uint32_t p = s.gen % DRLGX_MT_N;
+  uint32_t nvalid = DRLGX_MT_N - p;
+  if (nvalid > 64) nvalid = 64;
+  uint32_t i = p + (uint32_t)lane;
+  uint32_t a = 0, b = 0, c = 0;
+  if ((uint32_t)lane < nvalid) {
+    a = s.st[i];
+    b = s.st[(i + 1) % DRLGX_MT_N];
+    c = s.st[(i + 397) % DRLGX_MT_N];
+  }
+  wave_sync();
+  if ((uint32_t)lane < nvalid) {
+    uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    s.st[i] = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  }
+  wave_sync();
+  s.gen += nvalid;
+}
+// next 32-bit output; wave-uniform
+__device__ inline uint32_t mt_next(MtStream &s, int lane) {
+  if (s.cons == s.gen) mt_refill(s, lane);
+  uint32_t y = s.st[s.cons % DRLGX_MT_N];
+  s.cons += 1;
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+// std::generate_canonical<double,53>(mt19937): two draws, low word first
+__device__ inline double mt_canonical(MtStream &s, int lane) {
+  double lo = (double)mt_next(s, lane);
+  double hi = (double)mt_next(s, lane);
+  double sum = lo + hi * 4294967296.0;
+  double r = sum / 18446744073709551616.0;
+  if (r >= 1.0) r = 0.99999999999999988897769753748;  // nextafter(1, 0)
+  return r;
+}
+struct NormalState {
+  double saved;
+  int has;
+};
+// std::normal_distribution<double>(0,1)::operator() (Marsaglia polar, libstdc++ bits/random.tcc)
+__device__ inline double normal01(MtStream &s, NormalState &ns, int lane) {
+  if (ns.has) {
+    ns.has = 0;
+    return ns.saved;
+  }
+  double x, y, r2;
+  do {
+    x = 2.0 * mt_canonical(s, lane) - 1.0;
+    y = 2.0 * mt_canonical(s, lane) - 1.0;
+    r2 = x * x + y * y;
+  } while (r2 > 1.0 || r2 == 0.0);
+  double mult = sqrt(-2 * log(r2) / r2);
+  ns.saved = x * mult;
+  ns.has = 1;
+  return y * mult;
+}
+// RNG::normal(m, std) (RNG.h:87-96)
+__device__ inline double rng_normal(MtStream &s, NormalState &ns, double m, double sd, int lane) {
+  return normal01(s, ns, lane) * sd + m;
+}
+// RNG::uniformReal (RNG.h:68-71)
+__device__ inline double rng_uniform_real(MtStream &s, double lo, double hi, int lane) {
+  return (hi - lo) * mt_canonical(s, lane) + lo;
+}
+
+// ---- launchers implemented in the kernel translation units ------------------------------------
+struct DrlgxField;
+void drlgx_launch_reset(const DrlgxState &S, hipStream_t st, int n, const int32_t *env_ids_dev, const uint32_t *seeds_dev,
+                        const double *start_dev);
+void drlgx_launch_sim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride,
+                      int n_measure);
+void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel);
+void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel);  // sel.act_idx == -2: reductions only
+void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
+                       const int32_t *dst, int src_off, int dst_off, int skip_vm);
+void drlgx_launch_rebase(const DrlgxState &S, hipStream_t st, int base0, int n);
+void drlgx_launch_fix_rollouts(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0);
+void drlgx_launch_rewards(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0,
+                          double *rewards);
+void drlgx_launch_utility(const DrlgxState &S, hipStream_t st, const double *dist, double *out, int mode);
+void drlgx_launch_line_plan(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, const double *goal,
+                            double *actions, int32_t *n_actions);
+size_t drlgx_slam_lds_bytes(int P_max, int L_max, int M_max);

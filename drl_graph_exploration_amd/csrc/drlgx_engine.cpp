@@ -1,0 +1,698 @@
+// drlgx engine: host side of the C ABI (include/drlgx.h) — HBM state allocation, kernel
+// orchestration for reset / step / look-ahead, state export.  No CPU compute path exists here: every
+// belief-step quantity is produced by the HIP kernels in k_*.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "drlgx_dev.h"
+#include "drlgx_fields.h"
+
+#define HIPCHK(e, call)                                                                       \
+  do {                                                                                        \
+    hipError_t _r = (call);                                                                   \
+    if (_r != hipSuccess) {                                                                   \
+      (e)->last_error = std::string(#call) + ": " + hipGetErrorString(_r);                    \
+      return DRLGX_E_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+struct TimedSpan {
+  hipEvent_t a, b;
+  int id;
+};
+
+struct drlgx_engine {
+  DrlgxState S{};
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::vector<void *> allocs;
+  std::vector<DrlgxField> fields;       // per-instance fields (n_inst instances)
+  std::vector<DrlgxField> env_fields;   // extra fields that exist only for live envs (gt landmarks)
+  DrlgxField *fields_dev = nullptr;
+  std::vector<int> lm_order;
+  std::vector<std::vector<char *>> snaps;
+  // staging
+  int32_t *stage_i32 = nullptr;
+  uint32_t *stage_u32 = nullptr;
+  double *stage_f64 = nullptr;
+  uint8_t *stage_mask = nullptr;
+  // timing
+  bool timing = false;
+  std::vector<TimedSpan> spans;
+  std::vector<hipEvent_t> free_events;
+  double t_ms[DRLGX_N_TIMERS] = {0};
+  int64_t t_n[DRLGX_N_TIMERS] = {0};
+  std::string last_error;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(drlgx_engine *e, T **out, size_t count) {
+  void *p = nullptr;
+  size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+  HIPCHK(e, hipMalloc(&p, bytes));
+  HIPCHK(e, hipMemsetAsync(p, 0, bytes, e->stream));
+  e->allocs.push_back(p);
+  *out = reinterpret_cast<T *>(p);
+  return DRLGX_OK;
+}
+
+template <typename T>
+int field_alloc(drlgx_engine *e, T **out, size_t per_inst, bool is_vm = false) {
+  int r = dev_alloc(e, out, per_inst * (size_t)e->S.n_inst);
+  if (r) return r;
+  e->fields.push_back(DrlgxField{reinterpret_cast<char *>(*out), per_inst * sizeof(T), is_vm ? 1 : 0, 0});
+  return DRLGX_OK;
+}
+
+hipEvent_t get_event(drlgx_engine *e) {
+  if (!e->free_events.empty()) {
+    hipEvent_t ev = e->free_events.back();
+    e->free_events.pop_back();
+    return ev;
+  }
+  hipEvent_t ev;
+  hipEventCreate(&ev);
+  return ev;
+}
+struct ScopedTimer {
+  drlgx_engine *e;
+  TimedSpan s;
+  bool on;
+  ScopedTimer(drlgx_engine *e_, int id) : e(e_), on(e_->timing) {
+    if (on) {
+      s.a = get_event(e);
+      s.b = get_event(e);
+      s.id = id;
+      hipEventRecord(s.a, e->stream);
+    }
+  }
+  ~ScopedTimer() {
+    if (on) {
+      hipEventRecord(s.b, e->stream);
+      e->spans.push_back(s);
+    }
+  }
+};
+
+int check_launch(drlgx_engine *e) {
+  hipError_t r = hipGetLastError();
+  if (r != hipSuccess) {
+    e->last_error = std::string("kernel launch: ") + hipGetErrorString(r);
+    return DRLGX_E_HIP;
+  }
+  return DRLGX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *drlgx_strerror(int code) {
+  switch (code) {
+    case DRLGX_OK: return "ok";
+    case DRLGX_E_INVALID: return "invalid argument";
+    case DRLGX_E_NODEVICE: return "no HIP device";
+    case DRLGX_E_CAPACITY: return "instance capacity exceeded (max_poses / max_landmarks / max_factors / max_actions)";
+    case DRLGX_E_HIP: return "HIP runtime error";
+    case DRLGX_E_NUMERIC: return "indeterminate linear system in the SLAM solve";
+    default: return "unknown error";
+  }
+}
+
+const char *drlgx_last_error(const drlgx_engine *e) { return e ? e->last_error.c_str() : "null engine"; }
+
+int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device, drlgx_engine **out) {
+  if (!cfg || !out || n_envs <= 0 || n_rollouts < 0) return DRLGX_E_INVALID;
+  if (cfg->max_poses < 2 || cfg->max_landmarks < 1 || cfg->max_factors < 1 || cfg->num_landmarks < 0 ||
+      cfg->max_actions < 1 || cfg->num_samples < 1 || !(cfg->resolution > 0))
+    return DRLGX_E_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DRLGX_E_NODEVICE;
+  drlgx_engine *e = new drlgx_engine();
+  e->device = device;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete e;
+    return DRLGX_E_NODEVICE;
+  }
+  if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete e;
+    return DRLGX_E_NODEVICE;
+  }
+  e->stream = e->own_stream;
+  DrlgxState &S = e->S;
+  S.cfg = *cfg;
+  S.n_envs = n_envs;
+  S.n_roll = n_rollouts;
+  S.n_inst = 2 * n_envs + n_rollouts;
+  S.P_max = cfg->max_poses;
+  S.L_max = cfg->max_landmarks;
+  S.M_max = cfg->max_factors;
+  S.LG = std::max(cfg->num_landmarks, 1);
+  S.A_max = cfg->max_actions;
+  // VirtualMap::initialize (VirtualMap.cpp:318-343)
+  S.cols = (int)std::floor((cfg->map_max_x - cfg->map_min_x) / cfg->resolution);
+  S.rows = (int)std::floor((cfg->map_max_y - cfg->map_min_y) / cfg->resolution);
+  S.V = S.rows * S.cols;
+  S.Vu = (S.V + 3) / 4 * 4;
+  {
+    int extg = 20;
+    S.count_explored = (S.rows - extg * 2 / (int)cfg->resolution) * (S.cols - extg * 2 / (int)cfg->resolution);
+  }
+  // OccupancyMap uses ceil() for its grid (OccupancyMap.cpp:13-14); the reference asserts equal sizes
+  if ((int)std::ceil((cfg->map_max_x - cfg->map_min_x) / cfg->resolution) != S.cols ||
+      (int)std::ceil((cfg->map_max_y - cfg->map_min_y) / cfg->resolution) != S.rows || S.V <= 0) {
+    e->last_error = "map extent must be a multiple of the resolution";
+    drlgx_destroy(e);
+    return DRLGX_E_INVALID;
+  }
+  S.win = (int)std::ceil(2.0 * cfg->max_range / cfg->resolution) + 1;
+  if (S.win * S.win > 64) {
+    e->last_error = "max_range / resolution too large for the 64-lane cell window";
+    drlgx_destroy(e);
+    return DRLGX_E_INVALID;
+  }
+  // log-odds constants (OccupancyMap.h:10-19) evaluated with the HOST libm: exact ladder values
+  auto p2l = [](double p) { return std::log(p / (1.0 - p)); };
+  auto l2p = [](double l) { return std::exp(l) / (1.0 + std::exp(l)); };
+  S.lo_free = p2l(0.3);
+  S.lo_occ = p2l(0.7);
+  S.lo_min = p2l(0.05);
+  S.lo_max = l2p(0.95);  // sic: MAX_LOGODDS = LOGODDS2PROB(0.95)
+  S.occ_thresh = p2l(0.5);
+  // sector-sweep table (OccupancyMap.cpp:86): b accumulates in double exactly as the reference loop
+  std::vector<double> sweep;
+  for (double b = cfg->min_bearing; b < cfg->max_bearing + 1e-5; b += 3 * 0.01745329251994329575) sweep.push_back(b);
+  S.n_sweep = (int)sweep.size();
+  // libstdc++ iteration order of unordered_map<unsigned, ...> filled with keys 0..n-1 (Simulator2D.cpp:331-344)
+  {
+    std::unordered_map<unsigned, int> m;
+    for (int i = 0; i < cfg->num_landmarks; ++i) m.emplace((unsigned)i, i);
+    for (const auto &kv : m) e->lm_order.push_back((int)kv.first);
+    if (e->lm_order.empty()) e->lm_order.push_back(0);
+  }
+  int r = DRLGX_OK;
+  double *sweep_dev = nullptr;
+  int *order_dev = nullptr;
+#define TRY(x)            \
+  if ((r = (x)) != 0) {   \
+    drlgx_destroy(e);     \
+    return r;             \
+  }
+  TRY(dev_alloc(e, &sweep_dev, sweep.size()));
+  TRY(dev_alloc(e, &order_dev, e->lm_order.size()));
+  hipMemcpyAsync(sweep_dev, sweep.data(), sweep.size() * sizeof(double), hipMemcpyHostToDevice, e->stream);
+  hipMemcpyAsync(order_dev, e->lm_order.data(), e->lm_order.size() * sizeof(int), hipMemcpyHostToDevice, e->stream);
+  S.sweep_b = sweep_dev;
+  S.lm_order = order_dev;
+  const size_t P = S.P_max, L = S.L_max, M = S.M_max, V = S.V;
+  TRY(field_alloc(e, &S.gt_pose, 4));
+  TRY(field_alloc(e, &S.parent, 1));
+  TRY(field_alloc(e, &S.mt, 2 * DRLGX_MT_STRIDE));
+  TRY(field_alloc(e, &S.nrm_saved, 2));
+  TRY(field_alloc(e, &S.nrm_has, 2));
+  TRY(field_alloc(e, &S.cnt, DRLGX_CNT_STRIDE));
+  TRY(field_alloc(e, &S.th_pose, P * 4));
+  TRY(field_alloc(e, &S.d_pose, P * 3));
+  TRY(field_alloc(e, &S.th_lm, L * 2));
+  TRY(field_alloc(e, &S.d_lm, L * 2));
+  TRY(field_alloc(e, &S.lm_key, L));
+  TRY(field_alloc(e, &S.key_slot, (size_t)S.LG));
+  TRY(field_alloc(e, &S.prior, DRLGX_PRIOR_STRIDE));
+  TRY(field_alloc(e, &S.odo, P * 4));
+  TRY(field_alloc(e, &S.meas_pose, M));
+  TRY(field_alloc(e, &S.meas_lm, M));
+  TRY(field_alloc(e, &S.meas_br, M * 2));
+  TRY(field_alloc(e, &S.est_pose, P * 4));
+  TRY(field_alloc(e, &S.est_lm, L * 2));
+  TRY(field_alloc(e, &S.pose_info, P * 6));
+  TRY(field_alloc(e, &S.lm_info, L * 3));
+  TRY(field_alloc(e, &S.pose_tr, P));
+  TRY(field_alloc(e, &S.lm_tr, L));
+  TRY(field_alloc(e, &S.red, DRLGX_RED_STRIDE));
+  TRY(field_alloc(e, &S.vm_prob, V, true));
+  TRY(field_alloc(e, &S.vm_info, 3 * V, true));
+  TRY(field_alloc(e, &S.vm_upd, (size_t)S.Vu, true));
+  TRY(field_alloc(e, &S.vm_tr, V, true));
+  TRY(dev_alloc(e, &S.gt_lm, (size_t)n_envs * S.LG * 2));
+  e->env_fields.push_back(DrlgxField{reinterpret_cast<char *>(S.gt_lm), (size_t)S.LG * 2 * sizeof(double), 0, 0});
+  // SLAM workspace (not copied between instances)
+  {
+    const bool lds = drlgx_slam_lds_bytes(S.P_max, S.L_max, S.M_max) <= 160 * 1024;
+    size_t na = 3 * P + 1, ld = (na & 1) ? na : na + 1;
+    S.slam_ws_stride = M * 30 + L * 8 + 3 * P + 4 + (lds ? 0 : na * ld + 6 * P);
+    S.slam_iws_stride = L * P + P + 2;
+    TRY(dev_alloc(e, &S.slam_ws, S.slam_ws_stride * (size_t)S.n_inst));
+    TRY(dev_alloc(e, &S.slam_iws, S.slam_iws_stride * (size_t)S.n_inst));
+  }
+  TRY(dev_alloc(e, &S.status, 1));
+  TRY(dev_alloc(e, &e->fields_dev, e->fields.size()));
+  hipMemcpyAsync(e->fields_dev, e->fields.data(), e->fields.size() * sizeof(DrlgxField), hipMemcpyHostToDevice, e->stream);
+  TRY(dev_alloc(e, &e->stage_i32, (size_t)n_envs));
+  TRY(dev_alloc(e, &e->stage_u32, (size_t)n_envs));
+  TRY(dev_alloc(e, &e->stage_f64, (size_t)n_envs * 3));
+  TRY(dev_alloc(e, &e->stage_mask, (size_t)n_envs));
+#undef TRY
+  if (hipStreamSynchronize(e->stream) != hipSuccess) {
+    drlgx_destroy(e);
+    return DRLGX_E_HIP;
+  }
+  *out = e;
+  return DRLGX_OK;
+}
+
+int drlgx_destroy(drlgx_engine *e) {
+  if (!e) return DRLGX_E_INVALID;
+  hipSetDevice(e->device);
+  hipDeviceSynchronize();
+  for (void *p : e->allocs) hipFree(p);
+  for (auto &s : e->snaps)
+    for (char *p : s) hipFree(p);
+  for (auto &sp : e->spans) {
+    hipEventDestroy(sp.a);
+    hipEventDestroy(sp.b);
+  }
+  for (auto ev : e->free_events) hipEventDestroy(ev);
+  if (e->own_stream) hipStreamDestroy(e->own_stream);
+  delete e;
+  return DRLGX_OK;
+}
+
+int drlgx_set_stream(drlgx_engine *e, void *hip_stream) {
+  if (!e) return DRLGX_E_INVALID;
+  hipStreamSynchronize(e->stream);
+  e->stream = (hip_stream == reinterpret_cast<void *>(-1)) ? e->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
+  return DRLGX_OK;
+}
+
+int drlgx_synchronize(drlgx_engine *e) {
+  if (!e) return DRLGX_E_INVALID;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return DRLGX_OK;
+}
+
+int drlgx_status_host(drlgx_engine *e) {
+  if (!e) return DRLGX_E_INVALID;
+  int st = 0;
+  HIPCHK(e, hipMemcpyAsync(&st, e->S.status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return st;
+}
+
+int drlgx_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint32_t *seeds, const double *start) {
+  if (!e || n <= 0 || n > e->S.n_envs || !env_ids || !seeds || !start) return DRLGX_E_INVALID;
+  std::vector<uint8_t> mask(e->S.n_envs, 0);
+  for (int i = 0; i < n; ++i) {
+    if (env_ids[i] < 0 || env_ids[i] >= e->S.n_envs || mask[env_ids[i]]) return DRLGX_E_INVALID;
+    mask[env_ids[i]] = 1;
+  }
+  hipSetDevice(e->device);
+  HIPCHK(e, hipMemcpyAsync(e->stage_i32, env_ids, n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->stage_u32, seeds, n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->stage_f64, start, n * 3 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->stage_mask, mask.data(), e->S.n_envs, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemsetAsync(e->S.status, 0, sizeof(int), e->stream));
+  drlgx_launch_reset(e->S, e->stream, n, e->stage_i32, e->stage_u32, e->stage_f64);
+  LaunchSel sel{0, e->S.n_envs, e->stage_mask, nullptr, 0};
+  drlgx_launch_slam(e->S, e->stream, sel);
+  sel.act_idx = -2;  // reductions only: the virtual map is in its untouched state
+  drlgx_launch_map(e->S, e->stream, sel);
+  int r = check_launch(e);
+  if (r) return r;
+  HIPCHK(e, hipStreamSynchronize(e->stream));  // staging buffers are reused
+  return DRLGX_OK;
+}
+
+int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_dev) {
+  if (!e || !odom_dev) return DRLGX_E_INVALID;
+  LaunchSel sel{0, e->S.n_envs, active_dev, nullptr, 0};
+  {
+    ScopedTimer t(e, 0);
+    drlgx_launch_sim(e->S, e->stream, sel, odom_dev, 3, 2);
+  }
+  {
+    ScopedTimer t(e, 1);
+    drlgx_launch_slam(e->S, e->stream, sel);
+  }
+  {
+    ScopedTimer t(e, 2);
+    drlgx_launch_map(e->S, e->stream, sel);
+  }
+  return check_launch(e);
+}
+
+int drlgx_utility(drlgx_engine *e, const double *dist_dev, double *out_dev) {
+  if (!e || !out_dev) return DRLGX_E_INVALID;
+  drlgx_launch_utility(e->S, e->stream, dist_dev, out_dev, 0);
+  return check_launch(e);
+}
+int drlgx_uncertainty_em(drlgx_engine *e, int algorithm, double *out_dev) {
+  if (!e || !out_dev || (algorithm != DRLGX_ALG_EM_AOPT && algorithm != DRLGX_ALG_EM_DOPT)) return DRLGX_E_INVALID;
+  drlgx_launch_utility(e->S, e->stream, nullptr, out_dev, algorithm == DRLGX_ALG_EM_DOPT ? 3 : 2);
+  return check_launch(e);
+}
+int drlgx_explored(drlgx_engine *e, double *out_dev) {
+  if (!e || !out_dev) return DRLGX_E_INVALID;
+  drlgx_launch_utility(e->S, e->stream, nullptr, out_dev, 1);
+  return check_launch(e);
+}
+
+int drlgx_line_plan(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *goal_dev,
+                    double *actions_dev, int32_t *n_actions_dev) {
+  if (!e || n_cand < 0 || !cand_env_dev || !goal_dev || !actions_dev || !n_actions_dev) return DRLGX_E_INVALID;
+  if (n_cand == 0) return DRLGX_OK;
+  drlgx_launch_line_plan(e->S, e->stream, n_cand, cand_env_dev, goal_dev, actions_dev, n_actions_dev);
+  return check_launch(e);
+}
+
+int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *actions_dev,
+                    const int32_t *n_actions_dev, double *rewards_dev) {
+  if (!e || n_cand < 0 || n_cand > e->S.n_roll || !cand_env_dev || !actions_dev || !n_actions_dev || !rewards_dev)
+    return DRLGX_E_INVALID;
+  if (n_cand == 0) return DRLGX_OK;
+  const DrlgxState &S = e->S;
+  const int base0 = S.n_envs, roll0 = 2 * S.n_envs;
+  {
+    ScopedTimer t(e, 3);
+    // deep copy env -> base, SLAM2D::set_copy_isam (re-base at the best estimate + one batch update)
+    drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr, 0, base0, 1);
+    drlgx_launch_rebase(S, e->stream, base0, S.n_envs);
+  }
+  {
+    ScopedTimer t(e, 1);
+    drlgx_launch_slam(S, e->stream, LaunchSel{base0, S.n_envs, nullptr, nullptr, 0});
+  }
+  {
+    ScopedTimer t(e, 3);
+    drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, n_cand, cand_env_dev, nullptr, base0, roll0, 1);
+    drlgx_launch_fix_rollouts(S, e->stream, n_cand, cand_env_dev, roll0);
+  }
+  for (int a = 0; a < S.A_max; ++a) {
+    LaunchSel sel{roll0, n_cand, nullptr, n_actions_dev, a};
+    {
+      ScopedTimer t(e, 0);
+      drlgx_launch_sim(S, e->stream, sel, actions_dev, S.A_max * 3, 1);
+    }
+    {
+      ScopedTimer t(e, 1);
+      drlgx_launch_slam(S, e->stream, sel);
+    }
+    {
+      ScopedTimer t(e, 2);
+      drlgx_launch_map(S, e->stream, sel);
+    }
+  }
+  drlgx_launch_rewards(S, e->stream, n_cand, cand_env_dev, roll0, rewards_dev);
+  return check_launch(e);
+}
+
+// ---- getters -----------------------------------------------------------------------------------
+static int fetch(drlgx_engine *e, void *dst, const void *src, size_t bytes) {
+  HIPCHK(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
+  return DRLGX_OK;
+}
+#define INST_OK(e, inst) ((e) && (inst) >= 0 && (inst) < (e)->S.n_inst)
+
+int drlgx_get_counts_host(drlgx_engine *e, int inst, int32_t out[5]) {
+  if (!INST_OK(e, inst) || !out) return DRLGX_E_INVALID;
+  int c[DRLGX_CNT_STRIDE];
+  int r = fetch(e, c, e->S.cnt + (size_t)inst * DRLGX_CNT_STRIDE, sizeof(c));
+  if (r) return r;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  out[0] = c[C_P]; out[1] = c[C_L]; out[2] = c[C_M]; out[3] = c[C_STEP]; out[4] = c[C_ISAM];
+  return DRLGX_OK;
+}
+
+int drlgx_get_poses_host(drlgx_engine *e, int inst, double *xytheta, double *information) {
+  int32_t c[5];
+  int r = drlgx_get_counts_host(e, inst, c);
+  if (r) return r;
+  const DrlgxState &S = e->S;
+  const int P = c[0];
+  std::vector<double> ep((size_t)P * 4), pi((size_t)P * 6);
+  if ((r = fetch(e, ep.data(), S.est_pose + (size_t)inst * S.P_max * 4, ep.size() * 8))) return r;
+  if ((r = fetch(e, pi.data(), S.pose_info + (size_t)inst * S.P_max * 6, pi.size() * 8))) return r;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (int i = 0; i < P; ++i) {
+    if (xytheta) {
+      xytheta[3 * i] = ep[4 * i];
+      xytheta[3 * i + 1] = ep[4 * i + 1];
+      xytheta[3 * i + 2] = std::atan2(ep[4 * i + 3], ep[4 * i + 2]);
+    }
+    if (information) {
+      const double *s = &pi[6 * i];
+      double *o = information + 9 * i;
+      o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+      o[3] = s[1]; o[4] = s[3]; o[5] = s[4];
+      o[6] = s[2]; o[7] = s[4]; o[8] = s[5];
+    }
+  }
+  return DRLGX_OK;
+}
+
+static int sorted_slots(drlgx_engine *e, int inst, int L, std::vector<int> &keys, std::vector<int> &order) {
+  const DrlgxState &S = e->S;
+  keys.resize(L);
+  int r = fetch(e, keys.data(), S.lm_key + (size_t)inst * S.L_max, (size_t)L * sizeof(int));
+  if (r) return r;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  order.resize(L);
+  for (int j = 0; j < L; ++j) order[j] = j;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return keys[a] < keys[b]; });
+  return DRLGX_OK;
+}
+
+int drlgx_get_landmarks_host(drlgx_engine *e, int inst, int32_t *keys, double *xy, double *information) {
+  int32_t c[5];
+  int r = drlgx_get_counts_host(e, inst, c);
+  if (r) return r;
+  const DrlgxState &S = e->S;
+  const int L = c[1];
+  std::vector<int> k, ord;
+  if ((r = sorted_slots(e, inst, L, k, ord))) return r;
+  std::vector<double> el((size_t)L * 2), li((size_t)L * 3);
+  if ((r = fetch(e, el.data(), S.est_lm + (size_t)inst * S.L_max * 2, el.size() * 8))) return r;
+  if ((r = fetch(e, li.data(), S.lm_info + (size_t)inst * S.L_max * 3, li.size() * 8))) return r;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (int n = 0; n < L; ++n) {
+    int j = ord[n];
+    if (keys) keys[n] = k[j];
+    if (xy) {
+      xy[2 * n] = el[2 * j];
+      xy[2 * n + 1] = el[2 * j + 1];
+    }
+    if (information) {
+      information[4 * n] = li[3 * j];
+      information[4 * n + 1] = li[3 * j + 1];
+      information[4 * n + 2] = li[3 * j + 1];
+      information[4 * n + 3] = li[3 * j + 2];
+    }
+  }
+  return DRLGX_OK;
+}
+
+int drlgx_get_cov_traces_host(drlgx_engine *e, int inst, double *lm_trace, double *pose_trace) {
+  int32_t c[5];
+  int r = drlgx_get_counts_host(e, inst, c);
+  if (r) return r;
+  const DrlgxState &S = e->S;
+  const int P = c[0], L = c[1];
+  std::vector<int> k, ord;
+  if ((r = sorted_slots(e, inst, L, k, ord))) return r;
+  std::vector<double> lt(L), pt(P);
+  if ((r = fetch(e, lt.data(), S.lm_tr + (size_t)inst * S.L_max, (size_t)L * 8))) return r;
+  if ((r = fetch(e, pt.data(), S.pose_tr + (size_t)inst * S.P_max, (size_t)P * 8))) return r;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (lm_trace)
+    for (int n = 0; n < L; ++n) lm_trace[n] = lt[ord[n]];
+  if (pose_trace)
+    for (int i = 0; i < P; ++i) pose_trace[i] = pt[i];
+  return DRLGX_OK;
+}
+
+int drlgx_vm_shape(const drlgx_engine *e, int *rows, int *cols) {
+  if (!e) return DRLGX_E_INVALID;
+  if (rows) *rows = e->S.rows;
+  if (cols) *cols = e->S.cols;
+  return DRLGX_OK;
+}
+
+int drlgx_get_virtual_map_host(drlgx_engine *e, int inst, double *prob, double *info, double *cov_trace,
+                               uint8_t *updated) {
+  if (!INST_OK(e, inst)) return DRLGX_E_INVALID;
+  const DrlgxState &S = e->S;
+  const size_t V = S.V;
+  std::vector<double> pl(3 * V);
+  int r;
+  if (prob && (r = fetch(e, prob, S.vm_prob + (size_t)inst * V, V * 8))) return r;
+  if ((r = fetch(e, pl.data(), S.vm_info + (size_t)inst * 3 * V, 3 * V * 8))) return r;
+  if (updated && (r = fetch(e, updated, S.vm_upd + (size_t)inst * S.Vu, V))) return r;
+  if (cov_trace && (r = fetch(e, cov_trace, S.vm_tr + (size_t)inst * V, V * 8))) return r;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (info)
+    for (size_t v = 0; v < V; ++v) {
+      const double a = pl[v], b = pl[V + v], d = pl[2 * V + v];
+      info[4 * v] = a; info[4 * v + 1] = b; info[4 * v + 2] = b; info[4 * v + 3] = d;
+    }
+  return DRLGX_OK;
+}
+
+int drlgx_get_ground_truth_host(drlgx_engine *e, int inst, double *vehicle_xytheta, double *landmarks_xy) {
+  if (!INST_OK(e, inst)) return DRLGX_E_INVALID;
+  const DrlgxState &S = e->S;
+  double gp[4];
+  int parent = 0, r;
+  if ((r = fetch(e, gp, S.gt_pose + (size_t)inst * 4, sizeof(gp)))) return r;
+  if ((r = fetch(e, &parent, S.parent + inst, sizeof(int)))) return r;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (vehicle_xytheta) {
+    vehicle_xytheta[0] = gp[0];
+    vehicle_xytheta[1] = gp[1];
+    vehicle_xytheta[2] = std::atan2(gp[3], gp[2]);
+  }
+  if (landmarks_xy && S.cfg.num_landmarks > 0) {
+    if ((r = fetch(e, landmarks_xy, S.gt_lm + (size_t)parent * S.LG * 2, (size_t)S.cfg.num_landmarks * 2 * 8))) return r;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+  }
+  return DRLGX_OK;
+}
+
+int drlgx_get_factors_host(drlgx_engine *e, int inst, int32_t *pose, int32_t *key, double *bearing, double *range) {
+  int32_t c[5];
+  int r = drlgx_get_counts_host(e, inst, c);
+  if (r) return r;
+  const DrlgxState &S = e->S;
+  const int L = c[1], M = c[2];
+  std::vector<int> keys(L), mp(M), ml(M);
+  std::vector<double> br((size_t)M * 2);
+  if ((r = fetch(e, keys.data(), S.lm_key + (size_t)inst * S.L_max, (size_t)L * 4))) return r;
+  if ((r = fetch(e, mp.data(), S.meas_pose + (size_t)inst * S.M_max, (size_t)M * 4))) return r;
+  if ((r = fetch(e, ml.data(), S.meas_lm + (size_t)inst * S.M_max, (size_t)M * 4))) return r;
+  if ((r = fetch(e, br.data(), S.meas_br + (size_t)inst * S.M_max * 2, (size_t)M * 16))) return r;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (int m = 0; m < M; ++m) {
+    if (pose) pose[m] = mp[m];
+    if (key) key[m] = keys[ml[m]];
+    if (bearing) bearing[m] = br[2 * m];
+    if (range) range[m] = br[2 * m + 1];
+  }
+  return DRLGX_OK;
+}
+
+// SLAM2D::adjacency_degree_get (SLAM2D.cpp:198-273) assembled from the exported factor list.
+int drlgx_get_adjacency_host(drlgx_engine *e, int inst, double *adjacency, double *features) {
+  int32_t c[5];
+  int r = drlgx_get_counts_host(e, inst, c);
+  if (r) return r;
+  const DrlgxState &S = e->S;
+  const int P = c[0], L = c[1], M = c[2], N = P + L;
+  std::vector<int> k, ord;
+  if ((r = sorted_slots(e, inst, L, k, ord))) return r;
+  std::vector<int> node_of_slot(L);
+  for (int n = 0; n < L; ++n) node_of_slot[ord[n]] = n;
+  std::vector<int> mp(M), ml(M);
+  std::vector<double> br((size_t)M * 2), odo((size_t)P * 4), lt(L), pt(P);
+  if ((r = fetch(e, mp.data(), S.meas_pose + (size_t)inst * S.M_max, (size_t)M * 4))) return r;
+  if ((r = fetch(e, ml.data(), S.meas_lm + (size_t)inst * S.M_max, (size_t)M * 4))) return r;
+  if ((r = fetch(e, br.data(), S.meas_br + (size_t)inst * S.M_max * 2, (size_t)M * 16))) return r;
+  if ((r = fetch(e, odo.data(), S.odo + (size_t)inst * S.P_max * 4, (size_t)P * 32))) return r;
+  if ((r = fetch(e, lt.data(), S.lm_tr + (size_t)inst * S.L_max, (size_t)L * 8))) return r;
+  if ((r = fetch(e, pt.data(), S.pose_tr + (size_t)inst * S.P_max, (size_t)P * 8))) return r;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (adjacency) std::fill(adjacency, adjacency + (size_t)N * N, 0.0);
+  if (features) std::fill(features, features + N, 0.0);
+  for (int i = 0; i + 1 < P; ++i) {
+    double d = std::sqrt(std::pow(odo[4 * i], 2) + std::pow(odo[4 * i + 1], 2)) + 0.001;
+    int a = L + i, b = L + i + 1;
+    if (adjacency) adjacency[(size_t)a * N + b] = adjacency[(size_t)b * N + a] = d;
+    if (features) {
+      features[a] = pt[i];
+      features[b] = pt[i + 1];
+    }
+  }
+  for (int m = 0; m < M; ++m) {
+    int a = L + mp[m], b = node_of_slot[ml[m]];
+    if (adjacency) adjacency[(size_t)a * N + b] = adjacency[(size_t)b * N + a] = br[2 * m + 1];
+    if (features) {
+      features[a] = pt[mp[m]];
+      features[b] = lt[ml[m]];
+    }
+  }
+  return DRLGX_OK;
+}
+
+int drlgx_get_landmark_order_host(const drlgx_engine *e, int32_t *order) {
+  if (!e || !order) return DRLGX_E_INVALID;
+  for (int i = 0; i < e->S.cfg.num_landmarks; ++i) order[i] = e->lm_order[i];
+  return DRLGX_OK;
+}
+
+// ---- snapshots ---------------------------------------------------------------------------------
+int drlgx_snapshot(drlgx_engine *e, int slot) {
+  if (!e || slot < 0 || slot > 64) return DRLGX_E_INVALID;
+  const size_t nf = e->fields.size() + e->env_fields.size();
+  if ((int)e->snaps.size() <= slot) e->snaps.resize(slot + 1);
+  auto &s = e->snaps[slot];
+  if (s.empty()) {
+    s.resize(nf, nullptr);
+    for (size_t f = 0; f < nf; ++f) {
+      const DrlgxField &fd = f < e->fields.size() ? e->fields[f] : e->env_fields[f - e->fields.size()];
+      HIPCHK(e, hipMalloc(reinterpret_cast<void **>(&s[f]), fd.stride * (size_t)e->S.n_envs));
+    }
+  }
+  for (size_t f = 0; f < nf; ++f) {
+    const DrlgxField &fd = f < e->fields.size() ? e->fields[f] : e->env_fields[f - e->fields.size()];
+    HIPCHK(e, hipMemcpyAsync(s[f], fd.base, fd.stride * (size_t)e->S.n_envs, hipMemcpyDeviceToDevice, e->stream));
+  }
+  return DRLGX_OK;
+}
+
+int drlgx_restore(drlgx_engine *e, int slot) {
+  if (!e || slot < 0 || slot >= (int)e->snaps.size() || e->snaps[slot].empty()) return DRLGX_E_INVALID;
+  const size_t nf = e->fields.size() + e->env_fields.size();
+  auto &s = e->snaps[slot];
+  for (size_t f = 0; f < nf; ++f) {
+    const DrlgxField &fd = f < e->fields.size() ? e->fields[f] : e->env_fields[f - e->fields.size()];
+    HIPCHK(e, hipMemcpyAsync(fd.base, s[f], fd.stride * (size_t)e->S.n_envs, hipMemcpyDeviceToDevice, e->stream));
+  }
+  return DRLGX_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------------
+int drlgx_timing_enable(drlgx_engine *e, int on) {
+  if (!e) return DRLGX_E_INVALID;
+  e->timing = on != 0;
+  return DRLGX_OK;
+}
+
+int drlgx_timing_read_host(drlgx_engine *e, double ms[DRLGX_N_TIMERS], int64_t launches[DRLGX_N_TIMERS]) {
+  if (!e) return DRLGX_E_INVALID;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (auto &sp : e->spans) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess && sp.id >= 0 && sp.id < DRLGX_N_TIMERS) {
+      e->t_ms[sp.id] += t;
+      e->t_n[sp.id] += 1;
+    }
+    e->free_events.push_back(sp.a);
+    e->free_events.push_back(sp.b);
+  }
+  e->spans.clear();
+  for (int i = 0; i < DRLGX_N_TIMERS; ++i) {
+    if (ms) ms[i] = e->t_ms[i];
+    if (launches) launches[i] = e->t_n[i];
+    e->t_ms[i] = 0;
+    e->t_n[i] = 0;
+  }
+  return DRLGX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+// Virtual-map kernel: occupancy rebuild + covariance propagation (EKF push-through of every core
+// pose onto the virtual-landmark grid, fused by covariance intersection) + utility reductions.
+// One 256-thread workgroup per instance.
+//
+// Reference: src/em_exploration/OccupancyMap.cpp:55-138 (log-odds ladder, bbox sector sweep),
+// src/em_exploration/VirtualMap.cpp:47-84 (explored, updateProbability), :213-229
+// (predictVirtualLandmark), :256-316 (updateInformation), :364-378 (covarianceIntersection2D),
+// src/em_exploration/Planner2D.cpp:321-366 (calculateUncertainty / calculateUtility).
+//
+// Data flow (per instance): poses (x,y,c,s + 3x3 information) are staged in LDS once.
+//   phase O: cell-centric occupancy ladder, poses visited in trajectory order.
+//   phase A: one wave per pose, one lane per cell of the (win x win) window around the pose: the
+//            3x3 LLT solve and 2x2 algebra run in registers; the per-(pose,cell) 2x2 information
+//            is staged in LDS.
+//   phase B: cell-centric covariance-intersection fusion in trajectory order from the LDS stage.
+//   phase R: trace / determinant / known / explored reductions (wave shuffles + LDS).
+// Compiled with -ffp-contract=off (thresholded decisions must round like the CPU reference).
+#include "drlgx_dev.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kChunk = 32;  // poses per LDS stage
+
+__device__ __forceinline__ double logodds2prob(double l) { return exp(l) / (1.0 + exp(l)); }
+
+// VirtualMap::predictVirtualLandmark (VirtualMap.cpp:213-229). info: symmetric xx xy xt yy yt tt.
+__device__ __forceinline__ bool predict_cell(const Pose &ps, const double *pi, const P2 &pt, const drlgx_config &cfg,
+                                             double &oxx, double &oxy, double &oyy) {
+  double Hbx[3], Hbl[2], Hrx[3], Hrl[2];
+  double bearing = bearing_of<true>(ps, pt, Hbx, Hbl);
+  double range = range_of<true>(ps, pt, Hrx, Hrl);
+  if (!(bearing < cfg.max_bearing && bearing > cfg.min_bearing && range < cfg.max_range && range > cfg.min_range))
+    return false;
+  const double R0 = cfg.bearing_noise * cfg.bearing_noise, R3 = cfg.range_noise * cfg.range_noise;
+  const double Hl0 = Hbl[0], Hl1 = Hbl[1], Hl2 = Hrl[0], Hl3 = Hrl[1];
+  // (Hl^T Hl)^-1 Hl^T  (Eigen fixed 2x2 inverse = adjugate / det)
+  const double h00 = Hl0 * Hl0 + Hl2 * Hl2, h01 = Hl0 * Hl1 + Hl2 * Hl3;
+  const double h10 = Hl1 * Hl0 + Hl3 * Hl2, h11 = Hl1 * Hl1 + Hl3 * Hl3;
+  const double id = 1.0 / (h00 * h11 - h01 * h10);
+  const double i00 = h11 * id, i01 = -h01 * id, i10 = -h10 * id, i11 = h00 * id;
+  const double p00 = i00 * Hl0 + i01 * Hl1, p01 = i00 * Hl2 + i01 * Hl3;
+  const double p10 = i10 * Hl0 + i11 * Hl1, p11 = i10 * Hl2 + i11 * Hl3;
+  // S = R + Hx * info.llt().solve(Hx^T)
+  LLT3 llt(pi[0], pi[1], pi[2], pi[3], pi[4], pi[5]);
+  double xb0, xb1, xb2, xr0, xr1, xr2;
+  llt.solve(Hbx[0], Hbx[1], Hbx[2], xb0, xb1, xb2);
+  llt.solve(Hrx[0], Hrx[1], Hrx[2], xr0, xr1, xr2);
+  double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+  s00 += Hbx[0] * xb0; s00 += Hbx[1] * xb1; s00 += Hbx[2] * xb2;
+  s01 += Hbx[0] * xr0; s01 += Hbx[1] * xr1; s01 += Hbx[2] * xr2;
+  s10 += Hrx[0] * xb0; s10 += Hrx[1] * xb1; s10 += Hrx[2] * xb2;
+  s11 += Hrx[0] * xr0; s11 += Hrx[1] * xr1; s11 += Hrx[2] * xr2;
+  s00 = R0 + s00; s01 = 0.0 + s01; s10 = 0.0 + s10; s11 = R3 + s11;
+  // cov = Hp S Hp^T
+  const double t00 = p00 * s00 + p01 * s10, t01 = p00 * s01 + p01 * s11;
+  const double t10 = p10 * s00 + p11 * s10, t11 = p10 * s01 + p11 * s11;
+  const double c00 = t00 * p00 + t01 * p01;
+  const double c10 = t10 * p00 + t11 * p01, c11 = t10 * p10 + t11 * p11;
+  // information = inverse(cov) by LLT (lower triangle of cov)
+  inv2_llt_s(c00, c10, c11, oxx, oxy, oyy);
+  return true;
+}
+
+// VirtualMap::covarianceIntersection2D (VirtualMap.cpp:364-378), symmetric storage
+__device__ __forceinline__ void ci_fuse(double &axx, double &axy, double &ayy, double bxx, double bxy, double byy) {
+  const double a = axx * ayy - axy * axy;
+  const double b = bxx * byy - bxy * bxy;
+  // m1.llt().solve(m2).trace()
+  const double l00 = sqrt(axx), l10 = axy / l00, l11 = sqrt(ayy - l10 * l10);
+  double tr = 0;
+  {
+    double y0 = bxx / l00, y1 = (bxy - l10 * y0) / l11;
+    double x1 = y1 / l11, x0 = (y0 - l10 * x1) / l00;
+    tr += x0;
+    y0 = bxy / l00;
+    y1 = (byy - l10 * y0) / l11;
+    x1 = y1 / l11;
+    tr += x1;
+  }
+  const double c = a * tr;
+  const double d = a + b - c;
+  double w = 0.5 * (2 * b - c) / d;
+  if ((w < 0 && d < 0) || (w > 1 && d > 0))
+    w = 0.0;
+  else if ((w < 0 && d > 0) || (w > 1 && d < 0))
+    w = 1.0;
+  axx = w * axx + (1.0 - w) * bxx;
+  axy = w * axy + (1.0 - w) * bxy;
+  ayy = w * ayy + (1.0 - w) * byy;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *scratch, int tid) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = v;
+  __syncthreads();
+  double s = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+  return s;
+}
+
+__global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, int rebuild) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bi = blockIdx.x;
+  if (!sel.on(bi)) return;
+  const int inst = sel.base + bi;
+  const int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
+  if (cnt[C_FLAG]) return;
+  const drlgx_config &cfg = S.cfg;
+  const int P = cnt[C_P], L = cnt[C_L];
+  const int V = S.V, cols = S.cols, rows = S.rows, W = S.win, W2 = W * W;
+  // LDS carve
+  double *sp = smem;                       // [P_max][4]
+  double *si = sp + (size_t)S.P_max * 4;   // [P_max][6]
+  double *stage = si + (size_t)S.P_max * 6;  // [kChunk][64][3]
+  double *scratch = stage + (size_t)kChunk * 64 * 3;  // [8]
+  int *bbox = reinterpret_cast<int *>(scratch + 8);   // [P_max][4] min_row max_row min_col max_col
+  int *worg = bbox + (size_t)S.P_max * 4;             // [P_max][2] window origin row, col
+  int *pskip = worg + (size_t)S.P_max * 2;            // [P_max]
+  int *lmcell = pskip + S.P_max;                      // [L_max]
+  double *prob = S.vm_prob + (size_t)inst * V;
+  double *ixx = S.vm_info + ((size_t)inst * 3 + 0) * V, *ixy = S.vm_info + ((size_t)inst * 3 + 1) * V,
+         *iyy = S.vm_info + ((size_t)inst * 3 + 2) * V;
+  uint8_t *upd = S.vm_upd + (size_t)inst * S.Vu;
+  double *vtr = S.vm_tr + (size_t)inst * V;
+
+  if (rebuild) {
+    const double *ep = S.est_pose + (size_t)inst * S.P_max * 4;
+    const double *pin = S.pose_info + (size_t)inst * S.P_max * 6;
+    for (int e = tid; e < P * 4; e += kThreads) sp[e] = ep[e];
+    for (int e = tid; e < P * 6; e += kThreads) si[e] = pin[e];
+    const double *el = S.est_lm + (size_t)inst * S.L_max * 2;
+    for (int j = tid; j < L; j += kThreads) {
+      // OccupancyMap::update(map): landmark cell (OccupancyMap.cpp:127-131)
+      int r = (int)floor((el[2 * j + 1] - cfg.map_min_y) / cfg.resolution);
+      int c = (int)floor((el[2 * j] - cfg.map_min_x) / cfg.resolution);
+      lmcell[j] = (r >= rows || r < 0 || c >= cols || c < 0) ? -1 : r * cols + c;
+    }
+    __syncthreads();
+    for (int p = tid; p < P; p += kThreads) {
+      const double x = sp[4 * p], y = sp[4 * p + 1];
+      int orow = (int)floor((y - cfg.map_min_y) / cfg.resolution);
+      int ocol = (int)floor((x - cfg.map_min_x) / cfg.resolution);
+      orow = min(max(0, orow), rows - 1);
+      ocol = min(max(0, ocol), cols - 1);
+      bbox[4 * p + 0] = orow; bbox[4 * p + 1] = orow; bbox[4 * p + 2] = ocol; bbox[4 * p + 3] = ocol;
+      // window of candidate cells for the information update: one cell wider than the tightest
+      // (open) interval so that no cell the reference's radius query accepts can fall outside
+      worg[2 * p + 0] = (int)floor((y - cfg.max_range - cfg.map_min_y) / cfg.resolution - 0.5);
+      worg[2 * p + 1] = (int)floor((x - cfg.max_range - cfg.map_min_x) / cfg.resolution - 0.5);
+      const double *pi = si + 6 * p;
+      pskip[p] = det3s(pi[0], pi[1], pi[2], pi[3], pi[4], pi[5]) < 1e-10 ? 1 : 0;  // VirtualMap.cpp:293-294
+    }
+    __syncthreads();
+    // bbox of the 3-degree sector sweep (OccupancyMap.cpp:79-96): (pose, sample) pairs in parallel
+    for (int e = tid; e < P * S.n_sweep; e += kThreads) {
+      const int p = e / S.n_sweep, k = e - p * S.n_sweep;
+      const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
+      const double th0 = theta_of(ps), b = S.sweep_b[k];
+      const double x = ps.x + cfg.max_range * cos(th0 + b);
+      const double y = ps.y + cfg.max_range * sin(th0 + b);
+      int row = (int)floor((y - cfg.map_min_y) / cfg.resolution);
+      int col = (int)floor((x - cfg.map_min_x) / cfg.resolution);
+      row = min(max(0, row), rows - 1);
+      col = min(max(0, col), cols - 1);
+      atomicMin(&bbox[4 * p + 0], row);
+      atomicMax(&bbox[4 * p + 1], row);
+      atomicMin(&bbox[4 * p + 2], col);
+      atomicMax(&bbox[4 * p + 3], col);
+    }
+    __syncthreads();
+    // ---- phase O: occupancy ladder per cell, poses in trajectory order ----
+    const double i0 = 1.0 / pow(cfg.sigma0, 2);
+    for (int v = tid; v < V; v += kThreads) {
+      const int row = v / cols, col = v - row * cols;
+      double l = 0.0;  // LOGODDS_UNKNOWN
+      for (int j = 0; j < L; ++j)
+        if (lmcell[j] == v) l = fmin(S.lo_max, fmax(S.lo_min, l + S.lo_occ));
+      const P2 pt{cfg.map_min_x + cfg.resolution * (col + 0.5), cfg.map_min_y + cfg.resolution * (row + 0.5)};
+      for (int p = 0; p < P; ++p) {
+        if (row < bbox[4 * p] || row > bbox[4 * p + 1] || col < bbox[4 * p + 2] || col > bbox[4 * p + 3]) continue;
+        if (fabs(l - S.lo_min) < 1e-5) continue;
+        const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
+        const double range = range_of<false>(ps, pt, nullptr, nullptr);
+        if (!(range < cfg.max_range)) continue;
+        const double bearing = bearing_of<false>(ps, pt, nullptr, nullptr);
+        if (!(bearing < cfg.max_bearing && bearing > cfg.min_bearing)) continue;
+        const double add = (l > S.occ_thresh + 1e-8) ? S.lo_occ : S.lo_free;
+        l = fmin(S.lo_max, fmax(S.lo_min, l + add));
+      }
+      // VirtualMap::updateProbability: prob = sum over num_samples identical maps of p / n
+      const double pv = logodds2prob(l);
+      double acc = 0.0;
+      for (int s = 0; s < cfg.num_samples; ++s) acc += pv / cfg.num_samples;
+      prob[v] = acc;
+      ixx[v] = i0; ixy[v] = 0.0; iyy[v] = i0;
+      upd[v] = 0;
+    }
+    __syncthreads();
+    // ---- phases A/B: covariance propagation, kChunk poses at a time ----
+    for (int c0 = 0; c0 < P; c0 += kChunk) {
+      const int nc = min(kChunk, P - c0);
+      for (int pl = wave; pl < nc; pl += kThreads / 64) {
+        const int p = c0 + pl;
+        double oxx = __longlong_as_double(0x7ff8000000000000LL), oxy = 0, oyy = 0;  // NaN = "no update"
+        if (lane < W2 && !pskip[p]) {
+          const int wr = lane / W, wc = lane - wr * W;
+          const int row = worg[2 * p] + wr, col = worg[2 * p + 1] + wc;
+          if (row >= 0 && row < rows && col >= 0 && col < cols) {
+            const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
+            const P2 pt{(col + 0.5) * cfg.resolution + cfg.map_min_x, (row + 0.5) * cfg.resolution + cfg.map_min_y};
+            const double dx = ps.x - pt.x, dy = ps.y - pt.y;
+            if (sqrt(dx * dx + dy * dy) < cfg.max_range) {  // KDTreeR2::queryRadiusNeighbors
+              double a, b, d;
+              if (predict_cell(ps, si + 6 * p, pt, cfg, a, b, d)) {
+                oxx = a; oxy = b; oyy = d;
+              }
+            }
+          }
+        }
+        double *o = stage + ((size_t)pl * 64 + lane) * 3;
+        o[0] = oxx; o[1] = oxy; o[2] = oyy;
+      }
+      __syncthreads();
+      for (int v = tid; v < V; v += kThreads) {
+        const int row = v / cols, col = v - row * cols;
+        double axx = ixx[v], axy = ixy[v], ayy = iyy[v];
+        int u = upd[v];
+        bool touched = false;
+        for (int pl = 0; pl < nc; ++pl) {
+          const int p = c0 + pl;
+          const int wr = row - worg[2 * p], wc = col - worg[2 * p + 1];
+          if (wr < 0 || wr >= W || wc < 0 || wc >= W) continue;
+          const double *o = stage + ((size_t)pl * 64 + wr * W + wc) * 3;
+          const double bxx = o[0];
+          if (bxx != bxx) continue;
+          if (u) {
+            ci_fuse(axx, axy, ayy, bxx, o[1], o[2]);
+          } else {
+            axx = bxx; axy = o[1]; ayy = o[2];
+            u = 1;
+          }
+          touched = true;
+        }
+        if (touched) {
+          ixx[v] = axx; ixy[v] = axy; iyy[v] = ayy;
+          upd[v] = (uint8_t)u;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- phase R: reductions (Planner2D.cpp:321-366, VirtualMap.cpp:47-59) ----
+  double utr = 0, known = 0, expl = 0, udet = 0, uwtr = 0;
+  const int extg = 20;
+  for (int v = tid; v < V; v += kThreads) {
+    const int row = v / cols, col = v - row * cols;
+    const double a = ixx[v], b = ixy[v], d = iyy[v], pv = prob[v];
+    double ca, cb, cd;
+    inv2_llt_s(a, b, d, ca, cb, cd);
+    const double tr = ca + cd;
+    vtr[v] = tr;
+    utr += 1.0 * tr;
+    if (pv < cfg.occupancy_threshold) known += 1.0;
+    const double wgt = pv > 0.49 ? 1.0 : 0.0;
+    udet += wgt / (a * d - b * b);
+    uwtr += wgt * tr;
+    const double x = (col + 0.5) * cfg.resolution + cfg.map_min_x, y = (row + 0.5) * cfg.resolution + cfg.map_min_y;
+    if ((pv < 0.49 || pv > 0.6) && cfg.map_min_x + extg <= x && x <= cfg.map_max_x - extg && cfg.map_min_y + extg <= y &&
+        y <= cfg.map_max_y - extg)
+      expl += 1.0;
+  }
+  utr = block_sum(utr, scratch, tid);
+  known = block_sum(known, scratch, tid);
+  expl = block_sum(expl, scratch, tid);
+  udet = block_sum(udet, scratch, tid);
+  uwtr = block_sum(uwtr, scratch, tid);
+  if (tid == 0) {
+    double *red = S.red + (size_t)inst * DRLGX_RED_STRIDE;
+    red[R_UTR] = utr;
+    red[R_KNOWN] = known;
+    red[R_EXPL] = expl;
+    red[R_UDET] = udet;
+    red[R_UWTR] = uwtr;
+  }
+}
+
+}  // namespace
+
+static size_t map_lds_bytes(const DrlgxState &S) {
+  size_t d = (size_t)S.P_max * 10 + (size_t)kChunk * 64 * 3 + 8;
+  size_t i = (size_t)S.P_max * 7 + S.L_max;
+  return d * sizeof(double) + i * sizeof(int) + 16;
+}
+
+void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
+  // sel.act_idx < 0 encodes "reductions only" (used after reset)
+  int rebuild = 1;
+  if (sel.act_idx == -2) {
+    rebuild = 0;
+    sel.act_idx = 0;
+  }
+  const size_t lds = map_lds_bytes(S);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_map, dim3(sel.n), dim3(kThreads), lds, st, S, sel, rebuild);
+}

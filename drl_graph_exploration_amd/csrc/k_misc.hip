@@ -1,0 +1,171 @@
+// Small kernels around the belief step: instance copies for the look-ahead (deep copies of
+// SLAM2D / Simulator2D state, Planner2D.cpp:1417-1420), SLAM2D::set_copy_isam re-basing
+// (SLAM2D.cpp:490-497), rewards / utility (Planner2D.cpp:354-366, 1463-1464) and the closed-form
+// line planner (Planner2D.cpp:937-1041).
+#include "drlgx_dev.h"
+#include "drlgx_fields.h"
+
+namespace {
+
+// copy every non-virtual-map field of instance src[i] to dst[i]
+__global__ __launch_bounds__(256) void k_copy_instances(const DrlgxField *fields, int n_fields, const int32_t *src,
+                                                        const int32_t *dst, int src_off, int dst_off, int skip_vm) {
+  const int i = blockIdx.x;
+  const int s = (src ? src[i] : i) + src_off, d = (dst ? dst[i] : i) + dst_off;
+  for (int f = 0; f < n_fields; ++f) {
+    if (skip_vm && fields[f].is_vm) continue;
+    const uint32_t *sp = reinterpret_cast<const uint32_t *>(fields[f].base + (size_t)s * fields[f].stride);
+    uint32_t *dp = reinterpret_cast<uint32_t *>(fields[f].base + (size_t)d * fields[f].stride);
+    const size_t nw = fields[f].stride / 4;
+    for (size_t k = threadIdx.x; k < nw; k += 256) dp[k] = sp[k];
+  }
+}
+
+// SLAM2D::set_copy_isam: theta := calculateBestEstimate(), delta := 0, fresh ISAM2 (update count 0)
+__global__ __launch_bounds__(64) void k_rebase(DrlgxState S, int base0, int n) {
+  const int inst = base0 + blockIdx.x;
+  int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
+  const int P = cnt[C_P], L = cnt[C_L];
+  for (int i = threadIdx.x; i < P; i += 64) {
+    for (int k = 0; k < 4; ++k)
+      S.th_pose[((size_t)inst * S.P_max + i) * 4 + k] = S.est_pose[((size_t)inst * S.P_max + i) * 4 + k];
+    for (int k = 0; k < 3; ++k) S.d_pose[((size_t)inst * S.P_max + i) * 3 + k] = 0.0;
+  }
+  for (int j = threadIdx.x; j < L; j += 64) {
+    for (int k = 0; k < 2; ++k) {
+      S.th_lm[((size_t)inst * S.L_max + j) * 2 + k] = S.est_lm[((size_t)inst * S.L_max + j) * 2 + k];
+      S.d_lm[((size_t)inst * S.L_max + j) * 2 + k] = 0.0;
+    }
+  }
+  if (threadIdx.x == 0) {
+    cnt[C_ISAM] = 0;
+    cnt[C_NEWP] = 0;
+    cnt[C_NEWL] = 0;
+    cnt[C_FLAG] = 0;
+  }
+}
+
+// after copying base -> rollout: result_ (est_pose) is the ORIGINAL estimate of the live env
+// (SLAM2D copy keeps result_; set_copy_isam does not touch it), distance accumulator reset.
+__global__ __launch_bounds__(64) void k_fix_rollouts(DrlgxState S, const int32_t *cand_env, int roll0) {
+  const int c = blockIdx.x;
+  const int env = cand_env[c], inst = roll0 + c;
+  const int P = S.cnt[(size_t)inst * DRLGX_CNT_STRIDE + C_P];
+  for (int e = threadIdx.x; e < P * 4; e += 64)
+    S.est_pose[(size_t)inst * S.P_max * 4 + e] = S.est_pose[(size_t)env * S.P_max * 4 + e];
+  if (threadIdx.x == 0) {
+    S.parent[inst] = env;
+    S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST] = 0.0;
+  }
+}
+
+__device__ __forceinline__ double utility_of(const DrlgxState &S, int inst, double dist) {
+  const double *red = S.red + (size_t)inst * DRLGX_RED_STRIDE;
+  const drlgx_config &cfg = S.cfg;
+  const double pk = red[R_KNOWN] / (double)S.V;
+  const double dw = cfg.distance_weight0 - (cfg.distance_weight0 - cfg.distance_weight1) * pk;
+  return red[R_UTR] + dist * dw;
+}
+
+__global__ void k_rewards(DrlgxState S, int n_cand, const int32_t *cand_env, int roll0, double *rewards) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cand) return;
+  const int inst = roll0 + c;
+  const double u0 = utility_of(S, cand_env[c], 0.0);
+  const double u1 = utility_of(S, inst, S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST]);
+  rewards[c] = u0 - u1;
+}
+
+// mode 0: calculateUtility(dist); 1: explored(); 2: uncertainty_EM trace-weighted; 3: uncertainty_EM det
+__global__ void k_utility(DrlgxState S, const double *dist, double *out, int mode) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S.n_envs) return;
+  const double *red = S.red + (size_t)e * DRLGX_RED_STRIDE;
+  if (mode == 0) out[e] = utility_of(S, e, dist ? dist[e] : 0.0);
+  else if (mode == 1) out[e] = red[R_EXPL] / (double)S.count_explored;
+  else if (mode == 2) out[e] = red[R_UWTR];
+  else out[e] = red[R_UDET];
+}
+
+// EMPlanner2D::line_planner (Planner2D.cpp:937-1041), goal = frontier point
+__global__ void k_line_plan(DrlgxState S, int n_cand, const int32_t *cand_env, const double *goal, double *actions,
+                            int32_t *n_actions) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cand) return;
+  const int env = cand_env[c];
+  const int P = S.cnt[(size_t)env * DRLGX_CNT_STRIDE + C_P];
+  const double *ep = S.est_pose + ((size_t)env * S.P_max + (P - 1)) * 4;
+  const double rx = ep[0], ry = ep[1];
+  double rth = atan2(ep[3], ep[2]);
+  const double gx = goal[2 * c], gy = goal[2 * c + 1];
+  double gth = atan2(gy - ry, gx - rx);
+  const double PI = 3.14159265358979323846;
+  if (rth < 0) rth = PI * 2 + rth;
+  if (gth < 0) gth = PI * 2 + gth;
+  const double dr = 180 * PI / 180;
+  double diff = gth - rth;
+  double *out = actions + (size_t)c * S.A_max * 3;
+  int n = 0;
+  double d, sign;
+  if (diff > PI) {
+    d = 2 * PI - diff;
+    sign = -1.0;
+  } else if (diff > -PI && diff < 0) {
+    d = fabs(diff);
+    sign = -1.0;
+  } else if (diff <= -PI) {
+    d = 2 * PI - fabs(diff);
+    sign = 1.0;
+  } else {
+    d = diff;
+    sign = 1.0;
+  }
+  auto push = [&](double x, double y, double th) {
+    if (n < S.A_max) {
+      // a Pose2 action: theta() = atan2(sin, cos)
+      out[3 * n] = x;
+      out[3 * n + 1] = y;
+      out[3 * n + 2] = atan2(sin(th), cos(th));
+    }
+    n++;
+  };
+  {
+    const int q = (int)(d / dr);
+    const double rem = d - dr * q;
+    for (int i = 0; i < q; ++i) push(0, 0, sign * dr);
+    push(0, 0, sign * rem);
+  }
+  const double dist = sqrt(pow(rx - gx, 2) + pow(ry - gy, 2));
+  const int dq = (int)(dist / S.cfg.max_edge_length);
+  const double drem = dist - dq * S.cfg.max_edge_length;
+  for (int i = 0; i < dq; ++i) push(S.cfg.max_edge_length, 0, 0);
+  push(drem, 0, 0);
+  n_actions[c] = n;
+  if (n > S.A_max) atomicMin(S.status, DRLGX_E_CAPACITY);
+}
+
+}  // namespace
+
+void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
+                       const int32_t *dst, int src_off, int dst_off, int skip_vm) {
+  hipLaunchKernelGGL(k_copy_instances, dim3(n), dim3(256), 0, st, fields_dev, n_fields, src, dst, src_off, dst_off,
+                     skip_vm);
+}
+void drlgx_launch_rebase(const DrlgxState &S, hipStream_t st, int base0, int n) {
+  hipLaunchKernelGGL(k_rebase, dim3(n), dim3(64), 0, st, S, base0, n);
+}
+void drlgx_launch_fix_rollouts(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0) {
+  hipLaunchKernelGGL(k_fix_rollouts, dim3(n_cand), dim3(64), 0, st, S, cand_env, roll0);
+}
+void drlgx_launch_rewards(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0,
+                          double *rewards) {
+  hipLaunchKernelGGL(k_rewards, dim3((n_cand + 127) / 128), dim3(128), 0, st, S, n_cand, cand_env, roll0, rewards);
+}
+void drlgx_launch_utility(const DrlgxState &S, hipStream_t st, const double *dist, double *out, int mode) {
+  hipLaunchKernelGGL(k_utility, dim3((S.n_envs + 127) / 128), dim3(128), 0, st, S, dist, out, mode);
+}
+void drlgx_launch_line_plan(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, const double *goal,
+                            double *actions, int32_t *n_actions) {
+  hipLaunchKernelGGL(k_line_plan, dim3((n_cand + 127) / 128), dim3(128), 0, st, S, n_cand, cand_env, goal, actions,
+                     n_actions);
+}

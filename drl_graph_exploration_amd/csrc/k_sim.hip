@@ -1,0 +1,250 @@
+// Simulator kernels: environment reset (SS2D.__init__) and the move/measure/factor-append part of a
+// belief step.  One 64-lane wave per instance: the lanes scan the ground-truth landmarks in
+// parallel (ballot keeps libstdc++'s hash iteration order), RNG consumption is wave-uniform and
+// reproduces the reference's draw order exactly.
+//
+// Reference: src/em_exploration/Simulator2D.cpp:113-132,161-182,445-464,491-527;
+// src/em_exploration/SLAM2D.cpp:44-57,70-89,103-124; scripts/envs/pyss2d.py:102-138,171-206.
+// Compiled with -ffp-contract=off so that products/sums round as in the CPU reference.
+#include "drlgx_dev.h"
+
+namespace {
+
+struct SimCtx {
+  const DrlgxState &S;
+  int inst, lane;
+  MtStream sensor, control;
+  NormalState ns_sensor, ns_control;
+  Pose veh;
+  int P, L, M;
+  int err;
+};
+
+// SLAM2D::addMeasurement (SLAM2D.cpp:103-124); wave-uniform, lane 0 writes.
+__device__ inline void add_measurement(SimCtx &c, int key, double bearing, double range) {
+  const DrlgxState &S = c.S;
+  int *key_slot = S.key_slot + (size_t)c.inst * S.LG;
+  int slot = key_slot[key];
+  if (slot < 0) {
+    if (c.L >= S.L_max) {
+      c.err = DRLGX_E_CAPACITY;
+      return;
+    }
+    slot = c.L;
+    // origin = initial estimate of the measuring pose (it is never in result_ yet)
+    const double *tp = S.th_pose + ((size_t)c.inst * S.P_max + (c.P - 1)) * 4;
+    Pose origin{tp[0], tp[1], tp[2], tp[3]};
+    P2 g = transform_from(origin, P2{range * cos(bearing), range * sin(bearing)});  // Simulator2D.cpp:95-98
+    if (c.lane == 0) {
+      double *tl = S.th_lm + ((size_t)c.inst * S.L_max + slot) * 2;
+      tl[0] = g.x;
+      tl[1] = g.y;
+      double *dl = S.d_lm + ((size_t)c.inst * S.L_max + slot) * 2;
+      dl[0] = 0;
+      dl[1] = 0;
+      S.lm_key[(size_t)c.inst * S.L_max + slot] = key;
+      key_slot[key] = slot;
+    }
+    c.L++;
+  }
+  if (c.M >= S.M_max) {
+    c.err = DRLGX_E_CAPACITY;
+    return;
+  }
+  if (c.lane == 0) {
+    S.meas_pose[(size_t)c.inst * S.M_max + c.M] = c.P - 1;
+    S.meas_lm[(size_t)c.inst * S.M_max + c.M] = slot;
+    double *br = S.meas_br + ((size_t)c.inst * S.M_max + c.M) * 2;
+    br[0] = bearing;
+    br[1] = range;
+  }
+  c.M++;
+}
+
+// Simulator2D::measure (Simulator2D.cpp:505-527)
+__device__ inline void measure(SimCtx &c, bool record) {
+  const DrlgxState &S = c.S;
+  const drlgx_config &cfg = S.cfg;
+  const double *gl = S.gt_lm + (size_t)S.parent[c.inst] * S.LG * 2;
+  const int n_gt = cfg.num_landmarks;
+  for (int base = 0; base < n_gt; base += 64) {
+    int idx = base + c.lane;
+    bool valid = idx < n_gt;
+    int key = valid ? S.lm_order[idx] : 0;
+    double lx = valid ? gl[2 * key] : 0.0, ly = valid ? gl[2 * key + 1] : 0.0;
+    double dx = lx - c.veh.x, dy = ly - c.veh.y;
+    bool in = valid && (sqrt(dx * dx + dy * dy) < cfg.max_range);
+    unsigned long long mask = __ballot(in);
+    while (mask) {
+      int b = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      int k = __shfl(key, b);
+      P2 lm{__shfl(lx, b), __shfl(ly, b)};
+      // noise is drawn BEFORE the validity check (BearingRangeSensorModel::measure, Simulator2D.cpp:113-132)
+      double bn = rng_normal(c.sensor, c.ns_sensor, 0.0, cfg.bearing_noise, c.lane);
+      double rn = rng_normal(c.sensor, c.ns_sensor, 0.0, cfg.range_noise, c.lane);
+      double bearing = bearing_of<false>(c.veh, lm, nullptr, nullptr) + bn;
+      double range = range_of<false>(c.veh, lm, nullptr, nullptr) + rn;
+      bool ok = bearing < cfg.max_bearing && bearing > cfg.min_bearing && range < cfg.max_range && range > cfg.min_range;
+      if (ok && record) add_measurement(c, k, bearing, range);
+    }
+  }
+}
+
+__device__ inline void store_ctx(SimCtx &c) {
+  const DrlgxState &S = c.S;
+  mt_store(c.sensor, S.mt + ((size_t)c.inst * 2 + 0) * DRLGX_MT_STRIDE, c.lane);
+  mt_store(c.control, S.mt + ((size_t)c.inst * 2 + 1) * DRLGX_MT_STRIDE, c.lane);
+  if (c.lane == 0) {
+    S.nrm_saved[c.inst * 2 + 0] = c.ns_sensor.saved;
+    S.nrm_has[c.inst * 2 + 0] = c.ns_sensor.has;
+    S.nrm_saved[c.inst * 2 + 1] = c.ns_control.saved;
+    S.nrm_has[c.inst * 2 + 1] = c.ns_control.has;
+    double *gp = S.gt_pose + (size_t)c.inst * 4;
+    gp[0] = c.veh.x; gp[1] = c.veh.y; gp[2] = c.veh.c; gp[3] = c.veh.s;
+    int *cnt = S.cnt + (size_t)c.inst * DRLGX_CNT_STRIDE;
+    cnt[C_P] = c.P;
+    cnt[C_L] = c.L;
+    cnt[C_M] = c.M;
+    if (c.err) atomicMin(S.status, c.err);
+  }
+}
+
+// SS2D.__init__ (pyss2d.py:102-138): seed, vehicle, landmarks, prior, first measure.
+__global__ __launch_bounds__(64) void k_reset(DrlgxState S, const int32_t *env_ids, const uint32_t *seeds,
+                                              const double *start) {
+  __shared__ uint32_t lds[3][DRLGX_MT_STRIDE];
+  const int lane = threadIdx.x;
+  const int inst = env_ids[blockIdx.x];
+  const uint32_t seed = seeds[blockIdx.x];
+  const drlgx_config &cfg = S.cfg;
+  SimCtx c{S, inst, lane, {}, {}, {0, 0}, {0, 0}, {}, 0, 0, 0, 0};
+  c.sensor = mt_seed(lds[0], seed, lane);   // Simulator2D.cpp:436-443: three RNGs, same seed
+  c.control = mt_seed(lds[1], seed, lane);
+  MtStream simrng = mt_seed(lds[2], seed, lane);
+  const double *sp = start + (size_t)blockIdx.x * 3;
+  c.veh = make_pose(sp[0], sp[1], sp[2]);
+  // Simulator2D::addLandmarks (Simulator2D.cpp:445-464)
+  double *gl = S.gt_lm + (size_t)inst * S.LG * 2;
+  for (int i = 0; i < cfg.num_landmarks;) {
+    double x = rng_uniform_real(simrng, cfg.env_min_x, cfg.env_max_x, lane);
+    double y = rng_uniform_real(simrng, cfg.env_min_y, cfg.env_max_y, lane);
+    double dx = x - c.veh.x, dy = y - c.veh.y;
+    if (sqrt(dx * dx + dy * dy) < 2.0) continue;
+    if (lane == 0) {
+      gl[2 * i] = x;
+      gl[2 * i + 1] = y;
+    }
+    i++;
+  }
+  for (int k = lane; k < S.LG; k += 64) S.key_slot[(size_t)inst * S.LG + k] = -1;
+  if (lane == 0) {
+    S.parent[inst] = inst;
+    int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
+    cnt[C_STEP] = 1;
+    cnt[C_ISAM] = 0;
+    cnt[C_NEWP] = 0;
+    cnt[C_NEWL] = 0;
+    cnt[C_FLAG] = 0;
+    // SLAM2D::addPrior (SLAM2D.cpp:44-57)
+    double *pr = S.prior + (size_t)inst * DRLGX_PRIOR_STRIDE;
+    pr[0] = c.veh.x; pr[1] = c.veh.y; pr[2] = c.veh.c; pr[3] = c.veh.s;
+    for (int k = 0; k < 9; ++k) pr[4 + k] = 0.0;
+    pr[4 + 0] = 1.0 / (cfg.sigma_x0 * cfg.sigma_x0);
+    pr[4 + 4] = 1.0 / (cfg.sigma_y0 * cfg.sigma_y0);
+    pr[4 + 8] = 1.0 / (cfg.sigma_theta0 * cfg.sigma_theta0);
+    double *tp = S.th_pose + (size_t)inst * S.P_max * 4;
+    tp[0] = c.veh.x; tp[1] = c.veh.y; tp[2] = c.veh.c; tp[3] = c.veh.s;
+    double *ep = S.est_pose + (size_t)inst * S.P_max * 4;
+    ep[0] = c.veh.x; ep[1] = c.veh.y; ep[2] = c.veh.c; ep[3] = c.veh.s;
+    double *dp = S.d_pose + (size_t)inst * S.P_max * 3;
+    dp[0] = dp[1] = dp[2] = 0;
+    double *red = S.red + (size_t)inst * DRLGX_RED_STRIDE;
+    for (int k = 0; k < DRLGX_RED_STRIDE; ++k) red[k] = 0;
+  }
+  __syncthreads();
+  c.P = 1;
+  measure(c, true);  // pyss2d.py:135 self.measure()
+  store_ctx(c);
+  // VirtualMap::initialize (VirtualMap.cpp:318-362): prob 0.5, information I / sigma0^2
+  const double i0 = 1.0 / pow(cfg.sigma0, 2);
+  for (int v = lane; v < S.V; v += 64) {
+    S.vm_prob[(size_t)inst * S.V + v] = 0.5;
+    S.vm_info[((size_t)inst * 3 + 0) * S.V + v] = i0;
+    S.vm_info[((size_t)inst * 3 + 1) * S.V + v] = 0.0;
+    S.vm_info[((size_t)inst * 3 + 2) * S.V + v] = i0;
+    S.vm_upd[(size_t)inst * S.Vu + v] = 0;
+  }
+}
+
+// move + addOdometry + measure(s) + addMeasurement for one belief step.
+__global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
+                                                 int n_measure) {
+  __shared__ uint32_t lds[2][DRLGX_MT_STRIDE];
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x;
+  if (!sel.on(i)) return;
+  const int inst = sel.base + i;
+  const drlgx_config &cfg = S.cfg;
+  int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
+  const double *od = odom + (size_t)i * odom_stride + (size_t)sel.act_idx * 3;
+  const double ox = od[0], oy = od[1], oth = od[2];
+  // SS2D.simulate bounds-checks the odometry increment against the map box (pyss2d.py:173-176)
+  if (!(cfg.map_min_x < ox && ox < cfg.map_max_x) || !(cfg.map_min_y < oy && oy < cfg.map_max_y)) {
+    if (lane == 0) cnt[C_FLAG] = 1;
+    return;
+  }
+  SimCtx c{S, inst, lane, {}, {}, {0, 0}, {0, 0}, {}, cnt[C_P], cnt[C_L], cnt[C_M], 0};
+  if (c.P >= S.P_max) {
+    if (lane == 0) {
+      cnt[C_FLAG] = 1;
+      atomicMin(S.status, DRLGX_E_CAPACITY);
+    }
+    return;
+  }
+  c.sensor = mt_load(lds[0], S.mt + ((size_t)inst * 2 + 0) * DRLGX_MT_STRIDE, lane);
+  c.control = mt_load(lds[1], S.mt + ((size_t)inst * 2 + 1) * DRLGX_MT_STRIDE, lane);
+  c.ns_sensor = NormalState{S.nrm_saved[inst * 2 + 0], S.nrm_has[inst * 2 + 0]};
+  c.ns_control = NormalState{S.nrm_saved[inst * 2 + 1], S.nrm_has[inst * 2 + 1]};
+  const double *gp = S.gt_pose + (size_t)inst * 4;
+  c.veh = Pose{gp[0], gp[1], gp[2], gp[3]};
+  const Pose odomP = make_pose(ox, oy, oth);
+  // SimpleControlModel::evolve (Simulator2D.cpp:161-182)
+  double xn = rng_normal(c.control, c.ns_control, 0.0, cfg.translation_noise, lane);
+  double yn = rng_normal(c.control, c.ns_control, 0.0, cfg.translation_noise, lane);
+  double tn = rng_normal(c.control, c.ns_control, 0.0, cfg.rotation_noise, lane);
+  c.veh = compose(compose(c.veh, odomP), make_pose(xn, yn, tn));
+  // SLAM2D::addOdometry (SLAM2D.cpp:70-89): initial guess = last estimate * odom
+  const double *ep = S.est_pose + ((size_t)inst * S.P_max + (c.P - 1)) * 4;
+  Pose p2 = compose(Pose{ep[0], ep[1], ep[2], ep[3]}, odomP);
+  if (lane == 0) {
+    double *tp = S.th_pose + ((size_t)inst * S.P_max + c.P) * 4;
+    tp[0] = p2.x; tp[1] = p2.y; tp[2] = p2.c; tp[3] = p2.s;
+    double *dp = S.d_pose + ((size_t)inst * S.P_max + c.P) * 3;
+    dp[0] = dp[1] = dp[2] = 0;
+    double *oo = S.odo + ((size_t)inst * S.P_max + (c.P - 1)) * 4;
+    oo[0] = odomP.x; oo[1] = odomP.y; oo[2] = odomP.c; oo[3] = odomP.s;
+    cnt[C_NEWP] = c.P;
+    cnt[C_NEWL] = c.L;
+    cnt[C_FLAG] = 0;
+    cnt[C_STEP] += 1;
+    // Planner2D.cpp:1440: dist += sqrt(x^2 + y^2 + angle_weight * theta^2), theta = Pose2::theta()
+    double th = theta_of(odomP);
+    S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST] += sqrt(ox * ox + oy * oy + cfg.angle_weight * (th * th));
+  }
+  __syncthreads();
+  c.P += 1;
+  for (int m = 0; m < n_measure; ++m) measure(c, m == n_measure - 1);
+  store_ctx(c);
+}
+
+}  // namespace
+
+void drlgx_launch_reset(const DrlgxState &S, hipStream_t st, int n, const int32_t *env_ids_dev,
+                        const uint32_t *seeds_dev, const double *start_dev) {
+  hipLaunchKernelGGL(k_reset, dim3(n), dim3(64), 0, st, S, env_ids_dev, seeds_dev, start_dev);
+}
+void drlgx_launch_sim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride,
+                      int n_measure) {
+  hipLaunchKernelGGL(k_sim_step, dim3(sel.n), dim3(64), 0, st, S, sel, odom, odom_stride, n_measure);
+}

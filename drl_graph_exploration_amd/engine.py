@@ -1,0 +1,204 @@
+"""Thin object wrapper over the C ABI (include/drlgx.h): one `Engine` = one drlgx_engine handle.
+
+Bulk inputs/outputs are torch CUDA tensors (torch is used only for device memory and streams); the
+`*_host` getters return numpy arrays and mirror the getters of the reference's pybind modules.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import DrlgxConfig, start_pose
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Engine(object):
+    def __init__(self, cfg, n_envs, n_rollouts=0, device=0):
+        if not isinstance(cfg, DrlgxConfig):
+            raise TypeError("cfg must be a DrlgxConfig")
+        if not torch.cuda.is_available():
+            raise _lib.DrlgxError("no HIP device visible: the drlgx engine has no CPU fallback")
+        self.L = _lib.lib()
+        self.cfg = cfg
+        self.n_envs = n_envs
+        self.n_rollouts = n_rollouts
+        self.device = torch.device("cuda", device)
+        self.h = C.c_void_p()
+        _lib.check(self.L.drlgx_create(C.byref(cfg), n_envs, n_rollouts, device, C.byref(self.h)))
+        r, c = C.c_int32(), C.c_int32()
+        self.L.drlgx_vm_shape(self.h, C.byref(r), C.byref(c))
+        self.rows, self.cols = r.value, c.value
+        self.use_torch_stream()
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.L.drlgx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        _lib.check(rc, self.h)
+
+    def use_torch_stream(self):
+        """Enqueue engine kernels on torch's current stream so tensors can be shared without syncs."""
+        with torch.cuda.device(self.device):
+            s = torch.cuda.current_stream().cuda_stream
+        self._chk(self.L.drlgx_set_stream(self.h, C.c_void_p(s)))
+
+    def synchronize(self):
+        self._chk(self.L.drlgx_synchronize(self.h))
+
+    def status(self):
+        return self.L.drlgx_status_host(self.h)
+
+    def check_status(self):
+        st = self.status()
+        if st != 0:
+            _lib.check(st, self.h)
+
+    # ---- life cycle
+    def reset(self, env_ids, seeds, starts=None, los=None):
+        """SS2D.__init__ for the listed envs. starts: (n,3) x,y,theta; or `los` to use the reference's
+        legacy numpy start-pose stream (pyss2d.py:89-95)."""
+        env_ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        if starts is None:
+            starts = np.array([start_pose(int(lo), self.cfg.map_max_x) for lo in los], dtype=np.float64)
+        starts = np.ascontiguousarray(starts, dtype=np.float64)
+        self._chk(self.L.drlgx_reset_host(self.h, len(env_ids), env_ids.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          seeds.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                          starts.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def step(self, odom, active=None):
+        """SS2D.simulate(core=True) for all envs. odom: CUDA float64 [n_envs,3]; active: CUDA uint8 [n_envs]."""
+        assert odom.is_cuda and odom.dtype == torch.float64 and odom.is_contiguous()
+        self._chk(self.L.drlgx_step(self.h, _p(odom), _p(active)))
+
+    def utility(self, dist=None):
+        out = torch.empty(self.n_envs, dtype=torch.float64, device=self.device)
+        self._chk(self.L.drlgx_utility(self.h, _p(dist), _p(out)))
+        return out
+
+    def uncertainty_em(self, algorithm):
+        out = torch.empty(self.n_envs, dtype=torch.float64, device=self.device)
+        self._chk(self.L.drlgx_uncertainty_em(self.h, int(algorithm), _p(out)))
+        return out
+
+    def explored(self):
+        out = torch.empty(self.n_envs, dtype=torch.float64, device=self.device)
+        self._chk(self.L.drlgx_explored(self.h, _p(out)))
+        return out
+
+    def line_plan(self, cand_env, goals):
+        n = cand_env.numel()
+        A = self.cfg.max_actions
+        actions = torch.zeros(n, A, 3, dtype=torch.float64, device=self.device)
+        n_act = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self._chk(self.L.drlgx_line_plan(self.h, n, _p(cand_env), _p(goals), _p(actions), _p(n_act)))
+        return actions, n_act
+
+    def lookahead(self, cand_env, actions, n_actions):
+        n = cand_env.numel()
+        rewards = torch.empty(n, dtype=torch.float64, device=self.device)
+        self._chk(self.L.drlgx_lookahead(self.h, n, _p(cand_env), _p(actions), _p(n_actions), _p(rewards)))
+        return rewards
+
+    def snapshot(self, slot=0):
+        self._chk(self.L.drlgx_snapshot(self.h, slot))
+
+    def restore(self, slot=0):
+        self._chk(self.L.drlgx_restore(self.h, slot))
+
+    def timing_enable(self, on=True):
+        self._chk(self.L.drlgx_timing_enable(self.h, int(on)))
+
+    def timing_read(self):
+        ms = (C.c_double * _lib.N_TIMERS)()
+        n = (C.c_int64 * _lib.N_TIMERS)()
+        self._chk(self.L.drlgx_timing_read_host(self.h, ms, n))
+        names = ["sim", "slam", "map", "copy", "graph", "t5", "t6", "t7"]
+        return {names[i]: (ms[i], n[i]) for i in range(_lib.N_TIMERS)}
+
+    # ---- getters (host)
+    def counts(self, inst):
+        out = (C.c_int32 * 5)()
+        self._chk(self.L.drlgx_get_counts_host(self.h, inst, out))
+        return dict(poses=out[0], landmarks=out[1], factors=out[2], step=out[3], isam_count=out[4])
+
+    def poses(self, inst):
+        P = self.counts(inst)["poses"]
+        xyt = np.zeros((P, 3))
+        info = np.zeros((P, 3, 3))
+        dp = C.POINTER(C.c_double)
+        self._chk(self.L.drlgx_get_poses_host(self.h, inst, xyt.ctypes.data_as(dp), info.ctypes.data_as(dp)))
+        return xyt, info
+
+    def landmarks(self, inst):
+        n = self.counts(inst)["landmarks"]
+        keys = np.zeros(n, dtype=np.int32)
+        xy = np.zeros((n, 2))
+        info = np.zeros((n, 2, 2))
+        dp = C.POINTER(C.c_double)
+        self._chk(self.L.drlgx_get_landmarks_host(self.h, inst, keys.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                  xy.ctypes.data_as(dp), info.ctypes.data_as(dp)))
+        return keys, xy, info
+
+    def cov_traces(self, inst):
+        c = self.counts(inst)
+        lm = np.zeros(c["landmarks"])
+        ps = np.zeros(c["poses"])
+        dp = C.POINTER(C.c_double)
+        self._chk(self.L.drlgx_get_cov_traces_host(self.h, inst, lm.ctypes.data_as(dp), ps.ctypes.data_as(dp)))
+        return lm, ps
+
+    def virtual_map(self, inst):
+        V = self.rows * self.cols
+        prob = np.zeros(V)
+        info = np.zeros((V, 2, 2))
+        tr = np.zeros(V)
+        upd = np.zeros(V, dtype=np.uint8)
+        dp = C.POINTER(C.c_double)
+        self._chk(self.L.drlgx_get_virtual_map_host(self.h, inst, prob.ctypes.data_as(dp), info.ctypes.data_as(dp),
+                                                    tr.ctypes.data_as(dp), upd.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return prob.reshape(self.rows, self.cols), info, tr.reshape(self.rows, self.cols), upd
+
+    def ground_truth(self, inst):
+        veh = np.zeros(3)
+        lms = np.zeros((max(self.cfg.num_landmarks, 1), 2))
+        dp = C.POINTER(C.c_double)
+        self._chk(self.L.drlgx_get_ground_truth_host(self.h, inst, veh.ctypes.data_as(dp), lms.ctypes.data_as(dp)))
+        return veh, lms[:self.cfg.num_landmarks]
+
+    def adjacency(self, inst):
+        c = self.counts(inst)
+        N = c["poses"] + c["landmarks"]
+        A = np.zeros((N, N))
+        X = np.zeros(N)
+        dp = C.POINTER(C.c_double)
+        self._chk(self.L.drlgx_get_adjacency_host(self.h, inst, A.ctypes.data_as(dp), X.ctypes.data_as(dp)))
+        return A, X
+
+    def factors(self, inst):
+        m = self.counts(inst)["factors"]
+        pose = np.zeros(m, dtype=np.int32)
+        key = np.zeros(m, dtype=np.int32)
+        b = np.zeros(m)
+        r = np.zeros(m)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        self._chk(self.L.drlgx_get_factors_host(self.h, inst, pose.ctypes.data_as(ip), key.ctypes.data_as(ip),
+                                                b.ctypes.data_as(dp), r.ctypes.data_as(dp)))
+        return pose, key, b, r
+
+    def landmark_order(self):
+        o = np.zeros(max(self.cfg.num_landmarks, 1), dtype=np.int32)
+        self._chk(self.L.drlgx_get_landmark_order_host(self.h, o.ctypes.data_as(C.POINTER(C.c_int32))))
+        return o[:self.cfg.num_landmarks]

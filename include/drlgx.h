@@ -1,0 +1,206 @@
+/* drlgx — C ABI of the MI355X-native exploration belief-step / GCN hot path.
+ *
+ * This is the drop-in boundary: plain C types, opaque handle, int return codes, no
+ * torch types.  The reference has no C ABI today — its boundary is two pybind11 modules
+ * (`ss2d`: /root/reference/src/SS2D.cpp:18-258, `planner2d`: /root/reference/src/Planner2D.cpp:9-106);
+ * each entry point below names the reference interface it replaces.  The Python shims in
+ * drl_graph_exploration_amd/ (ss2d.py, planner2d.py, vecenv.py, networks.py) sit on top of it.
+ *
+ * Conventions
+ *  - "dev" pointers are DEVICE (HBM) pointers owned by the caller (e.g. torch tensor data_ptr());
+ *    "host" pointers are ordinary host memory.  Every function that takes host pointers says so
+ *    in its name (…_host) or parameter comment; those functions synchronise the engine stream.
+ *  - All kernels of an engine are enqueued on ONE HIP stream (drlgx_set_stream; default: a private
+ *    stream).  Non-_host calls are asynchronous with respect to the host.
+ *  - Instance = one belief state.  Instances [0, n_envs) are live environments; the engine owns
+ *    additional scratch instances for look-ahead rollouts (one "base" per env + n_rollouts).
+ *  - Return value: 0 = OK, <0 = DRLGX_E_* error (see drlgx_strerror).  Nothing aborts.
+ *  - There is NO CPU fallback: if no HIP device is present drlgx_create fails with DRLGX_E_NODEVICE.
+ */
+#ifndef DRLGX_H
+#define DRLGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRLGX_OK 0
+#define DRLGX_E_INVALID (-1)   /* bad argument */
+#define DRLGX_E_NODEVICE (-2)  /* no HIP device / runtime error */
+#define DRLGX_E_CAPACITY (-3)  /* an instance overflowed max_poses / max_landmarks / max_factors */
+#define DRLGX_E_HIP (-4)       /* HIP runtime error (message in drlgx_last_error) */
+#define DRLGX_E_NUMERIC (-5)   /* non-SPD system met by the SLAM solve (gtsam: IndeterminantLinearSystemException) */
+
+#define DRLGX_ALG_EM_AOPT 0 /* Planner2D.h OptimizationAlgorithm::EM_AOPT (trace) */
+#define DRLGX_ALG_EM_DOPT 1 /* OptimizationAlgorithm::EM_DOPT (determinant)      */
+
+/* Parameters of one engine.  Mirrors the ini sections read by scripts/envs/pyss2d.py:10-55 and
+ * scripts/envs/pyplanner2d.py:24-54 (values: scripts/envs/exploration_env.ini). Angles in radians,
+ * already wrapped through Rot2(x).theta() as the reference setters do (Simulation2D.h:52-55,152). */
+typedef struct drlgx_config {
+  /* [Sensor Model]  BearingRangeSensorModel::Parameter (include/em_exploration/Simulation2D.h:47-76) */
+  double bearing_noise, range_noise, min_bearing, max_bearing, min_range, max_range;
+  /* [Control Model]  SimpleControlModel::Parameter (Simulation2D.h:145-160) */
+  double translation_noise, rotation_noise;
+  /* [Environment]  unpadded box, Environment::Parameter (Simulation2D.h:243-268) */
+  double env_min_x, env_max_x, env_min_y, env_max_y, safe_distance;
+  /* map box = environment padded by ext = 20 m (pyss2d.py:48-55) */
+  double map_min_x, map_max_x, map_min_y, map_max_y;
+  /* [Virtual Map]  VirtualMap::Parameter (include/em_exploration/VirtualMap.h:17-38) */
+  double resolution, sigma0;
+  int32_t num_samples; /* only 1 is supported (the shipped value); >1 re-averages identical maps */
+  /* [Simulator] */
+  double sigma_x0, sigma_y0, sigma_theta0;
+  int32_t num_landmarks; /* Simulator.num: ground-truth landmarks sampled per env */
+  /* [Planner]  EMPlanner2D::Parameter (include/em_exploration/Planner2D.h; src/Planner2D.cpp:26-41) */
+  double angle_weight, distance_weight0, distance_weight1, occupancy_threshold, max_edge_length;
+  int32_t algorithm; /* DRLGX_ALG_* */
+  /* capacities (new: the reference grows std::vectors) */
+  int32_t max_poses;     /* P_max per instance  */
+  int32_t max_landmarks; /* L_max observed landmarks per instance */
+  int32_t max_factors;   /* M_max bearing-range factors per instance */
+  int32_t max_actions;   /* A_max actions per look-ahead candidate */
+} drlgx_config;
+
+typedef struct drlgx_engine drlgx_engine;
+
+/* ---- life cycle ----------------------------------------------------------------------------- */
+
+/* Create an engine with n_envs environments and n_rollouts look-ahead scratch instances on HIP
+ * device `device`.  Replaces the constructors ss2d.Simulator2D / SLAM2D / VirtualMap and
+ * planner2d.EMPlanner2D (src/SS2D.cpp:173-188,190-211,226-246; src/Planner2D.cpp:75-92). */
+int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device, drlgx_engine **out);
+int drlgx_destroy(drlgx_engine *e);
+/* Use the caller's HIP stream (hipStream_t) for all subsequent work: NULL = HIP's default (null)
+ * stream, (void*)-1 = back to the engine's private non-blocking stream (the initial state). */
+int drlgx_set_stream(drlgx_engine *e, void *hip_stream);
+int drlgx_synchronize(drlgx_engine *e);
+const char *drlgx_strerror(int code);
+const char *drlgx_last_error(const drlgx_engine *e);
+/* Device-side status word of the last kernels: 0 or a DRLGX_E_* code (synchronises). */
+int drlgx_status_host(drlgx_engine *e);
+
+/* ---- SS2D life cycle (scripts/envs/pyss2d.py:58-206) ----------------------------------------- */
+
+/* SS2D.__init__ for `n` environments: seed the three mt19937 streams with seeds[i]
+ * (Simulator2D.cpp:436-443), place the vehicle at start_xytheta[i], rejection-sample the landmarks
+ * (Simulator2D::addLandmarks, Simulator2D.cpp:445-464), add the prior (SLAM2D::addPrior,
+ * SLAM2D.cpp:44-57), first measure + optimize.  env_ids / seeds / start_xytheta are HOST arrays
+ * (n, n, n*3).  Resets the virtual map to its untouched state (VirtualMap::initialize). */
+int drlgx_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint32_t *seeds,
+                     const double *start_xytheta);
+
+/* SS2D.simulate(odom, core=True) for every environment with active[i] != 0 (NULL = all):
+ * Simulator2D::move + SLAM2D::addOdometry, two noisy Simulator2D::measure calls (the first only
+ * consumes noise: pyss2d.py:182), SLAM2D::addMeasurement, SLAM2D::optimize,
+ * VirtualMap::updateProbability + updateInformation.  odom_dev: DEVICE double[n_envs*3]
+ * (x, y, theta); active_dev: DEVICE uint8[n_envs] or NULL. */
+int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_dev);
+
+/* EMPlanner2D::calculateUtility (static; src/em_exploration/Planner2D.cpp:354-366) for every
+ * environment: U = sum_v tr(info_v^-1) + dist * (w0 - (w0 - w1) * known / V).
+ * dist_dev: DEVICE double[n_envs] or NULL (= 0); out_dev: DEVICE double[n_envs]. */
+int drlgx_utility(drlgx_engine *e, const double *dist_dev, double *out_dev);
+/* EMPlanner2D::calculateUncertainty_EM (Planner2D.cpp:321-341): weighted trace (EM_AOPT) or
+ * sum 1[p>0.49]/det(info) (EM_DOPT).  out_dev: DEVICE double[n_envs]. */
+int drlgx_uncertainty_em(drlgx_engine *e, int algorithm, double *out_dev);
+/* VirtualMap::explored (src/em_exploration/VirtualMap.cpp:47-59). out_dev: DEVICE double[n_envs]. */
+int drlgx_explored(drlgx_engine *e, double *out_dev);
+
+/* ---- planner calls used by the DRL loop ------------------------------------------------------ */
+
+/* EMPlanner2D::line_planner (Planner2D.cpp:937-1041), frontier-goal branch, for n_cand goals.
+ * cand_env_dev: DEVICE int32[n_cand]; goal_dev: DEVICE double[n_cand*2];
+ * actions_dev: DEVICE double[n_cand*max_actions*3] (x, y, theta); n_actions_dev: DEVICE int32[n_cand]. */
+int drlgx_line_plan(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *goal_dev,
+                    double *actions_dev, int32_t *n_actions_dev);
+
+/* EMPlanner2D::simulations_reward (Planner2D.cpp:1416-1468) for n_cand candidates
+ * (n_cand <= n_rollouts): deep-copies the belief and simulator state of env cand_env[i] (including
+ * the RNG states), re-solves at the best estimate (SLAM2D::set_copy_isam, SLAM2D.cpp:490-497), rolls
+ * the action list forward with one noisy move/measure + SLAM2D::copy_optimize + virtual-map rebuild
+ * per action and returns reward = U_before(0) - U_after(dist).  Live environments are not modified.
+ * rewards_dev: DEVICE double[n_cand]. */
+int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *actions_dev,
+                    const int32_t *n_actions_dev, double *rewards_dev);
+
+/* ---- graph export for the policy (a14-a17) --------------------------------------------------- */
+
+/* ExplorationEnv.frontier + graph_matrix (scripts/envs/exploration_env.py:196-348) on top of
+ * SLAM2D::adjacency_degree_get (SLAM2D.cpp:198-273) and DeepQ.data_process (scripts/policy.py:211-232),
+ * batched: one graph per environment, concatenated PyG-Batch style.
+ *   node order per graph: landmarks by ground-truth key, poses by index, frontier nodes.
+ * Outputs (DEVICE, caller-sized with the capacities from drlgx_graph_capacity):
+ *   node_off[n_envs+1], edge_off[n_envs+1]      int32 prefix offsets
+ *   x[total_nodes*5] float32                    features (trace, dist, bearing diff, prob, type)
+ *   edge_index[2*total_edges] int64             (row array then col array, global node ids)
+ *   edge_attr[total_edges] float32
+ *   n_frontier[n_envs] int32, frontier_xy[n_envs*max_frontier*2] double
+ *   nearest_frontier_node[n_envs] int32         local node id of the robot's nearest frontier
+ * Edge order inside a graph is DeepQ.data_process's (row-major first-seen, both directions). */
+int drlgx_graph_capacity(const drlgx_engine *e, int *max_nodes, int *max_edges, int *max_frontier);
+int drlgx_graph(drlgx_engine *e, int32_t *node_off_dev, int32_t *edge_off_dev, float *x_dev,
+                int64_t *edge_index_dev, float *edge_attr_dev, int32_t *n_frontier_dev, double *frontier_xy_dev,
+                int32_t *nearest_frontier_node_dev);
+
+/* ---- state export (getters of the pybind surface; HOST outputs, synchronise) ------------------ */
+
+/* counts per instance: out[0]=poses, out[1]=landmarks, out[2]=factors, out[3]=step, out[4]=isam update count */
+int drlgx_get_counts_host(drlgx_engine *e, int inst, int32_t out[5]);
+/* Environment.iter_trajectory / get_current_vehicle of SLAM2D.map (src/SS2D.cpp:141-171):
+ * xytheta[P*3], information[P*9] (may be NULL). */
+int drlgx_get_poses_host(drlgx_engine *e, int inst, double *xytheta, double *information);
+/* Environment.iter_landmarks of SLAM2D.map, sorted by ground-truth key: keys[L], xy[L*2], information[L*4]. */
+int drlgx_get_landmarks_host(drlgx_engine *e, int inst, int32_t *keys, double *xy, double *information);
+/* marginal-covariance traces (SLAM2D::features_out, SLAM2D.h:74-76): landmarks by key, then poses. */
+int drlgx_get_cov_traces_host(drlgx_engine *e, int inst, double *lm_trace, double *pose_trace);
+/* VirtualMap.to_array / to_cov_trace / iter_virtual_landmarks (src/SS2D.cpp:226-246):
+ * prob[V], info[V*4] (2x2 row-major), cov_trace[V], updated[V]; any may be NULL. rows/cols via drlgx_vm_shape. */
+int drlgx_vm_shape(const drlgx_engine *e, int *rows, int *cols);
+int drlgx_get_virtual_map_host(drlgx_engine *e, int inst, double *prob, double *info, double *cov_trace,
+                               uint8_t *updated);
+/* Simulator2D.vehicle / Simulator2D.environment (ground truth): vehicle_xytheta[3], landmarks_xy[num*2] by key. */
+int drlgx_get_ground_truth_host(drlgx_engine *e, int inst, double *vehicle_xytheta, double *landmarks_xy);
+/* SLAM2D::adjacency_out / features_out (dense, (L+P)^2 and L+P doubles) for one environment. */
+int drlgx_get_adjacency_host(drlgx_engine *e, int inst, double *adjacency, double *features);
+/* factor list: pose index, landmark key, bearing, range (M each). */
+int drlgx_get_factors_host(drlgx_engine *e, int inst, int32_t *pose, int32_t *key, double *bearing, double *range);
+/* libstdc++ iteration order of the ground-truth landmark hash map (Simulator2D.cpp:331-344): order[num]. */
+int drlgx_get_landmark_order_host(const drlgx_engine *e, int32_t *order);
+
+/* Snapshot / restore of live environments (device-to-device; used by benchmarks and by
+ * ExplorationEnv-style "copy" semantics).  slot in [0, n_snapshots) — allocated lazily. */
+int drlgx_snapshot(drlgx_engine *e, int slot);
+int drlgx_restore(drlgx_engine *e, int slot);
+
+/* Per-kernel timing (HIP events on the engine stream): enable, then read accumulated milliseconds and
+ * launch counts.  kernel ids: 0 sim, 1 slam, 2 map, 3 copy/prepare, 4 graph.  */
+#define DRLGX_N_TIMERS 8
+int drlgx_timing_enable(drlgx_engine *e, int on);
+int drlgx_timing_read_host(drlgx_engine *e, double ms[DRLGX_N_TIMERS], int64_t launches[DRLGX_N_TIMERS]);
+
+/* ---- GCN policy (scripts/Networks.py:12-70 over PyG GCNConv(improved=True)) ------------------- */
+
+/* Forward of GCN / PolicyGCN trunk: H1 = relu(Â X W1 + b1), H2 = relu(Â H1 W2 + b2) [* dropout mask],
+ * out = H2 Wf^T + bf, with Â = D^-1/2 (A_w + 2I) D^-1/2 built from (edge_index, edge_attr).
+ * All pointers DEVICE, fp32 (edge_index int64 as PyG).  hidden = W1 cols, out_dim = Wf rows.
+ * ws_dev: workspace of drlgx_gcn_workspace_bytes(). H1/H2 are kept in the workspace for backward. */
+size_t drlgx_gcn_workspace_bytes(int n_nodes, int n_edges, int hidden, int out_dim);
+int drlgx_gcn_forward(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim,
+                      const float *x, const int64_t *edge_index, const float *edge_attr, const float *W1,
+                      const float *b1, const float *W2, const float *b2, const float *Wf, const float *bf,
+                      const float *dropout_mask /* [n_nodes*hidden] or NULL */, float *out /* [n_nodes*out_dim] */,
+                      void *ws_dev);
+/* Backward: given d(out) returns gradients of all six parameter tensors (accumulated = overwritten). */
+int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim,
+                       const float *x, const int64_t *edge_index, const float *edge_attr, const float *W1,
+                       const float *W2, const float *Wf, const float *dropout_mask, const float *d_out,
+                       float *dW1, float *db1, float *dW2, float *db2, float *dWf, float *dbf, void *ws_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRLGX_H */

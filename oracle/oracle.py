@@ -145,11 +145,11 @@ def start_pose(lo, map_max_x):
 class OracleSim(object):
     """EMExplorer / SS2D facade (scripts/envs/pyss2d.py:58-206, pyplanner2d.py:56-81) on the C++ oracle."""
 
-    def __init__(self, cfg, seed, lo, handle=None):
+    def __init__(self, cfg, seed, lo, handle=None, start=None):
         self.cfg = cfg
         self.L = lib()
         if handle is None:
-            x0, y0, th0 = start_pose(lo, cfg.map_max_x)
+            x0, y0, th0 = start_pose(lo, cfg.map_max_x) if start is None else start
             self.h = C.c_void_p(self.L.orc_create(C.byref(cfg), seed, x0, y0, th0))
         else:
             self.h = handle
@@ -264,6 +264,28 @@ class OracleSim(object):
         cnt = C.c_int(0)
         self.L.orc_get_isam(self.h, _dp(thp), _dp(dp), _dp(thl), _dp(dl), C.byref(cnt))
         return thp, dp, thl, dl, cnt.value
+
+    def knife_edge_cells(self, eps=1e-9):
+        """Cells whose occupancy / information membership is decided by a margin below `eps` for some
+        pose (range == max_range, bearing == FOV limit, range == min_range): floating-point noise decides
+        them in the reference itself (e.g. the four cells at exactly 6 m from an integer start pose when
+        the trajectory is pure dead reckoning).  Returns a boolean [rows*cols] mask."""
+        xyt, _ = self.poses()
+        r, c = self.vm_shape()
+        cfg = self.cfg
+        cx = cfg.map_min_x + cfg.resolution * (np.arange(c) + 0.5)
+        cy = cfg.map_min_y + cfg.resolution * (np.arange(r) + 0.5)
+        X, Y = np.meshgrid(cx, cy)
+        mask = np.zeros((r, c), dtype=bool)
+        for x, y, t in xyt:
+            dx, dy = X - x, Y - y
+            rng = np.sqrt(dx * dx + dy * dy)
+            b = np.arctan2(-math.sin(t) * dx + math.cos(t) * dy, math.cos(t) * dx + math.sin(t) * dy)
+            near = rng < cfg.max_range + eps
+            mask |= np.abs(rng - cfg.max_range) < eps
+            mask |= near & (np.abs(rng - cfg.min_range) < eps)
+            mask |= near & ((np.abs(b - cfg.max_bearing) < eps) | (np.abs(b - cfg.min_bearing) < eps))
+        return mask.reshape(-1)
 
     def key_points(self):
         """SLAM2D::get_key_points for every node (landmarks by key, then poses) — SLAM2D.cpp:152-166."""
