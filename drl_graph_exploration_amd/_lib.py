@@ -28,7 +28,7 @@ SYMBOLS = [
     "drlgx_get_poses_host", "drlgx_get_landmarks_host", "drlgx_get_cov_traces_host", "drlgx_vm_shape",
     "drlgx_get_virtual_map_host", "drlgx_get_ground_truth_host", "drlgx_get_adjacency_host", "drlgx_get_factors_host",
     "drlgx_get_landmark_order_host", "drlgx_snapshot", "drlgx_restore", "drlgx_timing_enable",
-    "drlgx_timing_read_host", "drlgx_gcn_workspace_bytes", "drlgx_gcn_forward", "drlgx_gcn_backward",
+    "drlgx_timing_read_host", "drlgx_debug_phase_clocks_host", "drlgx_gcn_workspace_bytes", "drlgx_gcn_forward", "drlgx_gcn_backward",
 ]
 
 
@@ -37,6 +37,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own ROCm runtime: import it first so that libdrlgx.so binds to the SAME
+    # libamdhip64 (device pointers and streams are shared with torch tensors)
+    import torch  # noqa: F401
     if not os.path.exists(_PATH):
         raise DrlgxError(
             "libdrlgx.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -75,6 +78,7 @@ def lib():
     L.drlgx_restore.argtypes = [vp, C.c_int]
     L.drlgx_timing_enable.argtypes = [vp, C.c_int]
     L.drlgx_timing_read_host.argtypes = [vp, dp, C.POINTER(C.c_int64)]
+    L.drlgx_debug_phase_clocks_host.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     L.drlgx_gcn_workspace_bytes.restype = C.c_size_t
     L.drlgx_gcn_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.drlgx_gcn_forward.argtypes = [vp] + [C.c_int] * 5 + [vp] * 12

@@ -24,6 +24,7 @@ class DrlgxConfig(C.Structure):
         ("angle_weight", C.c_double), ("distance_weight0", C.c_double), ("distance_weight1", C.c_double),
         ("occupancy_threshold", C.c_double), ("max_edge_length", C.c_double), ("algorithm", C.c_int32),
         ("max_poses", C.c_int32), ("max_landmarks", C.c_int32), ("max_factors", C.c_int32), ("max_actions", C.c_int32),
+        ("max_snapshots", C.c_int32),
     ]
 
 
@@ -32,8 +33,8 @@ def _rot2_theta(th):
     return math.atan2(math.sin(th), math.cos(th))
 
 
-def default_config(map_size=40, num_landmarks=None, algorithm=0, max_poses=45, max_landmarks=None,
-                   max_factors=None, max_actions=24):
+def default_config(map_size=40, num_landmarks=None, algorithm=0, max_poses=41, max_landmarks=None,
+                   max_factors=None, max_actions=24, max_snapshots=1):
     """exploration_env.ini + ExplorationEnv.reset overrides + read_map_params(ext=20)."""
     c = DrlgxConfig()
     c.bearing_noise = _rot2_theta(math.radians(0.5))
@@ -66,6 +67,7 @@ def default_config(map_size=40, num_landmarks=None, algorithm=0, max_poses=45, m
     c.max_landmarks = max(1, min(c.num_landmarks, 128) if max_landmarks is None else max_landmarks)
     c.max_factors = max_factors if max_factors is not None else max(64, 12 * max_poses)
     c.max_actions = max_actions
+    c.max_snapshots = max_snapshots
     return c
 
 

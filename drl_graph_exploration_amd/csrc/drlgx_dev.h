@@ -72,7 +72,14 @@ struct DrlgxState {
   int *slam_iws;  // [n_inst][slam_iws_stride] observation table + per-pose factor ranges
   size_t slam_iws_stride;
   int *status;  // [1]
+  long long *prof;  // [64] development aid: wall_clock64() stamps of the phases of block 0 (or null)
 };
+
+// phase stamp (100 MHz constant clock) — only block 0 / thread 0, only when profiling is armed
+#define DRLGX_PROF(S, slot)                                                        \
+  do {                                                                             \
+    if ((S).prof && threadIdx.x == 0 && blockIdx.x == 0) (S).prof[slot] = wall_clock64(); \
+  } while (0)
 
 struct LaunchSel {
   int base;                // first instance
@@ -346,7 +353,7 @@ void drlgx_launch_sim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const 
 void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel);
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel);  // sel.act_idx == -2: reductions only
 void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
-                       const int32_t *dst, int src_off, int dst_off, int skip_vm);
+                       const int32_t *dst, int src_off, int dst_off, int skip_mask);  // skip fields with cls & mask
 void drlgx_launch_rebase(const DrlgxState &S, hipStream_t st, int base0, int n);
 void drlgx_launch_fix_rollouts(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0);
 void drlgx_launch_rewards(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0,

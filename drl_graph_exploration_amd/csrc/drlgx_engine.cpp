@@ -34,10 +34,8 @@ struct drlgx_engine {
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::vector<void *> allocs;
   std::vector<DrlgxField> fields;       // per-instance fields (n_inst instances)
-  std::vector<DrlgxField> env_fields;   // extra fields that exist only for live envs (gt landmarks)
   DrlgxField *fields_dev = nullptr;
   std::vector<int> lm_order;
-  std::vector<std::vector<char *>> snaps;
   // staging
   int32_t *stage_i32 = nullptr;
   uint32_t *stage_u32 = nullptr;
@@ -66,10 +64,10 @@ int dev_alloc(drlgx_engine *e, T **out, size_t count) {
 }
 
 template <typename T>
-int field_alloc(drlgx_engine *e, T **out, size_t per_inst, bool is_vm = false) {
+int field_alloc(drlgx_engine *e, T **out, size_t per_inst, int cls = 0) {
   int r = dev_alloc(e, out, per_inst * (size_t)e->S.n_inst);
   if (r) return r;
-  e->fields.push_back(DrlgxField{reinterpret_cast<char *>(*out), per_inst * sizeof(T), is_vm ? 1 : 0, 0});
+  e->fields.push_back(DrlgxField{reinterpret_cast<char *>(*out), per_inst * sizeof(T), cls, 0});
   return DRLGX_OK;
 }
 
@@ -152,7 +150,12 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   S.cfg = *cfg;
   S.n_envs = n_envs;
   S.n_roll = n_rollouts;
-  S.n_inst = 2 * n_envs + n_rollouts;
+  if (cfg->max_snapshots < 0 || cfg->max_snapshots > 16) {
+    drlgx_destroy(e);
+    return DRLGX_E_INVALID;
+  }
+  // instances: [0,n) live envs | [n,2n) look-ahead bases | rollouts | max_snapshots x n snapshot copies
+  S.n_inst = 2 * n_envs + n_rollouts + cfg->max_snapshots * n_envs;
   S.P_max = cfg->max_poses;
   S.L_max = cfg->max_landmarks;
   S.M_max = cfg->max_factors;
@@ -238,18 +241,19 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   TRY(field_alloc(e, &S.pose_tr, P));
   TRY(field_alloc(e, &S.lm_tr, L));
   TRY(field_alloc(e, &S.red, DRLGX_RED_STRIDE));
-  TRY(field_alloc(e, &S.vm_prob, V, true));
-  TRY(field_alloc(e, &S.vm_info, 3 * V, true));
-  TRY(field_alloc(e, &S.vm_upd, (size_t)S.Vu, true));
-  TRY(field_alloc(e, &S.vm_tr, V, true));
-  TRY(dev_alloc(e, &S.gt_lm, (size_t)n_envs * S.LG * 2));
-  e->env_fields.push_back(DrlgxField{reinterpret_cast<char *>(S.gt_lm), (size_t)S.LG * 2 * sizeof(double), 0, 0});
+  TRY(field_alloc(e, &S.vm_prob, V, 1));
+  TRY(field_alloc(e, &S.vm_info, 3 * V, 1));
+  TRY(field_alloc(e, &S.vm_upd, (size_t)S.Vu, 1));
+  TRY(field_alloc(e, &S.vm_tr, V, 1));
+  TRY(field_alloc(e, &S.gt_lm, (size_t)S.LG * 2, 2));  // rollouts read their parent's landmarks
   // SLAM workspace (not copied between instances)
   {
+    // k_slam overflow workspace: per-factor G (6) + partials (4) + the landmark x pose table, and — only when
+    // the dense system does not fit the 160 KB LDS — the padded (3P+4)^2 system and its 3-column panel
     const bool lds = drlgx_slam_lds_bytes(S.P_max, S.L_max, S.M_max) <= 160 * 1024;
-    size_t na = 3 * P + 1, ld = (na & 1) ? na : na + 1;
-    S.slam_ws_stride = M * 30 + L * 8 + 3 * P + 4 + (lds ? 0 : na * ld + 6 * P);
-    S.slam_iws_stride = L * P + P + 2;
+    const size_t nd = 3 * P + 6;
+    S.slam_ws_stride = M * 12 + (L * P * 2 + 7) / 8 + 16 + (lds ? 0 : nd * nd);
+    S.slam_iws_stride = 2;
     TRY(dev_alloc(e, &S.slam_ws, S.slam_ws_stride * (size_t)S.n_inst));
     TRY(dev_alloc(e, &S.slam_iws, S.slam_iws_stride * (size_t)S.n_inst));
   }
@@ -274,8 +278,6 @@ int drlgx_destroy(drlgx_engine *e) {
   hipSetDevice(e->device);
   hipDeviceSynchronize();
   for (void *p : e->allocs) hipFree(p);
-  for (auto &s : e->snaps)
-    for (char *p : s) hipFree(p);
   for (auto &sp : e->spans) {
     hipEventDestroy(sp.a);
     hipEventDestroy(sp.b);
@@ -383,7 +385,7 @@ int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
   {
     ScopedTimer t(e, 3);
     // deep copy env -> base, SLAM2D::set_copy_isam (re-base at the best estimate + one batch update)
-    drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr, 0, base0, 1);
+    drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr, 0, base0, 3);
     drlgx_launch_rebase(S, e->stream, base0, S.n_envs);
   }
   {
@@ -392,7 +394,7 @@ int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
   }
   {
     ScopedTimer t(e, 3);
-    drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, n_cand, cand_env_dev, nullptr, base0, roll0, 1);
+    drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, n_cand, cand_env_dev, nullptr, base0, roll0, 3);
     drlgx_launch_fix_rollouts(S, e->stream, n_cand, cand_env_dev, roll0);
   }
   for (int a = 0; a < S.A_max; ++a) {
@@ -636,32 +638,38 @@ int drlgx_get_landmark_order_host(const drlgx_engine *e, int32_t *order) {
 }
 
 // ---- snapshots ---------------------------------------------------------------------------------
+// Snapshots are extra instances in the same HBM arrays: one copy kernel moves every field.
 int drlgx_snapshot(drlgx_engine *e, int slot) {
-  if (!e || slot < 0 || slot > 64) return DRLGX_E_INVALID;
-  const size_t nf = e->fields.size() + e->env_fields.size();
-  if ((int)e->snaps.size() <= slot) e->snaps.resize(slot + 1);
-  auto &s = e->snaps[slot];
-  if (s.empty()) {
-    s.resize(nf, nullptr);
-    for (size_t f = 0; f < nf; ++f) {
-      const DrlgxField &fd = f < e->fields.size() ? e->fields[f] : e->env_fields[f - e->fields.size()];
-      HIPCHK(e, hipMalloc(reinterpret_cast<void **>(&s[f]), fd.stride * (size_t)e->S.n_envs));
-    }
-  }
-  for (size_t f = 0; f < nf; ++f) {
-    const DrlgxField &fd = f < e->fields.size() ? e->fields[f] : e->env_fields[f - e->fields.size()];
-    HIPCHK(e, hipMemcpyAsync(s[f], fd.base, fd.stride * (size_t)e->S.n_envs, hipMemcpyDeviceToDevice, e->stream));
-  }
-  return DRLGX_OK;
+  if (!e || slot < 0 || slot >= e->S.cfg.max_snapshots) return DRLGX_E_INVALID;
+  const DrlgxState &S = e->S;
+  ScopedTimer t(e, 3);
+  drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr, 0,
+                    2 * S.n_envs + S.n_roll + slot * S.n_envs, 0);
+  return check_launch(e);
 }
 
 int drlgx_restore(drlgx_engine *e, int slot) {
-  if (!e || slot < 0 || slot >= (int)e->snaps.size() || e->snaps[slot].empty()) return DRLGX_E_INVALID;
-  const size_t nf = e->fields.size() + e->env_fields.size();
-  auto &s = e->snaps[slot];
-  for (size_t f = 0; f < nf; ++f) {
-    const DrlgxField &fd = f < e->fields.size() ? e->fields[f] : e->env_fields[f - e->fields.size()];
-    HIPCHK(e, hipMemcpyAsync(fd.base, s[f], fd.stride * (size_t)e->S.n_envs, hipMemcpyDeviceToDevice, e->stream));
+  if (!e || slot < 0 || slot >= e->S.cfg.max_snapshots) return DRLGX_E_INVALID;
+  const DrlgxState &S = e->S;
+  ScopedTimer t(e, 3);
+  drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr,
+                    2 * S.n_envs + S.n_roll + slot * S.n_envs, 0, 0);
+  return check_launch(e);
+}
+
+// ---- development aid: in-kernel phase stamps of block 0 ------------------------------------------
+int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]) {
+  if (!e) return DRLGX_E_INVALID;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (out && e->S.prof) HIPCHK(e, hipMemcpy(out, e->S.prof, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  if (arm && !e->S.prof) {
+    long long *p = nullptr;
+    int r = dev_alloc(e, &p, 64);
+    if (r) return r;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->S.prof = p;
+  } else if (!arm) {
+    e->S.prof = nullptr;
   }
   return DRLGX_OK;
 }

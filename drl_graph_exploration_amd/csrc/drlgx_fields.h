@@ -5,6 +5,6 @@
 struct DrlgxField {
   char *base;
   size_t stride;  // bytes per instance (multiple of 4)
-  int is_vm;      // virtual-map arrays are rebuilt by every step and not copied into rollouts
+  int cls;        // 0 = belief/simulator state, 1 = virtual-map planes (rebuilt every step), 2 = ground-truth landmarks
   int pad;
 };

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
   uint8_t *upd = S.vm_upd + (size_t)inst * S.Vu;
   double *vtr = S.vm_tr + (size_t)inst * V;
 
+  DRLGX_PROF(S, 16);
   if (rebuild) {
     const double *ep = S.est_pose + (size_t)inst * S.P_max * 4;
     const double *pin = S.pose_info + (size_t)inst * S.P_max * 6;
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
       atomicMax(&bbox[4 * p + 3], col);
     }
     __syncthreads();
+    DRLGX_PROF(S, 17);
     // ---- phase O: occupancy ladder per cell, poses in trajectory order ----
     const double i0 = 1.0 / pow(cfg.sigma0, 2);
     for (int v = tid; v < V; v += kThreads) {
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
       upd[v] = 0;
     }
     __syncthreads();
+    DRLGX_PROF(S, 18);
     // ---- phases A/B: covariance propagation, kChunk poses at a time ----
     for (int c0 = 0; c0 < P; c0 += kChunk) {
       const int nc = min(kChunk, P - c0);
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
         o[0] = oxx; o[1] = oxy; o[2] = oyy;
       }
       __syncthreads();
+      if (c0 == 0) DRLGX_PROF(S, 21);
       for (int v = tid; v < V; v += kThreads) {
         const int row = v / cols, col = v - row * cols;
         double axx = ixx[v], axy = ixy[v], ayy = iyy[v];
@@ -251,6 +255,7 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
       __syncthreads();
     }
   }
+  DRLGX_PROF(S, 19);
   // ---- phase R: reductions (Planner2D.cpp:321-366, VirtualMap.cpp:47-59) ----
   double utr = 0, known = 0, expl = 0, udet = 0, uwtr = 0;
   const int extg = 20;
@@ -276,6 +281,7 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
   expl = block_sum(expl, scratch, tid);
   udet = block_sum(udet, scratch, tid);
   uwtr = block_sum(uwtr, scratch, tid);
+  DRLGX_PROF(S, 20);
   if (tid == 0) {
     double *red = S.red + (size_t)inst * DRLGX_RED_STRIDE;
     red[R_UTR] = utr;

@@ -9,14 +9,24 @@ namespace {
 
 // copy every non-virtual-map field of instance src[i] to dst[i]
 __global__ __launch_bounds__(256) void k_copy_instances(const DrlgxField *fields, int n_fields, const int32_t *src,
-                                                        const int32_t *dst, int src_off, int dst_off, int skip_vm) {
-  const int i = blockIdx.x;
+                                                        const int32_t *dst, int src_off, int dst_off, int skip_mask) {
+  // grid = (instances, fields): every (instance, field) slice is streamed by its own workgroup with
+  // 16-byte accesses when the slice is 16-byte aligned (all large fields are)
+  const int i = blockIdx.x, f = blockIdx.y;
+  if (f >= n_fields || (fields[f].cls & skip_mask)) return;
   const int s = (src ? src[i] : i) + src_off, d = (dst ? dst[i] : i) + dst_off;
-  for (int f = 0; f < n_fields; ++f) {
-    if (skip_vm && fields[f].is_vm) continue;
-    const uint32_t *sp = reinterpret_cast<const uint32_t *>(fields[f].base + (size_t)s * fields[f].stride);
-    uint32_t *dp = reinterpret_cast<uint32_t *>(fields[f].base + (size_t)d * fields[f].stride);
-    const size_t nw = fields[f].stride / 4;
+  const size_t stride = fields[f].stride;
+  const char *sb = fields[f].base + (size_t)s * stride;
+  char *db = fields[f].base + (size_t)d * stride;
+  if ((stride & 15) == 0) {
+    const uint4 *sp = reinterpret_cast<const uint4 *>(sb);
+    uint4 *dp = reinterpret_cast<uint4 *>(db);
+    const size_t nq = stride / 16;
+    for (size_t k = threadIdx.x; k < nq; k += 256) dp[k] = sp[k];
+  } else {
+    const uint32_t *sp = reinterpret_cast<const uint32_t *>(sb);
+    uint32_t *dp = reinterpret_cast<uint32_t *>(db);
+    const size_t nw = stride / 4;
     for (size_t k = threadIdx.x; k < nw; k += 256) dp[k] = sp[k];
   }
 }
@@ -147,9 +157,9 @@ __global__ void k_line_plan(DrlgxState S, int n_cand, const int32_t *cand_env, c
 }  // namespace
 
 void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
-                       const int32_t *dst, int src_off, int dst_off, int skip_vm) {
-  hipLaunchKernelGGL(k_copy_instances, dim3(n), dim3(256), 0, st, fields_dev, n_fields, src, dst, src_off, dst_off,
-                     skip_vm);
+                       const int32_t *dst, int src_off, int dst_off, int skip_mask) {
+  hipLaunchKernelGGL(k_copy_instances, dim3(n, n_fields), dim3(256), 0, st, fields_dev, n_fields, src, dst, src_off,
+                     dst_off, skip_mask);
 }
 void drlgx_launch_rebase(const DrlgxState &S, hipStream_t st, int base0, int n) {
   hipLaunchKernelGGL(k_rebase, dim3(n), dim3(64), 0, st, S, base0, n);

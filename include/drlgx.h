@@ -63,6 +63,7 @@ typedef struct drlgx_config {
   int32_t max_landmarks; /* L_max observed landmarks per instance */
   int32_t max_factors;   /* M_max bearing-range factors per instance */
   int32_t max_actions;   /* A_max actions per look-ahead candidate */
+  int32_t max_snapshots; /* device-resident snapshot slots of the live environments (0..16) */
 } drlgx_config;
 
 typedef struct drlgx_engine drlgx_engine;
@@ -181,6 +182,10 @@ int drlgx_restore(drlgx_engine *e, int slot);
 #define DRLGX_N_TIMERS 8
 int drlgx_timing_enable(drlgx_engine *e, int on);
 int drlgx_timing_read_host(drlgx_engine *e, double ms[DRLGX_N_TIMERS], int64_t launches[DRLGX_N_TIMERS]);
+
+/* Development aid: arm (1) / disarm (0) in-kernel phase stamps (wall_clock64, 100 MHz) written by block 0
+ * of k_slam (slots 0-10) and k_map (slots 16-22); out (may be NULL) receives the last stamps. */
+int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]);
 
 /* ---- GCN policy (scripts/Networks.py:12-70 over PyG GCNConv(improved=True)) ------------------- */
 

@@ -1,0 +1,31 @@
+"""Dev tool: in-kernel phase breakdown (block 0) of k_slam / k_map at the bench workload."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+eng, cfg = bench.make_engine(0, 0)
+odom = torch.tensor([bench.STEP_ACTION] * bench.N_ENVS, dtype=torch.float64, device=eng.device)
+out = (C.c_int64 * 64)()
+eng.L.drlgx_debug_phase_clocks_host(eng.h, 1, None)
+acc = np.zeros(64); n = 0
+for it in range(20):
+    eng.restore(0); eng.step(odom)
+    eng.L.drlgx_debug_phase_clocks_host(eng.h, 1, out)
+    a = np.array(out[:], dtype=np.float64)
+    if it >= 5:
+        acc += a; n += 1
+a = acc / n
+names = {0:"start",1:"relin+clear+tables",2:"landmark+pose blocks",3:"G",4:"Schur",5:"sweeps",6:"landmark partials",7:"outputs"}
+print("k_slam phases (us, block 0):")
+for k in range(1, 8): print("  %-24s %8.2f" % (names[k], (a[k]-a[k-1]) / 100.0))
+print("  total %.2f" % ((a[7]-a[0]) / 100.0))
+mn = {17:"load+bbox sweep",18:"occupancy",21:"phase A (chunk 0)",19:"phase B + rest",20:"reductions"}
+print("k_map phases (us, block 0):")
+prev = a[16]
+for k in (17, 18, 21, 19, 20):
+    print("  %-24s %8.2f" % (mn[k], (a[k]-prev) / 100.0)); prev = a[k]
+print("  total %.2f" % ((a[20]-a[16]) / 100.0))
+eng.timing_enable(True); eng.timing_read()
+for it in range(50):
+    eng.restore(0); eng.step(odom)
+print(eng.timing_read())

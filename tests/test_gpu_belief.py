@@ -21,7 +21,7 @@ SCRIPT = [(1, 1, math.pi / 2)] * 4 + [(0, 0, 0.7), (2, 0, 0), (2, 0, 0), (1.3, 0
                                       (0.4, 0, 0), (0, 0, 2.9), (2, 0, 0), (2, 0, 0), (2, 0, 0), (0, 0, -0.3), (2, 0, 0)]
 
 
-def make_engine(n_envs, n_roll=0, num_landmarks=None, max_poses=45):
+def make_engine(n_envs, n_roll=0, num_landmarks=None, max_poses=41):
     from drl_graph_exploration_amd import default_config
     from drl_graph_exploration_amd.engine import Engine
     cfg = default_config(MAP, num_landmarks=num_landmarks, max_poses=max_poses)
@@ -244,4 +244,24 @@ def test_many_landmarks_64_node_graphs():
     assert eng.status() == 0
     c = eng.counts(0)
     assert c["poses"] + c["landmarks"] >= 32 and c["factors"] >= 60
+    eng.close()
+
+
+@pytest.mark.parametrize("max_poses", [43, 60, 86])
+def test_larger_capacities_use_other_kernel_variants(max_poses):
+    """Capacities beyond 43 poses move the dense system of k_slam from LDS to the HBM/L2 workspace (one register
+    tile per thread up to 60 poses, two up to 86): same results."""
+    n = 3
+    eng, cfg = make_engine(n, max_poses=max_poses)
+    ocfg = O.default_config(MAP)
+    starts = generic_starts(n)
+    sims = [O.OracleSim(ocfg, lo, lo, start=tuple(starts[lo])) for lo in range(n)]
+    eng.reset(np.arange(n), np.arange(n), starts=starts)
+    for s, act in enumerate(SCRIPT[:12]):
+        eng.step(torch.tensor([act] * n, dtype=torch.float64, device=eng.device))
+        for sim in sims:
+            sim.simulate(act)
+    assert eng.status() == 0
+    for i in range(n):
+        compare_state(eng, i, sims[i], "hbm-ws env %d" % i)
     eng.close()
