@@ -30,6 +30,12 @@ struct DrlgxState {
   int win;  // (win x win) candidate window of cells around a pose = ceil(2*max_range/res)+1
   int count_explored;
   double lo_free, lo_occ, lo_min, lo_max, occ_thresh;  // log-odds constants computed on the HOST (bit-exact ladder)
+  int bbox_noop;   // 1: the sector-sweep bounding box provably contains every in-range cell (full-circle FOV)
+  int fov_fast;    // 1: cells with d.x >= 0 or |d.y| > fov_tan |d.x| are provably inside the field of view
+  double fov_tan;  // tan(blind half-angle + 1 mrad)
+  // exact squared-distance thresholds (host-computed for IEEE sqrt):
+  //   sqrt(x) < max_range  <=>  x < r2_max_lt ;   sqrt(x) > min_range  <=>  x > r2_min_gt
+  double r2_max_lt, r2_min_gt;
   int n_sweep;                                         // bbox sweep table length
   const double *sweep_b;                               // [n_sweep] b values of OccupancyMap.cpp:86
   const int *lm_order;                                 // [LG] libstdc++ unordered_map iteration order of GT keys

@@ -195,6 +195,31 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   std::vector<double> sweep;
   for (double b = cfg->min_bearing; b < cfg->max_bearing + 1e-5; b += 3 * 0.01745329251994329575) sweep.push_back(b);
   S.n_sweep = (int)sweep.size();
+  {
+    // The bbox only prunes work if an in-range cell can fall outside it.  A cell centre within max_range of the
+    // pose lies at most (max_range - res/2) past the pose's own cell boundary, so the box contains it as soon as
+    // some sweep sample is within acos(1 - res / (2 max_range)) of each axis direction (k_map).
+    const double two_pi = 6.283185307179586476925286766559;
+    double max_gap = 3 * 0.01745329251994329575;
+    if (!sweep.empty()) max_gap = std::max(max_gap, two_pi - (sweep.back() - sweep.front()));
+    const double need = std::acos(std::max(-1.0, 1.0 - cfg->resolution / (2.0 * cfg->max_range)));
+    S.bbox_noop = (0.5 * max_gap + 1e-6 <= need) ? 1 : 0;
+    // field of view: blind half-angle around the backwards ray
+    const double pi = 3.14159265358979323846;
+    const double blind = std::max(pi - cfg->max_bearing, pi + cfg->min_bearing);
+    S.fov_fast = (cfg->max_bearing > 1.7 && cfg->min_bearing < -1.7 && blind >= 0 && blind + 1e-3 < 1.4) ? 1 : 0;
+    S.fov_tan = S.fov_fast ? std::tan(blind + 1e-3) : 0.0;
+    // smallest x with sqrt(x) >= max_range, largest x with sqrt(x) <= min_range (sqrt is correctly rounded
+    // and monotone on both host and device, so the squared comparisons are EXACTLY the reference's tests)
+    double t = cfg->max_range * cfg->max_range;
+    while (std::sqrt(std::nextafter(t, 0.0)) >= cfg->max_range) t = std::nextafter(t, 0.0);
+    while (std::sqrt(t) < cfg->max_range) t = std::nextafter(t, INFINITY);
+    S.r2_max_lt = t;
+    t = cfg->min_range * cfg->min_range;
+    while (std::sqrt(std::nextafter(t, INFINITY)) <= cfg->min_range) t = std::nextafter(t, INFINITY);
+    while (t > 0 && std::sqrt(t) > cfg->min_range) t = std::nextafter(t, 0.0);
+    S.r2_min_gt = t;
+  }
   // libstdc++ iteration order of unordered_map<unsigned, ...> filled with keys 0..n-1 (Simulator2D.cpp:331-344)
   {
     std::unordered_map<unsigned, int> m;

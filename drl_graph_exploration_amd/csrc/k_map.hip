@@ -1,6 +1,6 @@
 // Virtual-map kernel: occupancy rebuild + covariance propagation (EKF push-through of every core
 // pose onto the virtual-landmark grid, fused by covariance intersection) + utility reductions.
-// One 256-thread workgroup per instance.
+// One 1024-thread workgroup (16 waves) per instance.
 //
 // Reference: src/em_exploration/OccupancyMap.cpp:55-138 (log-odds ladder, bbox sector sweep),
 // src/em_exploration/VirtualMap.cpp:47-84 (explored, updateProbability), :213-229
@@ -14,24 +14,67 @@
 //            is staged in LDS.
 //   phase B: cell-centric covariance-intersection fusion in trajectory order from the LDS stage.
 //   phase R: trace / determinant / known / explored reductions (wave shuffles + LDS).
+// fp64 transcendentals are the expensive instructions here, so two exact shortcuts are taken:
+//   * the field-of-view test needs atan2 only inside a thin wedge around the sensor's blind ray; cells
+//     that are provably inside the FOV (d.x >= 0, or |d.y| > tan(blind half-angle + 1 mrad) |d.x|) skip it;
+//   * when the 3-degree sector sweep covers the whole circle its bounding box provably contains every
+//     in-range cell, so the sweep (120 sincos per pose) and the box tests are skipped.
 // Compiled with -ffp-contract=off (thresholded decisions must round like the CPU reference).
 #include "drlgx_dev.h"
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
 constexpr int kChunk = 32;  // poses per LDS stage
 
 __device__ __forceinline__ double logodds2prob(double l) { return exp(l) / (1.0 + exp(l)); }
 
+// BearingRangeSensorModel::check / checkWithoutMinRange on the bearing only (Simulator2D.cpp:100-111)
+__device__ __forceinline__ bool in_fov(const DrlgxState &S, const Pose &ps, const P2 &pt) {
+  const drlgx_config &cfg = S.cfg;
+  if (S.fov_fast) {
+    const P2 d = transform_to(ps, pt);
+    if (d.x >= 0.0 || fabs(d.y) > S.fov_tan * fabs(d.x)) return true;  // provably inside: no atan2 needed
+  }
+  const double bearing = bearing_of<false>(ps, pt, nullptr, nullptr);
+  return bearing < cfg.max_bearing && bearing > cfg.min_bearing;
+}
+
 // VirtualMap::predictVirtualLandmark (VirtualMap.cpp:213-229). info: symmetric xx xy xt yy yt tt.
-__device__ __forceinline__ bool predict_cell(const Pose &ps, const double *pi, const P2 &pt, const drlgx_config &cfg,
+__device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps, const double *pi, const P2 &pt,
                                              double &oxx, double &oxy, double &oyy) {
+  const drlgx_config &cfg = S.cfg;
+  // Jacobians of bearing (Pose2::bearing) and range (Pose2::range); the bearing VALUE is only needed for the
+  // FOV check, which in_fov() answers without atan2 for almost every cell
+  const P2 d = transform_to(ps, pt);
+  const double d2 = d.x * d.x + d.y * d.y, n = sqrt(d2);
+  const double gx = pt.x - ps.x, gy = pt.y - ps.y;
+  const double g2 = gx * gx + gy * gy;
+  // range < max_range && range > min_range, decided exactly on the squared distance (host-computed thresholds)
+  if (!(g2 < S.r2_max_lt && g2 > S.r2_min_gt)) return false;
+  if (!in_fov(S, ps, pt)) return false;
+  const double range = sqrt(g2);
   double Hbx[3], Hbl[2], Hrx[3], Hrl[2];
-  double bearing = bearing_of<true>(ps, pt, Hbx, Hbl);
-  double range = range_of<true>(ps, pt, Hrx, Hrl);
-  if (!(bearing < cfg.max_bearing && bearing > cfg.min_bearing && range < cfg.max_range && range > cfg.min_range))
-    return false;
+  if (fabs(n) > 1e-5) {
+    const double a = -d.y / d2, b = d.x / d2;
+    Hbx[0] = a * -1.0;
+    Hbx[1] = b * -1.0;
+    Hbx[2] = a * d.y + b * -d.x;
+    Hbl[0] = a * ps.c + b * -ps.s;
+    Hbl[1] = a * ps.s + b * ps.c;
+  } else {
+    Hbx[0] = Hbx[1] = Hbx[2] = 0;
+    Hbl[0] = Hbl[1] = 0;
+  }
+  {
+    const double ux = gx / range, uy = gy / range;
+    Hrx[0] = ux * -ps.c + uy * -ps.s;
+    Hrx[1] = ux * ps.s + uy * -ps.c;
+    Hrx[2] = 0;
+    Hrl[0] = ux;
+    Hrl[1] = uy;
+  }
   const double R0 = cfg.bearing_noise * cfg.bearing_noise, R3 = cfg.range_noise * cfg.range_noise;
   const double Hl0 = Hbl[0], Hl1 = Hbl[1], Hl2 = Hrl[0], Hl3 = Hrl[1];
   // (Hl^T Hl)^-1 Hl^T  (Eigen fixed 2x2 inverse = adjugate / det)
@@ -41,11 +84,16 @@ __device__ __forceinline__ bool predict_cell(const Pose &ps, const double *pi, c
   const double i00 = h11 * id, i01 = -h01 * id, i10 = -h10 * id, i11 = h00 * id;
   const double p00 = i00 * Hl0 + i01 * Hl1, p01 = i00 * Hl2 + i01 * Hl3;
   const double p10 = i10 * Hl0 + i11 * Hl1, p11 = i10 * Hl2 + i11 * Hl3;
-  // S = R + Hx * info.llt().solve(Hx^T)
-  LLT3 llt(pi[0], pi[1], pi[2], pi[3], pi[4], pi[5]);
+  // S = R + Hx * info.llt().solve(Hx^T); the LLT factor of the pose information (and the reciprocals of its
+  // diagonal) was computed once per pose: pi = l00 l10 l11 l20 l21 l22 r00 r11 r22
   double xb0, xb1, xb2, xr0, xr1, xr2;
-  llt.solve(Hbx[0], Hbx[1], Hbx[2], xb0, xb1, xb2);
-  llt.solve(Hrx[0], Hrx[1], Hrx[2], xr0, xr1, xr2);
+  {
+    const double l10 = pi[1], l20 = pi[3], l21 = pi[4], r00 = pi[6], r11 = pi[7], r22 = pi[8];
+    double y0 = Hbx[0] * r00, y1 = (Hbx[1] - l10 * y0) * r11, y2 = (Hbx[2] - l20 * y0 - l21 * y1) * r22;
+    xb2 = y2 * r22; xb1 = (y1 - l21 * xb2) * r11; xb0 = (y0 - l10 * xb1 - l20 * xb2) * r00;
+    y0 = Hrx[0] * r00; y1 = (Hrx[1] - l10 * y0) * r11; y2 = (Hrx[2] - l20 * y0 - l21 * y1) * r22;
+    xr2 = y2 * r22; xr1 = (y1 - l21 * xr2) * r11; xr0 = (y0 - l10 * xr1 - l20 * xr2) * r00;
+  }
   double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
   s00 += Hbx[0] * xb0; s00 += Hbx[1] * xb1; s00 += Hbx[2] * xb2;
   s01 += Hbx[0] * xr0; s01 += Hbx[1] * xr1; s01 += Hbx[2] * xr2;
@@ -62,20 +110,23 @@ __device__ __forceinline__ bool predict_cell(const Pose &ps, const double *pi, c
   return true;
 }
 
-// VirtualMap::covarianceIntersection2D (VirtualMap.cpp:364-378), symmetric storage
+// VirtualMap::covarianceIntersection2D (VirtualMap.cpp:364-378), symmetric storage.  The LLT solve is
+// written with two reciprocals instead of eight divisions (fp64 division is ~30 instructions here).
 __device__ __forceinline__ void ci_fuse(double &axx, double &axy, double &ayy, double bxx, double bxy, double byy) {
   const double a = axx * ayy - axy * axy;
   const double b = bxx * byy - bxy * bxy;
   // m1.llt().solve(m2).trace()
-  const double l00 = sqrt(axx), l10 = axy / l00, l11 = sqrt(ayy - l10 * l10);
+  const double l00 = sqrt(axx), r00 = 1.0 / l00;
+  const double l10 = axy * r00;
+  const double l11 = sqrt(ayy - l10 * l10), r11 = 1.0 / l11;
   double tr = 0;
   {
-    double y0 = bxx / l00, y1 = (bxy - l10 * y0) / l11;
-    double x1 = y1 / l11, x0 = (y0 - l10 * x1) / l00;
+    double y0 = bxx * r00, y1 = (bxy - l10 * y0) * r11;
+    double x1 = y1 * r11, x0 = (y0 - l10 * x1) * r00;
     tr += x0;
-    y0 = bxy / l00;
-    y1 = (byy - l10 * y0) / l11;
-    x1 = y1 / l11;
+    y0 = bxy * r00;
+    y1 = (byy - l10 * y0) * r11;
+    x1 = y1 * r11;
     tr += x1;
   }
   const double c = a * tr;
@@ -95,7 +146,8 @@ __device__ __forceinline__ double block_sum(double v, double *scratch, int tid) 
   __syncthreads();
   if ((tid & 63) == 0) scratch[tid >> 6] = v;
   __syncthreads();
-  double s = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+  double s = 0;
+  for (int w = 0; w < kWaves; ++w) s += scratch[w];
   return s;
 }
 
@@ -113,9 +165,10 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
   // LDS carve
   double *sp = smem;                       // [P_max][4]
   double *si = sp + (size_t)S.P_max * 4;   // [P_max][6]
-  double *stage = si + (size_t)S.P_max * 6;  // [kChunk][64][3]
-  double *scratch = stage + (size_t)kChunk * 64 * 3;  // [8]
-  int *bbox = reinterpret_cast<int *>(scratch + 8);   // [P_max][4] min_row max_row min_col max_col
+  double *sl = si + (size_t)S.P_max * 6;   // [P_max][9] LLT factor of the pose information + reciprocals
+  double *stage = sl + (size_t)S.P_max * 9;  // [kChunk][64][3]
+  double *scratch = stage + (size_t)kChunk * 64 * 3;  // [kWaves]
+  int *bbox = reinterpret_cast<int *>(scratch + kWaves);  // [P_max][4] min_row max_row min_col max_col
   int *worg = bbox + (size_t)S.P_max * 4;             // [P_max][2] window origin row, col
   int *pskip = worg + (size_t)S.P_max * 2;            // [P_max]
   int *lmcell = pskip + S.P_max;                      // [L_max]
@@ -152,25 +205,33 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
       worg[2 * p + 1] = (int)floor((x - cfg.max_range - cfg.map_min_x) / cfg.resolution - 0.5);
       const double *pi = si + 6 * p;
       pskip[p] = det3s(pi[0], pi[1], pi[2], pi[3], pi[4], pi[5]) < 1e-10 ? 1 : 0;  // VirtualMap.cpp:293-294
+      // state.information.llt(): factor once per pose, keep reciprocals of the diagonal
+      const LLT3 f(pi[0], pi[1], pi[2], pi[3], pi[4], pi[5]);
+      double *o = sl + 9 * p;
+      o[0] = f.l00; o[1] = f.l10; o[2] = f.l11; o[3] = f.l20; o[4] = f.l21; o[5] = f.l22;
+      o[6] = 1.0 / f.l00; o[7] = 1.0 / f.l11; o[8] = 1.0 / f.l22;
     }
     __syncthreads();
-    // bbox of the 3-degree sector sweep (OccupancyMap.cpp:79-96): (pose, sample) pairs in parallel
-    for (int e = tid; e < P * S.n_sweep; e += kThreads) {
-      const int p = e / S.n_sweep, k = e - p * S.n_sweep;
-      const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
-      const double th0 = theta_of(ps), b = S.sweep_b[k];
-      const double x = ps.x + cfg.max_range * cos(th0 + b);
-      const double y = ps.y + cfg.max_range * sin(th0 + b);
-      int row = (int)floor((y - cfg.map_min_y) / cfg.resolution);
-      int col = (int)floor((x - cfg.map_min_x) / cfg.resolution);
-      row = min(max(0, row), rows - 1);
-      col = min(max(0, col), cols - 1);
-      atomicMin(&bbox[4 * p + 0], row);
-      atomicMax(&bbox[4 * p + 1], row);
-      atomicMin(&bbox[4 * p + 2], col);
-      atomicMax(&bbox[4 * p + 3], col);
+    const bool use_bbox = !S.bbox_noop;
+    if (use_bbox) {
+      // bbox of the 3-degree sector sweep (OccupancyMap.cpp:79-96): (pose, sample) pairs in parallel
+      for (int e = tid; e < P * S.n_sweep; e += kThreads) {
+        const int p = e / S.n_sweep, k = e - p * S.n_sweep;
+        const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
+        const double th0 = theta_of(ps), b = S.sweep_b[k];
+        const double x = ps.x + cfg.max_range * cos(th0 + b);
+        const double y = ps.y + cfg.max_range * sin(th0 + b);
+        int row = (int)floor((y - cfg.map_min_y) / cfg.resolution);
+        int col = (int)floor((x - cfg.map_min_x) / cfg.resolution);
+        row = min(max(0, row), rows - 1);
+        col = min(max(0, col), cols - 1);
+        atomicMin(&bbox[4 * p + 0], row);
+        atomicMax(&bbox[4 * p + 1], row);
+        atomicMin(&bbox[4 * p + 2], col);
+        atomicMax(&bbox[4 * p + 3], col);
+      }
+      __syncthreads();
     }
-    __syncthreads();
     DRLGX_PROF(S, 17);
     // ---- phase O: occupancy ladder per cell, poses in trajectory order ----
     const double i0 = 1.0 / pow(cfg.sigma0, 2);
@@ -181,13 +242,14 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
         if (lmcell[j] == v) l = fmin(S.lo_max, fmax(S.lo_min, l + S.lo_occ));
       const P2 pt{cfg.map_min_x + cfg.resolution * (col + 0.5), cfg.map_min_y + cfg.resolution * (row + 0.5)};
       for (int p = 0; p < P; ++p) {
-        if (row < bbox[4 * p] || row > bbox[4 * p + 1] || col < bbox[4 * p + 2] || col > bbox[4 * p + 3]) continue;
+        if (use_bbox && (row < bbox[4 * p] || row > bbox[4 * p + 1] || col < bbox[4 * p + 2] || col > bbox[4 * p + 3]))
+          continue;
         if (fabs(l - S.lo_min) < 1e-5) continue;
+        // sqrt(d2) < max_range  <=>  d2 < r2_max_lt (exact: threshold precomputed on the host for IEEE sqrt)
+        const double gx = pt.x - sp[4 * p], gy = pt.y - sp[4 * p + 1];
+        if (!(gx * gx + gy * gy < S.r2_max_lt)) continue;
         const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
-        const double range = range_of<false>(ps, pt, nullptr, nullptr);
-        if (!(range < cfg.max_range)) continue;
-        const double bearing = bearing_of<false>(ps, pt, nullptr, nullptr);
-        if (!(bearing < cfg.max_bearing && bearing > cfg.min_bearing)) continue;
+        if (!in_fov(S, ps, pt)) continue;
         const double add = (l > S.occ_thresh + 1e-8) ? S.lo_occ : S.lo_free;
         l = fmin(S.lo_max, fmax(S.lo_min, l + add));
       }
@@ -204,7 +266,7 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
     // ---- phases A/B: covariance propagation, kChunk poses at a time ----
     for (int c0 = 0; c0 < P; c0 += kChunk) {
       const int nc = min(kChunk, P - c0);
-      for (int pl = wave; pl < nc; pl += kThreads / 64) {
+      for (int pl = wave; pl < nc; pl += kWaves) {
         const int p = c0 + pl;
         double oxx = __longlong_as_double(0x7ff8000000000000LL), oxy = 0, oyy = 0;  // NaN = "no update"
         if (lane < W2 && !pskip[p]) {
@@ -214,9 +276,9 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
             const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
             const P2 pt{(col + 0.5) * cfg.resolution + cfg.map_min_x, (row + 0.5) * cfg.resolution + cfg.map_min_y};
             const double dx = ps.x - pt.x, dy = ps.y - pt.y;
-            if (sqrt(dx * dx + dy * dy) < cfg.max_range) {  // KDTreeR2::queryRadiusNeighbors
+            if (dx * dx + dy * dy < S.r2_max_lt) {  // KDTreeR2::queryRadiusNeighbors: sqrt(d2) < max_range, exactly
               double a, b, d;
-              if (predict_cell(ps, si + 6 * p, pt, cfg, a, b, d)) {
+              if (predict_cell(S, ps, sl + 9 * p, pt, a, b, d)) {
                 oxx = a; oxy = b; oyy = d;
               }
             }
@@ -255,8 +317,8 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
       __syncthreads();
     }
   }
-  DRLGX_PROF(S, 19);
   // ---- phase R: reductions (Planner2D.cpp:321-366, VirtualMap.cpp:47-59) ----
+  DRLGX_PROF(S, 19);
   double utr = 0, known = 0, expl = 0, udet = 0, uwtr = 0;
   const int extg = 20;
   for (int v = tid; v < V; v += kThreads) {
@@ -276,11 +338,24 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
         y <= cfg.map_max_y - extg)
       expl += 1.0;
   }
-  utr = block_sum(utr, scratch, tid);
-  known = block_sum(known, scratch, tid);
-  expl = block_sum(expl, scratch, tid);
-  udet = block_sum(udet, scratch, tid);
-  uwtr = block_sum(uwtr, scratch, tid);
+  {
+    double r5[5] = {utr, known, expl, udet, uwtr};
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+      for (int o = 32; o > 0; o >>= 1) r5[k] += __shfl_down(r5[k], o);
+    __syncthreads();  // stage[] is free again
+    if ((tid & 63) == 0)
+      for (int k = 0; k < 5; ++k) stage[k * kWaves + (tid >> 6)] = r5[k];
+    __syncthreads();
+    if (tid < 5) {
+      double acc = 0;
+      for (int w = 0; w < kWaves; ++w) acc += stage[tid * kWaves + w];
+      stage[5 * kWaves + tid] = acc;
+    }
+    __syncthreads();
+    utr = stage[5 * kWaves + 0]; known = stage[5 * kWaves + 1]; expl = stage[5 * kWaves + 2];
+    udet = stage[5 * kWaves + 3]; uwtr = stage[5 * kWaves + 4];
+  }
   DRLGX_PROF(S, 20);
   if (tid == 0) {
     double *red = S.red + (size_t)inst * DRLGX_RED_STRIDE;
@@ -295,13 +370,13 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
 }  // namespace
 
 static size_t map_lds_bytes(const DrlgxState &S) {
-  size_t d = (size_t)S.P_max * 10 + (size_t)kChunk * 64 * 3 + 8;
+  size_t d = (size_t)S.P_max * 19 + (size_t)kChunk * 64 * 3 + kWaves;
   size_t i = (size_t)S.P_max * 7 + S.L_max;
   return d * sizeof(double) + i * sizeof(int) + 16;
 }
 
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
-  // sel.act_idx < 0 encodes "reductions only" (used after reset)
+  // sel.act_idx == -2 encodes "reductions only" (used after reset)
   int rebuild = 1;
   if (sel.act_idx == -2) {
     rebuild = 0;

@@ -265,3 +265,31 @@ def test_larger_capacities_use_other_kernel_variants(max_poses):
     for i in range(n):
         compare_state(eng, i, sims[i], "hbm-ws env %d" % i)
     eng.close()
+
+
+@pytest.mark.parametrize("fov_deg,max_range,num_lm", [(60.0, 6.0, 40), (110.0, 4.5, 40)])
+def test_narrow_field_of_view_uses_exact_paths(fov_deg, max_range, num_lm):
+    """With a narrow sensor the sector-sweep bounding box and the atan2 field-of-view test are no longer
+    provably redundant: k_map must take the exact paths (and a different cell window) and still agree."""
+    from drl_graph_exploration_amd import default_config
+    from drl_graph_exploration_amd.engine import Engine
+    n = 4
+    cfg = default_config(MAP, num_landmarks=num_lm)
+    ocfg = O.default_config(MAP, num_landmarks=num_lm)
+    for c in (cfg, ocfg):
+        c.min_bearing = -math.radians(fov_deg)
+        c.max_bearing = math.radians(fov_deg)
+        c.max_range = max_range
+    eng = Engine(cfg, n, 0)
+    starts = generic_starts(n)
+    sims = [O.OracleSim(ocfg, lo, lo, start=tuple(starts[lo])) for lo in range(n)]
+    eng.reset(np.arange(n), np.arange(n), starts=starts)
+    for s, act in enumerate(SCRIPT):
+        eng.step(torch.tensor([act] * n, dtype=torch.float64, device=eng.device))
+        for sim in sims:
+            sim.simulate(act)
+        if s % 4 == 3:
+            for i in range(n):
+                compare_state(eng, i, sims[i], "fov %g step %d env %d" % (fov_deg, s, i))
+    assert eng.status() == 0
+    eng.close()
