@@ -41,6 +41,8 @@ struct drlgx_engine {
   uint32_t *stage_u32 = nullptr;
   double *stage_f64 = nullptr;
   uint8_t *stage_mask = nullptr;
+  int *graph_gi = nullptr;
+  int graph_gi_stride = 0;
   // timing
   bool timing = false;
   std::vector<TimedSpan> spans;
@@ -289,6 +291,8 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   TRY(dev_alloc(e, &e->stage_u32, (size_t)n_envs));
   TRY(dev_alloc(e, &e->stage_f64, (size_t)n_envs * 3));
   TRY(dev_alloc(e, &e->stage_mask, (size_t)n_envs));
+  e->graph_gi_stride = 4 * S.L_max + 8;
+  TRY(dev_alloc(e, &e->graph_gi, (size_t)n_envs * e->graph_gi_stride));
 #undef TRY
   if (hipStreamSynchronize(e->stream) != hipSuccess) {
     drlgx_destroy(e);
@@ -438,6 +442,27 @@ int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
     }
   }
   drlgx_launch_rewards(S, e->stream, n_cand, cand_env_dev, roll0, rewards_dev);
+  return check_launch(e);
+}
+
+// ---- graph export ------------------------------------------------------------------------------
+int drlgx_graph_capacity(const drlgx_engine *e, int *max_nodes, int *max_edges, int *max_frontier) {
+  if (!e) return DRLGX_E_INVALID;
+  const DrlgxState &S = e->S;
+  if (max_nodes) *max_nodes = S.n_envs * (2 * S.L_max + S.P_max + 1);
+  if (max_edges) *max_edges = S.n_envs * 2 * (S.M_max + S.P_max + S.L_max + 1);
+  if (max_frontier) *max_frontier = S.L_max + 1;
+  return DRLGX_OK;
+}
+
+int drlgx_graph(drlgx_engine *e, int32_t *node_off_dev, int32_t *edge_off_dev, float *x_dev, int64_t *edge_index_dev,
+                float *edge_attr_dev, int32_t *n_frontier_dev, double *frontier_xy_dev, int32_t *nearest_frontier_node_dev) {
+  if (!e || !node_off_dev || !edge_off_dev || !x_dev || !edge_index_dev || !edge_attr_dev || !n_frontier_dev ||
+      !frontier_xy_dev || !nearest_frontier_node_dev)
+    return DRLGX_E_INVALID;
+  ScopedTimer t(e, 4);
+  drlgx_launch_graph(e->S, e->stream, e->graph_gi, e->graph_gi_stride, node_off_dev, edge_off_dev, x_dev, edge_index_dev,
+                     edge_attr_dev, n_frontier_dev, frontier_xy_dev, nearest_frontier_node_dev, e->S.L_max + 1);
   return check_launch(e);
 }
 

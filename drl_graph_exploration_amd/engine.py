@@ -112,6 +112,33 @@ class Engine(object):
         self._chk(self.L.drlgx_lookahead(self.h, n, _p(cand_env), _p(actions), _p(n_actions), _p(rewards)))
         return rewards
 
+    def graph(self):
+        """Batched ExplorationEnv.graph_matrix + DeepQ.data_process for all envs (one PyG-style batch).
+        Returns a dict of CUDA tensors: x [N,5] f32, edge_index [2,E] i64, edge_attr [E] f32, node_off / edge_off
+        [n_envs+1] i32, batch [N] i64, n_frontier [n_envs] i32, frontier_xy [n_envs,Fmax,2] f64,
+        nearest_frontier_node [n_envs] i32 (local node id)."""
+        if not hasattr(self, "_gcap"):
+            a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+            self._chk(self.L.drlgx_graph_capacity(self.h, C.byref(a), C.byref(b), C.byref(c)))
+            self._gcap = (a.value, b.value, c.value)
+        mn, me, mf = self._gcap
+        dev = self.device
+        node_off = torch.empty(self.n_envs + 1, dtype=torch.int32, device=dev)
+        edge_off = torch.empty(self.n_envs + 1, dtype=torch.int32, device=dev)
+        x = torch.empty(mn, 5, dtype=torch.float32, device=dev)
+        ei = torch.empty(2 * me, dtype=torch.int64, device=dev)
+        ea = torch.empty(me, dtype=torch.float32, device=dev)
+        nfr = torch.empty(self.n_envs, dtype=torch.int32, device=dev)
+        fxy = torch.zeros(self.n_envs, mf, 2, dtype=torch.float64, device=dev)
+        near = torch.empty(self.n_envs, dtype=torch.int32, device=dev)
+        self._chk(self.L.drlgx_graph(self.h, _p(node_off), _p(edge_off), _p(x), _p(ei), _p(ea), _p(nfr), _p(fxy), _p(near)))
+        tot = torch.stack([node_off[-1], edge_off[-1]]).cpu()
+        N, E = int(tot[0]), int(tot[1])
+        counts = (node_off[1:] - node_off[:-1]).to(torch.int64)
+        batch = torch.repeat_interleave(torch.arange(self.n_envs, device=dev), counts)
+        return dict(x=x[:N], edge_index=ei[:2 * E].view(2, E), edge_attr=ea[:E], node_off=node_off, edge_off=edge_off,
+                    batch=batch, n_frontier=nfr, frontier_xy=fxy, nearest_frontier_node=near)
+
     def snapshot(self, slot=0):
         self._chk(self.L.drlgx_snapshot(self.h, slot))
 

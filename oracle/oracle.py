@@ -297,9 +297,10 @@ class OracleSim(object):
 class OracleEnv(object):
     """scripts/envs/exploration_env.py ExplorationEnv restated (TEST seeding only)."""
 
-    def __init__(self, map_size, env_index, num_landmarks=None, algorithm=0):
+    def __init__(self, map_size, env_index, num_landmarks=None, algorithm=0, start=None):
         self.map_size = map_size
         self.env_index = env_index
+        self.start = start  # optional explicit (x, y, theta) instead of the reference's integer start pose
         self.num_landmarks = num_landmarks
         self.algorithm = algorithm
         self.dist = 0.0
@@ -319,7 +320,7 @@ class OracleEnv(object):
         while True:
             seed1 = seed2 = self.env_index
             self.cfg = default_config(self.map_size, self.num_landmarks, self.algorithm)
-            self._sim = OracleSim(self.cfg, seed1, seed2)
+            self._sim = OracleSim(self.cfg, seed1, seed2, start=self.start)
             for _ in range(4):
                 self._sim.simulate((1, 1, math.pi / 2.0))
             if self._sim.num_landmarks() < 1:
