@@ -1,0 +1,192 @@
+"""Policy networks with the reference's API (scripts/Networks.py:12-70) on the HIP GCN kernels.
+
+`GCN`, `PolicyGCN` and `ValueGCN` keep the reference's constructor signature, `forward(data, prob_or_mask,
+batch=None)` and `state_dict` keys/shapes (`conv1.weight [5,1000]` i.e. [in,out] as PyG 1.x stores it,
+`conv1.bias`, `conv2.weight [1000,1000]`, `conv2.bias`, `fully_con1.weight`, `fully_con1.bias`), so the shipped
+`MyModel.pt` files load unchanged (scripts/test.py:38-45, scripts/run_training.py:22-36).
+
+The trunk  H1 = relu(Â X W1 + b1), H2 = relu(Â H1 W2 + b2) * dropout_mask, out = H2 Wf^T + bf  runs in
+`drlgx_gcn_forward / drlgx_gcn_backward` (csrc/k_gcn.hip: CSR aggregation + fp32-MFMA GEMMs); torch supplies only
+device memory, the dropout mask (torch RNG) and the tiny heads (segment softmax / mean pool).
+`data` is duck-typed like a PyG `Data`/`Batch`: `.x [N,5] f32`, `.edge_index [2,E] i64`, `.edge_attr [E] f32`.
+There is no CPU fallback: tensors must live on a HIP device.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _GCNTrunk(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf, mask):
+        if not x.is_cuda:
+            raise _lib.DrlgxError("drlgx GCN kernels need HIP tensors (no CPU fallback)")
+        L = _lib.lib()
+        x = x.contiguous().float()
+        edge_index = edge_index.contiguous().long()
+        edge_attr = edge_attr.contiguous().float()
+        W1c, b1c, W2c, b2c, Wfc, bfc = (t.contiguous().float() for t in (W1, b1, W2, b2, Wf, bf))
+        N, in_dim = x.shape
+        E = edge_index.shape[1]
+        hidden = W1c.shape[1]
+        out_dim = Wfc.shape[0]
+        nbytes = L.drlgx_gcn_workspace_bytes(N, E, hidden, out_dim)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        out = torch.empty(N, out_dim, dtype=torch.float32, device=x.device)
+        if mask is not None:
+            mask = mask.contiguous().float()
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        rc = L.drlgx_gcn_forward(C.c_void_p(stream), N, E, in_dim, hidden, out_dim, _p(x), _p(edge_index), _p(edge_attr),
+                                 _p(W1c), _p(b1c), _p(W2c), _p(b2c), _p(Wfc), _p(bfc), _p(mask), _p(out), _p(ws))
+        _lib.check(rc)
+        ctx.save_for_backward(x, edge_index, edge_attr, W1c, W2c, Wfc, mask if mask is not None else torch.empty(0, device=x.device), ws)
+        ctx.has_mask = mask is not None
+        ctx.dims = (N, E, in_dim, hidden, out_dim)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        L = _lib.lib()
+        x, edge_index, edge_attr, W1, W2, Wf, mask, ws = ctx.saved_tensors
+        N, E, in_dim, hidden, out_dim = ctx.dims
+        d_out = d_out.contiguous().float()
+        dev = x.device
+        dW1 = torch.empty(in_dim, hidden, dtype=torch.float32, device=dev)
+        db1 = torch.empty(hidden, dtype=torch.float32, device=dev)
+        dW2 = torch.empty(hidden, hidden, dtype=torch.float32, device=dev)
+        db2 = torch.empty(hidden, dtype=torch.float32, device=dev)
+        dWf = torch.empty(out_dim, hidden, dtype=torch.float32, device=dev)
+        dbf = torch.empty(out_dim, dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = L.drlgx_gcn_backward(C.c_void_p(stream), N, E, in_dim, hidden, out_dim, _p(x), _p(edge_index), _p(edge_attr), _p(W1),
+                                  _p(W2), _p(Wf), _p(mask) if ctx.has_mask else None, _p(d_out), _p(dW1), _p(db1), _p(dW2), _p(db2),
+                                  _p(dWf), _p(dbf), _p(ws))
+        _lib.check(rc)
+        return None, None, None, dW1, db1, dW2, db2, dWf, dbf, None
+
+
+def gcn_trunk(x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf, mask=None):
+    return _GCNTrunk.apply(x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf, mask)
+
+
+class GCNConvParams(torch.nn.Module):
+    """Parameter holder with PyG-1.x GCNConv's layout and init (weight [in, out] glorot, bias zeros)."""
+
+    def __init__(self, in_channels, out_channels, improved=True):
+        super().__init__()
+        assert improved, "only GCNConv(improved=True) is used by the reference"
+        self.weight = torch.nn.Parameter(torch.empty(in_channels, out_channels))
+        self.bias = torch.nn.Parameter(torch.zeros(out_channels))
+        stdv = math.sqrt(6.0 / (in_channels + out_channels))
+        with torch.no_grad():
+            self.weight.uniform_(-stdv, stdv)
+
+
+def _dropout_mask(n, hidden, p, device):
+    """F.dropout(x, p) is the FUNCTIONAL form in the reference => always active."""
+    if p <= 0.0:
+        return None
+    if p >= 1.0:
+        return torch.zeros(n, hidden, device=device)
+    keep = (torch.rand(n, hidden, device=device) >= p).float()
+    return keep / (1.0 - p)
+
+
+class GCN(torch.nn.Module):
+    """scripts/Networks.py:12-28 (DQN head: one Q value per node)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = GCNConvParams(5, 1000, improved=True)
+        self.conv2 = GCNConvParams(1000, 1000, improved=True)
+        self.fully_con1 = torch.nn.Linear(1000, 1)
+
+    def forward(self, data, prob, batch=None):
+        x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
+        mask = _dropout_mask(x.shape[0], 1000, float(prob), x.device)
+        return gcn_trunk(x, edge_index, edge_weight, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                         self.fully_con1.weight, self.fully_con1.bias, mask)
+
+
+def segment_softmax(src, index, num_segments):
+    """torch_geometric.utils.softmax (PyG 1.x): exp(src - segment max) / (segment sum + 1e-16)."""
+    mx = torch.full((num_segments,), -float("inf"), dtype=src.dtype, device=src.device)
+    mx = mx.scatter_reduce(0, index, src, reduce="amax", include_self=True)
+    out = (src - mx[index]).exp()
+    s = torch.zeros(num_segments, dtype=src.dtype, device=src.device).index_add_(0, index, out)
+    return out / (s[index] + 1e-16)
+
+
+class PolicyGCN(torch.nn.Module):
+    """scripts/Networks.py:31-50 (A2C actor: softmax over the masked (frontier) nodes of every graph)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = GCNConvParams(5, 1000, improved=True)
+        self.conv2 = GCNConvParams(1000, 1000, improved=True)
+        self.fully_con1 = torch.nn.Linear(1000, 1)
+
+    def forward(self, data, mask, batch=None):
+        x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
+        dmask = _dropout_mask(x.shape[0], 1000, 0.5, x.device)  # F.dropout(x): p = 0.5 even at inference
+        q = gcn_trunk(x, edge_index, edge_weight, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                      self.fully_con1.weight, self.fully_con1.bias, dmask)
+        q = torch.masked_select(q.view(-1), mask)
+        b = torch.masked_select(batch, mask)
+        return segment_softmax(q, b, int(batch.max().item()) + 1 if batch.numel() else 0)
+
+
+class ValueGCN(torch.nn.Module):
+    """scripts/Networks.py:53-70 (A2C critic: Linear 1000->100, global mean pool, mean over the 100)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = GCNConvParams(5, 1000, improved=True)
+        self.conv2 = GCNConvParams(1000, 1000, improved=True)
+        self.fully_con1 = torch.nn.Linear(1000, 100)
+
+    def forward(self, data, mask, batch=None):
+        x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
+        dmask = _dropout_mask(x.shape[0], 1000, 0.5, x.device)
+        h = gcn_trunk(x, edge_index, edge_weight, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                      self.fully_con1.weight, self.fully_con1.bias, dmask)
+        g = int(batch.max().item()) + 1
+        s = torch.zeros(g, h.shape[1], dtype=h.dtype, device=h.device).index_add_(0, batch, h)
+        cnt = torch.zeros(g, dtype=h.dtype, device=h.device).index_add_(0, batch, torch.ones_like(batch, dtype=h.dtype))
+        return (s / cnt.clamp(min=1).unsqueeze(1)).mean(dim=1)  # global_mean_pool(x, batch).mean(dim=1)
+
+
+class GraphData(object):
+    """Minimal stand-in for torch_geometric.data.Data / Batch (x, edge_index, edge_attr, batch, .to())."""
+
+    def __init__(self, x, edge_index, edge_attr, batch=None):
+        self.x, self.edge_index, self.edge_attr, self.batch = x, edge_index, edge_attr, batch
+
+    def to(self, device):
+        self.x = self.x.to(device)
+        self.edge_index = self.edge_index.to(device)
+        self.edge_attr = self.edge_attr.to(device)
+        if self.batch is not None:
+            self.batch = self.batch.to(device)
+        return self
+
+    @staticmethod
+    def collate(items):
+        """torch_geometric DataLoader/Batch semantics: concatenate, offset edge_index by cumulative node counts."""
+        xs, eis, eas, bs = [], [], [], []
+        off = 0
+        for g, d in enumerate(items):
+            xs.append(d.x)
+            eis.append(d.edge_index + off)
+            eas.append(d.edge_attr)
+            bs.append(torch.full((d.x.shape[0],), g, dtype=torch.long, device=d.x.device))
+            off += d.x.shape[0]
+        return GraphData(torch.cat(xs), torch.cat(eis, dim=1), torch.cat(eas), torch.cat(bs))
