@@ -483,6 +483,13 @@ int drlgx_get_counts_host(drlgx_engine *e, int inst, int32_t out[5]) {
   return DRLGX_OK;
 }
 
+int drlgx_counts(drlgx_engine *e, int32_t *counts_dev) {
+  if (!e || !counts_dev) return DRLGX_E_INVALID;
+  HIPCHK(e, hipMemcpy2DAsync(counts_dev, 5 * sizeof(int32_t), e->S.cnt, DRLGX_CNT_STRIDE * sizeof(int32_t), 5 * sizeof(int32_t),
+                             (size_t)e->S.n_envs, hipMemcpyDeviceToDevice, e->stream));
+  return DRLGX_OK;
+}
+
 int drlgx_get_poses_host(drlgx_engine *e, int inst, double *xytheta, double *information) {
   int32_t c[5];
   int r = drlgx_get_counts_host(e, inst, c);

@@ -161,6 +161,12 @@ class Engine(object):
         self._chk(self.L.drlgx_get_counts_host(self.h, inst, out))
         return dict(poses=out[0], landmarks=out[1], factors=out[2], step=out[3], isam_count=out[4])
 
+    def counts_dev(self):
+        """[n_envs, 5] int32 CUDA tensor: poses, landmarks, factors, step, isam update count (no sync)."""
+        out = torch.empty(self.n_envs, 5, dtype=torch.int32, device=self.device)
+        self._chk(self.L.drlgx_counts(self.h, _p(out)))
+        return out
+
     def poses(self, inst):
         P = self.counts(inst)["poses"]
         xyt = np.zeros((P, 3))

@@ -1,0 +1,238 @@
+"""`DeepQ` — the reference's DQN trainer (scripts/policy.py:16-262) over a `VecExplorationEnv`.
+
+Same constructor `DeepQ(case_path, model_name)`, hyper-parameters, `running / data_process / cost / train / test` and
+target computation as the reference; the differences are the ones the batched hot path implies:
+
+* `running` steps `n_envs` environments in lock-step (one decision of every env per iteration; `step_t` advances by
+  `n_envs`), graphs never leave the device: `data_process` slices the engine's batched export instead of scanning a
+  dense adjacency matrix in Python (the edge order it would have produced is what the engine emits).
+* replay transitions hold device `GraphData`; mini-batches are collated on the device.
+* multi-GPU: one process per GPU, each with its own env shard and replay buffer; `allreduce_gradients` averages the
+  flattened policy gradient over ranks (RCCL over xGMI, one collective per train step) before the clamp + Adam step.
+"""
+import csv
+import os
+import random
+from collections import deque
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .networks import GraphData
+from .vecenv import VecExplorationEnv
+
+
+def allreduce_gradients(model, group=None):
+    """Average the gradients of `model` over all ranks with ONE flat all-reduce (3 MB..4 MB for the GCN: far below
+    the xGMI per-link bandwidth-delay product, so a single bucket is optimal). No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    ws = dist.get_world_size(group)
+    if ws == 1:
+        return
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(ws)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+def broadcast_parameters(model, src=0, group=None):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+class DeepQ(object):
+    def __init__(self, case_path, model_name, data_root="../data"):
+        self.case_path = case_path
+        self.weights_path = os.path.join(data_root, "torch_weights", self.case_path)
+        self.reward_data_path = os.path.join(data_root, "reward_data", self.case_path)
+        self.object_path = os.path.join(data_root, "training_object_data", self.case_path)
+        for p in (self.weights_path, self.reward_data_path, self.object_path):
+            os.makedirs(p, exist_ok=True)
+        with open(os.path.join(self.reward_data_path, "reward_data.csv"), "w", newline="") as f:
+            csv.writer(f).writerow(["Step", "Reward"])
+
+        # RL parameters (policy.py:33-52)
+        self.BATCH = 64
+        self.REPLAY_MEMORY = 1e4
+        self.GAMMA = 0.99
+        self.OBSERVE = 5e3
+        self.EXPLORE = 1e6
+        self.epoch = 1e4
+        self.TARGET_UPDATE = 15000 if model_name == "GCN" else 9000
+        self.FINAL_EPSILON = 0
+        self.INITIAL_EPSILON = 0.9
+        self.max_grad_norm = 0.5
+        self.map_size = 40
+        self.buffer = deque()
+        self.step_t = 0
+        self.epsilon = self.INITIAL_EPSILON
+        self.temp_loss = 0
+        self.total_reward = np.empty([0, 0])
+
+    # ------------------------------------------------------------------ data
+    @staticmethod
+    def data_process(g, i):
+        """Graph of env `i` out of the engine's batched export `g` (Engine.graph) as one `GraphData` with local node
+        ids — what policy.py:211-232 builds from the dense (A, X) pair."""
+        n0, n1 = int(g["node_off_h"][i]), int(g["node_off_h"][i + 1])
+        e0, e1 = int(g["edge_off_h"][i]), int(g["edge_off_h"][i + 1])
+        return GraphData(g["x"][n0:n1].clone(), g["edge_index"][:, e0:e1] - n0, g["edge_attr"][e0:e1].clone())
+
+    @staticmethod
+    def _host_offsets(g):
+        g["node_off_h"] = g["node_off"].cpu().numpy()
+        g["edge_off_h"] = g["edge_off"].cpu().numpy()
+        return g
+
+    def cost(self, pred, target, action):
+        pred_flat = pred.view(-1)
+        target_flat = target.view(-1)
+        readout_action = torch.mul(pred_flat, action)
+        return torch.pow(readout_action - target_flat, 2).sum() / self.BATCH
+
+    def train(self, data, action, y, device, model, optimizer):
+        model.train()
+        data = data.to(device)
+        optimizer.zero_grad()
+        out = model(data, 0.5, batch=data.batch)
+        y = torch.as_tensor(y, dtype=out.dtype, device=device)
+        action = torch.as_tensor(action, dtype=out.dtype, device=device)
+        loss = self.cost(out, y, action)
+        self.temp_loss = loss.item()
+        loss.backward()
+        allreduce_gradients(model)
+        for param in model.parameters():
+            param.grad.data.clamp_(-self.max_grad_norm, self.max_grad_norm)
+        optimizer.step()
+
+    def test(self, data, prob, device, model):
+        model.eval()
+        data = data.to(device)
+        return model(data, prob)
+
+    # ------------------------------------------------------------------ one mini-batch (policy.py:139-177)
+    def _train_minibatch(self, device, policy_net, target_net, optimizer):
+        minibatch = random.sample(self.buffer, self.BATCH)
+        s_j = GraphData.collate([d[0] for d in minibatch])
+        s_j1 = GraphData.collate([d[3] for d in minibatch])
+        with torch.no_grad():
+            q1 = self.test(s_j1, 0.0, device, target_net).view(-1)
+        n_j = torch.tensor([d[0].x.shape[0] for d in minibatch], device=device)
+        n_j1 = torch.tensor([d[3].x.shape[0] for d in minibatch], device=device)
+        fro1 = torch.tensor([d[5] for d in minibatch], device=device)
+        a_loc = torch.tensor([d[1] for d in minibatch], device=device)
+        r = torch.tensor([d[2] for d in minibatch], dtype=torch.float32, device=device)
+        term = torch.tensor([bool(d[4]) for d in minibatch], device=device)
+        off_j = torch.cumsum(n_j, 0) - n_j
+        end_j1 = torch.cumsum(n_j1, 0)
+        # max over the last `fro1` (frontier) nodes of every next-state graph
+        node_g = s_j1.batch
+        is_fr = torch.arange(q1.numel(), device=device) >= (end_j1 - fro1)[node_g]
+        max_q = torch.full((len(minibatch),), -float("inf"), device=device).scatter_reduce(
+            0, node_g[is_fr], q1[is_fr], reduce="amax")
+        target = torch.where(term, r, r + self.GAMMA * max_q)
+        N = int(n_j.sum())
+        a_batch = torch.zeros(N, device=device)
+        y_batch = torch.zeros(N, device=device)
+        a_batch[off_j + a_loc] = 1.0
+        y_batch[off_j + a_loc] = target
+        self.train(s_j, a_batch, y_batch, device, policy_net, optimizer)
+
+    # ------------------------------------------------------------------ main loop (policy.py:60-208)
+    def running(self, model, modelTarget, test=False, n_envs=64, env=None, log_every=0):
+        temp_i = 0
+        method = "bayesian"
+        own_env = env is None
+        if env is None:
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            env = VecExplorationEnv(self.map_size, n_envs, env_index=rank * n_envs, test=test,
+                                    device=torch.cuda.current_device(), seed=None if not test else rank)
+        n_envs = env.n_envs
+        device = env.device
+        policy_net, target_net = model, modelTarget
+        target_net.eval()
+        broadcast_parameters(policy_net)
+        optimizer = torch.optim.Adam(policy_net.parameters(), lr=1e-5)
+        temp_reward_data, temp_loss_data, rows = [], [], []
+
+        g = self._host_offsets(env.graph_matrix())
+        while temp_i < self.epoch:
+            if self.epsilon > self.FINAL_EPSILON and self.step_t > self.OBSERVE:
+                self.epsilon -= n_envs * (self.INITIAL_EPSILON - self.FINAL_EPSILON) / self.EXPLORE
+            s_t = [self.data_process(g, i) for i in range(n_envs)]
+            env.actions_all_goals()
+            rewards = env.rewards_all_goals()
+            cand_env, cand_node, cand_first = env.candidates
+            nfr = g["n_frontier"].long()
+            batch_data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"])
+            with torch.no_grad():
+                prob = self.epsilon if method == "bayesian" else 0.0
+                readout = self.test(batch_data, prob, device, policy_net).view(-1)
+            q_c = readout[cand_node]
+            e = cand_env.long()
+            best = torch.full((n_envs,), -float("inf"), device=device).scatter_reduce(0, e, q_c, reduce="amax")
+            idx = torch.arange(q_c.numel(), device=device)
+            pick = torch.full((n_envs,), q_c.numel(), dtype=torch.long, device=device).scatter_reduce(
+                0, e[q_c >= best[e]], idx[q_c >= best[e]], reduce="amin")  # np.argmax: first maximum
+            if method == "e-greedy":
+                explore = torch.rand(n_envs, device=device) <= self.epsilon
+                rnd = cand_first + (torch.rand(n_envs, device=device) * nfr).long().clamp(max=nfr - 1)
+                pick = torch.where(explore, rnd, pick)
+            choice = pick - cand_first
+            r_t = rewards[pick]
+            key_size = (g["node_off"][1:] - g["node_off"][:-1]).long() - nfr
+            a_loc = (key_size + choice).cpu().numpy()
+            _, done, _ = env.step(choice)
+            current_done = (done | env.loop_clo).cpu().numpy()
+            done_h = done.cpu().numpy()
+            r_h = r_t.cpu().numpy()
+
+            # finished envs are re-created before the next graph export (`env = ExplorationEnv(...)` in the reference);
+            # their transition keeps the terminal flag, so the (unused) s_t1 may be the new env's first graph
+            if done_h.any():
+                env.reset(np.nonzero(done_h)[0])
+            g1 = self._host_offsets(env.graph_matrix())
+            nfr1 = g1["n_frontier"].cpu().numpy()
+            for i in range(n_envs):
+                self.buffer.append((s_t[i], int(a_loc[i]), float(r_h[i]), self.data_process(g1, i),
+                                    bool(current_done[i] or done_h[i]), int(nfr1[i])))
+                if len(self.buffer) > self.REPLAY_MEMORY:
+                    self.buffer.popleft()
+            g = g1
+            self.step_t += n_envs
+            temp_i += n_envs
+
+            if self.step_t > self.OBSERVE and len(self.buffer) >= self.BATCH:
+                if (self.step_t // n_envs) % max(int(self.TARGET_UPDATE // n_envs), 1) == 0:
+                    target_net.load_state_dict(policy_net.state_dict())
+                self._train_minibatch(device, policy_net, target_net, optimizer)
+                temp_loss_data.append([self.step_t, self.temp_loss])
+
+            if log_every and (self.step_t // n_envs) % log_every == 0:
+                print("TIMESTEP", self.step_t, "/ EPSILON", self.epsilon, "/ Q_MAX %e" % float(readout.max()),
+                      "/ EXPLORED", float(env.status().mean()), "/ REWARD", float(r_h.mean()))
+            rows.extend([self.step_t, float(x)] for x in r_h)
+            self.total_reward = np.append(self.total_reward, r_h)
+            if self.step_t > 1000 and (self.step_t // n_envs) % max(100 // n_envs, 1) == 0:
+                temp_reward_data.append([self.step_t, float(np.average(self.total_reward[-1000:]))])
+
+        np.savetxt(os.path.join(self.object_path, "temp_reward.csv"), np.array(temp_reward_data).reshape(-1, 2), delimiter=",")
+        np.savetxt(os.path.join(self.object_path, "temp_loss.csv"), np.array(temp_loss_data).reshape(-1, 2), delimiter=",")
+        with open(os.path.join(self.reward_data_path, "reward_data.csv"), "a", newline="") as f:
+            csv.writer(f).writerows(rows)
+        torch.save(policy_net.state_dict(), os.path.join(self.object_path, "Model_Policy.pt"))
+        torch.save(target_net.state_dict(), os.path.join(self.object_path, "Model_Target.pt"))
+        torch.save(policy_net.state_dict(), os.path.join(self.weights_path, "MyModel.pt"))
+        if own_env:
+            env.close()

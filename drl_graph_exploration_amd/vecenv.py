@@ -1,0 +1,195 @@
+"""`VecExplorationEnv` — the batched counterpart of the reference's `ExplorationEnv`
+(scripts/envs/exploration_env.py:20-422): `n_envs` independent exploration environments stepped in lock-step on one
+GPU through the drlgx engine (one workgroup per environment per kernel).
+
+Method names and meaning follow the reference class; everything that was a scalar / list per environment becomes a
+device tensor over environments (or over (environment, frontier) candidates):
+
+    reset()              ExplorationEnv.reset      (:389-422)  SS2D.__init__, 4 x (1, 1, pi/2), regenerate (+50) if no landmark
+    graph_matrix()       frontier + graph_matrix + DeepQ.data_process (:196-348, policy.py:211-232) -> one PyG-style batch
+    actions_all_goals()  (:134-143)  line plan to every frontier of every env
+    rewards_all_goals()  (:145-162)  look-ahead reward of every plan + the per-decision np.interp normalisation / loop_clo
+    step(...)            (:98-105)   executes one chosen plan per env (ragged lengths -> active masks)
+    status() / done()    (:164-168, :107-110)
+
+There is no CPU path here: the engine raises if no HIP device is visible.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .config import default_config, start_pose
+from .engine import Engine
+
+
+def normalise_rewards(raw, cand_env, cand_first, n_envs):
+    """exploration_env.py:151-161 for every env at once. raw [C] f64 look-ahead rewards of the (env, frontier)
+    candidates in env-major order, cand_env [C] i64, cand_first [n_envs] i64 (index of each env's frontier 0 = the
+    vehicle's nearest frontier). Returns (normalised [C], loop_clo [n_envs] bool): the nearest frontier is the
+    (first) arg-max -> np.interp to [-1, 0], loop_clo False; otherwise [-1, 1], loop_clo True."""
+    e = cand_env
+    lo = torch.full((n_envs,), float("inf"), dtype=raw.dtype, device=raw.device).scatter_reduce(0, e, raw, reduce="amin")
+    hi = torch.full((n_envs,), -float("inf"), dtype=raw.dtype, device=raw.device).scatter_reduce(0, e, raw, reduce="amax")
+    nearest = raw[cand_first.clamp(max=max(raw.numel() - 1, 0))]
+    loop_clo = nearest < hi  # np.nanargmax returns the first maximum
+    top = torch.where(loop_clo, 1.0, 0.0).to(raw.dtype)
+    span = hi - lo
+    slope = (top + 1.0) / torch.where(span > 0, span, torch.ones_like(span))
+    r = slope[e] * (raw - lo[e]) - 1.0  # np.interp: slope * (x - xp[0]) + fp[0]
+    r = torch.where(raw >= hi[e], top[e], r)  # x >= xp[-1] -> fp[-1] (also the degenerate lo == hi case)
+    return r, loop_clo
+
+
+class VecExplorationEnv(object):
+    def __init__(self, map_size, n_envs, env_index=0, test=True, num_landmarks=None, algorithm=0, device=0,
+                 n_rollouts=None, max_poses=None, starts=None, seed=None):
+        self.map_size = map_size
+        self.n_envs = n_envs
+        self.test = test
+        if max_poses is None:
+            # a 40 m map is explored in ~35-45 poses between resets; the SLAM kernel keeps the whole
+            # information matrix in LDS up to 43 poses (csrc/k_slam.hip) and in HBM workspace up to 86
+            max_poses = 86
+        self.cfg = default_config(map_size, num_landmarks=num_landmarks, algorithm=algorithm, max_poses=max_poses)
+        if n_rollouts is None:
+            n_rollouts = min(n_envs * self.cfg.max_landmarks, 4096)
+        self.engine = Engine(self.cfg, n_envs, n_rollouts, device)
+        self.device = self.engine.device
+        self.np_random = np.random.RandomState(seed)
+        self.env_index = np.arange(n_envs, dtype=np.int64) + int(env_index)  # one TEST seed per env
+        self._starts = None if starts is None else np.asarray(starts, dtype=np.float64).reshape(n_envs, 3)
+        self._max_steps = 5000
+        self.dist = torch.zeros(n_envs, dtype=torch.float64, device=self.device)
+        self.loop_clo = torch.zeros(n_envs, dtype=torch.bool, device=self.device)
+        self._graph = None
+        self._cand_env = None
+        self._scan = torch.tensor([(1.0, 1.0, math.pi / 2.0)] * n_envs, dtype=torch.float64, device=self.device)
+        self.reset()
+
+    def close(self):
+        self.engine.close()
+
+    # ------------------------------------------------------------------ reset (exploration_env.py:389-422)
+    def reset(self, ids=None):
+        """Re-create the listed environments (all by default)."""
+        n = self.n_envs
+        todo = np.arange(n, dtype=np.int64) if ids is None else np.asarray(ids, dtype=np.int64).reshape(-1)
+        self.dist[torch.as_tensor(todo, device=self.device)] = 0.0
+        while len(todo):
+            if self.test:
+                seeds = self.env_index[todo].astype(np.uint32)
+                los = self.env_index[todo]
+            else:
+                hi = np.iinfo(np.int32).max
+                seeds = np.array([self.np_random.randint(0, hi) for _ in todo], dtype=np.uint32)
+                los = np.array([self.np_random.randint(0, hi) for _ in todo], dtype=np.int64)
+            if self._starts is not None:
+                starts = self._starts[todo]
+            else:
+                starts = np.array([start_pose(int(lo), self.cfg.map_max_x) for lo in los], dtype=np.float64)
+            self.engine.reset(todo.astype(np.int32), seeds, starts=starts)
+            active = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            active[torch.as_tensor(todo, device=self.device)] = 1
+            for _ in range(4):
+                self.engine.step(self._scan, active)
+            self.engine.check_status()
+            n_lm = self.engine.counts_dev()[:, 1].cpu().numpy()
+            empty = np.array([i for i in todo if n_lm[i] < 1], dtype=np.int64)
+            self.env_index[empty] += 50  # "regenerate a environment"
+            todo = empty
+        self._graph = None
+        return self._get_obs()
+
+    def _get_obs(self):
+        return None  # the occupancy grids stay on the device; use obs(i) for one env's VirtualMap.to_array()
+
+    def obs(self, i):
+        return self.engine.virtual_map(int(i))[0]
+
+    # ------------------------------------------------------------------ graph export
+    def graph_matrix(self):
+        """All envs' graphs as one batch (see Engine.graph); node order per env = [landmarks (hash order), poses,
+        frontiers], edge order = DeepQ.data_process's. Candidate c = (env, frontier) in env-major order."""
+        g = self.engine.graph()
+        self.engine.check_status()
+        nfr = g["n_frontier"].to(torch.int64)
+        self._graph = g
+        self._cand_env = torch.repeat_interleave(torch.arange(self.n_envs, device=self.device), nfr).to(torch.int32)
+        first = torch.cumsum(nfr, 0) - nfr
+        self._cand_first = first
+        fidx = torch.arange(self._cand_env.numel(), device=self.device) - first[self._cand_env.long()]
+        self._cand_fidx = fidx
+        self._goals = g["frontier_xy"][self._cand_env.long(), fidx].contiguous()
+        # global node id of every candidate: node_off[e+1] - n_frontier[e] + f
+        self._cand_node = (g["node_off"][1:].to(torch.int64)[self._cand_env.long()] - nfr[self._cand_env.long()] + fidx)
+        return g
+
+    @property
+    def candidates(self):
+        """(cand_env [C] i32, cand_node [C] i64 global node ids, first candidate of each env [n_envs] i64)."""
+        return self._cand_env, self._cand_node, self._cand_first
+
+    def actions_all_goals(self):
+        """Line plan to every frontier: (actions [C, max_actions, 3] f64, n_actions [C] i32)."""
+        if self._graph is None:
+            self.graph_matrix()
+        self._actions, self._n_act = self.engine.line_plan(self._cand_env, self._goals)
+        return self._actions, self._n_act
+
+    def rewards_all_goals(self, all_actions=None, return_raw=False):
+        """Look-ahead reward per candidate, normalised per env like exploration_env.py:151-161:
+        nearest frontier is the arg-max -> interp to [-1, 0], loop_clo False; else [-1, 1], loop_clo True."""
+        actions, n_act = all_actions if all_actions is not None else (self._actions, self._n_act)
+        raw = self.engine.lookahead(self._cand_env, actions, n_act)
+        r, self.loop_clo = normalise_rewards(raw, self._cand_env.long(), self._cand_first, self.n_envs)
+        return (r, raw) if return_raw else r
+
+    # ------------------------------------------------------------------ step (exploration_env.py:98-105)
+    def step(self, choice):
+        """Execute, for every env, the plan of its chosen candidate. `choice` [n_envs] = frontier index within the env
+        (int tensor / array) — `all_actions[key_size + action_index]` of policy.py:120."""
+        choice = torch.as_tensor(choice, device=self.device).long()
+        c = self._cand_first + choice
+        acts = self._actions[c]  # [n_envs, A, 3]
+        nact = self._n_act[c]
+        return self.step_actions(acts, nact)
+
+    def step_actions(self, acts, nact):
+        kmax = int(nact.max().item())
+        for k in range(kmax):
+            active = (nact > k).to(torch.uint8)
+            odom = acts[:, k].contiguous()
+            self.engine.step(odom, active)
+            self.dist += torch.where(active.bool(), torch.sqrt(odom[:, 0] ** 2 + odom[:, 1] ** 2), torch.zeros_like(self.dist))
+        self.engine.check_status()
+        self._graph = None
+        return self._get_obs(), self.done(), {}
+
+    def status(self):
+        return self.engine.explored()
+
+    def done(self):
+        """exploration_env.py:107-110 (`_done or step > max_steps or status() > 0.85`), plus one engine-side condition
+        the reference does not have: an env whose trajectory is within one plan (max_actions poses) of the engine's
+        pose capacity is reported done so that the caller resets it instead of overflowing (DRLGX_E_CAPACITY)."""
+        c = self.engine.counts_dev()
+        full = c[:, 0] + self.cfg.max_actions + 1 > self.cfg.max_poses
+        return (self.status() > 0.85) | (c[:, 3] > self._max_steps) | full
+
+    # ------------------------------------------------------------------ reporting (host, one env)
+    def get_landmark_size(self, i):
+        return self.engine.counts(int(i))["landmarks"]
+
+    def get_landmark_error(self, i, sigma0=1.0):
+        """exploration_env.py:170-177."""
+        keys, xy, _ = self.engine.landmarks(int(i))
+        _, gt = self.engine.ground_truth(int(i))
+        err = float(np.sqrt(((gt[keys] - xy) ** 2).sum(axis=1)).sum()) if len(keys) else 0.0
+        n_gt = self.cfg.num_landmarks
+        return (err + sigma0 * (n_gt - len(keys))) / n_gt
+
+    def max_uncertainty_of_trajectory(self, i):
+        """exploration_env.py:190-194."""
+        _, X = self.engine.adjacency(int(i))
+        return float(np.amax(X[self.get_landmark_size(i):]))

@@ -151,6 +151,9 @@ int drlgx_graph(drlgx_engine *e, int32_t *node_off_dev, int32_t *edge_off_dev, f
 
 /* counts per instance: out[0]=poses, out[1]=landmarks, out[2]=factors, out[3]=step, out[4]=isam update count */
 int drlgx_get_counts_host(drlgx_engine *e, int inst, int32_t out[5]);
+/* the same five counts for every live env, asynchronously on the engine stream: counts_dev[n_envs*5] (device).
+ * Replaces the per-env Python reads `slam.key_size()`, `slam.map.get_landmark_size()`, `sim.step` in a batched loop. */
+int drlgx_counts(drlgx_engine *e, int32_t *counts_dev);
 /* Environment.iter_trajectory / get_current_vehicle of SLAM2D.map (src/SS2D.cpp:141-171):
  * xytheta[P*3], information[P*9] (may be NULL). */
 int drlgx_get_poses_host(drlgx_engine *e, int inst, double *xytheta, double *information);

@@ -1,0 +1,120 @@
+"""GPU parity tests of the reference-shaped host layer: `VecExplorationEnv` against the oracle's ExplorationEnv
+restatement driven with the same decisions, the single-env `EMExplorer` facade, and a short `DeepQ.running`."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O  # noqa: E402  (checker only)
+
+MAP = 40
+
+
+def test_vec_env_follows_oracle_env_over_decisions():
+    from drl_graph_exploration_amd.vecenv import VecExplorationEnv
+    n = 5
+    starts = np.array([O.start_pose(lo, MAP / 2 + 20) for lo in range(n)]) + np.array([0.2871, -0.3179, 0.0917])
+    env = VecExplorationEnv(MAP, n, env_index=0, test=True, starts=starts, max_poses=60)
+    refs = [O.OracleEnv(MAP, lo, start=tuple(starts[lo])) for lo in range(n)]
+    assert [int(s) for s in env.env_index] == [r.env_index for r in refs]
+    for decision in range(6):
+        g = env.graph_matrix()
+        env.actions_all_goals()
+        rew, raw = env.rewards_all_goals(return_raw=True)
+        cand_env, cand_node, first = env.candidates
+        rew_h, raw_h, first_h = rew.cpu().numpy(), raw.cpu().numpy(), first.cpu().numpy()
+        nfr = g["n_frontier"].cpu().numpy()
+        node_off = g["node_off"].cpu().numpy()
+        choice = np.zeros(n, dtype=np.int64)
+        plans = []
+        for i, r in enumerate(refs):
+            A, X, _, fro = r.graph_matrix()
+            assert fro == nfr[i] and A.shape[0] == node_off[i + 1] - node_off[i]
+            acts = r.actions_all_goals()
+            exp = r.rewards_all_goals(acts)
+            ks = A.shape[0] - fro
+            got = rew_h[first_h[i]:first_h[i] + fro]
+            # the normalisation divides by (max - min) of rewards that agree to ~1e-7
+            np.testing.assert_allclose(got, exp[ks:], atol=5e-5)
+            assert bool(env.loop_clo[i]) == r.loop_clo
+            assert int(cand_node[first_h[i]]) - node_off[i] == ks
+            choice[i] = int(np.argmax(exp[ks:])) if decision % 2 == 0 else decision % fro
+            plans.append(acts[ks + choice[i]])
+        _, done, _ = env.step(choice)
+        for i, r in enumerate(refs):
+            for a in plans[i]:
+                r.step(a)
+        ex = env.status().cpu().numpy()
+        dist = env.dist.cpu().numpy()
+        for i, r in enumerate(refs):
+            assert ex[i] == r.status()
+            assert dist[i] == pytest.approx(r.dist, abs=1e-12)
+            assert bool(done[i]) == r.done()
+    assert env.get_landmark_error(0) == pytest.approx(refs[0].get_landmark_error(), abs=1e-6)
+    assert env.max_uncertainty_of_trajectory(1) == pytest.approx(refs[1].max_uncertainty_of_trajectory(), rel=1e-5)
+    env.close()
+
+
+def test_emexplorer_facade_single_env():
+    from configparser import ConfigParser
+    from drl_graph_exploration_amd.pyplanner2d import EMExplorer
+    cp = ConfigParser()
+    cp.read_dict({
+        "Sensor Model": dict(bearing_noise="0.5", range_noise="0.02", min_bearing="-179.9", max_bearing="179.9",
+                             min_range="0.1", max_range="6.0"),
+        "Control Model": dict(translation_noise="0.1", rotation_noise="0.2"),
+        "Environment": dict(min_x="-20", max_x="20", min_y="-20", max_y="20", max_steps="5000", safe_distance="0.0"),
+        "Virtual Map": dict(resolution="2.0", sigma0="1.0", num_samples="1"),
+        "Simulator": dict(seed="3", lo="3", num="8", sigma_x0="0.05", sigma_y0="0.05", sigma_theta0="0.01"),
+        "Planner": dict(seed="3", angle_weight="0.4", distance_weight0="5.0", distance_weight1="2.0", d_weight="0.0",
+                        max_edge_length="2.0", max_nodes="0.5", occupancy_threshold="0.4", safe_distance="1.0",
+                        algorithm="EM_AOPT", reg_out="false"),
+    })
+    sim = EMExplorer(cp)
+    ref = O.OracleSim(O.default_config(MAP), 3, 3)
+    for _ in range(4):
+        assert sim.simulate((1, 1, math.pi / 2)) is False
+        ref.simulate((1, 1, math.pi / 2))
+    assert sim.step == ref.step
+    assert sim._slam.map.get_landmark_size() == ref.num_landmarks()
+    assert sim._slam.key_size() == ref.key_size()
+    # integer start poses leave knife-edge cells (range == max_range up to round-off): compare the others
+    mask = np.ones(ref.vm_shape(), dtype=bool)
+    for (i, j) in ref.knife_edge_cells():
+        mask[i, j] = False
+    np.testing.assert_array_equal(sim._virtual_map.to_array()[mask], ref.virtual_map()[0][mask])
+    veh = sim.vehicle_position
+    np.testing.assert_allclose([veh.x, veh.y, veh.theta], ref.poses()[0][-1], atol=1e-7)
+    assert sim.calculate_utility(1.5) == pytest.approx(ref.calculate_utility(1.5), rel=1e-6)
+    sim._slam.adjacency_degree_get()
+    A, X = ref.adjacency()
+    np.testing.assert_allclose(sim._slam.adjacency_out(), A, atol=1e-7)
+    np.testing.assert_allclose(sim._slam.features_out()[:, 0], X, rtol=1e-5, atol=1e-9)
+    goal = (veh.x + 3.0, veh.y - 2.0)
+    plan = sim.line_plan(0, goal)
+    oplan = ref.line_plan(goal)
+    assert len(plan) == len(oplan)
+    np.testing.assert_allclose([[a.x, a.y, a.theta] for a in plan], oplan, atol=1e-9)
+    assert sim.simulations_reward(plan) == pytest.approx(ref.simulations_reward(oplan), abs=1e-6)
+    assert sim.simulate((100.0, 0.0, 0.0)) is True  # rejected odometry, state untouched
+    assert sim.step == ref.step
+
+
+def test_deepq_running_smoke(tmp_path):
+    from drl_graph_exploration_amd.networks import GCN
+    from drl_graph_exploration_amd.policy import DeepQ
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    dq = DeepQ("smoke/", "GCN", data_root=str(tmp_path))
+    dq.OBSERVE, dq.epoch, dq.BATCH = 16, 48, 16
+    pol, tgt = GCN().to(dev), GCN().to(dev)
+    tgt.load_state_dict(pol.state_dict())
+    w0 = pol.conv2.weight.detach().clone()
+    dq.running(pol, tgt, test=True, n_envs=8)
+    assert dq.step_t == 48 and len(dq.buffer) == 48
+    assert dq.temp_loss > 0 and math.isfinite(dq.temp_loss)
+    assert not torch.equal(w0, pol.conv2.weight.detach())  # at least one Adam step on the HIP backward
+    assert (tmp_path / "training_object_data" / "smoke" / "Model_Policy.pt").exists()
