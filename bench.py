@@ -51,7 +51,7 @@ def make_engine(device_index, seed0):
     from drl_graph_exploration_amd import default_config
     from drl_graph_exploration_amd.engine import Engine
     cfg = default_config(MAP, num_landmarks=NUM_LM, max_poses=41, max_landmarks=100, max_factors=512, max_snapshots=1)
-    eng = Engine(cfg, N_ENVS, 0, device=device_index)
+    eng = Engine(cfg, N_ENVS, 2048, device=device_index)  # 2048 rollout instances for the look-ahead waves
     ids = np.arange(N_ENVS)
     eng.reset(ids, seed0 + ids, los=seed0 + ids)
     for act in WARM_SCRIPT:
@@ -90,12 +90,78 @@ def cpu_baseline(budget_s=12.0):
             "host_cores_available": os.cpu_count()}
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector rate
+
+
+def policy_bench(eng, dev, iters=10):
+    """Secondary measurements on the same engine (NOT the headline metric): the decision-side path (graph export,
+    line plans + look-ahead rewards for every frontier, GCN forward over the 256-graph batch) and one DQN train step
+    (GCN forward + backward on a 64-graph batch). The GCN is fp32 on f32-input MFMA (`v_mfma_f32_32x32x2_f32`)."""
+    from drl_graph_exploration_amd.networks import GCN, GraphData
+
+    def timed(fn, n=iters):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    torch.manual_seed(0)
+    model = GCN().to(dev)
+    eng.restore(0)
+    out = {}
+    g = eng.graph()
+    N, E = int(g["x"].shape[0]), int(g["edge_index"].shape[1])
+    nfr = g["n_frontier"].long()
+    cand_env = torch.repeat_interleave(torch.arange(N_ENVS, device=dev), nfr).to(torch.int32)
+    first = torch.cumsum(nfr, 0) - nfr
+    fidx = torch.arange(cand_env.numel(), device=dev) - first[cand_env.long()]
+    goals = g["frontier_xy"][cand_env.long(), fidx].contiguous()
+    data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"])
+    out["graph_nodes"], out["graph_edges"], out["candidates"] = N, E, int(cand_env.numel())
+    out["graph_export_ms"] = timed(lambda: eng.graph()) * 1e3
+    acts, nact = eng.line_plan(cand_env, goals)
+    out["line_plan_ms"] = timed(lambda: eng.line_plan(cand_env, goals)) * 1e3
+    out["lookahead_ms"] = timed(lambda: eng.lookahead(cand_env, acts, nact), n=3) * 1e3
+    with torch.no_grad():
+        t_f = timed(lambda: model(data, 0.0))
+    flops_f = 2.0 * N * (5 * 1000 + 1000 * 1000 + 1000) + 2.0 * 2 * (E + N) * 1000  # GEMMs + two aggregations
+    out["gcn_forward_ms"] = t_f * 1e3
+    out["gcn_forward_TFLOPs"] = flops_f / t_f / 1e12
+    out["decisions_per_sec"] = N_ENVS / (out["graph_export_ms"] + out["line_plan_ms"] + out["lookahead_ms"] + t_f * 1e3) * 1e3
+    # train step: 64-graph minibatch (the first 64 envs' graphs)
+    n64 = int(g["node_off"][64])
+    e64 = int(g["edge_off"][64])
+    d64 = GraphData(g["x"][:n64], g["edge_index"][:, :e64], g["edge_attr"][:e64], g["batch"][:n64])
+    opt = torch.optim.Adam(model.parameters(), lr=1e-5)
+    w = torch.randn(n64, 1, device=dev)
+
+    def train_step():
+        opt.zero_grad()
+        q = model(d64, 0.5, batch=d64.batch)
+        ((q * w) ** 2).sum().div(64).backward()
+        for p in model.parameters():
+            p.grad.data.clamp_(-0.5, 0.5)
+        opt.step()
+    t_t = timed(train_step)
+    flops_t = 3 * (2.0 * n64 * (5 * 1000 + 1000 * 1000 + 1000)) + 2.0 * 4 * (e64 + n64) * 1000
+    out["train_step_ms"] = t_t * 1e3
+    out["train_step_nodes"] = n64
+    out["train_step_TFLOPs"] = flops_t / t_t / 1e12
+    out["mfma_f32_peak_TFLOPs"] = MFMA_F32_PEAK_TFLOPS
+    out["gcn_forward_frac_mfma_peak"] = out["gcn_forward_TFLOPs"] / MFMA_F32_PEAK_TFLOPS
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-policy", action="store_true", help="skip the secondary decision-path / GCN measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,11 +219,13 @@ def main():
         V = eng.rows * eng.cols
         ab = algorithmic_bytes(P + 1, L, M, V)
         kernels = {}
+        # an empty event pair is recorded once per step: its duration is the measurement overhead of a span
+        ev_over_us = tm["t7"][0] / max(tm["t7"][1], 1) * 1e3
         for name in ("sim", "slam", "map", "copy"):
             ms, n = tm[name]
             if n == 0:
                 continue
-            avg_us = ms / n * 1e3
+            avg_us = ms / n * 1e3 - ev_over_us
             b = ab.get(name)
             ent = {"avg_us_per_launch": avg_us, "launches": int(n)}
             if b is not None:
@@ -170,6 +238,16 @@ def main():
                     "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kernels[dom]["frac_hbm_peak"], "traffic": None,
                     "avg_us_per_launch": kernels[dom]["avg_us_per_launch"]}
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this same command (counters cannot be
+        # read in-process); profiles/r01_pmc_traffic.json holds the corrected per-kernel figures (scripts/rocpd_pmc.py)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)["kernels"]
+            roofline["traffic"] = pmc[roofline["kernel"]]["hbm_traffic_bytes_per_launch"]
+            roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+            roofline["algorithmic_bytes_per_launch"] = kernels[dom]["algorithmic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         total_steps = args.steps * N_ENVS * world
         out = {
             "metric": "env-steps/sec (256 parallel envs, ~64-node graphs)", "value": total_steps / elapsed,
@@ -180,8 +258,10 @@ def main():
                                    "~%.0f-node graphs (P=%.1f poses, L=%.1f landmarks, M=%.0f factors) from a device snapshot"
                                    % (P + 1 + L, P + 1, L, M),
                        "envs_per_gpu": N_ENVS, "map_size": MAP, "num_landmarks": NUM_LM, "parallelism": "env-sharded x%d" % world},
-            "roofline": roofline, "kernels": kernels,
+            "roofline": roofline, "kernels": kernels, "event_pair_overhead_us": ev_over_us,
         }
+        if not args.no_policy:
+            out["policy_path"] = policy_bench(eng, dev)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu_thread"] = (out["value"] / world) / out["cpu_baseline"]["value"]

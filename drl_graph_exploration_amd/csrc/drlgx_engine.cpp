@@ -377,6 +377,9 @@ int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_de
     ScopedTimer t(e, 2);
     drlgx_launch_map(e->S, e->stream, sel);
   }
+  {
+    ScopedTimer t(e, 7);  // empty span: the event-pair overhead, so that callers can subtract it
+  }
   return check_launch(e);
 }
 
@@ -406,9 +409,9 @@ int drlgx_line_plan(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
 
 int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *actions_dev,
                     const int32_t *n_actions_dev, double *rewards_dev) {
-  if (!e || n_cand < 0 || n_cand > e->S.n_roll || !cand_env_dev || !actions_dev || !n_actions_dev || !rewards_dev)
-    return DRLGX_E_INVALID;
+  if (!e || n_cand < 0 || !cand_env_dev || !actions_dev || !n_actions_dev || !rewards_dev) return DRLGX_E_INVALID;
   if (n_cand == 0) return DRLGX_OK;
+  if (e->S.n_roll < 1) return DRLGX_E_CAPACITY;
   const DrlgxState &S = e->S;
   const int base0 = S.n_envs, roll0 = 2 * S.n_envs;
   {
@@ -421,27 +424,34 @@ int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
     ScopedTimer t(e, 1);
     drlgx_launch_slam(S, e->stream, LaunchSel{base0, S.n_envs, nullptr, nullptr, 0});
   }
-  {
-    ScopedTimer t(e, 3);
-    drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, n_cand, cand_env_dev, nullptr, base0, roll0, 3);
-    drlgx_launch_fix_rollouts(S, e->stream, n_cand, cand_env_dev, roll0);
+  // candidates beyond the rollout capacity are processed in successive waves over the same rollout instances
+  for (int c0 = 0; c0 < n_cand; c0 += S.n_roll) {
+    const int nc = std::min(S.n_roll, n_cand - c0);
+    const int32_t *ce = cand_env_dev + c0;
+    const double *act = actions_dev + (size_t)c0 * S.A_max * 3;
+    const int32_t *na = n_actions_dev + c0;
+    {
+      ScopedTimer t(e, 3);
+      drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, nc, ce, nullptr, base0, roll0, 3);
+      drlgx_launch_fix_rollouts(S, e->stream, nc, ce, roll0);
+    }
+    for (int a = 0; a < S.A_max; ++a) {
+      LaunchSel sel{roll0, nc, nullptr, na, a};
+      {
+        ScopedTimer t(e, 0);
+        drlgx_launch_sim(S, e->stream, sel, act, S.A_max * 3, 1);
+      }
+      {
+        ScopedTimer t(e, 1);
+        drlgx_launch_slam(S, e->stream, sel);
+      }
+      {
+        ScopedTimer t(e, 2);
+        drlgx_launch_map(S, e->stream, sel);
+      }
+    }
+    drlgx_launch_rewards(S, e->stream, nc, ce, roll0, rewards_dev + c0);
   }
-  for (int a = 0; a < S.A_max; ++a) {
-    LaunchSel sel{roll0, n_cand, nullptr, n_actions_dev, a};
-    {
-      ScopedTimer t(e, 0);
-      drlgx_launch_sim(S, e->stream, sel, actions_dev, S.A_max * 3, 1);
-    }
-    {
-      ScopedTimer t(e, 1);
-      drlgx_launch_slam(S, e->stream, sel);
-    }
-    {
-      ScopedTimer t(e, 2);
-      drlgx_launch_map(S, e->stream, sel);
-    }
-  }
-  drlgx_launch_rewards(S, e->stream, n_cand, cand_env_dev, roll0, rewards_dev);
   return check_launch(e);
 }
 

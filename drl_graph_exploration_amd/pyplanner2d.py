@@ -185,7 +185,7 @@ class _Sim(object):
 class SS2D(object):
     """scripts/envs/pyss2d.py:56-330 (construction + simulate + getters)."""
 
-    def __init__(self, config, verbose=False, device=0, max_poses=86):
+    def __init__(self, config, verbose=False, device=0, max_poses=86, start=None):
         self._config = load_config(config) if isinstance(config, str) else config
         cfg, prm = config_from_ini(self._config, max_poses=max_poses)
         self._sensor_params, self._control_params = prm["sensor"], prm["control"]
@@ -194,7 +194,8 @@ class SS2D(object):
         self.engine = Engine(cfg, 1, max(cfg.max_landmarks, 1), device)
         lo = int(self._config.getfloat("Simulator", "lo"))
         seed = self._config.getint("Simulator", "seed")
-        self.engine.reset([0], [seed], starts=np.array([start_pose(lo, cfg.map_max_x)]))
+        # `start` (x, y, theta) overrides the reference's integer start pose (extension used by tests)
+        self.engine.reset([0], [seed], starts=np.array([start_pose(lo, cfg.map_max_x) if start is None else start]))
         self.engine.check_status()
         self._slam, self._virtual_map, self._sim = _Slam(self), _VirtualMap(self), _Sim(self)
         self.verbose = verbose

@@ -53,7 +53,8 @@ class VecExplorationEnv(object):
             max_poses = 86
         self.cfg = default_config(map_size, num_landmarks=num_landmarks, algorithm=algorithm, max_poses=max_poses)
         if n_rollouts is None:
-            n_rollouts = min(n_envs * self.cfg.max_landmarks, 4096)
+            # one rollout instance per (env, frontier) candidate up to 4096; more candidates run in waves
+            n_rollouts = min(n_envs * (self.cfg.max_landmarks + 1), 4096)
         self.engine = Engine(self.cfg, n_envs, n_rollouts, device)
         self.device = self.engine.device
         self.np_random = np.random.RandomState(seed)

@@ -120,7 +120,8 @@ int drlgx_line_plan(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
                     double *actions_dev, int32_t *n_actions_dev);
 
 /* EMPlanner2D::simulations_reward (Planner2D.cpp:1416-1468) for n_cand candidates
- * (n_cand <= n_rollouts): deep-copies the belief and simulator state of env cand_env[i] (including
+ * (any n_cand >= 0; more than n_rollouts candidates run in successive waves of n_rollouts; n_rollouts must be
+ * >= 1): deep-copies the belief and simulator state of env cand_env[i] (including
  * the RNG states), re-solves at the best estimate (SLAM2D::set_copy_isam, SLAM2D.cpp:490-497), rolls
  * the action list forward with one noisy move/measure + SLAM2D::copy_optimize + virtual-map rebuild
  * per action and returns reward = U_before(0) - U_after(dist).  Live environments are not modified.
@@ -181,7 +182,8 @@ int drlgx_snapshot(drlgx_engine *e, int slot);
 int drlgx_restore(drlgx_engine *e, int slot);
 
 /* Per-kernel timing (HIP events on the engine stream): enable, then read accumulated milliseconds and
- * launch counts.  kernel ids: 0 sim, 1 slam, 2 map, 3 copy/prepare, 4 graph.  */
+ * launch counts.  kernel ids: 0 sim, 1 slam, 2 map, 3 copy/prepare, 4 graph, 7 = an EMPTY span recorded once per
+ * drlgx_step (the event-pair overhead a caller subtracts from the per-launch averages).  */
 #define DRLGX_N_TIMERS 8
 int drlgx_timing_enable(drlgx_engine *e, int on);
 int drlgx_timing_read_host(drlgx_engine *e, double ms[DRLGX_N_TIMERS], int64_t launches[DRLGX_N_TIMERS]);

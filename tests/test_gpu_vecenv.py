@@ -17,9 +17,15 @@ def test_vec_env_follows_oracle_env_over_decisions():
     from drl_graph_exploration_amd.vecenv import VecExplorationEnv
     n = 5
     starts = np.array([O.start_pose(lo, MAP / 2 + 20) for lo in range(n)]) + np.array([0.2871, -0.3179, 0.0917])
-    env = VecExplorationEnv(MAP, n, env_index=0, test=True, starts=starts, max_poses=60)
+    # 7 rollout instances < number of (env, frontier) candidates: the look-ahead runs in several waves
+    env = VecExplorationEnv(MAP, n, env_index=0, test=True, starts=starts, max_poses=60, n_rollouts=7)
     refs = [O.OracleEnv(MAP, lo, start=tuple(starts[lo])) for lo in range(n)]
     assert [int(s) for s in env.env_index] == [r.env_index for r in refs]
+    # Dead-reckoned estimates sit on "round" coordinates and line plans run along 3-4-5 directions towards odd-integer
+    # cell centres, so cells at EXACTLY max_range from a pose occur structurally; 1 ulp of pose round-off decides them
+    # (in the reference too). An env whose grids differ ONLY in such knife-edge cells is dropped from the comparison
+    # from then on (its frontier set, hence its decisions, legitimately fork); any other difference fails.
+    alive = [True] * n
     for decision in range(6):
         g = env.graph_matrix()
         env.actions_all_goals()
@@ -31,6 +37,9 @@ def test_vec_env_follows_oracle_env_over_decisions():
         choice = np.zeros(n, dtype=np.int64)
         plans = []
         for i, r in enumerate(refs):
+            if not alive[i]:
+                plans.append([])
+                continue
             A, X, _, fro = r.graph_matrix()
             assert fro == nfr[i] and A.shape[0] == node_off[i + 1] - node_off[i]
             acts = r.actions_all_goals()
@@ -50,11 +59,23 @@ def test_vec_env_follows_oracle_env_over_decisions():
         ex = env.status().cpu().numpy()
         dist = env.dist.cpu().numpy()
         for i, r in enumerate(refs):
+            if not alive[i]:
+                continue
+            pe, po = env.obs(i), r._sim.virtual_map()[0]
+            if not np.array_equal(pe, po):
+                knife = r._sim.knife_edge_cells(1e-9).reshape(pe.shape)
+                assert knife[pe != po].all(), "grids differ outside knife-edge cells"
+                alive[i] = False
+                continue
             assert ex[i] == r.status()
             assert dist[i] == pytest.approx(r.dist, abs=1e-12)
-            assert bool(done[i]) == r.done()
-    assert env.get_landmark_error(0) == pytest.approx(refs[0].get_landmark_error(), abs=1e-6)
-    assert env.max_uncertainty_of_trajectory(1) == pytest.approx(refs[1].max_uncertainty_of_trajectory(), rel=1e-5)
+            # done() = the reference's condition OR "within one plan of the engine's pose capacity"
+            near_full = r._sim.num_poses() + env.cfg.max_actions + 1 > env.cfg.max_poses
+            assert bool(done[i]) == (r.done() or near_full)
+    assert sum(alive) >= 3
+    k = alive.index(True)
+    assert env.get_landmark_error(k) == pytest.approx(refs[k].get_landmark_error(), abs=1e-6)
+    assert env.max_uncertainty_of_trajectory(k) == pytest.approx(refs[k].max_uncertainty_of_trajectory(), rel=1e-5)
     env.close()
 
 
@@ -73,8 +94,9 @@ def test_emexplorer_facade_single_env():
                         max_edge_length="2.0", max_nodes="0.5", occupancy_threshold="0.4", safe_distance="1.0",
                         algorithm="EM_AOPT", reg_out="false"),
     })
-    sim = EMExplorer(cp)
-    ref = O.OracleSim(O.default_config(MAP), 3, 3)
+    start = tuple(np.array(O.start_pose(3, MAP / 2 + 20)) + np.array([0.2871, -0.3179, 0.0917]))
+    sim = EMExplorer(cp, start=start)
+    ref = O.OracleSim(O.default_config(MAP), 3, 3, start=start)
     for _ in range(4):
         assert sim.simulate((1, 1, math.pi / 2)) is False
         ref.simulate((1, 1, math.pi / 2))
@@ -82,9 +104,7 @@ def test_emexplorer_facade_single_env():
     assert sim._slam.map.get_landmark_size() == ref.num_landmarks()
     assert sim._slam.key_size() == ref.key_size()
     # integer start poses leave knife-edge cells (range == max_range up to round-off): compare the others
-    mask = np.ones(ref.vm_shape(), dtype=bool)
-    for (i, j) in ref.knife_edge_cells():
-        mask[i, j] = False
+    mask = ~ref.knife_edge_cells().reshape(ref.vm_shape())
     np.testing.assert_array_equal(sim._virtual_map.to_array()[mask], ref.virtual_map()[0][mask])
     veh = sim.vehicle_position
     np.testing.assert_allclose([veh.x, veh.y, veh.theta], ref.poses()[0][-1], atol=1e-7)
