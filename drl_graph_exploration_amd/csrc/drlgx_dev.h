@@ -256,8 +256,9 @@ __device__ inline void mt_store(const MtStream &s, uint32_t *g, int lane) {
   wave_sync();
   for (int i = lane; i < DRLGX_MT_N; i += 64) g[i] = s.st[i];
   if (lane == 0) {
-    g[DRLGX_MT_N] = s.gen;
-    g[DRLGX_MT_N + 1] = s.cons;
+    const uint32_t k = (s.cons / DRLGX_MT_N) * DRLGX_MT_N;  // keep the monotonic counters small (same positions mod 624)
+    g[DRLGX_MT_N] = s.gen - k;
+    g[DRLGX_MT_N + 1] = s.cons - k;
   }
 }
 // std::mt19937(seed) state (bits/random.tcc seed()); gen = cons = 0 <=> libstdc++'s _M_p = 624
@@ -320,6 +321,56 @@ __device__ inline double mt_canonical(MtStream &s, int lane) {
   if (r >= 1.0) r = 0.99999999999999988897769753748;  // nextafter(1, 0)
   return r;
 }
+// Same recurrence, up to 192 words per call (3 per lane).  A batch of n <= 227 words that does not straddle the wrap
+// has no internal dependency: word i reads the OLD words i, i+1 and word (i+397)%624, which is old for i < 227 and was
+// renewed >= 227 words earlier otherwise.  All lanes read before any lane writes.
+__device__ inline void mt_refill_wide(MtStream &s, int lane) {
+  const uint32_t p = s.gen % DRLGX_MT_N;
+  uint32_t nvalid = DRLGX_MT_N - p;
+  if (nvalid > 192) nvalid = 192;
+  uint32_t a[3], b[3], c[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const uint32_t o = (uint32_t)lane + 64u * k, i = p + o;
+    a[k] = b[k] = c[k] = 0;
+    if (o < nvalid) {
+      a[k] = s.st[i];
+      b[k] = s.st[(i + 1) % DRLGX_MT_N];
+      c[k] = s.st[(i + 397) % DRLGX_MT_N];
+    }
+  }
+  wave_sync();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const uint32_t o = (uint32_t)lane + 64u * k, i = p + o;
+    if (o < nvalid) {
+      uint32_t y = (a[k] & 0x80000000u) | (b[k] & 0x7fffffffu);
+      s.st[i] = c[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+  }
+  wave_sync();
+  s.gen += nvalid;
+}
+// make at least n (<= 256) generated-but-unconsumed words available.  A refill overwrites outputs produced 624 words
+// earlier, all consumed because gen - cons never exceeds 255 + 192 here.
+__device__ inline void mt_ensure(MtStream &s, int lane, uint32_t n) {
+  while (s.gen - s.cons < n) mt_refill_wide(s, lane);
+}
+// tempered output word number `idx` (cons <= idx < gen) without consuming it
+__device__ inline uint32_t mt_peek(const MtStream &s, uint32_t idx) {
+  uint32_t y = s.st[idx % DRLGX_MT_N];
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+__device__ inline double mt_canonical_words(uint32_t w_lo, uint32_t w_hi) {
+  double sum = (double)w_lo + (double)w_hi * 4294967296.0;
+  double r = sum / 18446744073709551616.0;
+  if (r >= 1.0) r = 0.99999999999999988897769753748;
+  return r;
+}
 struct NormalState {
   double saved;
   int has;
@@ -340,6 +391,54 @@ __device__ inline double normal01(MtStream &s, NormalState &ns, int lane) {
   ns.saved = x * mult;
   ns.has = 1;
   return y * mult;
+}
+// The next `count` variates of std::normal_distribution<double>(0,1) on this stream, written to out[0..count)
+// (LDS, count + 1 doubles), all lanes cooperating: lane i examines candidate pair i of the Marsaglia polar loop
+// speculatively (words cons+4i .. cons+4i+3), a ballot ranks the accepted pairs, the j-th accepted pair yields variates
+// 2j (y*mult) and 2j+1 (x*mult, libstdc++'s saved value), and exactly the words up to the last pair that the sequential
+// loop would have examined are consumed.  Bit-identical to `count` successive normal01() calls.
+__device__ inline void draw_normals(MtStream &s, NormalState &ns, int count, double *out, int lane) {
+  if (count <= 0) return;
+  int offset = 0;
+  if (ns.has) {
+    if (lane == 0) out[0] = ns.saved;
+    offset = 1;
+    ns.has = 0;
+  }
+  const int R = count - offset;
+  const int Np = (R + 1) >> 1;
+  int have = 0;
+  while (have < Np) {
+    mt_ensure(s, lane, 256);
+    const uint32_t w = s.cons + 4u * (uint32_t)lane;
+    const double x = 2.0 * mt_canonical_words(mt_peek(s, w), mt_peek(s, w + 1)) - 1.0;
+    const double y = 2.0 * mt_canonical_words(mt_peek(s, w + 2), mt_peek(s, w + 3)) - 1.0;
+    const double r2 = x * x + y * y;
+    const bool acc = !(r2 > 1.0 || r2 == 0.0);
+    const unsigned long long m = __ballot(acc);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    const int j = have + rank;
+    if (acc && j < Np) {
+      const double mult = sqrt(-2 * log(r2) / r2);
+      out[offset + 2 * j] = y * mult;
+      out[offset + 2 * j + 1] = x * mult;
+    }
+    const int A = __popcll(m);
+    if (have + A >= Np) {
+      const unsigned long long last = __ballot(acc && rank == Np - have - 1);
+      const int t = __ffsll((long long)last) - 1;
+      s.cons += 4u * (uint32_t)(t + 1);
+      have = Np;
+    } else {
+      s.cons += 256u;
+      have += A;
+    }
+  }
+  wave_sync();
+  if (R & 1) {
+    ns.saved = out[count];
+    ns.has = 1;
+  }
 }
 // RNG::normal(m, std) (RNG.h:87-96)
 __device__ inline double rng_normal(MtStream &s, NormalState &ns, double m, double sd, int lane) {

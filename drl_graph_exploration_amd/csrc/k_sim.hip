@@ -1,7 +1,8 @@
 // Simulator kernels: environment reset (SS2D.__init__) and the move/measure/factor-append part of a
 // belief step.  One 64-lane wave per instance: the lanes scan the ground-truth landmarks in
-// parallel (ballot keeps libstdc++'s hash iteration order), RNG consumption is wave-uniform and
-// reproduces the reference's draw order exactly.
+// parallel (ballot keeps libstdc++'s hash iteration order); the normal variates of a measure() call are
+// produced by all lanes at once (speculative Marsaglia-polar candidates ranked by a ballot, drlgx_dev.h:
+// draw_normals) and consumed in the reference's draw order, so the RNG streams stay bit-identical.
 //
 // Reference: src/em_exploration/Simulator2D.cpp:113-132,161-182,445-464,491-527;
 // src/em_exploration/SLAM2D.cpp:44-57,70-89,103-124; scripts/envs/pyss2d.py:102-138,171-206.
@@ -20,22 +21,59 @@ struct SimCtx {
   int err;
 };
 
-// SLAM2D::addMeasurement (SLAM2D.cpp:103-124); wave-uniform, lane 0 writes.
-__device__ inline void add_measurement(SimCtx &c, int key, double bearing, double range) {
+// Simulator2D::measure (Simulator2D.cpp:505-527) + SLAM2D::addMeasurement (SLAM2D.cpp:103-124), wave-parallel.
+//  1. the in-range ground-truth landmarks are compacted in libstdc++'s hash iteration order (ballot + prefix rank);
+//  2. their 2 * n_in noise variates (bearing, range per landmark, drawn BEFORE the validity check:
+//     BearingRangeSensorModel::measure, Simulator2D.cpp:113-132) come from draw_normals in stream order;
+//  3. lane k evaluates landmark k; the valid ones are appended in order (factor index and new-landmark slot by prefix rank;
+//     a measure() call sees every key at most once, so there is no intra-call conflict).
+// `record == false` is SS2D.simulate's first measure() (obstacle logic, inert at safe_distance = 0): only the RNG advances.
+__device__ inline void measure(SimCtx &c, bool record, double *nrm, int *inr) {
   const DrlgxState &S = c.S;
+  const drlgx_config &cfg = S.cfg;
+  const double *gl = S.gt_lm + (size_t)S.parent[c.inst] * S.LG * 2;
+  const int n_gt = cfg.num_landmarks;
+  const unsigned long long below = (1ull << c.lane) - 1ull;
+  int n_in = 0;
+  for (int base = 0; base < n_gt; base += 64) {
+    const int idx = base + c.lane;
+    const bool valid = idx < n_gt;
+    const int key = valid ? S.lm_order[idx] : 0;
+    const double lx = valid ? gl[2 * key] : 0.0, ly = valid ? gl[2 * key + 1] : 0.0;
+    const double dx = lx - c.veh.x, dy = ly - c.veh.y;
+    const bool in = valid && (sqrt(dx * dx + dy * dy) < cfg.max_range);
+    const unsigned long long mask = __ballot(in);
+    if (in) inr[n_in + __popcll(mask & below)] = key;
+    n_in += __popcll(mask);
+  }
+  wave_sync();
+  draw_normals(c.sensor, c.ns_sensor, 2 * n_in, nrm, c.lane);
+  if (!record) return;
   int *key_slot = S.key_slot + (size_t)c.inst * S.LG;
-  int slot = key_slot[key];
-  if (slot < 0) {
-    if (c.L >= S.L_max) {
+  for (int base = 0; base < n_in; base += 64) {
+    const int k = base + c.lane;
+    const bool v = k < n_in;
+    const int key = v ? inr[k] : 0;
+    const P2 lm{gl[2 * key], gl[2 * key + 1]};
+    const double bn = (v ? nrm[2 * k] : 0.0) * cfg.bearing_noise + 0.0;  // RNG::normal(0, sd) = n01 * sd + 0
+    const double rn = (v ? nrm[2 * k + 1] : 0.0) * cfg.range_noise + 0.0;
+    const double bearing = bearing_of<false>(c.veh, lm, nullptr, nullptr) + bn;
+    const double range = range_of<false>(c.veh, lm, nullptr, nullptr) + rn;
+    const bool ok = v && bearing < cfg.max_bearing && bearing > cfg.min_bearing && range < cfg.max_range && range > cfg.min_range;
+    int slot = ok ? key_slot[key] : 0;
+    const bool isnew = ok && slot < 0;
+    const unsigned long long okm = __ballot(ok), newm = __ballot(isnew);
+    const int n_ok = __popcll(okm), n_new = __popcll(newm);
+    if (c.L + n_new > S.L_max || c.M + n_ok > S.M_max) {
       c.err = DRLGX_E_CAPACITY;
       return;
     }
-    slot = c.L;
-    // origin = initial estimate of the measuring pose (it is never in result_ yet)
-    const double *tp = S.th_pose + ((size_t)c.inst * S.P_max + (c.P - 1)) * 4;
-    Pose origin{tp[0], tp[1], tp[2], tp[3]};
-    P2 g = transform_from(origin, P2{range * cos(bearing), range * sin(bearing)});  // Simulator2D.cpp:95-98
-    if (c.lane == 0) {
+    if (isnew) {
+      slot = c.L + __popcll(newm & below);
+      // origin = initial estimate of the measuring pose (it is never in result_ yet)
+      const double *tp = S.th_pose + ((size_t)c.inst * S.P_max + (c.P - 1)) * 4;
+      const Pose origin{tp[0], tp[1], tp[2], tp[3]};
+      const P2 g = transform_from(origin, P2{range * cos(bearing), range * sin(bearing)});  // Simulator2D.cpp:95-98
       double *tl = S.th_lm + ((size_t)c.inst * S.L_max + slot) * 2;
       tl[0] = g.x;
       tl[1] = g.y;
@@ -45,49 +83,16 @@ __device__ inline void add_measurement(SimCtx &c, int key, double bearing, doubl
       S.lm_key[(size_t)c.inst * S.L_max + slot] = key;
       key_slot[key] = slot;
     }
-    c.L++;
-  }
-  if (c.M >= S.M_max) {
-    c.err = DRLGX_E_CAPACITY;
-    return;
-  }
-  if (c.lane == 0) {
-    S.meas_pose[(size_t)c.inst * S.M_max + c.M] = c.P - 1;
-    S.meas_lm[(size_t)c.inst * S.M_max + c.M] = slot;
-    double *br = S.meas_br + ((size_t)c.inst * S.M_max + c.M) * 2;
-    br[0] = bearing;
-    br[1] = range;
-  }
-  c.M++;
-}
-
-// Simulator2D::measure (Simulator2D.cpp:505-527)
-__device__ inline void measure(SimCtx &c, bool record) {
-  const DrlgxState &S = c.S;
-  const drlgx_config &cfg = S.cfg;
-  const double *gl = S.gt_lm + (size_t)S.parent[c.inst] * S.LG * 2;
-  const int n_gt = cfg.num_landmarks;
-  for (int base = 0; base < n_gt; base += 64) {
-    int idx = base + c.lane;
-    bool valid = idx < n_gt;
-    int key = valid ? S.lm_order[idx] : 0;
-    double lx = valid ? gl[2 * key] : 0.0, ly = valid ? gl[2 * key + 1] : 0.0;
-    double dx = lx - c.veh.x, dy = ly - c.veh.y;
-    bool in = valid && (sqrt(dx * dx + dy * dy) < cfg.max_range);
-    unsigned long long mask = __ballot(in);
-    while (mask) {
-      int b = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      int k = __shfl(key, b);
-      P2 lm{__shfl(lx, b), __shfl(ly, b)};
-      // noise is drawn BEFORE the validity check (BearingRangeSensorModel::measure, Simulator2D.cpp:113-132)
-      double bn = rng_normal(c.sensor, c.ns_sensor, 0.0, cfg.bearing_noise, c.lane);
-      double rn = rng_normal(c.sensor, c.ns_sensor, 0.0, cfg.range_noise, c.lane);
-      double bearing = bearing_of<false>(c.veh, lm, nullptr, nullptr) + bn;
-      double range = range_of<false>(c.veh, lm, nullptr, nullptr) + rn;
-      bool ok = bearing < cfg.max_bearing && bearing > cfg.min_bearing && range < cfg.max_range && range > cfg.min_range;
-      if (ok && record) add_measurement(c, k, bearing, range);
+    if (ok) {
+      const int f = c.M + __popcll(okm & below);
+      S.meas_pose[(size_t)c.inst * S.M_max + f] = c.P - 1;
+      S.meas_lm[(size_t)c.inst * S.M_max + f] = slot;
+      double *br = S.meas_br + ((size_t)c.inst * S.M_max + f) * 2;
+      br[0] = bearing;
+      br[1] = range;
     }
+    c.L += n_new;
+    c.M += n_ok;
   }
 }
 
@@ -114,6 +119,9 @@ __device__ inline void store_ctx(SimCtx &c) {
 __global__ __launch_bounds__(64) void k_reset(DrlgxState S, const int32_t *env_ids, const uint32_t *seeds,
                                               const double *start) {
   __shared__ uint32_t lds[3][DRLGX_MT_STRIDE];
+  extern __shared__ double dyn[];  // nrm[2 LG + 2] doubles, inr[LG] ints
+  double *nrm = dyn;
+  int *inr = reinterpret_cast<int *>(dyn + 2 * S.LG + 2);
   const int lane = threadIdx.x;
   const int inst = env_ids[blockIdx.x];
   const uint32_t seed = seeds[blockIdx.x];
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(64) void k_reset(DrlgxState S, const int32_t *env_i
   }
   __syncthreads();
   c.P = 1;
-  measure(c, true);  // pyss2d.py:135 self.measure()
+  measure(c, true, nrm, inr);  // pyss2d.py:135 self.measure()
   store_ctx(c);
   // VirtualMap::initialize (VirtualMap.cpp:318-362): prob 0.5, information I / sigma0^2
   const double i0 = 1.0 / pow(cfg.sigma0, 2);
@@ -181,6 +189,9 @@ __global__ __launch_bounds__(64) void k_reset(DrlgxState S, const int32_t *env_i
 __global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
                                                  int n_measure) {
   __shared__ uint32_t lds[2][DRLGX_MT_STRIDE];
+  extern __shared__ double dyn[];  // nrm[2 LG + 2] doubles, inr[LG] ints
+  double *nrm = dyn;
+  int *inr = reinterpret_cast<int *>(dyn + 2 * S.LG + 2);
   const int lane = threadIdx.x;
   const int i = blockIdx.x;
   if (!sel.on(i)) return;
@@ -210,9 +221,11 @@ __global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, co
   c.veh = Pose{gp[0], gp[1], gp[2], gp[3]};
   const Pose odomP = make_pose(ox, oy, oth);
   // SimpleControlModel::evolve (Simulator2D.cpp:161-182)
-  double xn = rng_normal(c.control, c.ns_control, 0.0, cfg.translation_noise, lane);
-  double yn = rng_normal(c.control, c.ns_control, 0.0, cfg.translation_noise, lane);
-  double tn = rng_normal(c.control, c.ns_control, 0.0, cfg.rotation_noise, lane);
+  draw_normals(c.control, c.ns_control, 3, nrm, lane);
+  const double xn = nrm[0] * cfg.translation_noise + 0.0;
+  const double yn = nrm[1] * cfg.translation_noise + 0.0;
+  const double tn = nrm[2] * cfg.rotation_noise + 0.0;
+  wave_sync();
   c.veh = compose(compose(c.veh, odomP), make_pose(xn, yn, tn));
   // SLAM2D::addOdometry (SLAM2D.cpp:70-89): initial guess = last estimate * odom
   const double *ep = S.est_pose + ((size_t)inst * S.P_max + (c.P - 1)) * 4;
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, co
   }
   __syncthreads();
   c.P += 1;
-  for (int m = 0; m < n_measure; ++m) measure(c, m == n_measure - 1);
+  for (int m = 0; m < n_measure; ++m) measure(c, m == n_measure - 1, nrm, inr);
   store_ctx(c);
 }
 
@@ -242,9 +255,11 @@ __global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, co
 
 void drlgx_launch_reset(const DrlgxState &S, hipStream_t st, int n, const int32_t *env_ids_dev,
                         const uint32_t *seeds_dev, const double *start_dev) {
-  hipLaunchKernelGGL(k_reset, dim3(n), dim3(64), 0, st, S, env_ids_dev, seeds_dev, start_dev);
+  const size_t dyn = (size_t)(2 * S.LG + 2) * sizeof(double) + (size_t)S.LG * sizeof(int);
+  hipLaunchKernelGGL(k_reset, dim3(n), dim3(64), dyn, st, S, env_ids_dev, seeds_dev, start_dev);
 }
 void drlgx_launch_sim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride,
                       int n_measure) {
-  hipLaunchKernelGGL(k_sim_step, dim3(sel.n), dim3(64), 0, st, S, sel, odom, odom_stride, n_measure);
+  const size_t dyn = (size_t)(2 * S.LG + 2) * sizeof(double) + (size_t)S.LG * sizeof(int);
+  hipLaunchKernelGGL(k_sim_step, dim3(sel.n), dim3(64), dyn, st, S, sel, odom, odom_stride, n_measure);
 }
