@@ -6,7 +6,7 @@ import os
 from .config import DrlgxConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "libdrlgx.so")
+_PATH = os.environ.get("DRLGX_LIB_DEV", os.path.join(_HERE, "libdrlgx.so"))  # DRLGX_LIB_DEV: kernel-variant experiments only
 _lib = None
 
 N_TIMERS = 8

@@ -467,6 +467,7 @@ void drlgx_launch_utility(const DrlgxState &S, hipStream_t st, const double *dis
 void drlgx_launch_line_plan(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, const double *goal,
                             double *actions, int32_t *n_actions);
 size_t drlgx_slam_lds_bytes(int P_max, int L_max, int M_max);
+bool drlgx_slam_in_lds(int P_max, int L_max, int M_max);
 void drlgx_launch_graph(const DrlgxState &S, hipStream_t st, int *gi, int gi_stride, int32_t *node_off, int32_t *edge_off,
                         float *x, int64_t *edge_index, float *edge_attr, int32_t *n_frontier, double *frontier_xy,
                         int32_t *nearest_node, int max_frontier);

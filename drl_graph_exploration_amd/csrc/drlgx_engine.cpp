@@ -277,8 +277,8 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   {
     // k_slam overflow workspace: per-factor G (6) + partials (4) + the landmark x pose table, and — only when
     // the dense system does not fit the 160 KB LDS — the padded (3P+4)^2 system and its 3-column panel
-    const bool lds = drlgx_slam_lds_bytes(S.P_max, S.L_max, S.M_max) <= 160 * 1024;
-    const size_t nd = 3 * P + 6;
+    const bool lds = drlgx_slam_in_lds(S.P_max, S.L_max, S.M_max);
+    const size_t nd = 3 * P + 16;  // >= 16 * ceil((3P + 1) / 16)
     S.slam_ws_stride = M * 12 + (L * P * 2 + 7) / 8 + 16 + (lds ? 0 : nd * nd);
     S.slam_iws_stride = 2;
     TRY(dev_alloc(e, &S.slam_ws, S.slam_ws_stride * (size_t)S.n_inst));

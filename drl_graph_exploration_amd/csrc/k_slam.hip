@@ -17,6 +17,14 @@
 // LDS: the padded (3P+1)^2 system (<= 43 poses) + panels + per-factor records; the records (and, for
 // larger capacities, the system itself) fall back to an HBM/L2 workspace.
 #include "drlgx_dev.h"
+#ifndef SWEEP_VARIANT
+#define SWEEP_VARIANT 0  // >0: timing experiments only (parts of the sweep disabled, wrong numerics)
+#endif
+#if SWEEP_VARIANT >= 7
+#define SV_BASE 4
+#else
+#define SV_BASE SWEEP_VARIANT
+#endif
 
 namespace {
 
@@ -47,9 +55,174 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return r;
 }
 
-__device__ __forceinline__ double sel3(unsigned k, double a, double b, double c) { return k == 0 ? a : (k == 1 ? b : c); }
+__device__ __forceinline__ double sel4(unsigned k, double a, double b, double c, double d) {
+  return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d));
+}
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kWaves = kThreads / 64;
 
-template <bool kLds, int NT>
+// ------------------------------------------------------------------------------------------------------------------
+// Fast sweep path (capacity N = 16 FT <= 128, i.e. <= 42 poses): FULL symmetric storage, wave w owns tile row w
+// (FT accumulator tiles), so every wave runs the same straight-line code and the pivot tile column KI is a compile-time
+// index (sweep_block<KI> is instantiated per tile column).  A scalar branch costs ~20-30 cycles on this machine and
+// the triangular tile scheme below spends most of its time in per-tile role tests; here a sweep has a handful.
+//   phase A  every wave publishes its 16 rows of the 4 pivot columns            -> barrier
+//   phase B  every lane forms one entry of nW = V E (its MFMA A operand), also published   -> barrier
+//   phase C  FT MFMAs A_Iu += nW_I V_u^T; pivot columns <- -nW; the wave owning the pivot rows overwrites them with
+//            -nW^T / E; the owner of the next pivot block inverts it (E for the next sweep)
+// ------------------------------------------------------------------------------------------------------------------
+struct SweepCtx {
+  int I, lane, lc, lr, np, N;
+  bool live;   // this wave's tile row holds real rows (I < number of 16-row blocks in use)
+  bool ewave;  // this wave inverts the pivot blocks (an idle tile row if there is one, else tile row 0)
+  double *Vb;
+  int *bad;
+};
+
+// E = -D^-1 of the 4x4 SPD pivot block at (k0, k0); lane (lr, lc) of the owning wave passes D[lr][lc - (k0 & 15)].
+// 2x2 block inversion (two reciprocals on the critical path), indices >= np act as identity.  dscr / eout: 16 doubles
+// each in LDS.
+__device__ __forceinline__ void pivot_inverse(const SweepCtx &x, int k0, double dval, double *dscr, double *eout) {
+  const int qc = k0 & 15;
+  if ((unsigned)(x.lc - qc) < 4u) dscr[4 * x.lr + (x.lc - qc)] = dval;  // dval = D[lr][lc - qc] in the lanes that hold it
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const bool m1 = k0 + 1 < x.np, m2 = k0 + 2 < x.np, m3 = k0 + 3 < x.np;
+  const double a00 = dscr[0];
+  const double a10 = m1 ? dscr[4] : 0.0, a11 = m1 ? dscr[5] : 1.0;
+  const double a20 = m2 ? dscr[8] : 0.0, a21 = (m2 && m1) ? dscr[9] : 0.0, a22 = m2 ? dscr[10] : 1.0;
+  const double a30 = m3 ? dscr[12] : 0.0, a31 = (m3 && m1) ? dscr[13] : 0.0, a32 = (m3 && m2) ? dscr[14] : 0.0;
+  const double a33 = m3 ? dscr[15] : 1.0;
+  // P = [a00 a10; a10 a11], Q = [a20 a21; a30 a31], R = [a22 a32; a32 a33]
+  const double detp = a00 * a11 - a10 * a10;
+  const double ip = fast_rcp(detp);
+  const double p00 = a11 * ip, p10 = -a10 * ip, p11 = a00 * ip;           // P^-1
+  const double t00 = a20 * p00 + a21 * p10, t01 = a20 * p10 + a21 * p11;  // T = Q P^-1
+  const double t10 = a30 * p00 + a31 * p10, t11 = a30 * p10 + a31 * p11;
+  const double s00 = a22 - (t00 * a20 + t01 * a21);                       // S = R - T Q^T
+  const double s10 = a32 - (t10 * a20 + t11 * a21);
+  const double s11 = a33 - (t10 * a30 + t11 * a31);
+  const double dets = s00 * s11 - s10 * s10;
+  const double is = fast_rcp(dets);
+  const double r00 = s11 * is, r10 = -s10 * is, r11 = s00 * is;           // S^-1
+  const double u00 = r00 * t00 + r10 * t10, u01 = r00 * t01 + r10 * t11;  // U = S^-1 T
+  const double u10 = r10 * t00 + r11 * t10, u11 = r10 * t01 + r11 * t11;
+  if (x.lane == 0 && (!(a00 > 0) || !(detp > 0) || !(s00 > 0) || !(dets > 0))) x.bad[0] = 1;
+  // D^-1 = [P^-1 + T^T U, -U^T; -U, S^-1];  E = -D^-1
+  const double e00 = -(p00 + t00 * u00 + t10 * u10), e10 = -(p10 + t01 * u00 + t11 * u10);
+  const double e11 = -(p11 + t01 * u01 + t11 * u11);
+  if (x.lane < 16) {
+    const int r = x.lane >> 2, c = x.lane & 3;
+    const int hi = max(r, c), lo = min(r, c);
+    double w;
+    if (hi < 2) w = (hi == 0) ? e00 : (lo == 0 ? e10 : e11);
+    else if (lo >= 2) w = -((lo == 3) ? r11 : (hi == 2 ? r00 : r10));
+    else w = (hi == 2) ? (lo == 0 ? u00 : u01) : (lo == 0 ? u10 : u11);
+    eout[x.lane] = w;
+  }
+}
+
+template <int KI, int FT>
+__device__ __forceinline__ void sweep_block(const SweepCtx &x, v4d (&acc)[FT], int &g) {
+  static_assert(FT == 8, "the MFMA switch below is written for 8 tile rows");
+  const int N = x.N, lc = x.lc, lr = x.lr, I = x.I;
+  const int bs = 8 * N + 32;  // per-sweep LDS buffer: planes 0-3 v, 4-7 nW, then E (16) + pivot scratch (16)
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    const int k0 = 16 * KI + 4 * q;
+    if (k0 >= x.np) return;
+    const int kc = 4 * q;
+    double *vb = x.Vb + (size_t)(g & 1) * bs;
+    double *nwb = vb + 4 * N;
+    const double *eb = vb + 8 * N;
+    const int c = lc - kc;
+    const bool mine = (unsigned)c < 4u;
+    const bool act = mine && k0 + c < x.np;
+    const bool rowact = k0 + lr < x.np;
+    const int row = 16 * I + lc;
+    // ---- phase A: panel v[c][i] = A[max(i,k0+c)][min(i,k0+c)].  Rows of tile rows >= KI come from the pivot columns of
+    //      tile (I, KI) (the diagonal tile is kept fully symmetric); rows above come from the pivot rows of tile row KI ----
+    if (SWEEP_VARIANT != 7 && SWEEP_VARIANT != 9 && x.live && I >= KI && mine) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vb[c * N + 16 * I + lr + 4 * r] = act ? acc[KI][r] : 0.0;
+    }
+    if (SWEEP_VARIANT != 7 && SWEEP_VARIANT != 9 && I == KI) {
+#pragma unroll
+      for (int u = 0; u < KI; ++u) vb[lr * N + 16 * u + lc] = rowact ? sel4(q, acc[u][0], acc[u][1], acc[u][2], acc[u][3]) : 0.0;
+    }
+    __syncthreads();
+    // ---- phase B: nW = V E: lane (lr, lc) forms nW[lr][16 I + lc], its MFMA A operand ----
+    double aop = 0.0;
+    if (SV_BASE < 3 && x.live) {
+      aop = fma(vb[3 * N + row], eb[12 + lr], fma(vb[2 * N + row], eb[8 + lr], fma(vb[N + row], eb[4 + lr], vb[row] * eb[lr])));
+      nwb[lr * N + row] = aop;
+    }
+    // The next pivot block D' = A_K'K' + nW_K' V_K'^T needs only the panels and the CURRENT values of that block: its
+    // owner publishes them (16 doubles) and a wave with little or no matrix work (x.ewave) forms and inverts D' during
+    // phase C, so that E_{g+1} is computed beside the MFMAs instead of after them.
+    const int k1 = k0 + 4, qn = (q + 1) & 3;
+    constexpr int KN = (KI + 1 < FT) ? KI + 1 : KI;
+    const int c1 = lc - 4 * qn, c1c = (unsigned)c1 < 4u ? c1 : 0;
+    double *nb = x.Vb + (size_t)((g + 1) & 1) * bs + 8 * N;  // E_{g+1} (16), then the pivot scratch (16)
+    if (SV_BASE < 1 && k1 < x.np && I == (k1 >> 4) && (unsigned)c1 < 4u) {
+      const v4d &t = (q == 3) ? acc[KN] : acc[KI];
+      nb[16 + 4 * lr + c1] = sel4(qn, t[0], t[1], t[2], t[3]);
+    }
+    __syncthreads();
+    if (SV_BASE < 1 && x.ewave && k1 < x.np) {
+      double dnext = nb[16 + 4 * lr + c1c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dnext = fma(nwb[k * N + k1 + lr], vb[k * N + k1 + c1c], dnext);
+      pivot_inverse(x, k1, dnext, nb + 16, nb);
+    }
+    // ---- phase C ----
+    if (SWEEP_VARIANT != 8 && SWEEP_VARIANT != 9 && x.live) {
+      double bop[FT], cf[4];
+#pragma unroll
+      for (int u = 0; u < FT; ++u) bop[u] = vb[lr * N + min(16 * u + lc, N - 1)];
+      const int cc = mine ? c : 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cf[r] = nwb[cc * N + 16 * I + lr + 4 * r];
+      // lower tiles u <= I, the diagonal tile first.  A skipped tile costs this wave one taken branch (~25 cycles) but
+      // no matrix-pipe time; a jump table would cost a scalar-cache miss per sweep.
+      if (SV_BASE < 4) {
+#pragma unroll
+        for (int u = FT - 1; u >= 0; --u)
+          if (u <= I) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop[u], acc[u], 0, 0, 0);
+      }
+      if (SV_BASE < 2 && I >= KI) {  // pivot columns: A_iK <- A_iK D^-1 = -nW
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[KI][r] = act ? -cf[r] : acc[KI][r];
+      }
+      if (SV_BASE < 2 && I == KI) {
+        // pivot rows (rows k0 + lr live in reg q): A_Kj <- (A_jK D^-1)^T = -nW^T, pivot block <- E = -D^-1
+        double val[KI + 1];
+#pragma unroll
+        for (int u = 0; u <= KI; ++u) val[u] = -nwb[lr * N + 16 * u + lc];
+        const double pv = eb[4 * lr + cc];
+        if (act) val[KI] = pv;
+#pragma unroll
+        for (int u = 0; u <= KI; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[u][r] = (rowact && r == q) ? val[u] : acc[u][r];
+      }
+    }
+    ++g;
+  }
+}
+
+template <int FT, int KI = 0>
+__device__ __forceinline__ void sweep_all(const SweepCtx &x, v4d (&acc)[FT], int &g) {
+  if constexpr (KI < FT) {
+    if (16 * KI < x.np) {
+      sweep_block<KI, FT>(x, acc, g);
+      sweep_all<FT, KI + 1>(x, acc, g);
+    }
+  }
+}
+
+template <bool kLds, int NTW, int FT>
 __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, int lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
@@ -63,8 +236,9 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
   const int n_old_p = cnt[C_NEWP], n_old_l = cnt[C_NEWL];
   const int count = cnt[C_ISAM] + 1;
   const int np = 3 * P, na = np + 1;
-  // padded to 6x6 tiles = 2x2 pose blocks; block P holds the rhs row (its other rows and all pad rows stay zero)
-  const int Tn = (P + 2) / 2, n6 = 6 * Tn, ld = n6;
+  // padded to 16x16 MFMA tiles; row np holds the rhs (its column and all pad rows / columns stay zero)
+  // fast path: rows padded by 2 doubles against LDS bank conflicts
+  const int Tn = (na + 15) / 16, N = 16 * Tn, ld = FT > 0 ? N + 2 : N;
   const int ntiles = Tn * (Tn + 1) / 2;
   DRLGX_PROF(S, 0);
 
@@ -78,13 +252,13 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
   unsigned short *ml = reinterpret_cast<unsigned short *>(smem_raw + off); off += up8((size_t)M * 2);
   int *bad = reinterpret_cast<int *>(smem_raw + off); off += 8;
   off = (off + 31) & ~(size_t)31;
-  double *Vb = reinterpret_cast<double *>(smem_raw + off); off += (size_t)2 * 3 * n6 * 8;  // 2 buffers x 3 planes
+  double *Vb = reinterpret_cast<double *>(smem_raw + off); off += (size_t)2 * (8 * N + 32) * 8;  // 2 buffers x (4 planes v, 4 planes v E, E, pivot scratch)
   double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
   double *A;
   if (kLds) {
-    A = reinterpret_cast<double *>(smem_raw + off); off += (size_t)n6 * ld * 8;
+    A = reinterpret_cast<double *>(smem_raw + off); off += (size_t)N * ld * 8;
   } else {
-    A = wsd; wsd += (size_t)(3 * S.P_max + 6) * (3 * S.P_max + 6);
+    A = wsd; wsd += (size_t)(3 * S.P_max + 16) * (3 * S.P_max + 16);
   }
   // per-factor records and the landmark x pose observation table: LDS if they fit
   const size_t big = (size_t)M * REC * 8 + up8((size_t)L * P * 2);
@@ -133,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
   // ---- 2. clear the system; factor tables (factors are appended in pose order: contiguous ranges) ----
   {
     double2 *A2 = reinterpret_cast<double2 *>(A);
-    const int n2 = n6 * ld / 2;
+    const int n2 = N * ld / 2;
     for (int e = tid; e < n2; e += kThreads) A2[e] = make_double2(0.0, 0.0);
   }
   for (int e = tid; e < L * P; e += kThreads) obs[e] = 0;
@@ -308,15 +482,52 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
   }
   __syncthreads();
   DRLGX_PROF(S, 4);
-  // ---- 5. block symmetric sweep (3x3 pose pivots) on register-resident 6x6 tiles (2x2 pose blocks) ----
-  //         tiles are aligned with the pose blocks, so a pivot row/column is always a whole 3x3 sub-block
-  {
-    int ti0[NT], tj0[NT];
-    bool live[NT];
-    double a[NT][6][6];
+  if constexpr (FT > 0) {
+    // ---- 5a. fast path: full symmetric storage, one tile row per wave (see sweep_block) ----
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // tile rows r and FT-1-r share a SIMD (waves w and w+4): lower-triangle MFMA work is balanced across the SIMDs
+    const int trow = wv < FT / 2 ? wv : (FT - 1) - (wv - FT / 2);
+    SweepCtx x{trow, lane, lane & 15, lane >> 4, np, N, trow < Tn, trow == (Tn < FT ? FT - 1 : 0), Vb, bad};
+    v4d acc[FT];
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      const int t = tid + u * kThreads;
+    for (int u = 0; u < FT; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * x.I + x.lr + 4 * r, j = 16 * u + x.lc;
+        acc[u][r] = (i < N && j < N) ? A[max(i, j) * ld + min(i, j)] : 0.0;
+      }
+    if (x.I == 0) pivot_inverse(x, 0, acc[0][0], Vb + 8 * N + 16, Vb + 8 * N);
+    int g = 0;
+    sweep_all<FT>(x, acc, g);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < FT; ++u) {
+      if (u > x.I) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * x.I + x.lr + 4 * r, j = 16 * u + x.lc;
+        if (j <= i && i < N) A[i * ld + j] = acc[u][r];
+      }
+    }
+  } else
+  // ---- 5. block symmetric sweep with 4-wide pivot groups on the fp64 matrix cores ----
+  // The lower triangle (+ full diagonal tiles) of the N x N system lives in v_mfma_f64_16x16x4_f64 accumulator tiles
+  // (C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg), NTW tiles per wave, for all sweeps.  Sweep g pivots on
+  // indices K = [4g, 4g+4) (those >= np - the rhs row and the pads - are masked out of the pivot):
+  //   panel   v[c][i] = A[max(i,k0+c)][min(i,k0+c)]  -> LDS, double buffered: ONE barrier per sweep
+  //   E = -D^-1 of the 4x4 pivot block by LDL^T (redundantly in every lane, broadcast LDS reads)
+  //   every tile: A_IJ += (V_I E) V_J^T, one MFMA (A operand = row k of V_I E, B operand = V_J^T)
+  //   then the entries in pivot rows / columns are overwritten with their exact sweep values.
+  {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave-uniform tile bookkeeping (SGPRs)
+    const int lc = lane & 15, lr = lane >> 4;
+    v4d acc[NTW];
+    int tI[NTW], tJ[NTW];
+    bool live[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+      const int t = wave + kWaves * u;
       live[u] = t < ntiles;
       int ib = 0, jb = 0;
       if (live[u]) {
@@ -325,125 +536,158 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
         while (ib * (ib + 1) / 2 > t) --ib;
         jb = t - ib * (ib + 1) / 2;
       }
-      ti0[u] = ib * 6;
-      tj0[u] = jb * 6;
+      tI[u] = ib;
+      tJ[u] = jb;
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          // diagonal 3x3 blocks are stored lower-only in LDS: mirror them so the tile is symmetric
-          const bool mirror = (ib == jb) && (r / 3 == c / 3) && (c > r);
-          const int rr = mirror ? c : r, cc = mirror ? r : c;
-          a[u][r][c] = live[u] ? A[(ti0[u] + rr) * ld + tj0[u] + cc] : 0.0;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ib + lr + 4 * r, j = 16 * jb + lc;
+        acc[u][r] = live[u] ? A[max(i, j) * ld + min(i, j)] : 0.0;
+      }
     }
-    for (int kb = 0; kb < P; ++kb) {
-      const int k0 = 3 * kb;
-      // planes vb[c * n6 + i] = A[max(i,k0+c)][min(i,k0+c)].  Every tile first takes the uniform rank-3 update
-      // A_ij -= (v_i D^-1) . v_j (pure fma chain, no predication); the few 3x3 sub-blocks that lie in the pivot
-      // row / column are then overwritten with their exact sweep values.  (Publishing D - I for the pivot rows
-      // would make the uniform formula produce those values by itself, but it cancels D-sized terms to get
-      // D^-1-sized results — 4 % error on the 3e7 prior block — so it is not used.)
-      double *vb = Vb + (size_t)(kb & 1) * 3 * n6;
+    const int G = (np + 3) >> 2;
+    // E_g = -D_g^-1 of the 4x4 SPD pivot block of group g, by the wave that holds the diagonal tile, from its
+    // accumulators via a 16-double LDS scratch (2x2 block inversion: two reciprocals on the critical path instead of
+    // four; indices >= np act as identity).  Written to `eout` (16 doubles, row major).
+    auto pivot_inverse = [&](int gq, const v4d &t, double *dscr, double *eout) {
+      const int q0i = 4 * gq, qc = q0i & 15, qr = qc >> 2;
+      const double x = sel4(qr, t[0], t[1], t[2], t[3]);   // rows q0i + lr, column 16 KI + lc
+      if ((unsigned)(lc - qc) < 4u) dscr[4 * lr + (lc - qc)] = x;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const bool m1 = q0i + 1 < np, m2 = q0i + 2 < np, m3 = q0i + 3 < np;
+      const double a00 = dscr[0];
+      const double a10 = m1 ? dscr[4] : 0.0, a11 = m1 ? dscr[5] : 1.0;
+      const double a20 = m2 ? dscr[8] : 0.0, a21 = (m2 && m1) ? dscr[9] : 0.0, a22 = m2 ? dscr[10] : 1.0;
+      const double a30 = m3 ? dscr[12] : 0.0, a31 = (m3 && m1) ? dscr[13] : 0.0, a32 = (m3 && m2) ? dscr[14] : 0.0;
+      const double a33 = m3 ? dscr[15] : 1.0;
+      // P = [a00 a10; a10 a11], Q = [a20 a21; a30 a31], R = [a22 a32; a32 a33]
+      const double detp = a00 * a11 - a10 * a10;
+      const double ip = fast_rcp(detp);
+      const double p00 = a11 * ip, p10 = -a10 * ip, p11 = a00 * ip;           // P^-1
+      const double t00 = a20 * p00 + a21 * p10, t01 = a20 * p10 + a21 * p11;  // T = Q P^-1
+      const double t10 = a30 * p00 + a31 * p10, t11 = a30 * p10 + a31 * p11;
+      const double s00 = a22 - (t00 * a20 + t01 * a21);                       // S = R - T Q^T
+      const double s10 = a32 - (t10 * a20 + t11 * a21);
+      const double s11 = a33 - (t10 * a30 + t11 * a31);
+      const double dets = s00 * s11 - s10 * s10;
+      const double is = fast_rcp(dets);
+      const double r00 = s11 * is, r10 = -s10 * is, r11 = s00 * is;           // S^-1
+      const double u00 = r00 * t00 + r10 * t10, u01 = r00 * t01 + r10 * t11;  // U = S^-1 T
+      const double u10 = r10 * t00 + r11 * t10, u11 = r10 * t01 + r11 * t11;
+      if (lane == 0 && (!(a00 > 0) || !(detp > 0) || !(s00 > 0) || !(dets > 0))) bad[0] = 1;
+      // D^-1 = [P^-1 + T^T U, -U^T; -U, S^-1];  E = -D^-1
+      const double e00 = -(p00 + t00 * u00 + t10 * u10), e10 = -(p10 + t01 * u00 + t11 * u10);
+      const double e11 = -(p11 + t01 * u01 + t11 * u11);
+      if (lane < 16) {
+        const int r = lane >> 2, c = lane & 3;
+        const int hi = max(r, c), lo = min(r, c);
+        double v;
+        if (hi < 2) v = (hi == 0) ? e00 : (lo == 0 ? e10 : e11);
+        else if (lo >= 2) v = -((lo == 3) ? r11 : (hi == 2 ? r00 : r10));
+        else v = (hi == 2) ? (lo == 0 ? u00 : u01) : (lo == 0 ? u10 : u11);
+        eout[lane] = v;
+      }
+    };
+    // E_0 before the first sweep
 #pragma unroll
-      for (int u = 0; u < NT; ++u) {
+    for (int u = 0; u < NTW; ++u)
+      if (live[u] && tI[u] == 0 && tJ[u] == 0) pivot_inverse(0, acc[u], Vb + 8 * N + 16, Vb + 8 * N);
+    for (int g = 0; g < G; ++g) {
+      const int k0 = 4 * g, KI = k0 >> 4, kc = k0 & 15, rg = kc >> 2;
+      double *vb = Vb + (size_t)(g & 1) * (8 * N + 32);  // planes 0-3: v, planes 4-7: nW = v E, then E (16) + scratch (16)
+      double *nwb = vb + 4 * N;
+      const double *eb = vb + 8 * N;
+      // ---- phase A: publish the pivot panel v[c][i] = A[max(i,k0+c)][min(i,k0+c)] ----
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) {
         if (!live[u]) continue;
-        const int bi0 = ti0[u] / 3, bj0 = tj0[u] / 3;
+        if (tJ[u] == KI && (unsigned)(lc - kc) < 4u) {  // pivot columns, rows at or below the pivot index
+          const int c = lc - kc, kk = k0 + c;
 #pragma unroll
-        for (int sr = 0; sr < 2; ++sr)
-#pragma unroll
-          for (int sc = 0; sc < 2; ++sc) {
-            const int bi = bi0 + sr, bj = bj0 + sc;
-            if (bj > bi) continue;
-            if (bj == kb) {  // column block K, rows of block bi >= kb:  v_i[c] = A[i][k0+c]
-#pragma unroll
-              for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) vb[c * n6 + 3 * bi + r] = a[u][3 * sr + r][3 * sc + c];
-            } else if (bi == kb) {  // row block K, columns of block bj < kb:  v_j[r] = A[k0+r][j]
-#pragma unroll
-              for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) vb[r * n6 + 3 * bj + c] = a[u][3 * sr + r][3 * sc + c];
-            }
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * tI[u] + lr + 4 * r;
+            if (i >= kk) vb[c * N + i] = (kk < np) ? acc[u][r] : 0.0;
           }
+        }
+        if (tI[u] == KI) {  // pivot rows, columns left of the pivot index (transposed part)
+          const int kk = k0 + lr, j = 16 * tJ[u] + lc;
+          const double x = sel4(rg, acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+          if (j < kk) vb[lr * N + j] = (kk < np) ? x : 0.0;
+        }
       }
       __syncthreads();
-      // D^-1 of the SPD pivot block by LDL^T, redundantly in every thread (broadcast LDS reads)
-      const double a00 = vb[k0], a10 = vb[k0 + 1], a20 = vb[k0 + 2];
-      const double a11 = vb[n6 + k0 + 1], a21 = vb[n6 + k0 + 2], a22 = vb[2 * n6 + k0 + 2];
-      const double q0 = fast_rcp(a00);
-      const double l10 = a10 * q0, l20 = a20 * q0;
-      const double d1 = a11 - l10 * a10;
-      const double q1 = fast_rcp(d1);
-      const double u21 = a21 - l20 * a10;
-      const double l21 = u21 * q1;
-      const double d2 = a22 - l20 * a20 - l21 * u21;
-      const double q2 = fast_rcp(d2);
-      if (tid == 0 && (!(a00 > 0) || !(d1 > 0) || !(d2 > 0))) bad[0] = 1;
-      const double m20 = l10 * l21 - l20;
-      // negated D^-1 so that the update is a pure fma chain
-      const double e00 = -(q0 + l10 * l10 * q1 + m20 * m20 * q2);
-      const double e10 = l10 * q1 + m20 * l21 * q2;
-      const double e11 = -(q1 + l21 * l21 * q2);
-      const double e20 = -(m20 * q2), e21 = l21 * q2, e22 = -q2;
+      // ---- phase B: nW = V E (4 planes; E_g was produced during the previous sweep) ----
+      for (int e = tid; e < 4 * N; e += kThreads) {
+        const int k = e / N, i = e - k * N;
+        nwb[e] = fma(vb[3 * N + i], eb[12 + k], fma(vb[2 * N + i], eb[8 + k], fma(vb[N + i], eb[4 + k], vb[i] * eb[k])));
+      }
+      __syncthreads();
+      // ---- phase C: every tile A_IJ += nW_I V_J^T (one MFMA each, operands fetched up front so the MFMAs issue back
+      //      to back), then the exact values of the pivot rows / columns; the owner of the next pivot's diagonal tile
+      //      inverts that block right away (off the other waves' critical path) ----
+      double aop[NTW], bop[NTW];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) {
+      for (int u = 0; u < NTW; ++u) {
+        aop[u] = live[u] ? nwb[lr * N + 16 * tI[u] + lc] : 0.0;
+        bop[u] = live[u] ? vb[lr * N + 16 * tJ[u] + lc] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < NTW; ++u)
+        if (live[u]) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[u], bop[u], acc[u], 0, 0, 0);
+      const int k1 = k0 + 4, KI1 = k1 >> 4;
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) {
         if (!live[u]) continue;
-        const int i0 = ti0[u], j0 = tj0[u];
-        double nT[6][3], vj[6][3];  // nT = -(v_i D^-1)
+        const int I = tI[u], J = tJ[u];
+        if (J == KI) {  // tile holds the pivot columns: A_iK <- A_iK D^-1 = -nW (diagonal tile: rows at/below the pivot)
+          const int c = lc - kc;
+          const bool mine = (unsigned)c < 4u && k0 + c < np;
+          const int cc = mine ? c : 0;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          const double x = vb[i0 + r], y = vb[n6 + i0 + r], z = vb[2 * n6 + i0 + r];
-          nT[r][0] = fma(z, e20, fma(y, e10, x * e00));
-          nT[r][1] = fma(z, e21, fma(y, e11, x * e10));
-          nT[r][2] = fma(z, e22, fma(y, e21, x * e20));
-          vj[r][0] = vb[j0 + r]; vj[r][1] = vb[n6 + j0 + r]; vj[r][2] = vb[2 * n6 + j0 + r];
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-          for (int c = 0; c < 6; ++c)
-            a[u][r][c] = fma(nT[r][2], vj[c][2], fma(nT[r][1], vj[c][1], fma(nT[r][0], vj[c][0], a[u][r][c])));
-        const int bi0 = i0 / 3, bj0 = j0 / 3;
-        if ((unsigned)(kb - bi0) < 2u || (unsigned)(kb - bj0) < 2u) {  // exact values for pivot row / column blocks
-#pragma unroll
-          for (int sr = 0; sr < 2; ++sr)
-#pragma unroll
-            for (int sc = 0; sc < 2; ++sc) {
-              const int bi = bi0 + sr, bj = bj0 + sc;
-              if (bi == kb && bj == kb) {  // A_KK <- -D^-1
-                a[u][3 * sr + 0][3 * sc + 0] = e00; a[u][3 * sr + 0][3 * sc + 1] = e10; a[u][3 * sr + 0][3 * sc + 2] = e20;
-                a[u][3 * sr + 1][3 * sc + 0] = e10; a[u][3 * sr + 1][3 * sc + 1] = e11; a[u][3 * sr + 1][3 * sc + 2] = e21;
-                a[u][3 * sr + 2][3 * sc + 0] = e20; a[u][3 * sr + 2][3 * sc + 1] = e21; a[u][3 * sr + 2][3 * sc + 2] = e22;
-              } else if (bj == kb) {  // A_iK <- A_iK D^-1
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                  for (int c = 0; c < 3; ++c) a[u][3 * sr + r][3 * sc + c] = -nT[3 * sr + r][c];
-              } else if (bi == kb) {  // A_Kj <- (A_jK D^-1)^T
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                  const double x = vj[3 * sc + c][0], y = vj[3 * sc + c][1], z = vj[3 * sc + c][2];
-                  a[u][3 * sr + 0][3 * sc + c] = -fma(z, e20, fma(y, e10, x * e00));
-                  a[u][3 * sr + 1][3 * sc + c] = -fma(z, e21, fma(y, e11, x * e10));
-                  a[u][3 * sr + 2][3 * sc + c] = -fma(z, e22, fma(y, e21, x * e20));
-                }
-              }
+          for (int r = 0; r < 4; ++r) {
+            if (I == KI && r < rg) continue;
+            const double val = -nwb[cc * N + 16 * I + lr + 4 * r];
+            if (mine) acc[u][r] = val;
+          }
+          if (I == KI) {  // the pivot block itself (rows k0 + lr live in reg rg): A_KK <- -D^-1
+            const double pv = eb[4 * lr + cc];
+            const bool pm = mine && k0 + lr < np;
+            switch (rg) {
+              case 0: if (pm) acc[u][0] = pv; break;
+              case 1: if (pm) acc[u][1] = pv; break;
+              case 2: if (pm) acc[u][2] = pv; break;
+              default: if (pm) acc[u][3] = pv; break;
             }
+          }
+        }
+        if (I == KI) {  // pivot rows: A_Kj <- (A_jK D^-1)^T for the columns left of the pivot
+          const int j = 16 * J + lc;
+          const double val = -nwb[lr * N + j];
+          const bool pm = j < k0 && k0 + lr < np;
+          switch (rg) {
+            case 0: if (pm) acc[u][0] = val; break;
+            case 1: if (pm) acc[u][1] = val; break;
+            case 2: if (pm) acc[u][2] = val; break;
+            default: if (pm) acc[u][3] = val; break;
+          }
+        }
+        if (g + 1 < G && I == KI1 && J == KI1) {
+          double *nb = Vb + (size_t)((g + 1) & 1) * (8 * N + 32) + 8 * N;
+          pivot_inverse(g + 1, acc[u], nb + 16, nb);
         }
       }
     }
     __syncthreads();
     // write the tiles back: lower triangle = -S^-1, row np = delta_p
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
+    for (int u = 0; u < NTW; ++u) {
       if (!live[u]) continue;
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c)
-          if (tj0[u] + c <= ti0[u] + r) A[(ti0[u] + r) * ld + tj0[u] + c] = a[u][r][c];
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * tI[u] + lr + 4 * r, j = 16 * tJ[u] + lc;
+        if (j <= i) A[i * ld + j] = acc[u][r];
+      }
     }
   }
   __syncthreads();
@@ -538,43 +782,52 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
 
 constexpr int kLdsBudget = 160 * 1024;
 
-// LDS needed by the always-resident small arrays + panels at full capacity
-size_t slam_small_bytes(int P_max, int L_max, int M_max) {
-  const size_t n6 = 6 * (((size_t)P_max + 2) / 2);
-  return (size_t)P_max * 32 + (size_t)L_max * 16 + (size_t)L_max * 64 + (size_t)(P_max + 2) * 4 + (size_t)M_max * 4 + 6 * n6 * 8 +
-         128;
+// LDS needed by the always-resident small arrays + panels for an N x N system
+size_t slam_dim(int P_max) { return 16 * (((size_t)3 * P_max + 1 + 15) / 16); }
+size_t slam_small_bytes_n(size_t N, int P_max, int L_max, int M_max) {
+  return (size_t)P_max * 32 + (size_t)L_max * 16 + (size_t)L_max * 64 + (size_t)(P_max + 2) * 4 + (size_t)M_max * 4 +
+         2 * (8 * N + 32) * 8 + 128;
 }
+size_t slam_small_bytes(int P_max, int L_max, int M_max) { return slam_small_bytes_n(slam_dim(P_max), P_max, L_max, M_max); }
+constexpr int kFastTiles = 8;  // fast path: N = 128 (<= 42 poses), system + panels in LDS
 
 }  // namespace
 
 size_t drlgx_slam_lds_bytes(int P_max, int L_max, int M_max) {
-  const size_t n6 = 6 * (((size_t)P_max + 2) / 2);
-  return slam_small_bytes(P_max, L_max, M_max) + n6 * n6 * 8;
+  const size_t N = slam_dim(P_max);
+  return slam_small_bytes(P_max, L_max, M_max) + N * N * 8;
+}
+
+// true when k_slam keeps the dense system in LDS (the fast path); otherwise the engine must provide the HBM workspace
+bool drlgx_slam_in_lds(int P_max, int L_max, int M_max) {
+  const size_t nf = 16 * kFastTiles;
+  return slam_dim(P_max) <= nf && slam_small_bytes_n(nf, P_max, L_max, M_max) + nf * (nf + 2) * 8 <= (size_t)kLdsBudget;
 }
 
 void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
-  const size_t need = drlgx_slam_lds_bytes(S.P_max, S.L_max, S.M_max);
-  const int Tn = (S.P_max + 2) / 2, ntiles = Tn * (Tn + 1) / 2;
+  const int Tn = (int)(slam_dim(S.P_max) / 16), ntiles = Tn * (Tn + 1) / 2;
   static bool attr_set = false;
   if (!attr_set) {
-    const void *fns[] = {reinterpret_cast<const void *>(&k_slam<true, 1>), reinterpret_cast<const void *>(&k_slam<false, 1>),
-                         reinterpret_cast<const void *>(&k_slam<false, 2>)};
-    for (const void *f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+    const void *fns[] = {reinterpret_cast<const void *>(&k_slam<true, 1, kFastTiles>),
+                         reinterpret_cast<const void *>(&k_slam<false, 10, 0>),
+                         reinterpret_cast<const void *>(&k_slam<false, 20, 0>)};
+    for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
     attr_set = true;
   }
-  if (need <= (size_t)kLdsBudget && ntiles <= kThreads) {
-    // whole LDS: whatever is left after the dense system holds the per-factor records
-    hipLaunchKernelGGL((k_slam<true, 1>), dim3(sel.n), dim3(kThreads), kLdsBudget, st, S, sel, kLdsBudget);
+  if (drlgx_slam_in_lds(S.P_max, S.L_max, S.M_max)) {
+    // fast path: the kernel always works on the full 128 x 128 capacity; whatever LDS is left holds the factor records
+    hipLaunchKernelGGL((k_slam<true, 1, kFastTiles>), dim3(sel.n), dim3(kThreads), kLdsBudget, st, S, sel, kLdsBudget);
   } else {
-    // dense system in the HBM/L2 workspace; <= 60 poses: one register tile per thread, <= 86: two (spills)
+    // dense system in the HBM/L2 workspace, triangular tile scheme with the accumulator tiles in registers:
+    // <= 58 poses: 10 tiles per wave, <= 86 poses: 20 tiles per wave
     const size_t small = slam_small_bytes(S.P_max, S.L_max, S.M_max);
-    if (small > (size_t)kLdsBudget || ntiles > 2 * kThreads) {
-      hipMemsetAsync(S.status, 0xff, sizeof(int), st);  // capacity beyond this kernel: flag an error (-1)
+    if (small > (size_t)kLdsBudget || ntiles > 20 * kWaves) {
+      (void)hipMemsetAsync(S.status, 0xff, sizeof(int), st);  // capacity beyond this kernel: flag an error (-1)
       return;
     }
-    if (ntiles <= kThreads)
-      hipLaunchKernelGGL((k_slam<false, 1>), dim3(sel.n), dim3(kThreads), small, st, S, sel, (int)small);
+    if (ntiles <= 10 * kWaves)
+      hipLaunchKernelGGL((k_slam<false, 10, 0>), dim3(sel.n), dim3(kThreads), small, st, S, sel, (int)small);
     else
-      hipLaunchKernelGGL((k_slam<false, 2>), dim3(sel.n), dim3(kThreads), small, st, S, sel, (int)small);
+      hipLaunchKernelGGL((k_slam<false, 20, 0>), dim3(sel.n), dim3(kThreads), small, st, S, sel, (int)small);
   }
 }

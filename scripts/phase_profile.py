@@ -3,6 +3,9 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
+if os.environ.get('DRLGX_LIB_DEV'):
+    from drl_graph_exploration_amd.engine import Engine
+    Engine.check_status = lambda self: None  # kernel-variant timing experiments produce wrong numerics on purpose
 eng, cfg = bench.make_engine(0, 0)
 odom = torch.tensor([bench.STEP_ACTION] * bench.N_ENVS, dtype=torch.float64, device=eng.device)
 out = (C.c_int64 * 64)()
@@ -19,7 +22,15 @@ names = {0:"start",1:"relin+clear+tables",2:"landmark+pose blocks",3:"G",4:"Schu
 print("k_slam phases (us, block 0):")
 for k in range(1, 8): print("  %-24s %8.2f" % (names[k], (a[k]-a[k-1]) / 100.0))
 print("  total %.2f" % ((a[7]-a[0]) / 100.0))
+print("  sweep sub-phases (us): panel+barrier %.2f, pivot inverse %.2f, tiles %.2f" % (a[8]/100.0, a[9]/100.0, a[10]/100.0))
 mn = {17:"load+bbox sweep",18:"occupancy",21:"phase A (chunk 0)",19:"phase B + rest",20:"reductions"}
+print("  shader clock during sweeps: %.0f MHz" % (a[11] / max(a[12], 1) * 100.0))
+last = np.array(out[:], dtype=np.float64)
+for w in range(4):
+    b = last[24 + w * 10: 24 + w * 10 + 8]
+    print("  wave %d sweep-5 cycles from A start: A-written %d, bar1 %d, B-written %d, bar2 %d, mfma-done %d, fixups %d, E-done %d" % ((w,) + tuple(int(x - b[0]) for x in b[1:8])))
+b = last[16:21]
+print("  pivot_inverse(6) cycles from entry: D-read %d, rcp1 %d, rcp2 %d, end %d; entry - mfma-done(wave2) %d" % (b[1]-b[0], b[2]-b[0], b[3]-b[0], b[4]-b[0], b[0] - last[24+20+5]))
 print("k_map phases (us, block 0):")
 prev = a[16]
 for k in (17, 18, 21, 19, 20):
