@@ -26,7 +26,6 @@ namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
-constexpr int kChunk = 32;  // poses per LDS stage
 
 __device__ __forceinline__ double logodds2prob(double l) { return exp(l) / (1.0 + exp(l)); }
 
@@ -42,6 +41,7 @@ __device__ __forceinline__ bool in_fov(const DrlgxState &S, const Pose &ps, cons
 }
 
 // VirtualMap::predictVirtualLandmark (VirtualMap.cpp:213-229). info: symmetric xx xy xt yy yt tt.
+template <bool kCheckFov>
 __device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps, const double *pi, const P2 &pt,
                                              double &oxx, double &oxy, double &oyy) {
   const drlgx_config &cfg = S.cfg;
@@ -53,7 +53,7 @@ __device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps
   const double g2 = gx * gx + gy * gy;
   // range < max_range && range > min_range, decided exactly on the squared distance (host-computed thresholds)
   if (!(g2 < S.r2_max_lt && g2 > S.r2_min_gt)) return false;
-  if (!in_fov(S, ps, pt)) return false;
+  if (kCheckFov && !in_fov(S, ps, pt)) return false;
   const double range = sqrt(g2);
   double Hbx[3], Hbl[2], Hrx[3], Hrl[2];
   if (fabs(n) > 1e-5) {
@@ -151,7 +151,7 @@ __device__ __forceinline__ double block_sum(double v, double *scratch, int tid) 
   return s;
 }
 
-__global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, int rebuild) {
+__global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, int rebuild, int chunk) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bi = blockIdx.x;
@@ -166,18 +166,21 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
   double *sp = smem;                       // [P_max][4]
   double *si = sp + (size_t)S.P_max * 4;   // [P_max][6]
   double *sl = si + (size_t)S.P_max * 6;   // [P_max][9] LLT factor of the pose information + reciprocals
-  double *stage = sl + (size_t)S.P_max * 9;  // [kChunk][64][3]
-  double *scratch = stage + (size_t)kChunk * 64 * 3;  // [kWaves]
+  double *stage = sl + (size_t)S.P_max * 9;  // [chunk][64][3]
+  unsigned long long *mask = reinterpret_cast<unsigned long long *>(stage + (size_t)chunk * 64 * 3);  // [V]
+  unsigned long long *omask = mask + V;  // [V] poses that see the cell (occupancy ladder)
+  double *scratch = reinterpret_cast<double *>(omask + V);  // [kWaves]
   int *bbox = reinterpret_cast<int *>(scratch + kWaves);  // [P_max][4] min_row max_row min_col max_col
   int *worg = bbox + (size_t)S.P_max * 4;             // [P_max][2] window origin row, col
   int *pskip = worg + (size_t)S.P_max * 2;            // [P_max]
-  int *lmcell = pskip + S.P_max;                      // [L_max]
+  int *lmc = pskip + S.P_max;                         // [V] estimated landmarks per cell
   double *prob = S.vm_prob + (size_t)inst * V;
   double *ixx = S.vm_info + ((size_t)inst * 3 + 0) * V, *ixy = S.vm_info + ((size_t)inst * 3 + 1) * V,
          *iyy = S.vm_info + ((size_t)inst * 3 + 2) * V;
   uint8_t *upd = S.vm_upd + (size_t)inst * S.Vu;
   double *vtr = S.vm_tr + (size_t)inst * V;
 
+  double utr = 0, known = 0, expl = 0, udet = 0, uwtr = 0;
   DRLGX_PROF(S, 16);
   if (rebuild) {
     const double *ep = S.est_pose + (size_t)inst * S.P_max * 4;
@@ -185,11 +188,13 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
     for (int e = tid; e < P * 4; e += kThreads) sp[e] = ep[e];
     for (int e = tid; e < P * 6; e += kThreads) si[e] = pin[e];
     const double *el = S.est_lm + (size_t)inst * S.L_max * 2;
+    for (int v = tid; v < V; v += kThreads) lmc[v] = 0;
+    __syncthreads();
     for (int j = tid; j < L; j += kThreads) {
-      // OccupancyMap::update(map): landmark cell (OccupancyMap.cpp:127-131)
+      // OccupancyMap::update(map): landmark cell (OccupancyMap.cpp:127-131); every landmark in a cell is one occupied update
       int r = (int)floor((el[2 * j + 1] - cfg.map_min_y) / cfg.resolution);
       int c = (int)floor((el[2 * j] - cfg.map_min_x) / cfg.resolution);
-      lmcell[j] = (r >= rows || r < 0 || c >= cols || c < 0) ? -1 : r * cols + c;
+      if (!(r >= rows || r < 0 || c >= cols || c < 0)) atomicAdd(&lmc[r * cols + c], 1);
     }
     __syncthreads();
     for (int p = tid; p < P; p += kThreads) {
@@ -233,42 +238,26 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
       __syncthreads();
     }
     DRLGX_PROF(S, 17);
-    // ---- phase O: occupancy ladder per cell, poses in trajectory order ----
+    // ---- phases A / C, `chunk` poses at a time (one chunk unless P > 64 or the stage does not fit the LDS) ----
+    // A (pose-centric): one wave per pose, one lane per cell of the W x W window around the pose: EKF push-through of the
+    //    pose covariance to the cell (predict_cell); the 2x2 information goes to the LDS stage and the pose's bit is set in
+    //    the cell's 64-bit mask (LDS atomic), so that
+    // C (cell-centric) visits exactly the poses that update a cell, in trajectory order (ascending bits), for the
+    //    covariance-intersection fusion - instead of testing every (cell, pose) pair.  The last chunk's C pass also runs
+    //    the occupancy ladder (branch-free over the poses), writes the cell and accumulates the reductions: every cell is
+    //    read and written once per belief update.
     const double i0 = 1.0 / pow(cfg.sigma0, 2);
-    for (int v = tid; v < V; v += kThreads) {
-      const int row = v / cols, col = v - row * cols;
-      double l = 0.0;  // LOGODDS_UNKNOWN
-      for (int j = 0; j < L; ++j)
-        if (lmcell[j] == v) l = fmin(S.lo_max, fmax(S.lo_min, l + S.lo_occ));
-      const P2 pt{cfg.map_min_x + cfg.resolution * (col + 0.5), cfg.map_min_y + cfg.resolution * (row + 0.5)};
-      for (int p = 0; p < P; ++p) {
-        if (use_bbox && (row < bbox[4 * p] || row > bbox[4 * p + 1] || col < bbox[4 * p + 2] || col > bbox[4 * p + 3]))
-          continue;
-        if (fabs(l - S.lo_min) < 1e-5) continue;
-        // sqrt(d2) < max_range  <=>  d2 < r2_max_lt (exact: threshold precomputed on the host for IEEE sqrt)
-        const double gx = pt.x - sp[4 * p], gy = pt.y - sp[4 * p + 1];
-        if (!(gx * gx + gy * gy < S.r2_max_lt)) continue;
-        const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
-        if (!in_fov(S, ps, pt)) continue;
-        const double add = (l > S.occ_thresh + 1e-8) ? S.lo_occ : S.lo_free;
-        l = fmin(S.lo_max, fmax(S.lo_min, l + add));
+    const int extg = 20;
+    for (int c0 = 0; c0 < P; c0 += chunk) {
+      const int nc = min(chunk, P - c0);
+      const bool last = c0 + nc >= P;
+      for (int v = tid; v < V; v += kThreads) {
+        mask[v] = 0ull;
+        omask[v] = 0ull;
       }
-      // VirtualMap::updateProbability: prob = sum over num_samples identical maps of p / n
-      const double pv = logodds2prob(l);
-      double acc = 0.0;
-      for (int s = 0; s < cfg.num_samples; ++s) acc += pv / cfg.num_samples;
-      prob[v] = acc;
-      ixx[v] = i0; ixy[v] = 0.0; iyy[v] = i0;
-      upd[v] = 0;
-    }
-    __syncthreads();
-    DRLGX_PROF(S, 18);
-    // ---- phases A/B: covariance propagation, kChunk poses at a time ----
-    for (int c0 = 0; c0 < P; c0 += kChunk) {
-      const int nc = min(kChunk, P - c0);
+      __syncthreads();
       for (int pl = wave; pl < nc; pl += kWaves) {
         const int p = c0 + pl;
-        double oxx = __longlong_as_double(0x7ff8000000000000LL), oxy = 0, oyy = 0;  // NaN = "no update"
         if (lane < W2 && !pskip[p]) {
           const int wr = lane / W, wc = lane - wr * W;
           const int row = worg[2 * p] + wr, col = worg[2 * p + 1] + wc;
@@ -276,68 +265,118 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
             const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
             const P2 pt{(col + 0.5) * cfg.resolution + cfg.map_min_x, (row + 0.5) * cfg.resolution + cfg.map_min_y};
             const double dx = ps.x - pt.x, dy = ps.y - pt.y;
-            if (dx * dx + dy * dy < S.r2_max_lt) {  // KDTreeR2::queryRadiusNeighbors: sqrt(d2) < max_range, exactly
+            // KDTreeR2::queryRadiusNeighbors / OccupancyMap range test: sqrt(d2) < max_range, exactly; then the field of view
+            if (dx * dx + dy * dy < S.r2_max_lt && in_fov(S, ps, pt)) {
+              const bool in_bbox = !use_bbox || !(row < bbox[4 * p] || row > bbox[4 * p + 1] || col < bbox[4 * p + 2] || col > bbox[4 * p + 3]);
+              if (in_bbox) atomicOr(&omask[row * cols + col], 1ull << pl);  // OccupancyMap::update visits this cell
               double a, b, d;
-              if (predict_cell(S, ps, sl + 9 * p, pt, a, b, d)) {
-                oxx = a; oxy = b; oyy = d;
+              if (predict_cell<false>(S, ps, sl + 9 * p, pt, a, b, d)) {
+                double *o = stage + ((size_t)pl * 64 + lane) * 3;
+                o[0] = a; o[1] = b; o[2] = d;
+                atomicOr(&mask[row * cols + col], 1ull << pl);
               }
             }
           }
         }
-        double *o = stage + ((size_t)pl * 64 + lane) * 3;
-        o[0] = oxx; o[1] = oxy; o[2] = oyy;
       }
       __syncthreads();
       if (c0 == 0) DRLGX_PROF(S, 21);
       for (int v = tid; v < V; v += kThreads) {
         const int row = v / cols, col = v - row * cols;
-        double axx = ixx[v], axy = ixy[v], ayy = iyy[v];
-        int u = upd[v];
-        bool touched = false;
-        for (int pl = 0; pl < nc; ++pl) {
+        double axx = i0, axy = 0.0, ayy = i0;
+        int u = 0;
+        if (c0 > 0) {
+          axx = ixx[v]; axy = ixy[v]; ayy = iyy[v];
+          u = upd[v];
+        }
+        unsigned long long m = mask[v];
+        while (m) {
+          const int pl = __ffsll((long long)m) - 1;
+          m &= m - 1;
           const int p = c0 + pl;
-          const int wr = row - worg[2 * p], wc = col - worg[2 * p + 1];
-          if (wr < 0 || wr >= W || wc < 0 || wc >= W) continue;
-          const double *o = stage + ((size_t)pl * 64 + wr * W + wc) * 3;
-          const double bxx = o[0];
-          if (bxx != bxx) continue;
+          const double *o = stage + ((size_t)pl * 64 + (row - worg[2 * p]) * W + (col - worg[2 * p + 1])) * 3;
           if (u) {
-            ci_fuse(axx, axy, ayy, bxx, o[1], o[2]);
+            ci_fuse(axx, axy, ayy, o[0], o[1], o[2]);
           } else {
-            axx = bxx; axy = o[1]; ayy = o[2];
+            axx = o[0]; axy = o[1]; ayy = o[2];
             u = 1;
           }
-          touched = true;
         }
-        if (touched) {
-          ixx[v] = axx; ixy[v] = axy; iyy[v] = ayy;
-          upd[v] = (uint8_t)u;
+        ixx[v] = axx; ixy[v] = axy; iyy[v] = ayy;
+        upd[v] = (uint8_t)u;
+      }
+      if (c0 == 0) DRLGX_PROF(S, 18);
+      // second cell loop (last chunk only): occupancy, probabilities, reductions.  Kept apart from the fusion loop: fused,
+      // the two exceed the 128-VGPR budget of a 1024-thread workgroup and spill.
+      for (int v = tid; v < V; v += kThreads) {
+        const int row = v / cols, col = v - row * cols;
+        // occupancy ladder (OccupancyMap.cpp:64-138): the landmarks of the cell, then the poses that see it in
+        // trajectory order (ascending mask bits); between chunks the log-odds value is parked in prob[]
+        double l = 0.0;  // LOGODDS_UNKNOWN
+        if (c0 == 0) {
+          for (int n = lmc[v]; n > 0; --n) l = fmin(S.lo_max, fmax(S.lo_min, l + S.lo_occ));
+        } else {
+          l = prob[v];
         }
+        unsigned long long m = omask[v];
+        while (m) {
+          m &= m - 1;
+          if (fabs(l - S.lo_min) < 1e-5) continue;
+          const double add = (l > S.occ_thresh + 1e-8) ? S.lo_occ : S.lo_free;
+          l = fmin(S.lo_max, fmax(S.lo_min, l + add));
+        }
+        if (!last) {
+          prob[v] = l;
+          continue;
+        }
+        const double axx = ixx[v], axy = ixy[v], ayy = iyy[v];  // written by this thread just above
+        if (S.prof && tid == 0 && blockIdx.x == 0 && v == 0) S.prof[22] = wall_clock64() + (l == 1.2345e300 ? 1 : 0);
+        // VirtualMap::updateProbability: prob = sum over num_samples identical maps of p / n
+        const double pv1 = logodds2prob(l);
+        double pv = 0.0;
+        for (int s = 0; s < cfg.num_samples; ++s) pv += pv1 / cfg.num_samples;
+        prob[v] = pv;
+        if (S.prof && tid == 0 && blockIdx.x == 0 && v == 0) S.prof[23] = wall_clock64() + (pv == 1.2345e300 ? 1 : 0);
+        // reductions (Planner2D.cpp:321-366, VirtualMap.cpp:47-59)
+        double ca, cb, cd;
+        inv2_llt_s(axx, axy, ayy, ca, cb, cd);
+        const double tr = ca + cd;
+        vtr[v] = tr;
+        utr += 1.0 * tr;
+        if (pv < cfg.occupancy_threshold) known += 1.0;
+        const double wgt = pv > 0.49 ? 1.0 : 0.0;
+        udet += wgt / (axx * ayy - axy * axy);
+        uwtr += wgt * tr;
+        const double x = (col + 0.5) * cfg.resolution + cfg.map_min_x, y = (row + 0.5) * cfg.resolution + cfg.map_min_y;
+        if ((pv < 0.49 || pv > 0.6) && cfg.map_min_x + extg <= x && x <= cfg.map_max_x - extg && cfg.map_min_y + extg <= y &&
+            y <= cfg.map_max_y - extg)
+          expl += 1.0;
       }
       __syncthreads();
     }
+  } else {
+    // reductions only (after reset): the cells are read back
+    const int extg = 20;
+    for (int v = tid; v < V; v += kThreads) {
+      const int row = v / cols, col = v - row * cols;
+      const double a = ixx[v], b = ixy[v], d = iyy[v], pv = prob[v];
+      double ca, cb, cd;
+      inv2_llt_s(a, b, d, ca, cb, cd);
+      const double tr = ca + cd;
+      vtr[v] = tr;
+      utr += 1.0 * tr;
+      if (pv < cfg.occupancy_threshold) known += 1.0;
+      const double wgt = pv > 0.49 ? 1.0 : 0.0;
+      udet += wgt / (a * d - b * b);
+      uwtr += wgt * tr;
+      const double x = (col + 0.5) * cfg.resolution + cfg.map_min_x, y = (row + 0.5) * cfg.resolution + cfg.map_min_y;
+      if ((pv < 0.49 || pv > 0.6) && cfg.map_min_x + extg <= x && x <= cfg.map_max_x - extg && cfg.map_min_y + extg <= y &&
+          y <= cfg.map_max_y - extg)
+        expl += 1.0;
+    }
   }
-  // ---- phase R: reductions (Planner2D.cpp:321-366, VirtualMap.cpp:47-59) ----
+  // ---- phase R: block reduction of the five utility sums ----
   DRLGX_PROF(S, 19);
-  double utr = 0, known = 0, expl = 0, udet = 0, uwtr = 0;
-  const int extg = 20;
-  for (int v = tid; v < V; v += kThreads) {
-    const int row = v / cols, col = v - row * cols;
-    const double a = ixx[v], b = ixy[v], d = iyy[v], pv = prob[v];
-    double ca, cb, cd;
-    inv2_llt_s(a, b, d, ca, cb, cd);
-    const double tr = ca + cd;
-    vtr[v] = tr;
-    utr += 1.0 * tr;
-    if (pv < cfg.occupancy_threshold) known += 1.0;
-    const double wgt = pv > 0.49 ? 1.0 : 0.0;
-    udet += wgt / (a * d - b * b);
-    uwtr += wgt * tr;
-    const double x = (col + 0.5) * cfg.resolution + cfg.map_min_x, y = (row + 0.5) * cfg.resolution + cfg.map_min_y;
-    if ((pv < 0.49 || pv > 0.6) && cfg.map_min_x + extg <= x && x <= cfg.map_max_x - extg && cfg.map_min_y + extg <= y &&
-        y <= cfg.map_max_y - extg)
-      expl += 1.0;
-  }
   {
     double r5[5] = {utr, known, expl, udet, uwtr};
 #pragma unroll
@@ -369,9 +408,9 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
 
 }  // namespace
 
-static size_t map_lds_bytes(const DrlgxState &S) {
-  size_t d = (size_t)S.P_max * 19 + (size_t)kChunk * 64 * 3 + kWaves;
-  size_t i = (size_t)S.P_max * 7 + S.L_max;
+static size_t map_lds_bytes(const DrlgxState &S, int chunk) {
+  size_t d = (size_t)S.P_max * 19 + (size_t)chunk * 64 * 3 + 2 * (size_t)S.V + kWaves;  // doubles + two u64 masks per cell
+  size_t i = (size_t)S.P_max * 7 + (size_t)S.V;
   return d * sizeof(double) + i * sizeof(int) + 16;
 }
 
@@ -382,11 +421,14 @@ void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
     rebuild = 0;
     sel.act_idx = 0;
   }
-  const size_t lds = map_lds_bytes(S);
+  // poses per A/C pass: all of them when the stage fits the LDS (<= 64: one mask bit per pose)
+  int chunk = S.P_max < 64 ? S.P_max : 64;
+  while (chunk > 1 && map_lds_bytes(S, chunk) > 160 * 1024) chunk /= 2;
+  const size_t lds = map_lds_bytes(S, chunk);
   static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_map, dim3(sel.n), dim3(kThreads), lds, st, S, sel, rebuild);
+  hipLaunchKernelGGL(k_map, dim3(sel.n), dim3(kThreads), lds, st, S, sel, rebuild, chunk);
 }

@@ -23,7 +23,7 @@ print("k_slam phases (us, block 0):")
 for k in range(1, 8): print("  %-24s %8.2f" % (names[k], (a[k]-a[k-1]) / 100.0))
 print("  total %.2f" % ((a[7]-a[0]) / 100.0))
 print("  sweep sub-phases (us): panel+barrier %.2f, pivot inverse %.2f, tiles %.2f" % (a[8]/100.0, a[9]/100.0, a[10]/100.0))
-mn = {17:"load+bbox sweep",18:"occupancy",21:"phase A (chunk 0)",19:"phase B + rest",20:"reductions"}
+mn = {17:"load+bbox sweep",21:"phase A + masks",18:"CI fusion",19:"occupancy + sums",20:"block reduction"}
 print("  shader clock during sweeps: %.0f MHz" % (a[11] / max(a[12], 1) * 100.0))
 last = np.array(out[:], dtype=np.float64)
 for w in range(4):
@@ -33,9 +33,10 @@ b = last[16:21]
 print("  pivot_inverse(6) cycles from entry: D-read %d, rcp1 %d, rcp2 %d, end %d; entry - mfma-done(wave2) %d" % (b[1]-b[0], b[2]-b[0], b[3]-b[0], b[4]-b[0], b[0] - last[24+20+5]))
 print("k_map phases (us, block 0):")
 prev = a[16]
-for k in (17, 18, 21, 19, 20):
+for k in (17, 21, 18, 19, 20):
     print("  %-24s %8.2f" % (mn[k], (a[k]-prev) / 100.0)); prev = a[k]
 print("  total %.2f" % ((a[20]-a[16]) / 100.0))
+print("  first cell of thread 0: ladder loops done at +%.2f us, prob at +%.2f us (from the start of the occupancy loop)" % ((a[22]-a[18]) / 100.0, (a[23]-a[18]) / 100.0))
 eng.timing_enable(True); eng.timing_read()
 for it in range(50):
     eng.restore(0); eng.step(odom)
