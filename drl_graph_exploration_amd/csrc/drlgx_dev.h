@@ -10,6 +10,7 @@
 
 #include "../../include/drlgx.h"
 
+#define DRLGX_LO_TAB 64
 #define DRLGX_MT_N 624
 #define DRLGX_MT_STRIDE 626  // 624 state words + gen index + cons index
 #define DRLGX_CNT_STRIDE 8
@@ -38,6 +39,13 @@ struct DrlgxState {
   double r2_max_lt, r2_min_gt;
   int n_sweep;                                         // bbox sweep table length
   const double *sweep_b;                               // [n_sweep] b values of OccupancyMap.cpp:86
+  // occupancy ladder as a finite state machine (closure of l -> clamp(l + lo_occ / lo_free) from l = 0, built on the
+  // host): state 0 is LOGODDS_UNKNOWN; lo_tr[4 i] = {next on occupied, next on free, flags (1: at the minimum - frozen,
+  // 2: above the occupancy threshold), 0}; lo_pv[i] = cell probability of state i (host libm).  lo_ntab == 0: not closed
+  // within DRLGX_LO_TAB states, the kernels fall back to the arithmetic ladder.
+  int lo_ntab;
+  const double *lo_pv;
+  const uint8_t *lo_tr;
   const int *lm_order;                                 // [LG] libstdc++ unordered_map iteration order of GT keys
   // --- simulator
   double *gt_pose;    // [n_inst][4] x,y,c,s
@@ -193,6 +201,31 @@ __device__ __forceinline__ double range_of(const Pose &p, const P2 &pt, double *
 // small SPD helpers — symmetric storage: 3x3 = (a00,a01,a02,a11,a12,a22); 2x2 = (a00,a01,a11)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double det2s(double a, double b, double d) { return a * d - b * b; }
+// 1/x and 1/sqrt(x) to double round-off (v_rcp_f64 / v_rsq_f64 + two Newton steps): a correctly rounded fp64 division or
+// sqrt is ~30 instructions here, and these per-cell / per-(pose, cell) kernels are bound by instruction issue.  Used only
+// where the parity bar is a tolerance (information / covariance values), never where a decision is taken.
+__device__ __forceinline__ double rcp_n(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r;
+}
+__device__ __forceinline__ double rsqrt_n(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r;
+}
+// inv2_llt_s with reciprocals (same algebra, each division / sqrt replaced by a ~1 ulp reciprocal product)
+__device__ __forceinline__ void inv2_llt_fast(double a, double b, double d, double &oa, double &ob, double &od) {
+  const double r00 = rsqrt_n(a);         // 1 / l00
+  const double l10 = b * r00;
+  const double r11 = rsqrt_n(d - l10 * l10);  // 1 / l11
+  const double x1 = (0.0 - l10 * r00) * r11 * r11;
+  oa = (r00 - l10 * x1) * r00;
+  ob = x1;
+  od = r11 * r11;
+}
 __device__ __forceinline__ void inv2_llt_s(double a, double b, double d, double &oa, double &ob, double &od) {
   // m.llt().solve(I) for symmetric [[a,b],[b,d]]
   double l00 = sqrt(a), l10 = b / l00, l11 = sqrt(d - l10 * l10);

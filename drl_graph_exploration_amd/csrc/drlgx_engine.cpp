@@ -193,6 +193,42 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   S.lo_min = p2l(0.05);
   S.lo_max = l2p(0.95);  // sic: MAX_LOGODDS = LOGODDS2PROB(0.95)
   S.occ_thresh = p2l(0.5);
+  // occupancy ladder closure (see DrlgxState::lo_tr)
+  std::vector<double> lo_val{0.0}, lo_pv;
+  std::vector<uint8_t> lo_tr;
+  {
+    auto clampl = [&](double l) { return std::fmin(S.lo_max, std::fmax(S.lo_min, l)); };
+    auto find_or_add = [&](double l) -> int {
+      for (size_t i = 0; i < lo_val.size(); ++i)
+        if (lo_val[i] == l) return (int)i;
+      lo_val.push_back(l);
+      return (int)lo_val.size() - 1;
+    };
+    bool closed = true;
+    for (size_t i = 0; i < lo_val.size(); ++i) {
+      if (lo_val.size() > DRLGX_LO_TAB) {
+        closed = false;
+        break;
+      }
+      const double l = lo_val[i];
+      const int o = find_or_add(clampl(l + S.lo_occ)), f = find_or_add(clampl(l + S.lo_free));
+      const uint8_t flags = (uint8_t)((std::fabs(l - S.lo_min) < 1e-5 ? 1 : 0) | (l > S.occ_thresh + 1e-8 ? 2 : 0));
+      lo_tr.push_back((uint8_t)o); lo_tr.push_back((uint8_t)f); lo_tr.push_back(flags); lo_tr.push_back(0);
+    }
+    if (closed && lo_val.size() <= DRLGX_LO_TAB) {
+      for (double l : lo_val) {  // OccupancyMap LOGODDS2PROB + VirtualMap::updateProbability (num_samples identical maps)
+        const double pv1 = l2p(l);
+        double acc = 0.0;
+        for (int s2 = 0; s2 < cfg->num_samples; ++s2) acc += pv1 / cfg->num_samples;
+        lo_pv.push_back(acc);
+      }
+      S.lo_ntab = (int)lo_val.size();
+    } else {
+      S.lo_ntab = 0;
+      lo_pv.assign(1, 0.5);
+      lo_tr.assign(4, 0);
+    }
+  }
   // sector-sweep table (OccupancyMap.cpp:86): b accumulates in double exactly as the reference loop
   std::vector<double> sweep;
   for (double b = cfg->min_bearing; b < cfg->max_bearing + 1e-5; b += 3 * 0.01745329251994329575) sweep.push_back(b);
@@ -243,6 +279,16 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   hipMemcpyAsync(order_dev, e->lm_order.data(), e->lm_order.size() * sizeof(int), hipMemcpyHostToDevice, e->stream);
   S.sweep_b = sweep_dev;
   S.lm_order = order_dev;
+  {
+    double *pv_dev = nullptr;
+    uint8_t *tr_dev = nullptr;
+    TRY(dev_alloc(e, &pv_dev, lo_pv.size()));
+    TRY(dev_alloc(e, &tr_dev, lo_tr.size()));
+    HIPCHK(e, hipMemcpyAsync(pv_dev, lo_pv.data(), lo_pv.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(tr_dev, lo_tr.data(), lo_tr.size(), hipMemcpyHostToDevice, e->stream));
+    S.lo_pv = pv_dev;
+    S.lo_tr = tr_dev;
+  }
   const size_t P = S.P_max, L = S.L_max, M = S.M_max, V = S.V;
   TRY(field_alloc(e, &S.gt_pose, 4));
   TRY(field_alloc(e, &S.parent, 1));

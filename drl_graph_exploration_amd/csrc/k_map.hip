@@ -48,16 +48,17 @@ __device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps
   // Jacobians of bearing (Pose2::bearing) and range (Pose2::range); the bearing VALUE is only needed for the
   // FOV check, which in_fov() answers without atan2 for almost every cell
   const P2 d = transform_to(ps, pt);
-  const double d2 = d.x * d.x + d.y * d.y, n = sqrt(d2);
+  const double d2 = d.x * d.x + d.y * d.y;
   const double gx = pt.x - ps.x, gy = pt.y - ps.y;
   const double g2 = gx * gx + gy * gy;
   // range < max_range && range > min_range, decided exactly on the squared distance (host-computed thresholds)
   if (!(g2 < S.r2_max_lt && g2 > S.r2_min_gt)) return false;
   if (kCheckFov && !in_fov(S, ps, pt)) return false;
-  const double range = sqrt(g2);
+  const double rrange = rsqrt_n(g2);  // 1 / range
   double Hbx[3], Hbl[2], Hrx[3], Hrl[2];
-  if (fabs(n) > 1e-5) {
-    const double a = -d.y / d2, b = d.x / d2;
+  if (d2 > 1e-10) {  // |d| > 1e-5
+    const double rd2 = rcp_n(d2);
+    const double a = -d.y * rd2, b = d.x * rd2;
     Hbx[0] = a * -1.0;
     Hbx[1] = b * -1.0;
     Hbx[2] = a * d.y + b * -d.x;
@@ -68,7 +69,7 @@ __device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps
     Hbl[0] = Hbl[1] = 0;
   }
   {
-    const double ux = gx / range, uy = gy / range;
+    const double ux = gx * rrange, uy = gy * rrange;
     Hrx[0] = ux * -ps.c + uy * -ps.s;
     Hrx[1] = ux * ps.s + uy * -ps.c;
     Hrx[2] = 0;
@@ -80,7 +81,7 @@ __device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps
   // (Hl^T Hl)^-1 Hl^T  (Eigen fixed 2x2 inverse = adjugate / det)
   const double h00 = Hl0 * Hl0 + Hl2 * Hl2, h01 = Hl0 * Hl1 + Hl2 * Hl3;
   const double h10 = Hl1 * Hl0 + Hl3 * Hl2, h11 = Hl1 * Hl1 + Hl3 * Hl3;
-  const double id = 1.0 / (h00 * h11 - h01 * h10);
+  const double id = rcp_n(h00 * h11 - h01 * h10);
   const double i00 = h11 * id, i01 = -h01 * id, i10 = -h10 * id, i11 = h00 * id;
   const double p00 = i00 * Hl0 + i01 * Hl1, p01 = i00 * Hl2 + i01 * Hl3;
   const double p10 = i10 * Hl0 + i11 * Hl1, p11 = i10 * Hl2 + i11 * Hl3;
@@ -106,7 +107,7 @@ __device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps
   const double c00 = t00 * p00 + t01 * p01;
   const double c10 = t10 * p00 + t11 * p01, c11 = t10 * p10 + t11 * p11;
   // information = inverse(cov) by LLT (lower triangle of cov)
-  inv2_llt_s(c00, c10, c11, oxx, oxy, oyy);
+  inv2_llt_fast(c00, c10, c11, oxx, oxy, oyy);
   return true;
 }
 
@@ -115,10 +116,10 @@ __device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps
 __device__ __forceinline__ void ci_fuse(double &axx, double &axy, double &ayy, double bxx, double bxy, double byy) {
   const double a = axx * ayy - axy * axy;
   const double b = bxx * byy - bxy * bxy;
-  // m1.llt().solve(m2).trace()
-  const double l00 = sqrt(axx), r00 = 1.0 / l00;
+  // m1.llt().solve(m2).trace(), with reciprocal square roots instead of sqrt + divisions (this loop is issue-bound)
+  const double r00 = rsqrt_n(axx);
   const double l10 = axy * r00;
-  const double l11 = sqrt(ayy - l10 * l10), r11 = 1.0 / l11;
+  const double r11 = rsqrt_n(ayy - l10 * l10);
   double tr = 0;
   {
     double y0 = bxx * r00, y1 = (bxy - l10 * y0) * r11;
@@ -131,7 +132,7 @@ __device__ __forceinline__ void ci_fuse(double &axx, double &axy, double &ayy, d
   }
   const double c = a * tr;
   const double d = a + b - c;
-  double w = 0.5 * (2 * b - c) / d;
+  double w = 0.5 * (2 * b - c) * rcp_n(d);
   if ((w < 0 && d < 0) || (w > 1 && d > 0))
     w = 0.0;
   else if ((w < 0 && d > 0) || (w > 1 && d < 0))
@@ -170,10 +171,12 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
   unsigned long long *mask = reinterpret_cast<unsigned long long *>(stage + (size_t)chunk * 64 * 3);  // [V]
   unsigned long long *omask = mask + V;  // [V] poses that see the cell (occupancy ladder)
   double *scratch = reinterpret_cast<double *>(omask + V);  // [kWaves]
-  int *bbox = reinterpret_cast<int *>(scratch + kWaves);  // [P_max][4] min_row max_row min_col max_col
+  int *bbox = reinterpret_cast<int *>(scratch + kWaves + DRLGX_LO_TAB);  // [P_max][4] min_row max_row min_col max_col
   int *worg = bbox + (size_t)S.P_max * 4;             // [P_max][2] window origin row, col
   int *pskip = worg + (size_t)S.P_max * 2;            // [P_max]
   int *lmc = pskip + S.P_max;                         // [V] estimated landmarks per cell
+  uint8_t *ltr = reinterpret_cast<uint8_t *>(lmc + V);  // [DRLGX_LO_TAB][4] ladder transitions
+  double *lpv = scratch + kWaves;                      // [DRLGX_LO_TAB] ladder state -> cell probability
   double *prob = S.vm_prob + (size_t)inst * V;
   double *ixx = S.vm_info + ((size_t)inst * 3 + 0) * V, *ixy = S.vm_info + ((size_t)inst * 3 + 1) * V,
          *iyy = S.vm_info + ((size_t)inst * 3 + 2) * V;
@@ -189,6 +192,10 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
     for (int e = tid; e < P * 6; e += kThreads) si[e] = pin[e];
     const double *el = S.est_lm + (size_t)inst * S.L_max * 2;
     for (int v = tid; v < V; v += kThreads) lmc[v] = 0;
+    for (int t = tid; t < S.lo_ntab; t += kThreads) {
+      lpv[t] = S.lo_pv[t];
+      reinterpret_cast<uint32_t *>(ltr)[t] = reinterpret_cast<const uint32_t *>(S.lo_tr)[t];
+    }
     __syncthreads();
     for (int j = tid; j < L; j += kThreads) {
       // OccupancyMap::update(map): landmark cell (OccupancyMap.cpp:127-131); every landmark in a cell is one occupied update
@@ -256,10 +263,11 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
         omask[v] = 0ull;
       }
       __syncthreads();
-      for (int pl = wave; pl < nc; pl += kWaves) {
+      for (int e = tid; e < nc * W2; e += kThreads) {  // (pose, window cell) pairs spread evenly over the threads
+        const int pl = e / W2, widx = e - pl * W2;
         const int p = c0 + pl;
-        if (lane < W2 && !pskip[p]) {
-          const int wr = lane / W, wc = lane - wr * W;
+        if (!pskip[p]) {
+          const int wr = widx / W, wc = widx - wr * W;
           const int row = worg[2 * p] + wr, col = worg[2 * p + 1] + wc;
           if (row >= 0 && row < rows && col >= 0 && col < cols) {
             const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
               if (in_bbox) atomicOr(&omask[row * cols + col], 1ull << pl);  // OccupancyMap::update visits this cell
               double a, b, d;
               if (predict_cell<false>(S, ps, sl + 9 * p, pt, a, b, d)) {
-                double *o = stage + ((size_t)pl * 64 + lane) * 3;
+                double *o = stage + ((size_t)pl * 64 + widx) * 3;
                 o[0] = a; o[1] = b; o[2] = d;
                 atomicOr(&mask[row * cols + col], 1ull << pl);
               }
@@ -304,48 +312,60 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
         }
         ixx[v] = axx; ixy[v] = axy; iyy[v] = ayy;
         upd[v] = (uint8_t)u;
-      }
-      if (c0 == 0) DRLGX_PROF(S, 18);
-      // second cell loop (last chunk only): occupancy, probabilities, reductions.  Kept apart from the fusion loop: fused,
-      // the two exceed the 128-VGPR budget of a 1024-thread workgroup and spill.
-      for (int v = tid; v < V; v += kThreads) {
-        const int row = v / cols, col = v - row * cols;
         // occupancy ladder (OccupancyMap.cpp:64-138): the landmarks of the cell, then the poses that see it in
         // trajectory order (ascending mask bits); between chunks the log-odds value is parked in prob[]
         double l = 0.0;  // LOGODDS_UNKNOWN
+        int st = 0;      // ... as a state of the precomputed ladder (DrlgxState::lo_tr) when it is closed
+        const bool fsm = S.lo_ntab > 0;
         if (c0 == 0) {
-          for (int n = lmc[v]; n > 0; --n) l = fmin(S.lo_max, fmax(S.lo_min, l + S.lo_occ));
+          for (int n = lmc[v]; n > 0; --n) {
+            l = fmin(S.lo_max, fmax(S.lo_min, l + S.lo_occ));
+            st = ltr[4 * st];
+          }
         } else {
           l = prob[v];
+          st = (int)l;
         }
-        unsigned long long m = omask[v];
-        while (m) {
-          m &= m - 1;
-          if (fabs(l - S.lo_min) < 1e-5) continue;
-          const double add = (l > S.occ_thresh + 1e-8) ? S.lo_occ : S.lo_free;
-          l = fmin(S.lo_max, fmax(S.lo_min, l + add));
+        m = omask[v];
+        if (fsm) {
+          while (m) {
+            m &= m - 1;
+            const int f = ltr[4 * st + 2];
+            st = (f & 1) ? st : ((f & 2) ? ltr[4 * st] : ltr[4 * st + 1]);
+          }
+          l = (double)st;
+        } else {
+          while (m) {
+            m &= m - 1;
+            if (fabs(l - S.lo_min) < 1e-5) continue;
+            const double add = (l > S.occ_thresh + 1e-8) ? S.lo_occ : S.lo_free;
+            l = fmin(S.lo_max, fmax(S.lo_min, l + add));
+          }
         }
         if (!last) {
           prob[v] = l;
           continue;
         }
-        const double axx = ixx[v], axy = ixy[v], ayy = iyy[v];  // written by this thread just above
         if (S.prof && tid == 0 && blockIdx.x == 0 && v == 0) S.prof[22] = wall_clock64() + (l == 1.2345e300 ? 1 : 0);
         // VirtualMap::updateProbability: prob = sum over num_samples identical maps of p / n
-        const double pv1 = logodds2prob(l);
         double pv = 0.0;
-        for (int s = 0; s < cfg.num_samples; ++s) pv += pv1 / cfg.num_samples;
+        if (fsm) {
+          pv = lpv[st];
+        } else {
+          const double pv1 = logodds2prob(l);
+          for (int s = 0; s < cfg.num_samples; ++s) pv += pv1 / cfg.num_samples;
+        }
         prob[v] = pv;
         if (S.prof && tid == 0 && blockIdx.x == 0 && v == 0) S.prof[23] = wall_clock64() + (pv == 1.2345e300 ? 1 : 0);
         // reductions (Planner2D.cpp:321-366, VirtualMap.cpp:47-59)
         double ca, cb, cd;
-        inv2_llt_s(axx, axy, ayy, ca, cb, cd);
+        inv2_llt_fast(axx, axy, ayy, ca, cb, cd);
         const double tr = ca + cd;
         vtr[v] = tr;
         utr += 1.0 * tr;
         if (pv < cfg.occupancy_threshold) known += 1.0;
         const double wgt = pv > 0.49 ? 1.0 : 0.0;
-        udet += wgt / (axx * ayy - axy * axy);
+        udet += wgt * rcp_n(axx * ayy - axy * axy);
         uwtr += wgt * tr;
         const double x = (col + 0.5) * cfg.resolution + cfg.map_min_x, y = (row + 0.5) * cfg.resolution + cfg.map_min_y;
         if ((pv < 0.49 || pv > 0.6) && cfg.map_min_x + extg <= x && x <= cfg.map_max_x - extg && cfg.map_min_y + extg <= y &&
@@ -409,8 +429,8 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
 }  // namespace
 
 static size_t map_lds_bytes(const DrlgxState &S, int chunk) {
-  size_t d = (size_t)S.P_max * 19 + (size_t)chunk * 64 * 3 + 2 * (size_t)S.V + kWaves;  // doubles + two u64 masks per cell
-  size_t i = (size_t)S.P_max * 7 + (size_t)S.V;
+  size_t d = (size_t)S.P_max * 19 + (size_t)chunk * 64 * 3 + 2 * (size_t)S.V + kWaves + DRLGX_LO_TAB;  // + two u64 masks per cell
+  size_t i = (size_t)S.P_max * 7 + (size_t)S.V + DRLGX_LO_TAB;
   return d * sizeof(double) + i * sizeof(int) + 16;
 }
 
