@@ -34,13 +34,13 @@ __global__ void k_fill_i32(int *p, int v, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
-// deg[row] += w (PyG: scatter_add(edge_weight, row)); in/out degree counts for the two CSRs
-__global__ void k_degree(int E, const int64_t *ei, const float *ew, float *deg, int *cnt_dst, int *cnt_src) {
+// in/out degree counts for the two CSRs (the weighted degree is summed later in edge order: float atomics here would
+// make deg - and through the ReLU gates the whole forward/backward - depend on the arrival order)
+__global__ void k_degree(int E, const int64_t *ei, int *cnt_dst, int *cnt_src) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const int r = (int)ei[e], c = (int)ei[(size_t)E + e];
   if (r == c) return;  // explicit self loops are folded into the self term (none in this application)
-  atomicAdd(&deg[r], ew[e]);
   atomicAdd(&cnt_dst[c], 1);
   atomicAdd(&cnt_src[r], 1);
 }
@@ -90,10 +90,8 @@ __global__ void k_csr_fill(int E, const int64_t *ei, const int *ptr_dst, int *cu
   eid_dst[ptr_dst[c] + atomicAdd(&cur_dst[c], 1)] = e;
   eid_src[ptr_src[r] + atomicAdd(&cur_src[r], 1)] = e;
 }
-// sort each CSR row by edge id (rows are short) -> deterministic summation order; then resolve
-// (neighbour, normalised weight) per slot.  dis = deg^-1/2 (inf -> 0).
-__global__ void k_csr_finish(int N, int E, const int64_t *ei, const float *ew, const float *deg, const int *ptr, int *eid,
-                             int *nbr, float *wn, int by_dst) {
+// sort each CSR row by edge id (rows are short) -> deterministic summation order
+__global__ void k_csr_sort(int N, const int *ptr, int *eid) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const int a = ptr[n], b = ptr[n + 1];
@@ -105,7 +103,22 @@ __global__ void k_csr_finish(int N, int E, const int64_t *ei, const float *ew, c
     }
     eid[j + 1] = v;
   }
-  for (int i = a; i < b; ++i) {
+}
+// deg[row] = sum of the row's edge weights in edge order, then the self loop weight 2 appended by
+// add_remaining_self_loops(fill_value = 2)  (PyG: scatter_add(edge_weight, row) with row = source)
+__global__ void k_degree_sum(int N, const float *ew, const int *ptr_src, const int *eid_src, float *deg) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int i = ptr_src[n]; i < ptr_src[n + 1]; ++i) s += ew[eid_src[i]];
+  deg[n] = s + 2.0f;
+}
+// resolve (neighbour, normalised weight) per CSR slot.  dis = deg^-1/2 (inf -> 0).
+__global__ void k_csr_finish(int N, int E, const int64_t *ei, const float *ew, const float *deg, const int *ptr, const int *eid,
+                             int *nbr, float *wn, int by_dst) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  for (int i = ptr[n]; i < ptr[n + 1]; ++i) {
     const int e = eid[i];
     const int r = (int)ei[e], c = (int)ei[(size_t)E + e];
     float dr = deg[r] > 0 ? 1.0f / sqrtf(deg[r]) : 0.0f, dc = deg[c] > 0 ? 1.0f / sqrtf(deg[c]) : 0.0f;
@@ -425,21 +438,22 @@ void colsum(hipStream_t st, const GcnWs &w, int N, int C, const float *X, float 
 }
 
 void build_graph(hipStream_t st, const GcnWs &w, int N, int E, const int64_t *ei, const float *ew) {
-  hipLaunchKernelGGL(k_fill_f32, dim3((N + 255) / 256), dim3(256), 0, st, w.deg, 2.0f, N);  // add_remaining_self_loops(fill 2)
   hipMemsetAsync(w.cnt_dst, 0, (size_t)(N + 1) * 4, st);
   hipMemsetAsync(w.cnt_src, 0, (size_t)(N + 1) * 4, st);
   hipMemsetAsync(w.cur_dst, 0, (size_t)(N + 1) * 4, st);
   hipMemsetAsync(w.cur_src, 0, (size_t)(N + 1) * 4, st);
-  if (E > 0) hipLaunchKernelGGL(k_degree, dim3((E + 255) / 256), dim3(256), 0, st, E, ei, ew, w.deg, w.cnt_dst, w.cnt_src);
+  if (E > 0) hipLaunchKernelGGL(k_degree, dim3((E + 255) / 256), dim3(256), 0, st, E, ei, w.cnt_dst, w.cnt_src);
   hipLaunchKernelGGL(k_scan2, dim3(1), dim3(1024), 0, st, N, w.cnt_dst, w.ptr_dst, w.cnt_src, w.ptr_src);
   if (E > 0) {
     hipLaunchKernelGGL(k_csr_fill, dim3((E + 255) / 256), dim3(256), 0, st, E, ei, w.ptr_dst, w.cur_dst, w.eid_dst, w.ptr_src,
                        w.cur_src, w.eid_src);
   }
-  hipLaunchKernelGGL(k_csr_finish, dim3((N + 127) / 128), dim3(128), 0, st, N, E, ei, ew, w.deg, w.ptr_dst, w.eid_dst, w.nbr_dst,
-                     w.wn_dst, 1);
-  hipLaunchKernelGGL(k_csr_finish, dim3((N + 127) / 128), dim3(128), 0, st, N, E, ei, ew, w.deg, w.ptr_src, w.eid_src, w.nbr_src,
-                     w.wn_src, 0);
+  const dim3 gn((N + 127) / 128), bn(128);
+  hipLaunchKernelGGL(k_csr_sort, gn, bn, 0, st, N, w.ptr_dst, w.eid_dst);
+  hipLaunchKernelGGL(k_csr_sort, gn, bn, 0, st, N, w.ptr_src, w.eid_src);
+  hipLaunchKernelGGL(k_degree_sum, gn, bn, 0, st, N, ew, w.ptr_src, w.eid_src, w.deg);
+  hipLaunchKernelGGL(k_csr_finish, gn, bn, 0, st, N, E, ei, ew, w.deg, w.ptr_dst, w.eid_dst, w.nbr_dst, w.wn_dst, 1);
+  hipLaunchKernelGGL(k_csr_finish, gn, bn, 0, st, N, E, ei, ew, w.deg, w.ptr_src, w.eid_src, w.nbr_src, w.wn_src, 0);
 }
 
 }  // namespace

@@ -75,14 +75,21 @@ def test_gcn_forward_backward_matches_torch_reference(n_graphs, out_dim, with_ma
     wgt = torch.randn(N, out_dim, device=dev)
     (out * wgt).sum().backward()
     (ref * wgt.double()).sum().backward()
+    # the same plain-torch reference in float32, to calibrate what fp32 round-off does to this problem
+    p32 = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    (gcn_ref.gcn_forward(p32, x, ei, ea, mask) * wgt).sum().backward()
     for k in P:
         assert P[k].grad is not None, k
         # typical agreement is ~1e-6; a ReLU pre-activation within fp32 round-off of 0 flips its gate in ANY fp32
         # evaluation (here or in torch) and moves single gradient entries by up to ~1e-3 of the max: bound the
-        # max-norm loosely and the Frobenius norm tightly
+        # max-norm loosely, and the Frobenius norm by what the plain fp32 torch evaluation itself achieves against
+        # the float64 ground truth (x3), with 1e-4 as the floor
         g, r = P[k].grad.double(), ref_params[k].grad
-        assert rel_err(g, r) < 2e-3, k
-        assert float((g - r).norm() / r.norm()) < 1e-4, k
+        e_ours = float((g - r).norm() / r.norm())
+        e_torch32 = float((p32[k].grad.double() - r).norm() / r.norm())
+        m_ours, m_torch32 = rel_err(g, r), rel_err(p32[k].grad.double(), r)
+        assert m_ours < max(2e-3, 3.0 * m_torch32), (k, m_ours, m_torch32)
+        assert e_ours < max(1e-4, 3.0 * e_torch32), (k, e_ours, e_torch32)
 
 
 def test_reference_state_dict_loads_and_picks_reference_actions(golden_dir):
