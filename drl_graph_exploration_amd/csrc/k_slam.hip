@@ -222,6 +222,12 @@ __device__ __forceinline__ void sweep_all(const SweepCtx &x, v4d (&acc)[FT], int
   }
 }
 
+// iterate the poses p (ascending) whose bit is set in the two-word mask at `mk`
+#define FOR_EACH_OBSERVING_POSE(mk, p)                                         \
+  for (int _w = 0; _w < 2; ++_w)                                              \
+    for (unsigned long long _m = (mk)[_w]; _m; _m &= _m - 1)                  \
+      if (const int p = 64 * _w + __ffsll((long long)_m) - 1; true)
+
 template <bool kLds, int NTW, int FT>
 __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, int lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -251,6 +257,8 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
   unsigned short *mp = reinterpret_cast<unsigned short *>(smem_raw + off); off += up8((size_t)M * 2);
   unsigned short *ml = reinterpret_cast<unsigned short *>(smem_raw + off); off += up8((size_t)M * 2);
   int *bad = reinterpret_cast<int *>(smem_raw + off); off += 8;
+  // poses observing each landmark as bit masks (P <= 128): the per-landmark loops visit only those poses
+  unsigned long long *lmask = reinterpret_cast<unsigned long long *>(smem_raw + off); off += (size_t)L * 16;
   off = (off + 31) & ~(size_t)31;
   double *Vb = reinterpret_cast<double *>(smem_raw + off); off += (size_t)2 * (8 * N + 32) * 8;  // 2 buffers x (4 planes v, 4 planes v E, E, pivot scratch)
   double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
@@ -311,6 +319,7 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
     for (int e = tid; e < n2; e += kThreads) A2[e] = make_double2(0.0, 0.0);
   }
   for (int e = tid; e < L * P; e += kThreads) obs[e] = 0;
+  for (int e = tid; e < 2 * L; e += kThreads) lmask[e] = 0ull;
   for (int e = tid; e <= P; e += kThreads) mstart[e] = M;
   if (tid == 0) bad[0] = 0;
   __syncthreads();
@@ -321,6 +330,7 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
     ml[m] = (unsigned short)j;
     if (m == 0 || meas_pose[m - 1] != p) mstart[p] = m;
     obs[j * P + p] = (unsigned short)(m + 1);
+    atomicOr(&lmask[2 * j + (p >> 6)], 1ull << (p & 63));
     linearize_br(thp + 4 * p, thl + 2 * j, meas_br[2 * m], meas_br[2 * m + 1], rec + (size_t)REC * m);
   }
   __syncthreads();
@@ -334,9 +344,8 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
   const int pose_t0 = ((L + 63) & ~63) % kThreads;  // poses start on a fresh wave so both roles overlap
   for (int j = tid; j < L; j += kThreads) {
     double a = 0, b = 0, d = 0, g0 = 0, g1 = 0;
-    for (int p = 0; p < P; ++p) {
+    FOR_EACH_OBSERVING_POSE(lmask + 2 * j, p) {
       const int m1 = obs[j * P + p];
-      if (!m1) continue;
       const double *r = rec + (size_t)REC * (m1 - 1);
       a += r[6] * wb * r[6] + r[8] * wr * r[8];
       b += r[6] * wb * r[7] + r[8] * wr * r[9];
@@ -697,9 +706,8 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
   for (int m = tid; m < M; m += kThreads) {
     const int j = ml[m], p = mp[m];
     double Wm[6] = {0, 0, 0, 0, 0, 0};
-    for (int q = 0; q < P; ++q) {
+    FOR_EACH_OBSERVING_POSE(lmask + 2 * j, q) {
       const int mq1 = obs[j * P + q];
-      if (!mq1) continue;
       const double *gq = rec + (size_t)REC * (mq1 - 1);
       for (int r = 0; r < 3; ++r) {
         double s0 = 0, s1 = 0;
@@ -729,9 +737,8 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
     double c00 = lb[3], c01 = lb[4], c10 = lb[4], c11 = lb[5];
     // delta_j = Lambda^-1 eta_j - sum_m G_m^T delta_p
     double dx = lb[3] * lb[6] + lb[4] * lb[7], dy = lb[4] * lb[6] + lb[5] * lb[7];
-    for (int p = 0; p < P; ++p) {
+    FOR_EACH_OBSERVING_POSE(lmask + 2 * j, p) {
       const int m1 = obs[j * P + p];
-      if (!m1) continue;
       const double *g = rec + (size_t)REC * (m1 - 1);
       c00 += g[6]; c01 += g[7]; c10 += g[8]; c11 += g[9];
       const double dp0 = A[np * ld + 3 * p], dp1 = A[np * ld + 3 * p + 1], dp2 = A[np * ld + 3 * p + 2];
@@ -785,7 +792,7 @@ constexpr int kLdsBudget = 160 * 1024;
 // LDS needed by the always-resident small arrays + panels for an N x N system
 size_t slam_dim(int P_max) { return 16 * (((size_t)3 * P_max + 1 + 15) / 16); }
 size_t slam_small_bytes_n(size_t N, int P_max, int L_max, int M_max) {
-  return (size_t)P_max * 32 + (size_t)L_max * 16 + (size_t)L_max * 64 + (size_t)(P_max + 2) * 4 + (size_t)M_max * 4 +
+  return (size_t)P_max * 32 + (size_t)L_max * 16 + (size_t)L_max * 64 + (size_t)L_max * 16 + (size_t)(P_max + 2) * 4 + (size_t)M_max * 4 +
          2 * (8 * N + 32) * 8 + 128;
 }
 size_t slam_small_bytes(int P_max, int L_max, int M_max) { return slam_small_bytes_n(slam_dim(P_max), P_max, L_max, M_max); }
