@@ -77,6 +77,7 @@ struct SweepCtx {
   bool ewave;  // this wave inverts the pivot blocks (an idle tile row if there is one, else tile row 0)
   double *Vb;
   int *bad;
+  long long *tr;  // timing trace (dev)
 };
 
 // E = -D^-1 of the 4x4 SPD pivot block at (k0, k0); lane (lr, lc) of the owning wave passes D[lr][lc - (k0 & 15)].
@@ -222,6 +223,220 @@ __device__ __forceinline__ void sweep_all(const SweepCtx &x, v4d (&acc)[FT], int
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 16-wide block Gauss-Jordan (the sweep used by the fast path).  The 4-wide sweep above needs 2 block barriers and a
+// chain of small dependent steps per 4 pivots (~1.4 us per sweep, 28 sweeps at 37 poses); here a step pivots on a whole
+// 16 x 16 tile column K:
+//   P  wave I >= K publishes tile (I, K), wave K also the transposed tiles (K, u < K): panel PAN[i][.] = A[i][16 K + .]
+//      barrier
+//   W  every wave: W_I = PAN_I E_K  (4 chained MFMAs, E_K = -D_K^-1 from the look-ahead below), published to WT
+//      barrier
+//   U  every wave: A_Iu += W_I PAN_u^T for its tiles u <= I (4 MFMAs each); tile column K <- -W_I;
+//      wave K: its pivot rows <- -W_u^T, pivot block <- E_K
+//   look-ahead: the diagonal tile D_{K+1} = A_{K+1,K+1} + W_{K+1} PAN_{K+1}^T is formed and inverted (four 4-wide
+//      sub-sweeps inside ONE wave, wave-local LDS only) by a wave with little or no matrix work while the others run U.
+// Panels live in the LDS region of the dense matrix A, which is dead while the tiles are in registers.  Operand layout
+// "KS": a 16-vector v is stored as v[(c & 3) * 4 + (c >> 2)] so that the 4 K-steps of an MFMA operand lane are one
+// 32-byte read.
+// ------------------------------------------------------------------------------------------------------------------
+struct Sw16 {
+  double *pan[2];   // [N][16] KS
+  double *wt;       // [N][16] KS
+  double *einv[2];  // [16][16] KS (E is symmetric)
+  double *dscr[2];  // [64][4]: accumulator dump (lane, reg) of the next diagonal tile
+  double *es;       // inversion scratch of the E-wave: vs[4][16], e4[16], d4[16], ws[64]
+};
+__device__ __forceinline__ int ks16(int c) { return (c & 3) * 4 + (c >> 2); }
+
+__device__ __forceinline__ v4d mfma4(const double (&a)[4], const double (&b)[4], v4d c) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], c, 0, 0, 0);
+  return c;
+}
+__device__ __forceinline__ void ld4(const double *p, double (&o)[4]) {
+  const double2 a = *reinterpret_cast<const double2 *>(p), b = *reinterpret_cast<const double2 *>(p + 2);
+  o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+}
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// ---- in-wave 16 x 16 symmetric inversion: scalar Gauss-Jordan sweeps in registers ----
+// d (accumulator layout: lane (lr, lc), reg r = D[lr + 4 r][lc], full symmetric tile K of the system) <- -D^-1; pivots
+// 16 K + k >= np are skipped (identity).  Per pivot k: row k is broadcast to the four 16-lane rows with the gfx950
+// permlane swaps, the column entries of a lane's rows and the pivot come from DPP row broadcasts: no LDS, no shuffles
+// through memory - this dependent chain (16 reciprocals) is the critical path of the whole factorisation.
+template <int kLane>
+__device__ __forceinline__ double row_bcast_lane(double v) {  // value of lane kLane of each 16-lane row
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x150 + kLane, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + kLane, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int kRow>
+__device__ __forceinline__ double rowgroup_bcast(double v) {  // 16-lane row kRow (0..3) copied to all four rows
+  const long long b = __double_as_longlong(v);
+  unsigned w[2] = {(unsigned)b, (unsigned)(b >> 32)};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const auto p16 = __builtin_amdgcn_permlane16_swap(w[h], w[h], false, false);  // [x0 x0 x2 x2], [x1 x1 x3 x3]
+    const unsigned y = (kRow & 1) ? p16[1] : p16[0];
+    const auto p32 = __builtin_amdgcn_permlane32_swap(y, y, false, false);        // [A A A A], [B B B B]
+    w[h] = (kRow & 2) ? p32[1] : p32[0];
+  }
+  return __longlong_as_double(((long long)w[1] << 32) | w[0]);
+}
+template <int k>
+__device__ __forceinline__ void gj_pivot(const SweepCtx &x, v4d &d) {
+  constexpr int rk = k >> 2, lk = k & 3;
+  const double xr = rowgroup_bcast<lk>(d[rk]);  // D[k][lc]
+  const double p = row_bcast_lane<k>(xr);       // D[k][k]
+  const double q = fast_rcp(p);
+  if (x.lane == 0 && !(p > 0)) x.bad[0] = 1;
+  const double t = xr * q;
+  const bool colk = x.lc == k, rowk = x.lr == lk;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double c = row_bcast_lane<k>(d[r]);  // D[lr + 4 r][k]
+    double v = fma(-c, t, d[r]);
+    v = colk ? c * q : v;
+    if (r == rk) v = rowk ? (colk ? -q : t) : v;
+    d[r] = v;
+  }
+}
+template <int k = 0>
+__device__ __forceinline__ void inv16(const SweepCtx &x, int K, v4d &d) {
+  if constexpr (k < 16) {
+    if (16 * K + k < x.np) {
+      gj_pivot<k>(x, d);
+      inv16<k + 1>(x, K, d);
+    }
+  }
+}
+
+template <int KI, int FT>
+__device__ __forceinline__ void sweep16_block(const SweepCtx &x, const Sw16 &L, v4d (&acc)[FT]) {
+  const int N = x.N, lc = x.lc, lr = x.lr, I = x.I;
+  const int b = KI & 1;
+  double *pan = L.pan[b];
+  const int kb = 16 * KI;
+  const bool has_mask = x.np < kb + 16;  // the last block holds the rhs row / pads: they are not pivots
+  const bool trg = x.tr && KI == 3;
+  if (trg) x.tr[0] = clock64();
+  // ---- P: publish the pivot tile column (masked columns / rows as zeros) ----
+  if (x.live && I >= KI) {
+    const bool colact = kb + lc < x.np;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pan[(16 * I + lr + 4 * r) * 16 + ks16(lc)] = colact ? acc[KI][r] : 0.0;
+  }
+  if (I == KI) {
+#pragma unroll
+    for (int u = 0; u < KI; ++u) {
+      double *o = pan + (16 * u + lc) * 16 + lr * 4;  // A[16 K + lr + 4 r][16 u + lc] -> PAN[16 u + lc][KS(lr + 4 r)]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (kb + lr + 4 * r < x.np) ? acc[u][r] : 0.0;
+    }
+  }
+  constexpr int KN = (KI + 1 < FT) ? KI + 1 : KI;
+  const bool have_next = kb + 16 < x.np;
+  if (have_next && I == KI + 1) {  // current values of the next diagonal tile, for the look-ahead
+    double *o = L.dscr[(KI + 1) & 1] + 4 * x.lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = acc[KN][r];
+  }
+  if (trg) x.tr[1] = clock64();
+  __syncthreads();
+  // ---- W = PAN_I E_K ----
+  v4d w = {0.0, 0.0, 0.0, 0.0};
+  if (x.live) {
+    double aP[4], eB[4];
+    ld4(pan + (16 * I + lc) * 16 + lr * 4, aP);
+    ld4(L.einv[b] + lc * 16 + lr * 4, eB);
+    w = mfma4(aP, eB, w);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) L.wt[(16 * I + lr + 4 * r) * 16 + ks16(lc)] = w[r];
+  }
+  if (trg) x.tr[2] = clock64();
+  __syncthreads();
+  if (trg) x.tr[3] = clock64();
+  // ---- look-ahead: E_{K+1} ----
+  if (x.ewave && have_next) {
+    v4d d;
+    {
+      double t[4];
+      ld4(L.dscr[(KI + 1) & 1] + 4 * x.lane, t);
+      d = v4d{t[0], t[1], t[2], t[3]};
+    }
+    double aW[4], bP[4];
+    ld4(L.wt + (16 * (KI + 1) + lc) * 16 + lr * 4, aW);
+    ld4(pan + (16 * (KI + 1) + lc) * 16 + lr * 4, bP);
+    d = mfma4(aW, bP, d);
+    inv16(x, KI + 1, d);
+    double *eo = L.einv[(KI + 1) & 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) eo[(lr + 4 * r) * 16 + ks16(lc)] = d[r];
+  }
+  // ---- U ----
+  if (x.live) {
+    if (I != KI || has_mask) {
+      double aW[4];
+      ld4(L.wt + (16 * I + lc) * 16 + lr * 4, aW);
+#pragma unroll
+      for (int u = FT - 1; u >= 0; --u) {
+        if (u <= I && (u != KI || I == KI)) {  // tile column K is replaced below, except in wave K (masked rows keep the update)
+          double bP[4];
+          ld4(pan + (16 * u + lc) * 16 + lr * 4, bP);
+          acc[u] = mfma4(aW, bP, acc[u]);
+        }
+      }
+    }
+    if (I > KI) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[KI][r] = -w[r];  // A_IK <- A_IK D^-1 (masked columns: W = 0)
+    }
+    if (I == KI) {
+      // pivot rows: A_Ku <- -(W_u)^T, pivot block <- E_K; rows >= np (rhs, pads) keep the regular update, their pivot
+      // columns take -W like any other row
+#pragma unroll
+      for (int u = 0; u < KI; ++u) {
+        double t[4];
+        ld4(L.wt + (16 * u + lc) * 16 + lr * 4, t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[u][r] = (kb + lr + 4 * r < x.np) ? -t[r] : acc[u][r];
+      }
+      double e[4], t[4];
+      ld4(L.einv[b] + lc * 16 + lr * 4, e);       // E[lr + 4 r][lc]
+      ld4(L.wt + (16 * KI + lc) * 16 + lr * 4, t);  // W[16 K + lc][lr + 4 r]
+      const bool colact = kb + lc < x.np;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool rowact = kb + lr + 4 * r < x.np;
+        acc[KI][r] = rowact ? (colact ? e[r] : -t[r]) : (colact ? -w[r] : acc[KI][r]);
+      }
+    }
+  }
+  if (trg) x.tr[4] = clock64();
+}
+
+#define SW16_END_STAMP
+template <int FT, int KI = 0>
+__device__ __forceinline__ void sweep16_all(const SweepCtx &x, const Sw16 &L, v4d (&acc)[FT]) {
+  if constexpr (KI < FT) {
+    if (16 * KI < x.np) {
+      sweep16_block<KI, FT>(x, L, acc);
+      sweep16_all<FT, KI + 1>(x, L, acc);
+    }
+  }
+}
+
 // iterate the poses p (ascending) whose bit is set in the two-word mask at `mk`
 #define FOR_EACH_OBSERVING_POSE(mk, p)                                         \
   for (int _w = 0; _w < 2; ++_w)                                              \
@@ -264,7 +479,8 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
   double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
   double *A;
   if (kLds) {
-    A = reinterpret_cast<double *>(smem_raw + off); off += (size_t)N * ld * 8;
+    // (the fast path reuses this region for its sweep panels: 48 N + 1184 doubles)
+    A = reinterpret_cast<double *>(smem_raw + off); off += (FT > 0 ? max((size_t)N * ld, (size_t)48 * N + 1184) : (size_t)N * ld) * 8;
   } else {
     A = wsd; wsd += (size_t)(3 * S.P_max + 16) * (3 * S.P_max + 16);
   }
@@ -497,7 +713,7 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // tile rows r and FT-1-r share a SIMD (waves w and w+4): lower-triangle MFMA work is balanced across the SIMDs
     const int trow = wv < FT / 2 ? wv : (FT - 1) - (wv - FT / 2);
-    SweepCtx x{trow, lane, lane & 15, lane >> 4, np, N, trow < Tn, trow == (Tn < FT ? FT - 1 : 0), Vb, bad};
+    SweepCtx x{trow, lane, lane & 15, lane >> 4, np, N, trow < Tn, trow == (Tn < FT ? FT - 1 : 0), Vb, bad, (S.prof && blockIdx.x == 0 && lane == 0) ? S.prof + 24 + 5 * wv : nullptr};
     v4d acc[FT];
 #pragma unroll
     for (int u = 0; u < FT; ++u)
@@ -506,9 +722,36 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
         const int i = 16 * x.I + x.lr + 4 * r, j = 16 * u + x.lc;
         acc[u][r] = (i < N && j < N) ? A[max(i, j) * ld + min(i, j)] : 0.0;
       }
-    if (x.I == 0) pivot_inverse(x, 0, acc[0][0], Vb + 8 * N + 16, Vb + 8 * N);
-    int g = 0;
-    sweep_all<FT>(x, acc, g);
+    __syncthreads();  // every tile is in registers: the LDS region of A now holds the sweep panels
+    Sw16 Lp;
+    {
+      double *q = A;
+      Lp.pan[0] = q; q += 16 * N;
+      Lp.pan[1] = q; q += 16 * N;
+      Lp.wt = q; q += 16 * N;
+      Lp.einv[0] = q; q += 256;
+      Lp.einv[1] = q; q += 256;
+      Lp.dscr[0] = q; q += 256;
+      Lp.dscr[1] = q; q += 256;
+      Lp.es = q;  // 160 doubles
+    }
+    if (x.I == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Lp.dscr[0][4 * lane + r] = acc[0][r];
+    }
+    __syncthreads();
+    if (x.ewave) {  // E_0
+      v4d d;
+      {
+        double t[4];
+        ld4(Lp.dscr[0] + 4 * lane, t);
+        d = v4d{t[0], t[1], t[2], t[3]};
+      }
+      inv16(x, 0, d);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Lp.einv[0][(x.lr + 4 * r) * 16 + ks16(x.lc)] = d[r];
+    }
+    sweep16_all<FT>(x, Lp, acc);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < FT; ++u) {

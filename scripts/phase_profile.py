@@ -25,12 +25,11 @@ print("  total %.2f" % ((a[7]-a[0]) / 100.0))
 print("  sweep sub-phases (us): panel+barrier %.2f, pivot inverse %.2f, tiles %.2f" % (a[8]/100.0, a[9]/100.0, a[10]/100.0))
 mn = {17:"load+bbox sweep",21:"phase A + masks",18:"CI fusion",19:"occupancy + sums",20:"block reduction"}
 print("  shader clock during sweeps: %.0f MHz" % (a[11] / max(a[12], 1) * 100.0))
-last = np.array(out[:], dtype=np.float64)
-for w in range(4):
-    b = last[24 + w * 10: 24 + w * 10 + 8]
-    print("  wave %d sweep-5 cycles from A start: A-written %d, bar1 %d, B-written %d, bar2 %d, mfma-done %d, fixups %d, E-done %d" % ((w,) + tuple(int(x - b[0]) for x in b[1:8])))
-b = last[16:21]
-print("  pivot_inverse(6) cycles from entry: D-read %d, rcp1 %d, rcp2 %d, end %d; entry - mfma-done(wave2) %d" % (b[1]-b[0], b[2]-b[0], b[3]-b[0], b[4]-b[0], b[0] - last[24+20+5]))
+last = np.array(out[:], dtype=np.int64)
+t0 = min(last[24 + 5 * w] for w in range(8))
+for w in range(8):
+    b5 = last[24 + 5 * w: 29 + 5 * w] - t0
+    print("  wave %d (step K=3): start %5d  P done %5d  W done %5d  barrier2 passed %5d  end %5d" % (w, b5[0], b5[1], b5[2], b5[3], b5[4]))
 print("k_map phases (us, block 0):")
 prev = a[16]
 for k in (17, 21, 18, 19, 20):
