@@ -277,8 +277,8 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 template <int kLane>
 __device__ __forceinline__ double row_bcast_lane(double v) {  // value of lane kLane of each 16-lane row
   const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x150 + kLane, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + kLane, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_update_dpp((int)b, (int)b, 0x150 + kLane, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), 0x150 + kLane, 0xf, 0xf, true);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 template <int kRow>
@@ -313,13 +313,28 @@ __device__ __forceinline__ void gj_pivot(const SweepCtx &x, v4d &d) {
   }
 }
 template <int k = 0>
-__device__ __forceinline__ void inv16(const SweepCtx &x, int K, v4d &d) {
+__device__ __forceinline__ void inv16_masked(const SweepCtx &x, int K, v4d &d) {
   if constexpr (k < 16) {
     if (16 * K + k < x.np) {
       gj_pivot<k>(x, d);
-      inv16<k + 1>(x, K, d);
+      inv16_masked<k + 1>(x, K, d);
     }
   }
+}
+template <int k = 0>
+__device__ __forceinline__ void inv16_full(const SweepCtx &x, v4d &d) {
+  if constexpr (k < 16) {
+    gj_pivot<k>(x, d);
+    inv16_full<k + 1>(x, d);
+  }
+}
+__device__ __forceinline__ void inv16(const SweepCtx &x, int K, v4d &d) {
+  // all 16 pivots active (every block but the last): one straight-line block, so that the scheduler can start pivot
+  // k + 1's broadcast / reciprocal chain under the tail of pivot k's update
+  if (16 * K + 16 <= x.np)
+    inv16_full<0>(x, d);
+  else
+    inv16_masked<0>(x, K, d);
 }
 
 template <int KI, int FT>
@@ -364,25 +379,35 @@ __device__ __forceinline__ void sweep16_block(const SweepCtx &x, const Sw16 &L, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) L.wt[(16 * I + lr + 4 * r) * 16 + ks16(lc)] = w[r];
   }
+  // ---- look-ahead: E_{K+1}.  The E-wave forms W_{K+1} = PAN_{K+1} E_K itself (it must not wait for the wave that owns
+  //      that row to publish it), updates the diagonal tile D_{K+1} += W_{K+1} PAN_{K+1}^T before the second barrier and
+  //      inverts it right after ----
+  v4d dn = {0.0, 0.0, 0.0, 0.0};
+  if (x.ewave && have_next) {
+    double aP[4], eB[4], aW[4], bP[4], t[4];
+    ld4(pan + (16 * (KI + 1) + lc) * 16 + lr * 4, aP);  // also the B operand of the update (PAN_{K+1}^T)
+    ld4(L.einv[b] + lc * 16 + lr * 4, eB);
+    v4d w1 = {0.0, 0.0, 0.0, 0.0};
+    w1 = mfma4(aP, eB, w1);
+    // accumulator layout -> A-operand layout through the wave-private scratch
+#pragma unroll
+    for (int r = 0; r < 4; ++r) L.es[(lr + 4 * r) * 16 + ks16(lc)] = w1[r];
+    wave_lds_sync();
+    ld4(L.es + lc * 16 + lr * 4, aW);
+    ld4(L.dscr[(KI + 1) & 1] + 4 * x.lane, t);
+    dn = v4d{t[0], t[1], t[2], t[3]};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) bP[s2] = aP[s2];
+    dn = mfma4(aW, bP, dn);
+  }
   if (trg) x.tr[2] = clock64();
   __syncthreads();
   if (trg) x.tr[3] = clock64();
-  // ---- look-ahead: E_{K+1} ----
   if (x.ewave && have_next) {
-    v4d d;
-    {
-      double t[4];
-      ld4(L.dscr[(KI + 1) & 1] + 4 * x.lane, t);
-      d = v4d{t[0], t[1], t[2], t[3]};
-    }
-    double aW[4], bP[4];
-    ld4(L.wt + (16 * (KI + 1) + lc) * 16 + lr * 4, aW);
-    ld4(pan + (16 * (KI + 1) + lc) * 16 + lr * 4, bP);
-    d = mfma4(aW, bP, d);
-    inv16(x, KI + 1, d);
+    inv16(x, KI + 1, dn);
     double *eo = L.einv[(KI + 1) & 1];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) eo[(lr + 4 * r) * 16 + ks16(lc)] = d[r];
+    for (int r = 0; r < 4; ++r) eo[(lr + 4 * r) * 16 + ks16(lc)] = dn[r];
   }
   // ---- U ----
   if (x.live) {
@@ -479,8 +504,8 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
   double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
   double *A;
   if (kLds) {
-    // (the fast path reuses this region for its sweep panels: 48 N + 1184 doubles)
-    A = reinterpret_cast<double *>(smem_raw + off); off += (FT > 0 ? max((size_t)N * ld, (size_t)48 * N + 1184) : (size_t)N * ld) * 8;
+    // (the fast path reuses this region for its sweep panels: 48 N + 1280 doubles)
+    A = reinterpret_cast<double *>(smem_raw + off); off += (FT > 0 ? max((size_t)N * ld, (size_t)48 * N + 1280) : (size_t)N * ld) * 8;
   } else {
     A = wsd; wsd += (size_t)(3 * S.P_max + 16) * (3 * S.P_max + 16);
   }
@@ -733,7 +758,7 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
       Lp.einv[1] = q; q += 256;
       Lp.dscr[0] = q; q += 256;
       Lp.dscr[1] = q; q += 256;
-      Lp.es = q;  // 160 doubles
+      Lp.es = q;  // 256 doubles
     }
     if (x.I == 0) {
 #pragma unroll
