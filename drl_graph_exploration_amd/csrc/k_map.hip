@@ -1,20 +1,26 @@
 // Virtual-map kernel: occupancy rebuild + covariance propagation (EKF push-through of every core
 // pose onto the virtual-landmark grid, fused by covariance intersection) + utility reductions.
-// One 1024-thread workgroup (16 waves) per instance.
+// One 512-thread workgroup per instance (8 waves: 2 per SIMD is what the ~160 VGPRs of the propagation code allow
+// without spilling; the kernel is bound by fp64 instruction issue, not by latency, so more waves do not help).
 //
 // Reference: src/em_exploration/OccupancyMap.cpp:55-138 (log-odds ladder, bbox sector sweep),
 // src/em_exploration/VirtualMap.cpp:47-84 (explored, updateProbability), :213-229
 // (predictVirtualLandmark), :256-316 (updateInformation), :364-378 (covarianceIntersection2D),
 // src/em_exploration/Planner2D.cpp:321-366 (calculateUncertainty / calculateUtility).
 //
-// Data flow (per instance): poses (x,y,c,s + 3x3 information) are staged in LDS once.
-//   phase O: cell-centric occupancy ladder, poses visited in trajectory order.
-//   phase A: one wave per pose, one lane per cell of the (win x win) window around the pose: the
-//            3x3 LLT solve and 2x2 algebra run in registers; the per-(pose,cell) 2x2 information
-//            is staged in LDS.
-//   phase B: cell-centric covariance-intersection fusion in trajectory order from the LDS stage.
-//   phase R: trace / determinant / known / explored reductions (wave shuffles + LDS).
-// fp64 transcendentals are the expensive instructions here, so two exact shortcuts are taken:
+// Data flow (per instance): poses (x,y,c,s + 3x3 information, its LLT factor) are staged in LDS once.
+//   phase A (pose-centric): the (pose, window cell) pairs of the W x W cell windows around the poses are spread evenly
+//            over the threads: range + field-of-view test, EKF push-through of the pose covariance (3x3 LLT solve, 2x2
+//            algebra in registers); the 2x2 information goes to an LDS stage and the pose's bit is set (LDS atomics) in
+//            the cell's "updates me" mask and, for the occupancy model, in its "sees me" mask.
+//   phase C (cell-centric, one pass): covariance-intersection fusion over the set bits in trajectory order; occupancy
+//            ladder over the "sees me" bits as a host-built state machine (DrlgxState::lo_tr); probability, trace,
+//            and the five utility sums.  Every cell is written once per belief update and never read back.
+//   phase R: block reduction of the sums (wave shuffles + LDS).
+// The kernel is issue-bound on fp64, so (1) only (cell, pose) pairs that interact are visited, (2) divisions and square
+// roots whose results are only compared against a tolerance use v_rcp/v_rsq + Newton (rcp_n / rsqrt_n), never the
+// ones that feed a decision, and
+// (3) two exact shortcuts avoid fp64 transcendentals:
 //   * the field-of-view test needs atan2 only inside a thin wedge around the sensor's blind ray; cells
 //     that are provably inside the FOV (d.x >= 0, or |d.y| > tan(blind half-angle + 1 mrad) |d.x|) skip it;
 //   * when the 3-degree sector sweep covers the whole circle its bounding box provably contains every
@@ -24,7 +30,7 @@
 
 namespace {
 
-constexpr int kThreads = 1024;
+constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 
 __device__ __forceinline__ double logodds2prob(double l) { return exp(l) / (1.0 + exp(l)); }

@@ -8,23 +8,17 @@
 //      (the fp64 atan2/sincos chains are the expensive part); landmark 2x2 blocks (thread per
 //      landmark) and pose 3x3 blocks (thread per pose) are summed deterministically in factor order
 //   3. landmarks are eliminated analytically -> Schur complement S on the poses (3P x 3P, LDS)
-//   4. block symmetric SWEEP of [S rhs] with 3x3 pose pivots.  Every thread keeps one (or two)
-//      6x6 tile(s) (2x2 pose blocks) of the lower triangle in REGISTERS for all P sweeps; only the 3-column pivot panel goes
-//      through LDS (double buffered -> ONE barrier per sweep).  Afterwards the triangle holds -S^-1
-//      (every pose marginal and cross block) and the augmented row holds delta_p.
+//   4. symmetric Gauss-Jordan SWEEP of the augmented system [S rhs] on the fp64 matrix cores
+//      (v_mfma_f64_16x16x4_f64): the lower triangle lives in 16 x 16 accumulator tiles in registers for the whole
+//      factorisation; afterwards the triangle holds -S^-1 (every pose marginal and cross block) and the augmented row
+//      holds delta_p.  Fast path (<= 42 poses, everything in LDS): 16-wide block pivots, one tile row per wave, the next
+//      diagonal tile inverted in registers by an otherwise idle wave (sweep16_block).  Larger capacities (<= 86 poses,
+//      system in an HBM/L2 workspace): 4-wide pivots over triangular tiles (phase 5 in the kernel).
 //   5. landmark deltas and 2x2 landmark marginals by back-substitution through G = Lambda_pl Lambda_ll^-1
 //   6. estimates theta (+) delta, information blocks (3x3 LLT inverse / 2x2 inverse), traces
-// LDS: the padded (3P+1)^2 system (<= 43 poses) + panels + per-factor records; the records (and, for
-// larger capacities, the system itself) fall back to an HBM/L2 workspace.
+// Per-landmark loops walk a bit mask of the observing poses.  LDS: the padded system + per-factor records when they
+// fit; the records (and, for the larger capacities, the system itself) fall back to an HBM/L2 workspace.
 #include "drlgx_dev.h"
-#ifndef SWEEP_VARIANT
-#define SWEEP_VARIANT 0  // >0: timing experiments only (parts of the sweep disabled, wrong numerics)
-#endif
-#if SWEEP_VARIANT >= 7
-#define SV_BASE 4
-#else
-#define SV_BASE SWEEP_VARIANT
-#endif
 
 namespace {
 
@@ -61,172 +55,19 @@ __device__ __forceinline__ double sel4(unsigned k, double a, double b, double c,
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kWaves = kThreads / 64;
 
-// ------------------------------------------------------------------------------------------------------------------
-// Fast sweep path (capacity N = 16 FT <= 128, i.e. <= 42 poses): FULL symmetric storage, wave w owns tile row w
-// (FT accumulator tiles), so every wave runs the same straight-line code and the pivot tile column KI is a compile-time
-// index (sweep_block<KI> is instantiated per tile column).  A scalar branch costs ~20-30 cycles on this machine and
-// the triangular tile scheme below spends most of its time in per-tile role tests; here a sweep has a handful.
-//   phase A  every wave publishes its 16 rows of the 4 pivot columns            -> barrier
-//   phase B  every lane forms one entry of nW = V E (its MFMA A operand), also published   -> barrier
-//   phase C  FT MFMAs A_Iu += nW_I V_u^T; pivot columns <- -nW; the wave owning the pivot rows overwrites them with
-//            -nW^T / E; the owner of the next pivot block inverts it (E for the next sweep)
-// ------------------------------------------------------------------------------------------------------------------
 struct SweepCtx {
   int I, lane, lc, lr, np, N;
   bool live;   // this wave's tile row holds real rows (I < number of 16-row blocks in use)
-  bool ewave;  // this wave inverts the pivot blocks (an idle tile row if there is one, else tile row 0)
-  double *Vb;
+  bool ewave;  // this wave inverts the diagonal tiles (an idle tile row if there is one, else tile row 0)
   int *bad;
-  long long *tr;  // timing trace (dev)
+  long long *tr;  // dev aid: 5 cycle stamps per wave for one step (armed through drlgx_debug_phase_clocks_host)
 };
 
-// E = -D^-1 of the 4x4 SPD pivot block at (k0, k0); lane (lr, lc) of the owning wave passes D[lr][lc - (k0 & 15)].
-// 2x2 block inversion (two reciprocals on the critical path), indices >= np act as identity.  dscr / eout: 16 doubles
-// each in LDS.
-__device__ __forceinline__ void pivot_inverse(const SweepCtx &x, int k0, double dval, double *dscr, double *eout) {
-  const int qc = k0 & 15;
-  if ((unsigned)(x.lc - qc) < 4u) dscr[4 * x.lr + (x.lc - qc)] = dval;  // dval = D[lr][lc - qc] in the lanes that hold it
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const bool m1 = k0 + 1 < x.np, m2 = k0 + 2 < x.np, m3 = k0 + 3 < x.np;
-  const double a00 = dscr[0];
-  const double a10 = m1 ? dscr[4] : 0.0, a11 = m1 ? dscr[5] : 1.0;
-  const double a20 = m2 ? dscr[8] : 0.0, a21 = (m2 && m1) ? dscr[9] : 0.0, a22 = m2 ? dscr[10] : 1.0;
-  const double a30 = m3 ? dscr[12] : 0.0, a31 = (m3 && m1) ? dscr[13] : 0.0, a32 = (m3 && m2) ? dscr[14] : 0.0;
-  const double a33 = m3 ? dscr[15] : 1.0;
-  // P = [a00 a10; a10 a11], Q = [a20 a21; a30 a31], R = [a22 a32; a32 a33]
-  const double detp = a00 * a11 - a10 * a10;
-  const double ip = fast_rcp(detp);
-  const double p00 = a11 * ip, p10 = -a10 * ip, p11 = a00 * ip;           // P^-1
-  const double t00 = a20 * p00 + a21 * p10, t01 = a20 * p10 + a21 * p11;  // T = Q P^-1
-  const double t10 = a30 * p00 + a31 * p10, t11 = a30 * p10 + a31 * p11;
-  const double s00 = a22 - (t00 * a20 + t01 * a21);                       // S = R - T Q^T
-  const double s10 = a32 - (t10 * a20 + t11 * a21);
-  const double s11 = a33 - (t10 * a30 + t11 * a31);
-  const double dets = s00 * s11 - s10 * s10;
-  const double is = fast_rcp(dets);
-  const double r00 = s11 * is, r10 = -s10 * is, r11 = s00 * is;           // S^-1
-  const double u00 = r00 * t00 + r10 * t10, u01 = r00 * t01 + r10 * t11;  // U = S^-1 T
-  const double u10 = r10 * t00 + r11 * t10, u11 = r10 * t01 + r11 * t11;
-  if (x.lane == 0 && (!(a00 > 0) || !(detp > 0) || !(s00 > 0) || !(dets > 0))) x.bad[0] = 1;
-  // D^-1 = [P^-1 + T^T U, -U^T; -U, S^-1];  E = -D^-1
-  const double e00 = -(p00 + t00 * u00 + t10 * u10), e10 = -(p10 + t01 * u00 + t11 * u10);
-  const double e11 = -(p11 + t01 * u01 + t11 * u11);
-  if (x.lane < 16) {
-    const int r = x.lane >> 2, c = x.lane & 3;
-    const int hi = max(r, c), lo = min(r, c);
-    double w;
-    if (hi < 2) w = (hi == 0) ? e00 : (lo == 0 ? e10 : e11);
-    else if (lo >= 2) w = -((lo == 3) ? r11 : (hi == 2 ? r00 : r10));
-    else w = (hi == 2) ? (lo == 0 ? u00 : u01) : (lo == 0 ? u10 : u11);
-    eout[x.lane] = w;
-  }
-}
-
-template <int KI, int FT>
-__device__ __forceinline__ void sweep_block(const SweepCtx &x, v4d (&acc)[FT], int &g) {
-  static_assert(FT == 8, "the MFMA switch below is written for 8 tile rows");
-  const int N = x.N, lc = x.lc, lr = x.lr, I = x.I;
-  const int bs = 8 * N + 32;  // per-sweep LDS buffer: planes 0-3 v, 4-7 nW, then E (16) + pivot scratch (16)
-#pragma unroll 1
-  for (int q = 0; q < 4; ++q) {
-    const int k0 = 16 * KI + 4 * q;
-    if (k0 >= x.np) return;
-    const int kc = 4 * q;
-    double *vb = x.Vb + (size_t)(g & 1) * bs;
-    double *nwb = vb + 4 * N;
-    const double *eb = vb + 8 * N;
-    const int c = lc - kc;
-    const bool mine = (unsigned)c < 4u;
-    const bool act = mine && k0 + c < x.np;
-    const bool rowact = k0 + lr < x.np;
-    const int row = 16 * I + lc;
-    // ---- phase A: panel v[c][i] = A[max(i,k0+c)][min(i,k0+c)].  Rows of tile rows >= KI come from the pivot columns of
-    //      tile (I, KI) (the diagonal tile is kept fully symmetric); rows above come from the pivot rows of tile row KI ----
-    if (SWEEP_VARIANT != 7 && SWEEP_VARIANT != 9 && x.live && I >= KI && mine) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) vb[c * N + 16 * I + lr + 4 * r] = act ? acc[KI][r] : 0.0;
-    }
-    if (SWEEP_VARIANT != 7 && SWEEP_VARIANT != 9 && I == KI) {
-#pragma unroll
-      for (int u = 0; u < KI; ++u) vb[lr * N + 16 * u + lc] = rowact ? sel4(q, acc[u][0], acc[u][1], acc[u][2], acc[u][3]) : 0.0;
-    }
-    __syncthreads();
-    // ---- phase B: nW = V E: lane (lr, lc) forms nW[lr][16 I + lc], its MFMA A operand ----
-    double aop = 0.0;
-    if (SV_BASE < 3 && x.live) {
-      aop = fma(vb[3 * N + row], eb[12 + lr], fma(vb[2 * N + row], eb[8 + lr], fma(vb[N + row], eb[4 + lr], vb[row] * eb[lr])));
-      nwb[lr * N + row] = aop;
-    }
-    // The next pivot block D' = A_K'K' + nW_K' V_K'^T needs only the panels and the CURRENT values of that block: its
-    // owner publishes them (16 doubles) and a wave with little or no matrix work (x.ewave) forms and inverts D' during
-    // phase C, so that E_{g+1} is computed beside the MFMAs instead of after them.
-    const int k1 = k0 + 4, qn = (q + 1) & 3;
-    constexpr int KN = (KI + 1 < FT) ? KI + 1 : KI;
-    const int c1 = lc - 4 * qn, c1c = (unsigned)c1 < 4u ? c1 : 0;
-    double *nb = x.Vb + (size_t)((g + 1) & 1) * bs + 8 * N;  // E_{g+1} (16), then the pivot scratch (16)
-    if (SV_BASE < 1 && k1 < x.np && I == (k1 >> 4) && (unsigned)c1 < 4u) {
-      const v4d &t = (q == 3) ? acc[KN] : acc[KI];
-      nb[16 + 4 * lr + c1] = sel4(qn, t[0], t[1], t[2], t[3]);
-    }
-    __syncthreads();
-    if (SV_BASE < 1 && x.ewave && k1 < x.np) {
-      double dnext = nb[16 + 4 * lr + c1c];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dnext = fma(nwb[k * N + k1 + lr], vb[k * N + k1 + c1c], dnext);
-      pivot_inverse(x, k1, dnext, nb + 16, nb);
-    }
-    // ---- phase C ----
-    if (SWEEP_VARIANT != 8 && SWEEP_VARIANT != 9 && x.live) {
-      double bop[FT], cf[4];
-#pragma unroll
-      for (int u = 0; u < FT; ++u) bop[u] = vb[lr * N + min(16 * u + lc, N - 1)];
-      const int cc = mine ? c : 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cf[r] = nwb[cc * N + 16 * I + lr + 4 * r];
-      // lower tiles u <= I, the diagonal tile first.  A skipped tile costs this wave one taken branch (~25 cycles) but
-      // no matrix-pipe time; a jump table would cost a scalar-cache miss per sweep.
-      if (SV_BASE < 4) {
-#pragma unroll
-        for (int u = FT - 1; u >= 0; --u)
-          if (u <= I) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop[u], acc[u], 0, 0, 0);
-      }
-      if (SV_BASE < 2 && I >= KI) {  // pivot columns: A_iK <- A_iK D^-1 = -nW
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[KI][r] = act ? -cf[r] : acc[KI][r];
-      }
-      if (SV_BASE < 2 && I == KI) {
-        // pivot rows (rows k0 + lr live in reg q): A_Kj <- (A_jK D^-1)^T = -nW^T, pivot block <- E = -D^-1
-        double val[KI + 1];
-#pragma unroll
-        for (int u = 0; u <= KI; ++u) val[u] = -nwb[lr * N + 16 * u + lc];
-        const double pv = eb[4 * lr + cc];
-        if (act) val[KI] = pv;
-#pragma unroll
-        for (int u = 0; u <= KI; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[u][r] = (rowact && r == q) ? val[u] : acc[u][r];
-      }
-    }
-    ++g;
-  }
-}
-
-template <int FT, int KI = 0>
-__device__ __forceinline__ void sweep_all(const SweepCtx &x, v4d (&acc)[FT], int &g) {
-  if constexpr (KI < FT) {
-    if (16 * KI < x.np) {
-      sweep_block<KI, FT>(x, acc, g);
-      sweep_all<FT, KI + 1>(x, acc, g);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
-// 16-wide block Gauss-Jordan (the sweep used by the fast path).  The 4-wide sweep above needs 2 block barriers and a
-// chain of small dependent steps per 4 pivots (~1.4 us per sweep, 28 sweeps at 37 poses); here a step pivots on a whole
-// 16 x 16 tile column K:
+// Fast sweep path (N <= 128, i.e. <= 42 poses): 16-wide block Gauss-Jordan with one tile row per wave (lower tiles
+// u <= I in MFMA accumulators, diagonal tile kept fully symmetric).  Scalar branches cost ~20-30 cycles here and a block
+// barrier ~50 plus the arrival skew, so a step pivots on a whole 16 x 16 tile column K (7 steps at 37 poses) and every
+// wave runs the same straight-line code (sweep16_block<K> is instantiated per tile column):
 //   P  wave I >= K publishes tile (I, K), wave K also the transposed tiles (K, u < K): panel PAN[i][.] = A[i][16 K + .]
 //      barrier
 //   W  every wave: W_I = PAN_I E_K  (4 chained MFMAs, E_K = -D_K^-1 from the look-ahead below), published to WT
@@ -500,7 +341,8 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
   // poses observing each landmark as bit masks (P <= 128): the per-landmark loops visit only those poses
   unsigned long long *lmask = reinterpret_cast<unsigned long long *>(smem_raw + off); off += (size_t)L * 16;
   off = (off + 31) & ~(size_t)31;
-  double *Vb = reinterpret_cast<double *>(smem_raw + off); off += (size_t)2 * (8 * N + 32) * 8;  // 2 buffers x (4 planes v, 4 planes v E, E, pivot scratch)
+  double *Vb = reinterpret_cast<double *>(smem_raw + off); off += (size_t)(FT > 0 ? 0 : 2 * (8 * N + 32)) * 8;  // sweep panels of the triangular path (the fast path
+                                                                                   // keeps its panels in the dead matrix region)
   double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
   double *A;
   if (kLds) {
@@ -738,7 +580,7 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // tile rows r and FT-1-r share a SIMD (waves w and w+4): lower-triangle MFMA work is balanced across the SIMDs
     const int trow = wv < FT / 2 ? wv : (FT - 1) - (wv - FT / 2);
-    SweepCtx x{trow, lane, lane & 15, lane >> 4, np, N, trow < Tn, trow == (Tn < FT ? FT - 1 : 0), Vb, bad, (S.prof && blockIdx.x == 0 && lane == 0) ? S.prof + 24 + 5 * wv : nullptr};
+    SweepCtx x{trow, lane, lane & 15, lane >> 4, np, N, trow < Tn, trow == (Tn < FT ? FT - 1 : 0), bad, (S.prof && blockIdx.x == 0 && lane == 0) ? S.prof + 24 + 5 * wv : nullptr};
     v4d acc[FT];
 #pragma unroll
     for (int u = 0; u < FT; ++u)
@@ -930,24 +772,16 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
           if (I == KI) {  // the pivot block itself (rows k0 + lr live in reg rg): A_KK <- -D^-1
             const double pv = eb[4 * lr + cc];
             const bool pm = mine && k0 + lr < np;
-            switch (rg) {
-              case 0: if (pm) acc[u][0] = pv; break;
-              case 1: if (pm) acc[u][1] = pv; break;
-              case 2: if (pm) acc[u][2] = pv; break;
-              default: if (pm) acc[u][3] = pv; break;
-            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[u][r] = (pm && r == rg) ? pv : acc[u][r];  // (selects: a switch over vector inserts miscompiled)
           }
         }
         if (I == KI) {  // pivot rows: A_Kj <- (A_jK D^-1)^T for the columns left of the pivot
           const int j = 16 * J + lc;
           const double val = -nwb[lr * N + j];
           const bool pm = j < k0 && k0 + lr < np;
-          switch (rg) {
-            case 0: if (pm) acc[u][0] = val; break;
-            case 1: if (pm) acc[u][1] = val; break;
-            case 2: if (pm) acc[u][2] = val; break;
-            default: if (pm) acc[u][3] = val; break;
-          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[u][r] = (pm && r == rg) ? val : acc[u][r];
         }
         if (g + 1 < G && I == KI1 && J == KI1) {
           double *nb = Vb + (size_t)((g + 1) & 1) * (8 * N + 32) + 8 * N;
@@ -1059,11 +893,14 @@ constexpr int kLdsBudget = 160 * 1024;
 
 // LDS needed by the always-resident small arrays + panels for an N x N system
 size_t slam_dim(int P_max) { return 16 * (((size_t)3 * P_max + 1 + 15) / 16); }
-size_t slam_small_bytes_n(size_t N, int P_max, int L_max, int M_max) {
+size_t slam_small_bytes_n(size_t N, int P_max, int L_max, int M_max, bool fast) {
+  const size_t panels = fast ? 0 : 2 * (8 * N + 32);  // the fast path keeps its panels in the (dead) matrix region
   return (size_t)P_max * 32 + (size_t)L_max * 16 + (size_t)L_max * 64 + (size_t)L_max * 16 + (size_t)(P_max + 2) * 4 + (size_t)M_max * 4 +
-         2 * (8 * N + 32) * 8 + 128;
+         panels * 8 + 128;
 }
-size_t slam_small_bytes(int P_max, int L_max, int M_max) { return slam_small_bytes_n(slam_dim(P_max), P_max, L_max, M_max); }
+size_t slam_small_bytes(int P_max, int L_max, int M_max) {
+  return slam_small_bytes_n(slam_dim(P_max), P_max, L_max, M_max, false);
+}
 constexpr int kFastTiles = 8;  // fast path: N = 128 (<= 42 poses), system + panels in LDS
 
 }  // namespace
@@ -1076,7 +913,7 @@ size_t drlgx_slam_lds_bytes(int P_max, int L_max, int M_max) {
 // true when k_slam keeps the dense system in LDS (the fast path); otherwise the engine must provide the HBM workspace
 bool drlgx_slam_in_lds(int P_max, int L_max, int M_max) {
   const size_t nf = 16 * kFastTiles;
-  return slam_dim(P_max) <= nf && slam_small_bytes_n(nf, P_max, L_max, M_max) + nf * (nf + 2) * 8 <= (size_t)kLdsBudget;
+  return slam_dim(P_max) <= nf && slam_small_bytes_n(nf, P_max, L_max, M_max, true) + nf * (nf + 2) * 8 <= (size_t)kLdsBudget;
 }
 
 void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
