@@ -285,6 +285,30 @@ __device__ inline MtStream mt_load(uint32_t *lds, const uint32_t *g, int lane) {
   s.cons = lds[DRLGX_MT_N + 1];
   return s;
 }
+// both streams of an instance (contiguous in HBM, 2 x 626 words) in one go: every load is issued before the first wait
+__device__ inline void mt_load2(uint32_t *lds0, uint32_t *lds1, const uint32_t *g, int lane, MtStream &a, MtStream &b) {
+  const uint4 *g4 = reinterpret_cast<const uint4 *>(g);  // 2 * 626 words = 313 uint4, 16-byte aligned per instance
+  uint4 v[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int i = lane + 64 * k;
+    v[k] = (i < 313) ? g4[i] : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int w = 4 * (lane + 64 * k);
+    const uint32_t e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = w + t;
+      if (idx < DRLGX_MT_STRIDE) lds0[idx] = e[t];
+      else if (idx < 2 * DRLGX_MT_STRIDE) lds1[idx - DRLGX_MT_STRIDE] = e[t];
+    }
+  }
+  wave_sync();
+  a.st = lds0; a.gen = lds0[DRLGX_MT_N]; a.cons = lds0[DRLGX_MT_N + 1];
+  b.st = lds1; b.gen = lds1[DRLGX_MT_N]; b.cons = lds1[DRLGX_MT_N + 1];
+}
 __device__ inline void mt_store(const MtStream &s, uint32_t *g, int lane) {
   wave_sync();
   for (int i = lane; i < DRLGX_MT_N; i += 64) g[i] = s.st[i];

@@ -41,7 +41,7 @@ __device__ inline void measure(SimCtx &c, bool record, double *nrm, int *inr) {
     const int key = valid ? S.lm_order[idx] : 0;
     const double lx = valid ? gl[2 * key] : 0.0, ly = valid ? gl[2 * key + 1] : 0.0;
     const double dx = lx - c.veh.x, dy = ly - c.veh.y;
-    const bool in = valid && (sqrt(dx * dx + dy * dy) < cfg.max_range);
+    const bool in = valid && (dx * dx + dy * dy < S.r2_max_lt);  // sqrt(d2) < max_range, exactly (host-computed threshold)
     const unsigned long long mask = __ballot(in);
     if (in) inr[n_in + __popcll(mask & below)] = key;
     n_in += __popcll(mask);
@@ -213,13 +213,14 @@ __global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, co
     }
     return;
   }
-  c.sensor = mt_load(lds[0], S.mt + ((size_t)inst * 2 + 0) * DRLGX_MT_STRIDE, lane);
-  c.control = mt_load(lds[1], S.mt + ((size_t)inst * 2 + 1) * DRLGX_MT_STRIDE, lane);
+  DRLGX_PROF(S, 8);
+  mt_load2(lds[0], lds[1], S.mt + (size_t)inst * 2 * DRLGX_MT_STRIDE, lane, c.sensor, c.control);
   c.ns_sensor = NormalState{S.nrm_saved[inst * 2 + 0], S.nrm_has[inst * 2 + 0]};
   c.ns_control = NormalState{S.nrm_saved[inst * 2 + 1], S.nrm_has[inst * 2 + 1]};
   const double *gp = S.gt_pose + (size_t)inst * 4;
   c.veh = Pose{gp[0], gp[1], gp[2], gp[3]};
   const Pose odomP = make_pose(ox, oy, oth);
+  DRLGX_PROF(S, 9);
   // SimpleControlModel::evolve (Simulator2D.cpp:161-182)
   draw_normals(c.control, c.ns_control, 3, nrm, lane);
   const double xn = nrm[0] * cfg.translation_noise + 0.0;
@@ -246,9 +247,14 @@ __global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, co
     S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST] += sqrt(ox * ox + oy * oy + cfg.angle_weight * (th * th));
   }
   __syncthreads();
+  DRLGX_PROF(S, 10);
   c.P += 1;
-  for (int m = 0; m < n_measure; ++m) measure(c, m == n_measure - 1, nrm, inr);
+  for (int m = 0; m < n_measure; ++m) {
+    measure(c, m == n_measure - 1, nrm, inr);
+    DRLGX_PROF(S, 11 + m);
+  }
   store_ctx(c);
+  DRLGX_PROF(S, 13);
 }
 
 }  // namespace

@@ -30,6 +30,7 @@ t0 = min(last[24 + 5 * w] for w in range(8))
 for w in range(8):
     b5 = last[24 + 5 * w: 29 + 5 * w] - t0
     print("  wave %d (step K=3): start %5d  P done %5d  W done %5d  barrier2 passed %5d  end %5d" % (w, b5[0], b5[1], b5[2], b5[3], b5[4]))
+print("k_sim phases (us, block 0): load %.2f, move %.2f, measure-1 %.2f, measure-2 %.2f, store %.2f, total %.2f" % (tuple((a[i+1]-a[i])/100.0 for i in (8,9,10,11,12)) + ((a[13]-a[8])/100.0,)))
 print("k_map phases (us, block 0):")
 prev = a[16]
 for k in (17, 21, 18, 19, 20):
