@@ -135,47 +135,66 @@ __device__ __forceinline__ double rowgroup_bcast(double v) {  // 16-lane row kRo
   }
   return __longlong_as_double(((long long)w[1] << 32) | w[0]);
 }
+// One scalar pivot.  (xr, q) = (row k broadcast to every lane's column, 1 / D[k][k]) come from the previous step: the
+// register that holds row k + 1 is updated first and the next pivot's broadcast + reciprocal chain is started from it,
+// so that the rest of this pivot's update runs in the shadow of that chain.  ~50 VALU instructions per pivot at 4 cycles
+// each is the floor of this formulation (wave64 on a 16-lane SIMD).
 template <int k>
-__device__ __forceinline__ void gj_pivot(const SweepCtx &x, v4d &d) {
+__device__ __forceinline__ void gj_update_reg(const SweepCtx &x, v4d &d, int r, double t, double q) {
   constexpr int rk = k >> 2, lk = k & 3;
-  const double xr = rowgroup_bcast<lk>(d[rk]);  // D[k][lc]
-  const double p = row_bcast_lane<k>(xr);       // D[k][k]
-  const double q = fast_rcp(p);
-  if (x.lane == 0 && !(p > 0)) x.bad[0] = 1;
-  const double t = xr * q;
   const bool colk = x.lc == k, rowk = x.lr == lk;
+  const double c = row_bcast_lane<k>(d[r]);  // D[lr + 4 r][k]
+  double v = fma(-c, t, d[r]);
+  v = colk ? c * q : v;
+  if (r == rk) v = rowk ? (colk ? -q : t) : v;
+  d[r] = v;
+}
+template <int k>
+__device__ __forceinline__ void gj_head(const SweepCtx &x, const v4d &d, double &xr, double &q) {
+  constexpr int rk = k >> 2, lk = k & 3;
+  xr = rowgroup_bcast<lk>(d[rk]);                    // D[k][lc]
+  const double p = readlane_f64(d[rk], 16 * lk + k);  // D[k][k] (uniform; off the broadcast chain)
+  q = fast_rcp(p);
+  if (x.lane == 0 && !(p > 0)) x.bad[0] = 1;
+}
+template <int k, bool kChainNext>
+__device__ __forceinline__ void gj_pivot(const SweepCtx &x, v4d &d, double &xr, double &q) {
+  const double t = xr * q, qk = q;
+  constexpr int rn = (k + 1 < 16) ? ((k + 1) >> 2) : 0;
+  gj_update_reg<k>(x, d, rn, t, qk);
+  if constexpr (kChainNext && k + 1 < 16) gj_head<k + 1>(x, d, xr, q);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const double c = row_bcast_lane<k>(d[r]);  // D[lr + 4 r][k]
-    double v = fma(-c, t, d[r]);
-    v = colk ? c * q : v;
-    if (r == rk) v = rowk ? (colk ? -q : t) : v;
-    d[r] = v;
-  }
+  for (int r = 0; r < 4; ++r)
+    if (r != rn) gj_update_reg<k>(x, d, r, t, qk);
 }
 template <int k = 0>
 __device__ __forceinline__ void inv16_masked(const SweepCtx &x, int K, v4d &d) {
   if constexpr (k < 16) {
     if (16 * K + k < x.np) {
-      gj_pivot<k>(x, d);
+      double xr, q;
+      gj_head<k>(x, d, xr, q);
+      gj_pivot<k, false>(x, d, xr, q);
       inv16_masked<k + 1>(x, K, d);
     }
   }
 }
 template <int k = 0>
-__device__ __forceinline__ void inv16_full(const SweepCtx &x, v4d &d) {
+__device__ __forceinline__ void inv16_full(const SweepCtx &x, v4d &d, double &xr, double &q) {
   if constexpr (k < 16) {
-    gj_pivot<k>(x, d);
-    inv16_full<k + 1>(x, d);
+    gj_pivot<k, true>(x, d, xr, q);
+    inv16_full<k + 1>(x, d, xr, q);
   }
 }
 __device__ __forceinline__ void inv16(const SweepCtx &x, int K, v4d &d) {
   // all 16 pivots active (every block but the last): one straight-line block, so that the scheduler can start pivot
   // k + 1's broadcast / reciprocal chain under the tail of pivot k's update
-  if (16 * K + 16 <= x.np)
-    inv16_full<0>(x, d);
-  else
+  if (16 * K + 16 <= x.np) {
+    double xr, q;
+    gj_head<0>(x, d, xr, q);
+    inv16_full<0>(x, d, xr, q);
+  } else {
     inv16_masked<0>(x, K, d);
+  }
 }
 
 template <int KI, int FT>

@@ -7,7 +7,7 @@
 __global__ void k_inv16(const double *Din, double *Eout, long long *cyc, int np, int reps) {
   __shared__ int bad[2];
   const int lane = threadIdx.x & 63;
-  SweepCtx x{0, lane, lane & 15, lane >> 4, np, 16, true, true, nullptr, bad};
+  SweepCtx x{0, lane, lane & 15, lane >> 4, np, 16, true, true, bad, nullptr};
   v4d d;
   long long best = 1ll << 60;
   for (int it = 0; it < reps; ++it) {
