@@ -273,7 +273,13 @@ struct MtStream {
 };
 
 // one-wave barrier that also orders LDS accesses
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// The simulator code runs in ONE wave (alone in its workgroup, or as wave 0 of the fused step kernel): ordering of that
+// wave's LDS / global accesses needs fences and a wave barrier, not a workgroup barrier.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 // load a stream from HBM into LDS (64 lanes) and back
 __device__ inline MtStream mt_load(uint32_t *lds, const uint32_t *g, int lane) {
@@ -513,6 +519,10 @@ void drlgx_launch_reset(const DrlgxState &S, hipStream_t st, int n, const int32_
 void drlgx_launch_sim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride,
                       int n_measure);
 void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel);
+size_t drlgx_map_lds_bytes(const DrlgxState &S, int *chunk_out);
+// fused simulate + SLAM + map kernel (k_step.hip); usable when the SLAM system and the map stage fit the LDS
+bool drlgx_step_fusable(const DrlgxState &S);
+void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure);
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel);  // sel.act_idx == -2: reductions only
 void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
                        const int32_t *dst, int src_off, int dst_off, int skip_mask);  // skip fields with cls & mask

@@ -45,6 +45,7 @@ struct drlgx_engine {
   int graph_gi_stride = 0;
   // timing
   bool timing = false;
+  bool fused = false;  // the fused simulate + SLAM + map kernel is usable for this configuration
   std::vector<TimedSpan> spans;
   std::vector<hipEvent_t> free_events;
   double t_ms[DRLGX_N_TIMERS] = {0};
@@ -327,6 +328,7 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
     const size_t nd = 3 * P + 16;  // >= 16 * ceil((3P + 1) / 16)
     S.slam_ws_stride = M * 12 + (L * P * 2 + 7) / 8 + 16 + (lds ? 0 : nd * nd);
     S.slam_iws_stride = 2;
+    e->fused = drlgx_step_fusable(S);
     TRY(dev_alloc(e, &S.slam_ws, S.slam_ws_stride * (size_t)S.n_inst));
     TRY(dev_alloc(e, &S.slam_iws, S.slam_iws_stride * (size_t)S.n_inst));
   }
@@ -411,17 +413,23 @@ int drlgx_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint3
 int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_dev) {
   if (!e || !odom_dev) return DRLGX_E_INVALID;
   LaunchSel sel{0, e->S.n_envs, active_dev, nullptr, 0};
-  {
-    ScopedTimer t(e, 0);
-    drlgx_launch_sim(e->S, e->stream, sel, odom_dev, 3, 2);
-  }
-  {
-    ScopedTimer t(e, 1);
-    drlgx_launch_slam(e->S, e->stream, sel);
-  }
-  {
-    ScopedTimer t(e, 2);
-    drlgx_launch_map(e->S, e->stream, sel);
+  if (e->fused && !e->timing) {
+    // one fused kernel per step; the per-stage kernels are used when per-kernel timing is on (drlgx_timing_enable)
+    ScopedTimer t(e, 5);
+    drlgx_launch_step(e->S, e->stream, sel, odom_dev, 3, 2);
+  } else {
+    {
+      ScopedTimer t(e, 0);
+      drlgx_launch_sim(e->S, e->stream, sel, odom_dev, 3, 2);
+    }
+    {
+      ScopedTimer t(e, 1);
+      drlgx_launch_slam(e->S, e->stream, sel);
+    }
+    {
+      ScopedTimer t(e, 2);
+      drlgx_launch_map(e->S, e->stream, sel);
+    }
   }
   {
     ScopedTimer t(e, 7);  // empty span: the event-pair overhead, so that callers can subtract it
@@ -483,6 +491,10 @@ int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
     }
     for (int a = 0; a < S.A_max; ++a) {
       LaunchSel sel{roll0, nc, nullptr, na, a};
+      if (e->fused && !e->timing) {
+        drlgx_launch_step(S, e->stream, sel, act, S.A_max * 3, 1);
+        continue;
+      }
       {
         ScopedTimer t(e, 0);
         drlgx_launch_sim(S, e->stream, sel, act, S.A_max * 3, 1);

@@ -28,7 +28,7 @@
 // Compiled with -ffp-contract=off (thresholded decisions must round like the CPU reference).
 #include "drlgx_dev.h"
 
-namespace {
+namespace kmap {
 
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
@@ -158,7 +158,7 @@ __device__ __forceinline__ double block_sum(double v, double *scratch, int tid) 
   return s;
 }
 
-__global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, int rebuild, int chunk) {
+__device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &sel, int rebuild, int chunk) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bi = blockIdx.x;
@@ -432,12 +432,24 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
   }
 }
 
-}  // namespace
+__global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, int rebuild, int chunk) {
+  map_body(S, sel, rebuild, chunk);
+}
+
+}  // namespace kmap
 
 static size_t map_lds_bytes(const DrlgxState &S, int chunk) {
-  size_t d = (size_t)S.P_max * 19 + (size_t)chunk * 64 * 3 + 2 * (size_t)S.V + kWaves + DRLGX_LO_TAB;  // + two u64 masks per cell
+  size_t d = (size_t)S.P_max * 19 + (size_t)chunk * 64 * 3 + 2 * (size_t)S.V + kmap::kWaves + DRLGX_LO_TAB;  // + two u64 masks per cell
   size_t i = (size_t)S.P_max * 7 + (size_t)S.V + DRLGX_LO_TAB;
   return d * sizeof(double) + i * sizeof(int) + 16;
+}
+
+// LDS bytes of k_map and the poses per A/C pass: all of them when the stage fits the LDS (<= 64: one mask bit per pose)
+size_t drlgx_map_lds_bytes(const DrlgxState &S, int *chunk_out) {
+  int chunk = S.P_max < 64 ? S.P_max : 64;
+  while (chunk > 1 && map_lds_bytes(S, chunk) > 160 * 1024) chunk /= 2;
+  if (chunk_out) *chunk_out = chunk;
+  return map_lds_bytes(S, chunk);
 }
 
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
@@ -447,14 +459,12 @@ void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
     rebuild = 0;
     sel.act_idx = 0;
   }
-  // poses per A/C pass: all of them when the stage fits the LDS (<= 64: one mask bit per pose)
-  int chunk = S.P_max < 64 ? S.P_max : 64;
-  while (chunk > 1 && map_lds_bytes(S, chunk) > 160 * 1024) chunk /= 2;
-  const size_t lds = map_lds_bytes(S, chunk);
+  int chunk = 0;
+  const size_t lds = drlgx_map_lds_bytes(S, &chunk);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmap::k_map), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_map, dim3(sel.n), dim3(kThreads), lds, st, S, sel, rebuild, chunk);
+  hipLaunchKernelGGL(kmap::k_map, dim3(sel.n), dim3(kmap::kThreads), lds, st, S, sel, rebuild, chunk);
 }

@@ -9,7 +9,7 @@
 // Compiled with -ffp-contract=off so that products/sums round as in the CPU reference.
 #include "drlgx_dev.h"
 
-namespace {
+namespace ksim {
 
 struct SimCtx {
   const DrlgxState &S;
@@ -185,14 +185,13 @@ __global__ __launch_bounds__(64) void k_reset(DrlgxState S, const int32_t *env_i
   }
 }
 
-// move + addOdometry + measure(s) + addMeasurement for one belief step.
-__global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
-                                                 int n_measure) {
-  __shared__ uint32_t lds[2][DRLGX_MT_STRIDE];
-  extern __shared__ double dyn[];  // nrm[2 LG + 2] doubles, inr[LG] ints
+// move + addOdometry + measure(s) + addMeasurement for one belief step, executed by ONE wave (lane = 0..63).
+// lds0 / lds1: 626 words each, dyn: (2 LG + 2) doubles + LG ints of LDS scratch.
+__device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchSel &sel, const double *odom, int odom_stride,
+                                              int n_measure, uint32_t *lds0, uint32_t *lds1, double *dyn, int lane) {
+  uint32_t *lds[2] = {lds0, lds1};
   double *nrm = dyn;
   int *inr = reinterpret_cast<int *>(dyn + 2 * S.LG + 2);
-  const int lane = threadIdx.x;
   const int i = blockIdx.x;
   if (!sel.on(i)) return;
   const int inst = sel.base + i;
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, co
     double th = theta_of(odomP);
     S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST] += sqrt(ox * ox + oy * oy + cfg.angle_weight * (th * th));
   }
-  __syncthreads();
+  wave_sync();  // lane 0's writes (initial guess of the new pose) are read by every lane below
   DRLGX_PROF(S, 10);
   c.P += 1;
   for (int m = 0; m < n_measure; ++m) {
@@ -257,15 +256,22 @@ __global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, co
   DRLGX_PROF(S, 13);
 }
 
-}  // namespace
+__global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
+                                                 int n_measure) {
+  __shared__ uint32_t lds[2][DRLGX_MT_STRIDE];
+  extern __shared__ double dyn[];  // nrm[2 LG + 2] doubles, inr[LG] ints
+  sim_step_body(S, sel, odom, odom_stride, n_measure, lds[0], lds[1], dyn, threadIdx.x);
+}
+
+}  // namespace ksim
 
 void drlgx_launch_reset(const DrlgxState &S, hipStream_t st, int n, const int32_t *env_ids_dev,
                         const uint32_t *seeds_dev, const double *start_dev) {
   const size_t dyn = (size_t)(2 * S.LG + 2) * sizeof(double) + (size_t)S.LG * sizeof(int);
-  hipLaunchKernelGGL(k_reset, dim3(n), dim3(64), dyn, st, S, env_ids_dev, seeds_dev, start_dev);
+  hipLaunchKernelGGL(ksim::k_reset, dim3(n), dim3(64), dyn, st, S, env_ids_dev, seeds_dev, start_dev);
 }
 void drlgx_launch_sim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride,
                       int n_measure) {
   const size_t dyn = (size_t)(2 * S.LG + 2) * sizeof(double) + (size_t)S.LG * sizeof(int);
-  hipLaunchKernelGGL(k_sim_step, dim3(sel.n), dim3(64), dyn, st, S, sel, odom, odom_stride, n_measure);
+  hipLaunchKernelGGL(ksim::k_sim_step, dim3(sel.n), dim3(64), dyn, st, S, sel, odom, odom_stride, n_measure);
 }

@@ -19,8 +19,9 @@
 // Per-landmark loops walk a bit mask of the observing poses.  LDS: the padded system + per-factor records when they
 // fit; the records (and, for the larger capacities, the system itself) fall back to an HBM/L2 workspace.
 #include "drlgx_dev.h"
+#pragma clang fp contract(fast)  // (the unity build k_step.hip is compiled with -ffp-contract=off)
 
-namespace {
+namespace kslam {
 
 constexpr int kThreads = 512;
 constexpr int REC = 12;  // per-factor record: [0..5] Jx (2x3) -> later G (3x2); [6..9] Jl (2x2) -> later partial; [10..11] e
@@ -329,7 +330,7 @@ __device__ __forceinline__ void sweep16_all(const SweepCtx &x, const Sw16 &L, v4
       if (const int p = 64 * _w + __ffsll((long long)_m) - 1; true)
 
 template <bool kLds, int NTW, int FT>
-__global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, int lds_bytes) {
+__device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &sel, int lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int bi = blockIdx.x;
@@ -908,6 +909,11 @@ __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, 
   }
 }
 
+template <bool kLds, int NTW, int FT>
+__global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, int lds_bytes) {
+  slam_body<kLds, NTW, FT>(S, sel, lds_bytes);
+}
+
 constexpr int kLdsBudget = 160 * 1024;
 
 // LDS needed by the always-resident small arrays + panels for an N x N system
@@ -922,43 +928,44 @@ size_t slam_small_bytes(int P_max, int L_max, int M_max) {
 }
 constexpr int kFastTiles = 8;  // fast path: N = 128 (<= 42 poses), system + panels in LDS
 
-}  // namespace
+}  // namespace kslam
 
 size_t drlgx_slam_lds_bytes(int P_max, int L_max, int M_max) {
-  const size_t N = slam_dim(P_max);
-  return slam_small_bytes(P_max, L_max, M_max) + N * N * 8;
+  const size_t N = kslam::slam_dim(P_max);
+  return kslam::slam_small_bytes(P_max, L_max, M_max) + N * N * 8;
 }
 
 // true when k_slam keeps the dense system in LDS (the fast path); otherwise the engine must provide the HBM workspace
 bool drlgx_slam_in_lds(int P_max, int L_max, int M_max) {
-  const size_t nf = 16 * kFastTiles;
-  return slam_dim(P_max) <= nf && slam_small_bytes_n(nf, P_max, L_max, M_max, true) + nf * (nf + 2) * 8 <= (size_t)kLdsBudget;
+  const size_t nf = 16 * kslam::kFastTiles;
+  return kslam::slam_dim(P_max) <= nf && kslam::slam_small_bytes_n(nf, P_max, L_max, M_max, true) + nf * (nf + 2) * 8 <= (size_t)kslam::kLdsBudget;
 }
 
 void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
-  const int Tn = (int)(slam_dim(S.P_max) / 16), ntiles = Tn * (Tn + 1) / 2;
+  const int Tn = (int)(kslam::slam_dim(S.P_max) / 16), ntiles = Tn * (Tn + 1) / 2;
   static bool attr_set = false;
   if (!attr_set) {
-    const void *fns[] = {reinterpret_cast<const void *>(&k_slam<true, 1, kFastTiles>),
-                         reinterpret_cast<const void *>(&k_slam<false, 10, 0>),
-                         reinterpret_cast<const void *>(&k_slam<false, 20, 0>)};
-    for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+    const void *fns[] = {reinterpret_cast<const void *>(&kslam::k_slam<true, 1, kslam::kFastTiles>),
+                         reinterpret_cast<const void *>(&kslam::k_slam<false, 10, 0>),
+                         reinterpret_cast<const void *>(&kslam::k_slam<false, 20, 0>)};
+    for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kslam::kLdsBudget);
     attr_set = true;
   }
   if (drlgx_slam_in_lds(S.P_max, S.L_max, S.M_max)) {
     // fast path: the kernel always works on the full 128 x 128 capacity; whatever LDS is left holds the factor records
-    hipLaunchKernelGGL((k_slam<true, 1, kFastTiles>), dim3(sel.n), dim3(kThreads), kLdsBudget, st, S, sel, kLdsBudget);
+    hipLaunchKernelGGL((kslam::k_slam<true, 1, kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
   } else {
     // dense system in the HBM/L2 workspace, triangular tile scheme with the accumulator tiles in registers:
     // <= 58 poses: 10 tiles per wave, <= 86 poses: 20 tiles per wave
-    const size_t small = slam_small_bytes(S.P_max, S.L_max, S.M_max);
-    if (small > (size_t)kLdsBudget || ntiles > 20 * kWaves) {
+    const size_t small = kslam::slam_small_bytes(S.P_max, S.L_max, S.M_max);
+    if (small > (size_t)kslam::kLdsBudget || ntiles > 20 * kslam::kWaves) {
       (void)hipMemsetAsync(S.status, 0xff, sizeof(int), st);  // capacity beyond this kernel: flag an error (-1)
       return;
     }
-    if (ntiles <= 10 * kWaves)
-      hipLaunchKernelGGL((k_slam<false, 10, 0>), dim3(sel.n), dim3(kThreads), small, st, S, sel, (int)small);
+    if (ntiles <= 10 * kslam::kWaves)
+      hipLaunchKernelGGL((kslam::k_slam<false, 10, 0>), dim3(sel.n), dim3(kslam::kThreads), small, st, S, sel, (int)small);
     else
-      hipLaunchKernelGGL((k_slam<false, 20, 0>), dim3(sel.n), dim3(kThreads), small, st, S, sel, (int)small);
+      hipLaunchKernelGGL((kslam::k_slam<false, 20, 0>), dim3(sel.n), dim3(kslam::kThreads), small, st, S, sel, (int)small);
   }
 }
+#pragma clang fp contract(off)
