@@ -46,6 +46,7 @@ struct drlgx_engine {
   // timing
   bool timing = false;
   bool fused = false;  // the fused simulate + SLAM + map kernel is usable for this configuration
+  bool per_stage = false;  // timing mode 2: launch the three stage kernels separately so that each gets its own span
   std::vector<TimedSpan> spans;
   std::vector<hipEvent_t> free_events;
   double t_ms[DRLGX_N_TIMERS] = {0};
@@ -413,8 +414,8 @@ int drlgx_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint3
 int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_dev) {
   if (!e || !odom_dev) return DRLGX_E_INVALID;
   LaunchSel sel{0, e->S.n_envs, active_dev, nullptr, 0};
-  if (e->fused && !e->timing) {
-    // one fused kernel per step; the per-stage kernels are used when per-kernel timing is on (drlgx_timing_enable)
+  if (e->fused && !e->per_stage) {
+    // one fused kernel per step (timer 5); timing mode 2 launches the stage kernels separately (timers 0-2)
     ScopedTimer t(e, 5);
     drlgx_launch_step(e->S, e->stream, sel, odom_dev, 3, 2);
   } else {
@@ -491,7 +492,8 @@ int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
     }
     for (int a = 0; a < S.A_max; ++a) {
       LaunchSel sel{roll0, nc, nullptr, na, a};
-      if (e->fused && !e->timing) {
+      if (e->fused && !e->per_stage) {
+        ScopedTimer t(e, 5);
         drlgx_launch_step(S, e->stream, sel, act, S.A_max * 3, 1);
         continue;
       }
@@ -803,6 +805,7 @@ int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]) {
 int drlgx_timing_enable(drlgx_engine *e, int on) {
   if (!e) return DRLGX_E_INVALID;
   e->timing = on != 0;
+  e->per_stage = on == 2;
   return DRLGX_OK;
 }
 

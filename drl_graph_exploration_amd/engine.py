@@ -146,13 +146,14 @@ class Engine(object):
         self._chk(self.L.drlgx_restore(self.h, slot))
 
     def timing_enable(self, on=True):
+        """on: False / True (spans around what is launched, fused step = 'step') / 2 (per-stage kernels)."""
         self._chk(self.L.drlgx_timing_enable(self.h, int(on)))
 
     def timing_read(self):
         ms = (C.c_double * _lib.N_TIMERS)()
         n = (C.c_int64 * _lib.N_TIMERS)()
         self._chk(self.L.drlgx_timing_read_host(self.h, ms, n))
-        names = ["sim", "slam", "map", "copy", "graph", "t5", "t6", "t7"]
+        names = ["sim", "slam", "map", "copy", "graph", "step", "t6", "t7"]
         return {names[i]: (ms[i], n[i]) for i in range(_lib.N_TIMERS)}
 
     # ---- getters (host)

@@ -181,9 +181,11 @@ int drlgx_get_landmark_order_host(const drlgx_engine *e, int32_t *order);
 int drlgx_snapshot(drlgx_engine *e, int slot);
 int drlgx_restore(drlgx_engine *e, int slot);
 
-/* Per-kernel timing (HIP events on the engine stream): enable, then read accumulated milliseconds and
- * launch counts.  kernel ids: 0 sim, 1 slam, 2 map, 3 copy/prepare, 4 graph, 7 = an EMPTY span recorded once per
- * drlgx_step (the event-pair overhead a caller subtracts from the per-launch averages).  */
+/* Per-kernel timing (HIP events on the engine stream): enable (on = 1: spans around whatever is launched; on = 2: the
+ * belief step is launched as its three stage kernels instead of the fused kernel, so that each stage gets its own span),
+ * then read accumulated milliseconds and launch counts.  timer ids: 0 sim, 1 slam, 2 map, 3 copy/prepare, 4 graph,
+ * 5 fused belief step (sim + slam + map), 7 = an EMPTY span recorded once per drlgx_step (the event-pair overhead a caller
+ * subtracts from the per-launch averages).  */
 #define DRLGX_N_TIMERS 8
 int drlgx_timing_enable(drlgx_engine *e, int on);
 int drlgx_timing_read_host(drlgx_engine *e, double ms[DRLGX_N_TIMERS], int64_t launches[DRLGX_N_TIMERS]);

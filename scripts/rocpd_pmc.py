@@ -17,7 +17,7 @@ def per_kernel(path, counter):
 
 
 def short(name):
-    for k in ("k_slam", "k_map", "k_sim_step", "k_copy_instances", "k_reset"):
+    for k in ("k_step", "k_slam", "k_map", "k_sim_step", "k_copy_instances", "k_reset"):
         if k in name:
             return k
     return name
