@@ -247,6 +247,36 @@ def test_many_landmarks_64_node_graphs():
     eng.close()
 
 
+def test_fused_step_kernel_equals_stage_kernels():
+    """drlgx_step launches ONE fused kernel (simulate + SLAM + map); with drlgx_timing_enable(2) the same step runs as
+    its three stage kernels.  Same code, same order: the two engines must agree bit for bit, step after step."""
+    n = 5
+    fused, cfg = make_engine(n, num_landmarks=60)
+    staged, _ = make_engine(n, num_landmarks=60)
+    staged.timing_enable(2)
+    starts = generic_starts(n)
+    for e in (fused, staged):
+        e.reset(np.arange(n), np.arange(n), starts=starts)
+    for s, act in enumerate(SCRIPT):
+        odom = torch.tensor([act] * n, dtype=torch.float64, device=fused.device)
+        fused.step(odom)
+        staged.step(odom)
+        for i in range(n):
+            assert fused.counts(i) == staged.counts(i)
+            np.testing.assert_array_equal(fused.poses(i)[0], staged.poses(i)[0])
+            np.testing.assert_array_equal(fused.poses(i)[1], staged.poses(i)[1])
+            for a, b in zip(fused.landmarks(i), staged.landmarks(i)):
+                np.testing.assert_array_equal(a, b)
+            for a, b in zip(fused.virtual_map(i), staged.virtual_map(i)):
+                np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(fused.utility().cpu().numpy(), staged.utility().cpu().numpy())
+    assert fused.status() == 0 and staged.status() == 0
+    tm = staged.timing_read()
+    assert tm["slam"][1] == len(SCRIPT) and tm["step"][1] == 0  # the staged engine really ran the stage kernels
+    fused.close()
+    staged.close()
+
+
 @pytest.mark.parametrize("max_poses", [43, 60, 86])
 def test_larger_capacities_use_other_kernel_variants(max_poses):
     """Capacities beyond 43 poses move the dense system of k_slam from LDS to the HBM/L2 workspace (one register
