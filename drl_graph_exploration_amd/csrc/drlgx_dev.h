@@ -460,7 +460,7 @@ __device__ inline double normal01(MtStream &s, NormalState &ns, int lane) {
 // speculatively (words cons+4i .. cons+4i+3), a ballot ranks the accepted pairs, the j-th accepted pair yields variates
 // 2j (y*mult) and 2j+1 (x*mult, libstdc++'s saved value), and exactly the words up to the last pair that the sequential
 // loop would have examined are consumed.  Bit-identical to `count` successive normal01() calls.
-__device__ inline void draw_normals(MtStream &s, NormalState &ns, int count, double *out, int lane) {
+__device__ inline void draw_normals(MtStream &s, NormalState &ns, int count, double *out, int lane, bool values = true) {
   if (count <= 0) return;
   int offset = 0;
   if (ns.has) {
@@ -481,7 +481,8 @@ __device__ inline void draw_normals(MtStream &s, NormalState &ns, int count, dou
     const unsigned long long m = __ballot(acc);
     const int rank = __popcll(m & ((1ull << lane) - 1ull));
     const int j = have + rank;
-    if (acc && j < Np) {
+    // `values == false`: the caller only advances the stream; the one variate that survives the call is libstdc++'s saved one
+    if (acc && j < Np && (values || (j == Np - 1 && (R & 1)))) {
       const double mult = sqrt(-2 * log(r2) / r2);
       out[offset + 2 * j] = y * mult;
       out[offset + 2 * j + 1] = x * mult;

@@ -28,7 +28,9 @@ struct SimCtx {
 //  3. lane k evaluates landmark k; the valid ones are appended in order (factor index and new-landmark slot by prefix rank;
 //     a measure() call sees every key at most once, so there is no intra-call conflict).
 // `record == false` is SS2D.simulate's first measure() (obstacle logic, inert at safe_distance = 0): only the RNG advances.
-__device__ inline void measure(SimCtx &c, bool record, double *nrm, int *inr) {
+// in-range ground-truth landmarks in libstdc++'s hash iteration order (ballot + prefix rank) -> inr[0..n_in); the set only
+// depends on the vehicle pose, so the two measure() calls of a real step share one scan
+__device__ inline int scan_in_range(SimCtx &c, int *inr) {
   const DrlgxState &S = c.S;
   const drlgx_config &cfg = S.cfg;
   const double *gl = S.gt_lm + (size_t)S.parent[c.inst] * S.LG * 2;
@@ -47,7 +49,14 @@ __device__ inline void measure(SimCtx &c, bool record, double *nrm, int *inr) {
     n_in += __popcll(mask);
   }
   wave_sync();
-  draw_normals(c.sensor, c.ns_sensor, 2 * n_in, nrm, c.lane);
+  return n_in;
+}
+__device__ inline void measure(SimCtx &c, bool record, double *nrm, const int *inr, int n_in) {
+  const DrlgxState &S = c.S;
+  const drlgx_config &cfg = S.cfg;
+  const double *gl = S.gt_lm + (size_t)S.parent[c.inst] * S.LG * 2;
+  const unsigned long long below = (1ull << c.lane) - 1ull;
+  draw_normals(c.sensor, c.ns_sensor, 2 * n_in, nrm, c.lane, record);
   if (!record) return;
   int *key_slot = S.key_slot + (size_t)c.inst * S.LG;
   for (int base = 0; base < n_in; base += 64) {
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(64) void k_reset(DrlgxState S, const int32_t *env_i
   }
   __syncthreads();
   c.P = 1;
-  measure(c, true, nrm, inr);  // pyss2d.py:135 self.measure()
+  measure(c, true, nrm, inr, scan_in_range(c, inr));  // pyss2d.py:135 self.measure()
   store_ctx(c);
   // VirtualMap::initialize (VirtualMap.cpp:318-362): prob 0.5, information I / sigma0^2
   const double i0 = 1.0 / pow(cfg.sigma0, 2);
@@ -248,8 +257,9 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
   wave_sync();  // lane 0's writes (initial guess of the new pose) are read by every lane below
   DRLGX_PROF(S, 10);
   c.P += 1;
+  const int n_in = scan_in_range(c, inr);
   for (int m = 0; m < n_measure; ++m) {
-    measure(c, m == n_measure - 1, nrm, inr);
+    measure(c, m == n_measure - 1, nrm, inr, n_in);
     DRLGX_PROF(S, 11 + m);
   }
   store_ctx(c);
