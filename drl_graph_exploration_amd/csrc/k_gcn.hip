@@ -16,6 +16,7 @@
 // fp32 throughout (the reference trains in fp32); (Â X) W1 is used instead of Â (X W1) — same value up to fp32
 // rounding (tests: <= 2e-5 relative against the plain-torch reference).
 #include <algorithm>
+#include <cstdlib>
 
 #include "drlgx_dev.h"
 
@@ -181,130 +182,285 @@ __global__ __launch_bounds__(256) void k_aggregate(int N, int hidden, const floa
 
 // ------------------------------------------------------------------------------------------------
 // fp32 MFMA GEMM  C[M x N] = op(A) op(B)   (row-major; TA: A is stored [K x M]; TB: B is stored [N x K])
-// block 128x128x16, 256 threads = 2x2 waves, each wave 2x2 tiles of v_mfma_f32_32x32x2_f32
+// block 128x128x16, 256 threads = 2x2 waves, each wave 2x2 tiles of v_mfma_f32_32x32x2_f32.
+//  * global -> registers -> LDS with one 16-byte load/store per quarter tile row (scalar predicated loads only for
+//    operands whose contiguous dimension is not a multiple of 4: the [nodes x out_dim] head gradient);
+//  * an operand whose source is k-contiguous sits in LDS as [x][k] (stride 20 floats: ds_write_b128 straight from
+//    the load, fragment = two conflict-free ds_read_b128); an x-contiguous one as [k][x] (stride 132, ds_read_b32);
+//  * MFMA step s of a K-tile multiplies k = s (lanes 0-31) and k = 8 + s (lanes 32-63) - any pairing of the 16 k's is
+//    a valid 32x32x2 schedule, and this one makes each lane's 8 fragment values contiguous in the [x][k] layout;
+//  * all fragments of the K-tile are read up front, then 32 MFMAs issue back to back while the next tile's global
+//    loads are in flight; one barrier per K-tile (double-buffered LDS);
+//  * workgroup id -> tile mapping keeps the 8 column tiles of one row panel on one XCD (shared A panel in its L2).
 // EPI 0: C = acc (split-K partial when gridDim.z > 1: C += z * M * N)
 // EPI 1: C = relu(acc + bias[col]) * (mask ? mask[row][col] : 1)        (forward layer 2)
 // ------------------------------------------------------------------------------------------------
-constexpr int BM = 128, BN = 128, BK = 16, LDA_S = BM + 4, LDB_S = BN + 4;
+constexpr int BK = 16;
+constexpr int LDK = BK + 4;  // [x][k] tile stride (floats)
 
-template <bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B,
-                                              int ldb, float *__restrict__ C, int ldc, const float *__restrict__ bias,
-                                              const float *__restrict__ mask, int k_per_split) {
-  __shared__ float As[2][BK][LDA_S];
-  __shared__ float Bs[2][BK][LDB_S];
+// LDS footprint of one operand tile of XR * 64 rows/cols (either layout)
+template <int XR>
+struct TileF {
+  static constexpr int ldx = XR * 64 + 4;  // [k][x] tile stride
+  static constexpr int value = (XR * 64 * LDK > BK * ldx) ? XR * 64 * LDK : BK * ldx;
+};
+
+// quarter-tile loads of one operand tile (XR * 64 x 16): KC = source is k-contiguous (src[x * ld + k]), else
+// src[k * ld + x]; 256 threads move XR float4 each
+template <bool KC, bool VEC, int XR>
+__device__ __forceinline__ void g_load(float4 (&reg)[XR], bool (&okr)[XR], const float *__restrict__ src, int ld, int x0, int X,
+                                       int k0, int kend, int tid) {
+#pragma unroll
+  for (int r = 0; r < XR; ++r) {
+    const int x = KC ? x0 + (tid >> 2) + 64 * r : (XR == 2 ? x0 + (tid & 31) * 4 : x0 + (tid & 15) * 4);
+    const int k = KC ? k0 + (tid & 3) * 4 : (XR == 2 ? k0 + (tid >> 5) + 8 * r : k0 + (tid >> 4));
+    if (VEC) {
+      // contract (host): the contiguous dimension, ld and the base address are multiples of 4 floats, so a float4
+      // is all inside or all outside; outside ones load a clamped (valid) address unconditionally and are zeroed
+      // when they are stored to LDS (so that nothing waits on the load before the MFMAs of the current tile)
+      okr[r] = x < X && k < kend;
+      const int xc = min(x, X - (KC ? 1 : 4)), kc = min(k, kend - (KC ? 4 : 1));
+      const size_t at = KC ? (size_t)xc * ld + kc : (size_t)kc * ld + xc;
+      reg[r] = *reinterpret_cast<const float4 *>(src + at);
+    } else {
+      okr[r] = true;
+      const size_t at = KC ? (size_t)x * ld + k : (size_t)k * ld + x;
+      float e[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool ok = KC ? (x < X && k + c < kend) : (k < kend && x + c < X);
+        e[c] = ok ? src[at + c] : 0.f;
+      }
+      reg[r] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+  }
+}
+
+template <bool KC, int XR>
+__device__ __forceinline__ void s_store(float *T, const float4 (&reg)[XR], const bool (&okr)[XR], int tid) {
+  constexpr int ldx = TileF<XR>::ldx;
+#pragma unroll
+  for (int r = 0; r < XR; ++r) {
+    float *p = KC ? T + ((tid >> 2) + 64 * r) * LDK + (tid & 3) * 4
+                  : (XR == 2 ? T + ((tid >> 5) + 8 * r) * ldx + (tid & 31) * 4 : T + (tid >> 4) * ldx + (tid & 15) * 4);
+    const float4 v = reg[r];
+    const bool ok = okr[r];
+    *reinterpret_cast<float4 *>(p) = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+  }
+}
+
+// the 8 values lane (li, h) feeds to MFMA steps 0..7 for tile rows/cols xb + li: k = 8 h + s
+template <bool KC, int XR>
+__device__ __forceinline__ void s_frag(float (&f)[8], const float *T, int xb, int lane) {
+  constexpr int ldx = TileF<XR>::ldx;
+  const int li = lane & 31, h = lane >> 5;
+  if (KC) {
+    const float4 u0 = *reinterpret_cast<const float4 *>(T + (xb + li) * LDK + 8 * h);
+    const float4 u1 = *reinterpret_cast<const float4 *>(T + (xb + li) * LDK + 8 * h + 4);
+    f[0] = u0.x; f[1] = u0.y; f[2] = u0.z; f[3] = u0.w;
+    f[4] = u1.x; f[5] = u1.y; f[6] = u1.z; f[7] = u1.w;
+  } else {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) f[s] = T[(8 * h + s) * ldx + xb + li];
+  }
+}
+
+// MI x NI = 32x32 sub-tiles per wave; the workgroup tile is (64 MI) x (64 NI)
+template <bool TA, bool TB, int EPI, bool AV, bool BV, int MI, int NI>
+__global__ __launch_bounds__(256) void k_gemm(
+    int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
+    const float *__restrict__ bias, const float *__restrict__ mask, int k_per_split, int tiles_m, int tiles_n) {
+  constexpr int BM = 64 * MI, BN = 64 * NI;
+  __shared__ __attribute__((aligned(16))) float As[3][TileF<MI>::value];
+  __shared__ __attribute__((aligned(16))) float Bs[3][TileF<NI>::value];
+  // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give XCD x the row panels
+  // p = x, x + 8, ... and walk a panel's column tiles on consecutive slots of the same XCD
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tn = slot % tiles_n, tm = (slot / tiles_n) * 8 + xcd;
+  if (tm >= tiles_m) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
-  floatx16 acc[2][2];
+  floatx16 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging registers: each thread moves 8 floats of A and 8 of B per K-tile
-  float ra[8], rb[8];
-  auto load_tiles = [&](int k0) {
-    if (!TA) {  // A[m][k]: 128 rows x 16 k; thread -> (row = tid/4 + 64 r, k4 = (tid%4)*4)
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int row = m0 + (tid >> 2) + 64 * r, k = k0 + (tid & 3) * 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ra[r * 4 + c] = (row < M && k + c < kend) ? A[(size_t)row * lda + k + c] : 0.f;
-      }
-    } else {  // A stored [K][M]: 16 k x 128 m; thread -> (k = tid/32 + 8 r, m4 = (tid%32)*4)
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int k = k0 + (tid >> 5) + 8 * r, m = m0 + (tid & 31) * 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ra[r * 4 + c] = (k < kend && m + c < M) ? A[(size_t)k * lda + m + c] : 0.f;
-      }
-    }
-    if (!TB) {  // B[k][n]
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int k = k0 + (tid >> 5) + 8 * r, n = n0 + (tid & 31) * 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) rb[r * 4 + c] = (k < kend && n + c < N) ? B[(size_t)k * ldb + n + c] : 0.f;
-      }
-    } else {  // B stored [N][K]
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int col = n0 + (tid >> 2) + 64 * r, k = k0 + (tid & 3) * 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) rb[r * 4 + c] = (col < N && k + c < kend) ? B[(size_t)col * ldb + k + c] : 0.f;
-      }
-    }
-  };
-  auto store_tiles = [&](int buf) {
-    if (!TA) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) As[buf][(tid & 3) * 4 + c][(tid >> 2) + 64 * r] = ra[r * 4 + c];
-    } else {
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) As[buf][(tid >> 5) + 8 * r][(tid & 31) * 4 + c] = ra[r * 4 + c];
-    }
-    if (!TB) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Bs[buf][(tid >> 5) + 8 * r][(tid & 31) * 4 + c] = rb[r * 4 + c];
-    } else {
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Bs[buf][(tid & 3) * 4 + c][(tid >> 2) + 64 * r] = rb[r * 4 + c];
-    }
-  };
-
+  // software pipeline, per K-tile t (one barrier each):
+  //   MFMAs of tile t from fragment registers F[t & 1], and between them
+  //     ds_write  staging registers (tile t+2, loaded during t-1)  -> LDS buffer (t+2) % 3
+  //     global    loads of tile t+3                                -> staging registers
+  //     ds_read   fragments of tile t+1 from LDS buffer (t+1) % 3  -> F[(t+1) & 1]
+  // so a wave's LDS and global traffic issues under its own MFMAs (a lone workgroup on a CU - small problems, the
+  // tail of large ones - has no co-resident waves to hide it), and the barrier only orders tile t+2's stores
+  // before the next step's fragment reads (and this step's reads of buffer (t+1) % 3 before its reuse at t+2).
+  float4 ra[MI], rb[NI];
+  bool oka[MI], okb[NI];
+  float fa[2][MI][8], fb[2][NI][8];
   const int ntile = (kend - kbeg + BK - 1) / BK;
-  if (ntile > 0) {
-    load_tiles(kbeg);
-    store_tiles(0);
-  }
-  __syncthreads();
-  for (int t = 0; t < ntile; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntile) load_tiles(kbeg + (t + 1) * BK);  // global loads in flight during the MFMAs
+  auto load = [&](int t) {
+    g_load<!TA, AV, MI>(ra, oka, A, lda, m0, M, kbeg + t * BK, kend, tid);
+    g_load<TB, BV, NI>(rb, okb, B, ldb, n0, N, kbeg + t * BK, kend, tid);
+  };
+  auto store = [&](int buf) {
+    s_store<!TA, MI>(As[buf], ra, oka, tid);
+    s_store<TB, NI>(Bs[buf], rb, okb, tid);
+  };
+  auto frags = [&](int set, int buf) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const int kr = kk + (lane >> 5), li = lane & 31;
-      const float a0 = As[buf][kr][wm * 64 + li], a1 = As[buf][kr][wm * 64 + 32 + li];
-      const float b0 = Bs[buf][kr][wn * 64 + li], b1 = Bs[buf][kr][wn * 64 + 32 + li];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    if (t + 1 < ntile) store_tiles(buf ^ 1);
+    for (int i = 0; i < MI; ++i) s_frag<!TA, MI>(fa[set][i], As[buf], wm * 32 * MI + 32 * i, lane);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) s_frag<TB, NI>(fb[set][j], Bs[buf], wn * 32 * NI + 32 * j, lane);
+  };
+  auto mfma_steps = [&](int set, int s0, int s1) {
+#pragma unroll
+    for (int s = s0; s < s1; ++s)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][s], fb[set][j][s], acc[i][j], 0, 0, 0);
+  };
+  // one pipeline step; `set` is a compile-time constant at both call sites (loop unrolled by two)
+  auto step = [&](int set, int t, int b0) {  // b0 = t % 3
+    const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+    mfma_steps(set, 0, 2);
+    if (t + 2 < ntile) store(b2);
+    mfma_steps(set, 2, 4);
+    if (t + 3 < ntile) load(t + 3);
+    mfma_steps(set, 4, 6);
+    if (t + 1 < ntile) frags(set ^ 1, b1);
+    mfma_steps(set, 6, 8);
     __syncthreads();
+  };
+  if (ntile > 0) {
+    load(0);
+    store(0);
+  }
+  if (ntile > 1) {
+    load(1);
+    store(1);
+  }
+  if (ntile > 2) load(2);
+  __syncthreads();
+  if (ntile > 0) frags(0, 0);
+  int b = 0;
+  for (int t = 0; t < ntile; t += 2) {
+    step(0, t, b);
+    b = b == 2 ? 0 : b + 1;
+    if (t + 1 >= ntile) break;
+    step(1, t + 1, b);
+    b = b == 2 ? 0 : b + 1;
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   float *Cz = C + (EPI == 0 ? (size_t)blockIdx.z * M * ldc : 0);
+  if (m0 + BM <= M && n0 + BN <= N) {  // interior tile: straight-line loads and stores
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < NI; ++j) {
+      const int col = n0 + wn * 32 * NI + j * 32 + (lane & 31);
+      const float bj = EPI == 1 ? bias[col] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < MI; ++i) {
+        const size_t at = (size_t)(m0 + wm * 32 * MI + i * 32 + 4 * (lane >> 5)) * ldc + col;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-        if (row < M && col < N) {
-          float v = acc[i][j][r];
-          if (EPI == 1) {
-            v = fmaxf(v + bias[col], 0.f);
-            if (mask) v *= mask[(size_t)row * ldc + col];
+        for (int q = 0; q < 4; ++q) {  // rows 8 q + {0, 1, 2, 3} (+ 4 for the upper half wave)
+          float mk[4];
+          if (EPI == 1 && mask) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mk[r] = mask[at + (size_t)(r + 8 * q) * ldc];
           }
-          Cz[(size_t)row * ldc + col] = v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[i][j][4 * q + r];
+            if (EPI == 1) {
+              v = fmaxf(v + bj, 0.f);
+              if (mask) v *= mk[r];
+            }
+            Cz[at + (size_t)(r + 8 * q) * ldc] = v;
+          }
         }
       }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int col = n0 + wn * 32 * NI + j * 32 + (lane & 31);
+    if (col >= N) continue;
+    const float bj = EPI == 1 ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 * MI + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+        if (row >= M) continue;
+        float v = acc[i][j][r];
+        if (EPI == 1) {
+          v = fmaxf(v + bj, 0.f);
+          if (mask) v *= mask[(size_t)row * ldc + col];
+        }
+        Cz[(size_t)row * ldc + col] = v;
+      }
+  }
+}
+
+// thin-M products  out[m][n] = sum_k A[k][m] B[k][n]  (m < M <= 8; A stored [K x lda]) plus, as row M, the column sums
+// of B: one pass over B (HBM-bound). A thread owns 4 adjacent columns (N % 4 == 0), K is split over blockIdx.y;
+// partials -> part[y][M + 1][N]
+__global__ __launch_bounds__(256) void k_thin_tn_part(int K, int N, int M, const float *__restrict__ A, int lda,
+                                                      const float *__restrict__ B, int ldb, float *__restrict__ part,
+                                                      int rows_per_block) {
+  const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (n >= N) return;
+  const int k0 = blockIdx.y * rows_per_block, k1 = min(K, k0 + rows_per_block);
+  float4 acc[9];
+#pragma unroll
+  for (int m = 0; m < 9; ++m) acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = k0; k < k1; ++k) {
+    const float4 b = *reinterpret_cast<const float4 *>(B + (size_t)k * ldb + n);
+    const float *a = A + (size_t)k * lda;  // wave-uniform: scalar loads
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+      if (m < M) {
+        const float am = a[m];
+        acc[m].x += am * b.x; acc[m].y += am * b.y; acc[m].z += am * b.z; acc[m].w += am * b.w;
+      }
+    acc[8].x += b.x; acc[8].y += b.y; acc[8].z += b.z; acc[8].w += b.w;
+  }
+  float *o = part + (size_t)blockIdx.y * (M + 1) * N + n;
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    if (m < M) *reinterpret_cast<float4 *>(o + (size_t)m * N) = acc[m];
+  *reinterpret_cast<float4 *>(o + (size_t)M * N) = acc[8];
+}
+
+// second stage (deterministic): rows < rows_w of the [M x N] product -> outW, the column-sum row -> outB (either may
+// be null). 64 outputs per workgroup, the S partials of each summed by 16 threads in a fixed order.
+__global__ __launch_bounds__(1024) void k_thin_tn_reduce(int N, int M, int S, const float *part, float *outW, int rows_w,
+                                                         float *outB) {
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;
+  const int total = (M + 1) * N;
+  float s = 0.f;
+  if (i < total)
+    for (int z = q; z < S; z += 16) s += part[(size_t)z * total + i];
+  red[q][c] = s;
+  __syncthreads();
+  if (q != 0 || i >= total) return;
+  s = 0.f;
+#pragma unroll
+  for (int z = 0; z < 16; ++z) s += red[z][c];
+  const int m = i / N;
+  if (m < M) {
+    if (outW && m < rows_w) outW[i] = s;
+  } else if (outB) {
+    outB[i - M * N] = s;
+  }
 }
 
 // deterministic second stage of split-K: out = sum_z part[z]
@@ -409,18 +565,47 @@ size_t carve(GcnWs *w, char *base, int N, int E, int hidden, int out_dim) {
   return off;
 }
 
+bool vec_ok(const float *p, int ld, int contiguous_dim) {
+  return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0 && (contiguous_dim & 3) == 0;
+}
+
+// workgroup tile: 64x64 (four waves of 32x32) measured best or equal on every GCN shape (4k .. 33k nodes x 1000 x 1000:
+// 81 .. 118 TFLOP/s); DRLGX_GEMM_TILE=1 selects the 64x128 variant for experiments
+int pick_tile() {
+  static const int v = [] {
+    const char *e = getenv("DRLGX_GEMM_TILE");
+    return e ? atoi(e) : 2;
+  }();
+  return v;
+}
+
+template <bool TA, bool TB, int EPI, int MI, int NI>
+void gemm_tile(hipStream_t st, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+               const float *bias, const float *mask, int kps) {
+  const int tiles_m = (M + 64 * MI - 1) / (64 * MI), tiles_n = (N + 64 * NI - 1) / (64 * NI);
+  dim3 grid(tiles_n * ((tiles_m + 7) / 8) * 8, 1, (K + kps - 1) / kps);
+  const bool avec = vec_ok(A, lda, TA ? M : K), bvec = vec_ok(B, ldb, TB ? K : N);
+#define DRLGX_GEMM(AV, BV)                                                                                                     \
+  hipLaunchKernelGGL((k_gemm<TA, TB, EPI, AV, BV, MI, NI>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, \
+                     kps, tiles_m, tiles_n)
+  if (avec && bvec) DRLGX_GEMM(true, true);
+  else DRLGX_GEMM(false, false);
+#undef DRLGX_GEMM
+}
+
 template <bool TA, bool TB, int EPI>
 void gemm(hipStream_t st, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias,
           const float *mask, int splits) {
   const int kps = ((K + splits - 1) / splits + BK - 1) / BK * BK;
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, (K + kps - 1) / kps);
-  hipLaunchKernelGGL((k_gemm<TA, TB, EPI>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps);
+  if (pick_tile() == 1) gemm_tile<TA, TB, EPI, 1, 2>(st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps);
+  else gemm_tile<TA, TB, EPI, 1, 1>(st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps);
 }
 
-// weight-gradient GEMM  C[M x N] = A^T B with K = #nodes: split-K + deterministic reduce
+// weight-gradient GEMM  C[M x N] = A^T B with K = #nodes: split-K (enough splits to fill the chip) + deterministic reduce
 void gemm_tn_splitk(hipStream_t st, const GcnWs &w, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C) {
+  const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
   int splits = (int)std::min<size_t>(8, w.part_floats / ((size_t)M * N));
-  splits = std::max(1, std::min(splits, (K + 2047) / 2048));
+  splits = std::max(1, std::min({splits, (int)((1024 + tiles - 1) / tiles), (K + 255) / 256}));
   const int kps = ((K + splits - 1) / splits + BK - 1) / BK * BK;
   const int S = (K + kps - 1) / kps;
   if (S == 1) {
@@ -431,7 +616,23 @@ void gemm_tn_splitk(hipStream_t st, const GcnWs &w, int M, int N, int K, const f
   hipLaunchKernelGGL(k_splitk_reduce, dim3((M * N + 255) / 256), dim3(256), 0, st, M * N, S, w.part, C);
 }
 
+// outW[rows_w x N] = (A^T B)[:rows_w], outB[N] = column sums of B, for M <= 8 columns of A (M = 0: column sums
+// only): one pass over B. N % 4 == 0 and 16-byte aligned B rows (hidden-sized operands).
+void thin_tn(hipStream_t st, const GcnWs &w, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *outW,
+             int rows_w, float *outB) {
+  int nb = std::min(128, (K + 7) / 8);
+  nb = (int)std::max<size_t>(1, std::min<size_t>(nb, w.part_floats / ((size_t)(M + 1) * N)));
+  const int rpb = (K + nb - 1) / nb;
+  nb = (K + rpb - 1) / rpb;
+  hipLaunchKernelGGL(k_thin_tn_part, dim3((N / 4 + 255) / 256, nb), dim3(256), 0, st, K, N, M, A, lda, B, ldb, w.part, rpb);
+  hipLaunchKernelGGL(k_thin_tn_reduce, dim3(((M + 1) * N + 63) / 64), dim3(1024), 0, st, N, M, nb, w.part, outW, rows_w, outB);
+}
+
 void colsum(hipStream_t st, const GcnWs &w, int N, int C, const float *X, float *out) {
+  if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+    thin_tn(st, w, 0, C, N, nullptr, 0, X, C, nullptr, 0, out);
+    return;
+  }
   const int nb = 64, rpb = (N + nb - 1) / nb;
   hipLaunchKernelGGL(k_colsum_part, dim3((C + 255) / 256, nb), dim3(256), 0, st, N, C, X, w.part, rpb);
   hipLaunchKernelGGL(k_splitk_reduce, dim3((C + 255) / 256), dim3(256), 0, st, C, nb, w.part, out);
@@ -497,7 +698,11 @@ int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, i
   GcnWs w;
   carve(&w, reinterpret_cast<char *>(ws_dev), n_nodes, std::max(n_edges, 1), hidden, out_dim);
   // output layer
-  gemm_tn_splitk(st, w, out_dim, hidden, n_nodes, d_out, out_dim, w.H2, hidden, dWf);  // dWf = dOut^T H2m
+  if (out_dim <= 8) {
+    thin_tn(st, w, out_dim, hidden, n_nodes, d_out, out_dim, w.H2, hidden, dWf, out_dim, nullptr);  // dWf = dOut^T H2m
+  } else {
+    gemm_tn_splitk(st, w, out_dim, hidden, n_nodes, d_out, out_dim, w.H2, hidden, dWf);
+  }
   colsum(st, w, n_nodes, out_dim, d_out, dbf);
   hipLaunchKernelGGL(k_dz2, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, out_dim, d_out, Wf, dropout_mask, w.H2, w.T0);  // T0 = dZ2
   // layer 2
@@ -508,9 +713,7 @@ int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, i
   hipLaunchKernelGGL(k_aggregate, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, w.T1, w.deg, w.ptr_src, w.nbr_src, w.wn_src, w.H1,
                      w.T0);
   // layer 1
-  gemm_tn_splitk(st, w, 8, hidden, n_nodes, w.AX, 8, w.T0, hidden, w.T1);  // [8 x hidden], rows >= in_dim are zero
-  hipMemcpyAsync(dW1, w.T1, (size_t)in_dim * hidden * sizeof(float), hipMemcpyDeviceToDevice, st);
-  colsum(st, w, n_nodes, hidden, w.T0, db1);
+  thin_tn(st, w, 8, hidden, n_nodes, w.AX, 8, w.T0, hidden, dW1, in_dim, db1);  // dW1 = AX^T dZ1 (AX rows are 8 wide), db1 = colsum(dZ1)
   return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
 }
 
