@@ -329,6 +329,45 @@ __device__ __forceinline__ void sweep16_all(const SweepCtx &x, const Sw16 &L, v4
     for (unsigned long long _m = (mk)[_w]; _m; _m &= _m - 1)                  \
       if (const int p = 64 * _w + __ffsll((long long)_m) - 1; true)
 
+// E = -D^-1 of the 4x4 SPD pivot block at index q0i, read from `dscr` (16 doubles, row major, lower triangle valid), by
+// 2x2 block inversion (two reciprocals on the critical path instead of four; indices >= np act as identity); every
+// lane computes it redundantly, lanes 0-15 write `eout` (16 doubles, row major).
+__device__ __forceinline__ void pivot_inverse_from(int np, int q0i, const double *dscr, double *eout, int *bad, int lane) {
+      const bool m1 = q0i + 1 < np, m2 = q0i + 2 < np, m3 = q0i + 3 < np;
+      const double a00 = dscr[0];
+      const double a10 = m1 ? dscr[4] : 0.0, a11 = m1 ? dscr[5] : 1.0;
+      const double a20 = m2 ? dscr[8] : 0.0, a21 = (m2 && m1) ? dscr[9] : 0.0, a22 = m2 ? dscr[10] : 1.0;
+      const double a30 = m3 ? dscr[12] : 0.0, a31 = (m3 && m1) ? dscr[13] : 0.0, a32 = (m3 && m2) ? dscr[14] : 0.0;
+      const double a33 = m3 ? dscr[15] : 1.0;
+      // P = [a00 a10; a10 a11], Q = [a20 a21; a30 a31], R = [a22 a32; a32 a33]
+      const double detp = a00 * a11 - a10 * a10;
+      const double ip = fast_rcp(detp);
+      const double p00 = a11 * ip, p10 = -a10 * ip, p11 = a00 * ip;           // P^-1
+      const double t00 = a20 * p00 + a21 * p10, t01 = a20 * p10 + a21 * p11;  // T = Q P^-1
+      const double t10 = a30 * p00 + a31 * p10, t11 = a30 * p10 + a31 * p11;
+      const double s00 = a22 - (t00 * a20 + t01 * a21);                       // S = R - T Q^T
+      const double s10 = a32 - (t10 * a20 + t11 * a21);
+      const double s11 = a33 - (t10 * a30 + t11 * a31);
+      const double dets = s00 * s11 - s10 * s10;
+      const double is = fast_rcp(dets);
+      const double r00 = s11 * is, r10 = -s10 * is, r11 = s00 * is;           // S^-1
+      const double u00 = r00 * t00 + r10 * t10, u01 = r00 * t01 + r10 * t11;  // U = S^-1 T
+      const double u10 = r10 * t00 + r11 * t10, u11 = r10 * t01 + r11 * t11;
+      if (lane == 0 && (!(a00 > 0) || !(detp > 0) || !(s00 > 0) || !(dets > 0))) bad[0] = 1;
+      // D^-1 = [P^-1 + T^T U, -U^T; -U, S^-1];  E = -D^-1
+      const double e00 = -(p00 + t00 * u00 + t10 * u10), e10 = -(p10 + t01 * u00 + t11 * u10);
+      const double e11 = -(p11 + t01 * u01 + t11 * u11);
+      if (lane < 16) {
+        const int r = lane >> 2, c = lane & 3;
+        const int hi = max(r, c), lo = min(r, c);
+        double v;
+        if (hi < 2) v = (hi == 0) ? e00 : (lo == 0 ? e10 : e11);
+        else if (lo >= 2) v = -((lo == 3) ? r11 : (hi == 2 ? r00 : r10));
+        else v = (hi == 2) ? (lo == 0 ? u00 : u01) : (lo == 0 ? u10 : u11);
+        eout[lane] = v;
+      }
+}
+
 template <bool kLds, int NTW, int FT>
 __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &sel, int lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -649,8 +688,83 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
         if (j <= i && i < N) A[i * ld + j] = acc[u][r];
       }
     }
+  } else if constexpr (NTW == 0) {
+    // ---- 5c. the 4-wide sweeps of 5b with the tiles left in the HBM/L2 workspace (any capacity up to 127 poses;
+    //      config 5's ~120-pose graphs).  Per sweep g: panel v[c][i] and E_g = -D_g^-1 straight from memory, nW = V E,
+    //      then every tile is loaded, updated by one MFMA, patched on the pivot rows / columns and stored back.
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lc = lane & 15, lr = lane >> 4;
+    const int G = (np + 3) >> 2;
+    double *vb = Vb, *nwb = Vb + 4 * N, *eb = Vb + 8 * N;
+    for (int g = 0; g < G; ++g) {
+      const int k0 = 4 * g, KI = k0 >> 4, kc = k0 & 15, rg = kc >> 2;
+      for (int e = tid; e < 4 * N; e += kThreads) {
+        const int c = e / N, i = e - c * N, kk = k0 + c;
+        vb[e] = (kk < np) ? A[max(i, kk) * ld + min(i, kk)] : 0.0;
+      }
+      if (wave == 0) {
+        if (lane < 16) {
+          const int r = k0 + (lane >> 2), c = k0 + (lane & 3);
+          eb[16 + lane] = (max(r, c) < N) ? A[max(r, c) * ld + min(r, c)] : 0.0;
+        }
+        wave_sync();
+        pivot_inverse_from(np, k0, eb + 16, eb, bad, lane);
+      }
+      __syncthreads();
+      for (int e = tid; e < 4 * N; e += kThreads) {
+        const int k = e / N, i = e - k * N;
+        nwb[e] = fma(vb[3 * N + i], eb[12 + k], fma(vb[2 * N + i], eb[8 + k], fma(vb[N + i], eb[4 + k], vb[i] * eb[k])));
+      }
+      __syncthreads();
+      int I = 0, J = 0;  // tile t = wave, wave + kWaves, ... in row-major lower-triangle order
+      for (int t = 0; t < wave; ++t) {
+        if (++J > I) { ++I; J = 0; }
+      }
+      for (int t = wave; t < ntiles; t += kWaves) {
+        v4d acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * I + lr + 4 * r, j = 16 * J + lc;
+          acc[r] = A[max(i, j) * ld + min(i, j)];
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(nwb[lr * N + 16 * I + lc], vb[lr * N + 16 * J + lc], acc, 0, 0, 0);
+        if (J == KI) {  // pivot columns: A_iK <- A_iK D^-1 = -nW (diagonal tile: rows at/below the pivot)
+          const int c = lc - kc;
+          const bool mine = (unsigned)c < 4u && k0 + c < np;
+          const int cc = mine ? c : 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (I == KI && r < rg) continue;
+            const double val = -nwb[cc * N + 16 * I + lr + 4 * r];
+            if (mine) acc[r] = val;
+          }
+          if (I == KI) {  // the pivot block itself: A_KK <- -D^-1
+            const double pv = eb[4 * lr + cc];
+            const bool pm = mine && k0 + lr < np;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = (pm && r == rg) ? pv : acc[r];
+          }
+        }
+        if (I == KI) {  // pivot rows: A_Kj <- (A_jK D^-1)^T for the columns left of the pivot
+          const int j = 16 * J + lc;
+          const double val = -nwb[lr * N + j];
+          const bool pm = j < k0 && k0 + lr < np;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = (pm && r == rg) ? val : acc[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * I + lr + 4 * r, j = 16 * J + lc;
+          if (j <= i) A[i * ld + j] = acc[r];
+        }
+        for (int q = 0; q < kWaves; ++q) {
+          if (++J > I) { ++I; J = 0; }
+        }
+      }
+      __syncthreads();
+    }
   } else
-  // ---- 5. block symmetric sweep with 4-wide pivot groups on the fp64 matrix cores ----
+  // ---- 5b. block symmetric sweep with 4-wide pivot groups on the fp64 matrix cores ----
   // The lower triangle (+ full diagonal tiles) of the N x N system lives in v_mfma_f64_16x16x4_f64 accumulator tiles
   // (C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg), NTW tiles per wave, for all sweeps.  Sweep g pivots on
   // indices K = [4g, 4g+4) (those >= np - the rhs row and the pads - are masked out of the pivot):
@@ -694,39 +808,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const bool m1 = q0i + 1 < np, m2 = q0i + 2 < np, m3 = q0i + 3 < np;
-      const double a00 = dscr[0];
-      const double a10 = m1 ? dscr[4] : 0.0, a11 = m1 ? dscr[5] : 1.0;
-      const double a20 = m2 ? dscr[8] : 0.0, a21 = (m2 && m1) ? dscr[9] : 0.0, a22 = m2 ? dscr[10] : 1.0;
-      const double a30 = m3 ? dscr[12] : 0.0, a31 = (m3 && m1) ? dscr[13] : 0.0, a32 = (m3 && m2) ? dscr[14] : 0.0;
-      const double a33 = m3 ? dscr[15] : 1.0;
-      // P = [a00 a10; a10 a11], Q = [a20 a21; a30 a31], R = [a22 a32; a32 a33]
-      const double detp = a00 * a11 - a10 * a10;
-      const double ip = fast_rcp(detp);
-      const double p00 = a11 * ip, p10 = -a10 * ip, p11 = a00 * ip;           // P^-1
-      const double t00 = a20 * p00 + a21 * p10, t01 = a20 * p10 + a21 * p11;  // T = Q P^-1
-      const double t10 = a30 * p00 + a31 * p10, t11 = a30 * p10 + a31 * p11;
-      const double s00 = a22 - (t00 * a20 + t01 * a21);                       // S = R - T Q^T
-      const double s10 = a32 - (t10 * a20 + t11 * a21);
-      const double s11 = a33 - (t10 * a30 + t11 * a31);
-      const double dets = s00 * s11 - s10 * s10;
-      const double is = fast_rcp(dets);
-      const double r00 = s11 * is, r10 = -s10 * is, r11 = s00 * is;           // S^-1
-      const double u00 = r00 * t00 + r10 * t10, u01 = r00 * t01 + r10 * t11;  // U = S^-1 T
-      const double u10 = r10 * t00 + r11 * t10, u11 = r10 * t01 + r11 * t11;
-      if (lane == 0 && (!(a00 > 0) || !(detp > 0) || !(s00 > 0) || !(dets > 0))) bad[0] = 1;
-      // D^-1 = [P^-1 + T^T U, -U^T; -U, S^-1];  E = -D^-1
-      const double e00 = -(p00 + t00 * u00 + t10 * u10), e10 = -(p10 + t01 * u00 + t11 * u10);
-      const double e11 = -(p11 + t01 * u01 + t11 * u11);
-      if (lane < 16) {
-        const int r = lane >> 2, c = lane & 3;
-        const int hi = max(r, c), lo = min(r, c);
-        double v;
-        if (hi < 2) v = (hi == 0) ? e00 : (lo == 0 ? e10 : e11);
-        else if (lo >= 2) v = -((lo == 3) ? r11 : (hi == 2 ? r00 : r10));
-        else v = (hi == 2) ? (lo == 0 ? u00 : u01) : (lo == 0 ? u10 : u11);
-        eout[lane] = v;
-      }
+      pivot_inverse_from(np, q0i, dscr, eout, bad, lane);
     };
     // E_0 before the first sweep
 #pragma unroll
@@ -947,7 +1029,8 @@ void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
   if (!attr_set) {
     const void *fns[] = {reinterpret_cast<const void *>(&kslam::k_slam<true, 1, kslam::kFastTiles>),
                          reinterpret_cast<const void *>(&kslam::k_slam<false, 10, 0>),
-                         reinterpret_cast<const void *>(&kslam::k_slam<false, 20, 0>)};
+                         reinterpret_cast<const void *>(&kslam::k_slam<false, 20, 0>),
+                         reinterpret_cast<const void *>(&kslam::k_slam<false, 0, 0>)};
     for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kslam::kLdsBudget);
     attr_set = true;
   }
@@ -955,17 +1038,20 @@ void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
     // fast path: the kernel always works on the full 128 x 128 capacity; whatever LDS is left holds the factor records
     hipLaunchKernelGGL((kslam::k_slam<true, 1, kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
   } else {
-    // dense system in the HBM/L2 workspace, triangular tile scheme with the accumulator tiles in registers:
-    // <= 58 poses: 10 tiles per wave, <= 86 poses: 20 tiles per wave
+    // dense system in the HBM/L2 workspace, triangular tile scheme; accumulator tiles in registers
+    // (<= 58 poses: 10 tiles per wave, <= 86 poses: 20 tiles per wave) or, beyond that, streamed per sweep (<= 127 poses:
+    // the per-landmark pose masks are 128 bits)
     const size_t small = kslam::slam_small_bytes(S.P_max, S.L_max, S.M_max);
-    if (small > (size_t)kslam::kLdsBudget || ntiles > 20 * kslam::kWaves) {
+    if (small > (size_t)kslam::kLdsBudget || S.P_max > 127) {
       (void)hipMemsetAsync(S.status, 0xff, sizeof(int), st);  // capacity beyond this kernel: flag an error (-1)
       return;
     }
     if (ntiles <= 10 * kslam::kWaves)
       hipLaunchKernelGGL((kslam::k_slam<false, 10, 0>), dim3(sel.n), dim3(kslam::kThreads), small, st, S, sel, (int)small);
-    else
+    else if (ntiles <= 20 * kslam::kWaves)
       hipLaunchKernelGGL((kslam::k_slam<false, 20, 0>), dim3(sel.n), dim3(kslam::kThreads), small, st, S, sel, (int)small);
+    else
+      hipLaunchKernelGGL((kslam::k_slam<false, 0, 0>), dim3(sel.n), dim3(kslam::kThreads), small, st, S, sel, (int)small);
   }
 }
 #pragma clang fp contract(off)

@@ -277,10 +277,10 @@ def test_fused_step_kernel_equals_stage_kernels():
     staged.close()
 
 
-@pytest.mark.parametrize("max_poses", [43, 60, 86])
+@pytest.mark.parametrize("max_poses", [43, 60, 86, 127])
 def test_larger_capacities_use_other_kernel_variants(max_poses):
     """Capacities beyond 43 poses move the dense system of k_slam from LDS to the HBM/L2 workspace (one register
-    tile per thread up to 60 poses, two up to 86): same results."""
+    tile per thread up to 60 poses, two up to 86, tiles streamed per sweep up to 127): same results."""
     n = 3
     eng, cfg = make_engine(n, max_poses=max_poses)
     ocfg = O.default_config(MAP)
@@ -294,6 +294,32 @@ def test_larger_capacities_use_other_kernel_variants(max_poses):
     assert eng.status() == 0
     for i in range(n):
         compare_state(eng, i, sims[i], "hbm-ws env %d" % i)
+    eng.close()
+
+
+def test_config5_scale_120_pose_graphs():
+    """BASELINE config 5 scale: 50 m map, 500 landmarks, graphs grown to ~115 poses / ~100 landmarks (dense pose
+    system n = 3 P + 1 > 340: k_slam streams its tiles from the HBM/L2 workspace, k_map works in pose chunks)."""
+    from drl_graph_exploration_amd import default_config
+    from drl_graph_exploration_amd.engine import Engine
+    n, msize = 2, 50
+    cfg = default_config(msize, num_landmarks=500, max_poses=120, max_landmarks=128, max_factors=3600)
+    eng = Engine(cfg, n, 0)
+    ocfg = O.default_config(msize, num_landmarks=500)
+    starts = np.array([[-7.3183, -6.2718, 0.1234], [3.1, 4.7, 2.2]])
+    sims = [O.OracleSim(ocfg, lo, lo, start=tuple(starts[lo])) for lo in range(n)]
+    eng.reset(np.arange(n), np.arange(n), starts=starts)
+    loop = [(2, 0, 0)] * 3 + [(0, 0, math.pi / 2)] + [(2, 0, 0)] * 2 + [(0.7, 0, 0.4)]
+    for s in range(114):
+        act = loop[s % len(loop)]
+        eng.step(torch.tensor([act] * n, dtype=torch.float64, device=eng.device))
+        for sim in sims:
+            sim.simulate(act)
+        if s in (87, 113):  # 20-tile-per-wave register variant no longer fits from 87 poses on
+            assert eng.status() == 0
+            for i in range(n):
+                assert eng.counts(i)["poses"] == s + 2
+                compare_state(eng, i, sims[i], "config-5 env %d step %d" % (i, s), mask_knife_edge=True)
     eng.close()
 
 
