@@ -155,6 +155,35 @@ def policy_bench(eng, dev, iters=10):
     return out
 
 
+def config5_bench(device_index, n_envs=256, warm=108, timed=8):
+    """BASELINE config 5 scale as a secondary figure: 50 m map, 500 landmarks, graphs grown by a fixed motion loop to
+    ~110 poses / ~95 landmarks (k_slam's tile-streaming variant, k_map in pose chunks); per-stage kernels."""
+    from drl_graph_exploration_amd import default_config
+    from drl_graph_exploration_amd.engine import Engine
+    cfg = default_config(50, num_landmarks=500, max_poses=127, max_landmarks=128, max_factors=3800)
+    eng = Engine(cfg, n_envs, 0, device_index)
+    rng = np.random.RandomState(0)
+    starts = np.stack([rng.uniform(-12, 12, n_envs), rng.uniform(-12, 12, n_envs), rng.uniform(-3, 3, n_envs)], 1)
+    eng.reset(np.arange(n_envs), np.arange(n_envs), starts=starts)
+    loop = [(2, 0, 0)] * 3 + [(0, 0, math.pi / 2)] + [(2, 0, 0)] * 2 + [(0.7, 0, 0.4)]
+    odoms = [torch.tensor([a] * n_envs, dtype=torch.float64, device=eng.device) for a in loop]
+    for s in range(warm):
+        eng.step(odoms[s % len(loop)])
+    eng.synchronize()
+    eng.check_status()
+    c = eng.counts_dev().cpu().numpy()
+    t0 = time.perf_counter()
+    for s in range(timed):
+        eng.step(odoms[(warm + s) % len(loop)])
+    eng.synchronize()
+    dt = (time.perf_counter() - t0) / timed
+    eng.check_status()
+    eng.close()
+    return {"workload": "50x50 map (V=2025), 500 landmarks, %d envs" % n_envs, "poses": float(c[:, 0].mean()),
+            "landmarks": float(c[:, 1].mean()), "factors": float(c[:, 2].mean()), "ms_per_step": dt * 1e3,
+            "env_steps_per_sec": n_envs / dt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,6 +310,7 @@ def main():
         }
         if not args.no_policy:
             out["policy_path"] = policy_bench(eng, dev)
+            out["config5_scale"] = config5_bench(local_rank)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu_thread"] = (out["value"] / world) / out["cpu_baseline"]["value"]
