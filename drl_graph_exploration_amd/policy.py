@@ -236,3 +236,212 @@ class DeepQ(object):
         torch.save(policy_net.state_dict(), os.path.join(self.weights_path, "MyModel.pt"))
         if own_env:
             env.close()
+
+
+class A2C(object):
+    """The reference's advantage actor-critic trainer (scripts/policy.py:262-503) over a `VecExplorationEnv`.
+
+    Same constructor `A2C(case_path)`, hyper-parameters (nstep 40, gamma 0.99, entropy 0.01, value 0.25, grad clamp
+    0.5, Adam 1e-5 over actor + critic), costs and artefacts.  `running` steps `n_envs` environments in lock-step; every
+    env keeps its own n-step trajectory, and one optimiser step per `nstep` vector steps uses all `n_envs * nstep`
+    transitions with the reference's per-trajectory normalisation averaged over the envs (n_envs = 1 is exactly the
+    reference's update).  Multi-GPU: gradients of both networks are averaged over ranks before the clamp."""
+
+    def __init__(self, case_path, data_root="../data"):
+        self.case_path = case_path
+        self.weights_path = os.path.join(data_root, "torch_weights", self.case_path)
+        self.reward_data_path = os.path.join(data_root, "reward_data", self.case_path)
+        self.object_path = os.path.join(data_root, "training_object_data", self.case_path)
+        for p in (self.weights_path, self.reward_data_path, self.object_path):
+            os.makedirs(p, exist_ok=True)
+        with open(os.path.join(self.reward_data_path, "reward_data.csv"), "w", newline="") as f:
+            csv.writer(f).writerow(["Step", "Reward"])
+        self.GAMMA = 0.99
+        self.EXPLORE = 1e6
+        self.epoch = 1e4
+        self.nstep = 40
+        self.ent_coef = 0.01
+        self.vf_coef = 0.25
+        self.max_grad_norm = 0.5
+        self.graphs_per_pass = 256  # forward/backward chunk of the n_envs * nstep graphs (gradients accumulate)
+        self.buffer = deque()
+        self.map_size = 40
+        self.step_t = 0
+        self.temp_loss = 0
+        self.entro = 0
+        self.total_reward = np.empty([0, 0])
+
+    data_process = staticmethod(DeepQ.data_process)
+    _host_offsets = staticmethod(DeepQ._host_offsets)
+
+    # ------------------------------------------------------------------ costs (policy.py:452-472)
+    def policy_cost(self, prob, advantages, action, mask):
+        adv = torch.masked_select(advantages.view(-1), mask)
+        act = torch.masked_select(action, mask)
+        return torch.mul(-torch.mul(prob.view(-1).log(), adv), act).sum() / self.nstep
+
+    def value_cost(self, pred, target):
+        return torch.nn.functional.mse_loss(pred.view(-1), target.view(-1))
+
+    def entropy_loss(self, prob):
+        p = prob.view(-1).detach()
+        return -torch.mul(p.log(), p).sum() / self.nstep
+
+    def train(self, data, action, mask, dis_reward, y_adv, device, modelA, modelC, optimizer, n_traj=1):
+        """One optimiser step on a batch of `n_traj` trajectories of `nstep` graphs (policy.py:474-497 for n_traj = 1).
+        `data` is a list of GraphData (one per transition, trajectory-major) or one collated batch."""
+        modelA.train()
+        modelC.train()
+        items = data if isinstance(data, (list, tuple)) else None
+        if items is None:
+            chunks = [(data, 0, int(data.batch.max().item()) + 1)]
+        else:
+            chunks = []
+            for a in range(0, len(items), self.graphs_per_pass):
+                b = min(len(items), a + self.graphs_per_pass)
+                chunks.append((GraphData.collate(items[a:b]), a, b))
+        mask = torch.as_tensor(mask, dtype=torch.bool, device=device)
+        y_adv = torch.as_tensor(y_adv, dtype=torch.float32, device=device)
+        dis_reward = torch.as_tensor(dis_reward, dtype=torch.float32, device=device)
+        action = torch.as_tensor(action, dtype=torch.float32, device=device)
+        optimizer.zero_grad()
+        n_graphs = len(items) if items is not None else chunks[0][2]
+        total, entro, node0 = 0.0, 0.0, 0
+        for cdata, g0, g1 in chunks:
+            cdata = cdata.to(device)
+            nn_ = cdata.x.shape[0]
+            m = mask[node0:node0 + nn_]
+            actor_out = modelA(cdata, m, batch=cdata.batch) + 1e-35
+            critic_out = modelC(cdata, m, batch=cdata.batch)
+            actor_loss = self.policy_cost(actor_out, y_adv[node0:node0 + nn_], action[node0:node0 + nn_], m) / n_traj
+            # mse over all graphs of the batch: this chunk's share of the mean
+            critic_loss = ((critic_out.view(-1) - dis_reward[g0:g1]) ** 2).sum() / n_graphs
+            ent = self.entropy_loss(actor_out) / n_traj
+            loss = actor_loss - ent * self.ent_coef + critic_loss * self.vf_coef
+            loss.backward()
+            total += float(loss.item())
+            entro += float(ent.item())
+            node0 += nn_
+        self.temp_loss, self.entro = total, entro
+        allreduce_gradients(modelA)
+        allreduce_gradients(modelC)
+        for param in list(modelA.parameters()) + list(modelC.parameters()):
+            param.grad.data.clamp_(-self.max_grad_norm, self.max_grad_norm)
+        optimizer.step()
+
+    def test(self, data, batch, mask, device, model):
+        model.eval()
+        data = data.to(device)
+        mask = torch.as_tensor(mask, dtype=torch.bool, device=device)
+        return model(data, mask, batch=batch)
+
+    @staticmethod
+    def discounted_returns(rewards, terminal, last_value, gamma):
+        """policy.py:364-369 for every env column: ret_t = r_t + gamma * ret_{t+1} * (1 - terminal_t), bootstrapped
+        with the critic's value of the state after the last transition. rewards / terminal: [T, n_envs]."""
+        ret = np.asarray(last_value, dtype=np.float64)
+        out = np.zeros(np.shape(rewards), dtype=np.float64)
+        for t in reversed(range(out.shape[0])):
+            ret = rewards[t] + gamma * ret * (1.0 - np.asarray(terminal[t], dtype=np.float64))
+            out[t] = ret
+        return out
+
+    # ------------------------------------------------------------------ main loop (policy.py:297-427)
+    def running(self, actor, critic, test=False, n_envs=16, env=None, log_every=0):
+        temp_i = 0
+        own_env = env is None
+        if env is None:
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            env = VecExplorationEnv(self.map_size, n_envs, env_index=rank * n_envs, test=test,
+                                    device=torch.cuda.current_device(), seed=None if not test else rank)
+        n_envs = env.n_envs
+        device = env.device
+        policy_net, value_net = actor, critic
+        broadcast_parameters(policy_net)
+        broadcast_parameters(value_net)
+        optimizer = torch.optim.Adam(list(policy_net.parameters()) + list(value_net.parameters()), lr=1e-5)
+        temp_reward_data, temp_loss_data, rows = [], [], []
+        rng = np.random  # the reference samples actions from numpy's global stream
+        envs = torch.arange(n_envs, device=device)
+
+        def frontier_mask(g):
+            n = g["x"].shape[0]
+            end = g["node_off"][1:].long()[g["batch"]]
+            return torch.arange(n, device=device) >= end - g["n_frontier"].long()[g["batch"]]
+
+        g = self._host_offsets(env.graph_matrix())
+        while temp_i < self.epoch:
+            s_t = [self.data_process(g, i) for i in range(n_envs)]
+            env.actions_all_goals()
+            rewards = env.rewards_all_goals()
+            cand_env, cand_node, cand_first = env.candidates
+            nfr = g["n_frontier"].long()
+            batch_data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"])
+            mask = frontier_mask(g)
+            with torch.no_grad():
+                readout = self.test(batch_data, g["batch"], mask, device, policy_net).view(-1)  # [C], env-major
+                val = self.test(batch_data, g["batch"], mask, device, value_net).view(-1)       # [n_envs]
+            p_h, first_h, nfr_h = readout.cpu().numpy().astype(np.float64), cand_first.cpu().numpy(), nfr.cpu().numpy()
+            choice = np.zeros(n_envs, dtype=np.int64)
+            for i in range(n_envs):
+                p = p_h[first_h[i]:first_h[i] + nfr_h[i]]
+                choice[i] = rng.choice(int(nfr_h[i]), 1, p=p / p.sum())[0]
+            choice_t = torch.as_tensor(choice, device=device)
+            r_t = rewards[cand_first + choice_t]
+            key_size = (g["node_off"][1:] - g["node_off"][:-1]).long() - nfr
+            a_loc = (key_size + choice_t).cpu().numpy()
+            _, done, _ = env.step(choice_t)
+            current_done = (done | env.loop_clo).cpu().numpy()
+            done_h = done.cpu().numpy()
+            r_h = r_t.cpu().numpy()
+            val_h = val.cpu().numpy()
+            if done_h.any():
+                env.reset(np.nonzero(done_h)[0])
+            g1 = self._host_offsets(env.graph_matrix())
+            self.buffer.append((s_t, a_loc, r_h, current_done | done_h, nfr_h.copy(), val_h))
+            self.step_t += n_envs
+            temp_i += n_envs
+
+            if len(self.buffer) == self.nstep:
+                with torch.no_grad():
+                    b1 = GraphData(g1["x"], g1["edge_index"], g1["edge_attr"], g1["batch"])
+                    last_value = self.test(b1, g1["batch"], frontier_mask(g1), device, value_net).view(-1).cpu().numpy()
+                T = self.nstep
+                disc = self.discounted_returns(np.stack([b[2] for b in self.buffer]), np.stack([b[3] for b in self.buffer]),
+                                               last_value, self.GAMMA)
+                items, a_b, m_b, adv_b, dr_b = [], [], [], [], []
+                for i in range(n_envs):  # trajectory-major, as the reference's DataLoader over one env's buffer
+                    for t in range(T):
+                        st, al, _, _, fro, v = self.buffer[t]
+                        n_nodes = st[i].x.shape[0]
+                        a = np.zeros(n_nodes, dtype=np.float32)
+                        a[al[i]] = 1.0
+                        m = np.zeros(n_nodes, dtype=bool)
+                        m[n_nodes - int(fro[i]):] = True
+                        y = np.zeros(n_nodes, dtype=np.float32)
+                        y[al[i]] = disc[t, i] - v[i]
+                        items.append(st[i]); a_b.append(a); m_b.append(m); adv_b.append(y); dr_b.append(disc[t, i])
+                self.train(items, np.concatenate(a_b), np.concatenate(m_b), np.array(dr_b), np.concatenate(adv_b), device,
+                           policy_net, value_net, optimizer, n_traj=n_envs)
+                temp_loss_data.append([self.step_t, self.temp_loss])
+                self.buffer.clear()
+            g = g1
+
+            if log_every and (self.step_t // n_envs) % log_every == 0:
+                print("TIMESTEP", self.step_t, "/ Loss", self.temp_loss, "/ Entropy", self.entro,
+                      "/ EXPLORED", float(env.status().mean()), "/ REWARD", float(r_h.mean()))
+            rows.extend([self.step_t, float(x)] for x in r_h)
+            self.total_reward = np.append(self.total_reward, r_h)
+            if self.step_t % 5e4 < n_envs and self.step_t >= 5e4:
+                torch.save(policy_net.state_dict(), os.path.join(self.weights_path, "MyModel.pt"))
+            if self.step_t > 1000 and (self.step_t // n_envs) % max(100 // n_envs, 1) == 0:
+                temp_reward_data.append([self.step_t, float(np.average(self.total_reward[-1000:]))])
+
+        np.savetxt(os.path.join(self.object_path, "temp_reward.csv"), np.array(temp_reward_data).reshape(-1, 2), delimiter=",")
+        np.savetxt(os.path.join(self.object_path, "temp_loss.csv"), np.array(temp_loss_data).reshape(-1, 2), delimiter=",")
+        with open(os.path.join(self.reward_data_path, "reward_data.csv"), "a", newline="") as f:
+            csv.writer(f).writerows(rows)
+        torch.save(policy_net.state_dict(), os.path.join(self.object_path, "Model_Policy.pt"))
+        torch.save(value_net.state_dict(), os.path.join(self.object_path, "Model_Value.pt"))
+        if own_env:
+            env.close()

@@ -140,6 +140,28 @@ def test_deepq_running_smoke(tmp_path):
     assert (tmp_path / "training_object_data" / "smoke" / "Model_Policy.pt").exists()
 
 
+def test_a2c_running_smoke(tmp_path):
+    """A2C (scripts/policy.py:262-503) over the vectorised env: n-step returns per env, actor + critic on the HIP GCN,
+    one optimiser step per `nstep` vector steps."""
+    from drl_graph_exploration_amd.networks import PolicyGCN, ValueGCN
+    from drl_graph_exploration_amd.policy import A2C
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    a2c = A2C("smoke_a2c/", data_root=str(tmp_path))
+    a2c.nstep, a2c.epoch, a2c.graphs_per_pass = 3, 24, 5  # 6 vector steps of 4 envs -> 2 updates, 3 chunks each
+    actor, critic = PolicyGCN().to(dev), ValueGCN().to(dev)
+    wa, wc = actor.conv2.weight.detach().clone(), critic.fully_con1.weight.detach().clone()
+    a2c.running(actor, critic, test=True, n_envs=4)
+    assert a2c.step_t == 24 and len(a2c.buffer) == 0
+    assert math.isfinite(a2c.temp_loss) and a2c.temp_loss != 0 and a2c.entro > 0
+    assert not torch.equal(wa, actor.conv2.weight.detach()) and not torch.equal(wc, critic.fully_con1.weight.detach())
+    for f in ("Model_Policy.pt", "Model_Value.pt", "temp_loss.csv"):
+        assert (tmp_path / "training_object_data" / "smoke_a2c" / f).exists()
+    rows = (tmp_path / "reward_data" / "smoke_a2c" / "reward_data.csv").read_text().strip().splitlines()
+    assert rows[0] == "Step,Reward" and len(rows) == 25
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the reference's own golden data through the PRODUCT path: data/test_result/40_DQN_GCN.csv (fixture csv_pin.json)
 # ---------------------------------------------------------------------------------------------------------------------

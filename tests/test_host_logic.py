@@ -227,3 +227,26 @@ def test_gradient_allreduce_gloo_world_size_2():
     for a, b, x, y in zip(g0, g1, l0, l1):
         assert torch.equal(a, b)  # every rank holds the same averaged gradient
         assert torch.allclose(a, (x + y) / 2, rtol=1e-6, atol=1e-7)
+
+
+def test_a2c_costs_and_returns(tmp_path):
+    """A2C cost functions and n-step returns against hand evaluation (scripts/policy.py:364-369, 452-472)."""
+    import torch
+    from drl_graph_exploration_amd.policy import A2C
+    a = A2C("t/", data_root=str(tmp_path))
+    a.nstep = 2
+    # two graphs of 3 and 4 nodes, frontier nodes = last 2 of each; actor output = probs over masked nodes
+    mask = torch.tensor([0, 1, 1, 0, 0, 1, 1], dtype=torch.bool)
+    prob = torch.tensor([0.25, 0.75, 0.6, 0.4])
+    action = torch.tensor([0, 0, 1, 0, 0, 1, 0], dtype=torch.float32)
+    adv = torch.tensor([0, 0, 0.5, 0, 0, -2.0, 0])
+    expect = (-(np.log(0.75) * 0.5) - (np.log(0.6) * -2.0)) / 2
+    assert float(a.policy_cost(prob, adv, action, mask)) == pytest.approx(expect, rel=1e-6)
+    ent = -(0.25 * np.log(0.25) + 0.75 * np.log(0.75) + 0.6 * np.log(0.6) + 0.4 * np.log(0.4)) / 2
+    assert float(a.entropy_loss(prob)) == pytest.approx(ent, rel=1e-6)
+    assert float(a.value_cost(torch.tensor([1.0, 3.0]), torch.tensor([0.0, 1.0]))) == pytest.approx(2.5)
+    r = np.array([[1.0, 0.5], [2.0, -1.0], [0.0, 3.0]])
+    term = np.array([[False, False], [True, False], [False, False]])
+    out = A2C.discounted_returns(r, term, np.array([10.0, 20.0]), 0.9)
+    # env 0: t2 = 0 + .9*10 = 9; t1 terminal = 2; t0 = 1 + .9*2 = 2.8;  env 1: t2 = 3 + 18 = 21; t1 = -1 + 18.9; t0 = .5 + .9*17.9
+    np.testing.assert_allclose(out, [[2.8, 0.5 + 0.9 * 17.9], [2.0, 17.9], [9.0, 21.0]], rtol=1e-12)
