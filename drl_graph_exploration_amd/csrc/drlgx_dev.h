@@ -519,11 +519,13 @@ void drlgx_launch_reset(const DrlgxState &S, hipStream_t st, int n, const int32_
                         const double *start_dev);
 void drlgx_launch_sim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride,
                       int n_measure);
-void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel);
+// p_bound: host-side upper bound of the pose count of every selected instance after this launch (<= P_max); it picks
+// the kernel variant (the kernels flag DRLGX_E_CAPACITY instead of overrunning if the bound is violated)
+void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p_bound);
 size_t drlgx_map_lds_bytes(const DrlgxState &S, int *chunk_out);
 // fused simulate + SLAM + map kernel (k_step.hip); usable when the SLAM system and the map stage fit the LDS
-bool drlgx_step_fusable(const DrlgxState &S);
-void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure);
+bool drlgx_step_fusable(const DrlgxState &S, int p_bound);
+void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure);  // requires drlgx_step_fusable
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel);  // sel.act_idx == -2: reductions only
 void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
                        const int32_t *dst, int src_off, int dst_off, int skip_mask);  // skip fields with cls & mask

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <cstdlib>
 #include <vector>
 
 #include "drlgx_dev.h"
@@ -45,7 +46,13 @@ struct drlgx_engine {
   int graph_gi_stride = 0;
   // timing
   bool timing = false;
-  bool fused = false;  // the fused simulate + SLAM + map kernel is usable for this configuration
+  // Host-side upper bound of every env's pose count: exact after drlgx_reset_host / drlgx_status_host / a restore of a
+  // snapshot taken in an exact state, +1 per drlgx_step in between (the active mask lives on the device).  It selects
+  // the k_slam variant and whether the fused step kernel applies, per launch, so that a large pose capacity does not
+  // slow the steps of short trajectories down.
+  std::vector<int> pbound;
+  bool by_capacity = false;  // DRLGX_VARIANT_BY_CAPACITY=1 (tests): select the variants by max_poses as if every env were full
+  std::vector<std::vector<int>> snap_pbound;
   bool per_stage = false;  // timing mode 2: launch the three stage kernels separately so that each gets its own span
   std::vector<TimedSpan> spans;
   std::vector<hipEvent_t> free_events;
@@ -160,6 +167,12 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   }
   // instances: [0,n) live envs | [n,2n) look-ahead bases | rollouts | max_snapshots x n snapshot copies
   S.n_inst = 2 * n_envs + n_rollouts + cfg->max_snapshots * n_envs;
+  e->pbound.assign(n_envs, cfg->max_poses);  // unknown until the first reset
+  {
+    const char *v = getenv("DRLGX_VARIANT_BY_CAPACITY");
+    e->by_capacity = v && v[0] == '1';
+  }
+  e->snap_pbound.assign(cfg->max_snapshots > 0 ? cfg->max_snapshots : 0, std::vector<int>(n_envs, cfg->max_poses));
   S.P_max = cfg->max_poses;
   S.L_max = cfg->max_landmarks;
   S.M_max = cfg->max_factors;
@@ -329,7 +342,6 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
     const size_t nd = 3 * P + 16;  // >= 16 * ceil((3P + 1) / 16)
     S.slam_ws_stride = M * 12 + (L * P * 2 + 7) / 8 + 16 + (lds ? 0 : nd * nd);
     S.slam_iws_stride = 2;
-    e->fused = drlgx_step_fusable(S);
     TRY(dev_alloc(e, &S.slam_ws, S.slam_ws_stride * (size_t)S.n_inst));
     TRY(dev_alloc(e, &S.slam_iws, S.slam_iws_stride * (size_t)S.n_inst));
   }
@@ -379,11 +391,23 @@ int drlgx_synchronize(drlgx_engine *e) {
   return DRLGX_OK;
 }
 
+static int max_bound(const drlgx_engine *e) {
+  if (e->by_capacity) return e->S.P_max;
+  int m = 1;
+  for (int v : e->pbound) m = std::max(m, v);
+  return m;
+}
+
 int drlgx_status_host(drlgx_engine *e) {
   if (!e) return DRLGX_E_INVALID;
   int st = 0;
+  // the same synchronisation refreshes the host's pose-count bounds with the exact device values
+  std::vector<int32_t> poses(e->S.n_envs);
   HIPCHK(e, hipMemcpyAsync(&st, e->S.status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpy2DAsync(poses.data(), sizeof(int32_t), e->S.cnt + C_P, DRLGX_CNT_STRIDE * sizeof(int32_t), sizeof(int32_t),
+                             e->S.n_envs, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (int i = 0; i < e->S.n_envs; ++i) e->pbound[i] = std::min(std::max((int)poses[i], 1), e->S.P_max);
   return st;
 }
 
@@ -401,8 +425,9 @@ int drlgx_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint3
   HIPCHK(e, hipMemcpyAsync(e->stage_mask, mask.data(), e->S.n_envs, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipMemsetAsync(e->S.status, 0, sizeof(int), e->stream));
   drlgx_launch_reset(e->S, e->stream, n, e->stage_i32, e->stage_u32, e->stage_f64);
+  for (int i = 0; i < n; ++i) e->pbound[env_ids[i]] = 1;
   LaunchSel sel{0, e->S.n_envs, e->stage_mask, nullptr, 0};
-  drlgx_launch_slam(e->S, e->stream, sel);
+  drlgx_launch_slam(e->S, e->stream, sel, e->by_capacity ? e->S.P_max : 1);
   sel.act_idx = -2;  // reductions only: the virtual map is in its untouched state
   drlgx_launch_map(e->S, e->stream, sel);
   int r = check_launch(e);
@@ -414,7 +439,9 @@ int drlgx_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint3
 int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_dev) {
   if (!e || !odom_dev) return DRLGX_E_INVALID;
   LaunchSel sel{0, e->S.n_envs, active_dev, nullptr, 0};
-  if (e->fused && !e->per_stage) {
+  const int pb = std::min(max_bound(e) + 1, e->S.P_max);
+  for (int &v : e->pbound) v = std::min(v + 1, e->S.P_max);
+  if (drlgx_step_fusable(e->S, pb) && !e->per_stage) {
     // one fused kernel per step (timer 5); timing mode 2 launches the stage kernels separately (timers 0-2)
     ScopedTimer t(e, 5);
     drlgx_launch_step(e->S, e->stream, sel, odom_dev, 3, 2);
@@ -425,7 +452,7 @@ int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_de
     }
     {
       ScopedTimer t(e, 1);
-      drlgx_launch_slam(e->S, e->stream, sel);
+      drlgx_launch_slam(e->S, e->stream, sel, pb);
     }
     {
       ScopedTimer t(e, 2);
@@ -469,6 +496,7 @@ int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
   if (e->S.n_roll < 1) return DRLGX_E_CAPACITY;
   const DrlgxState &S = e->S;
   const int base0 = S.n_envs, roll0 = 2 * S.n_envs;
+  const int pbe = max_bound(e);  // rollouts start from their env's trajectory and add one pose per action
   {
     ScopedTimer t(e, 3);
     // deep copy env -> base, SLAM2D::set_copy_isam (re-base at the best estimate + one batch update)
@@ -477,7 +505,7 @@ int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
   }
   {
     ScopedTimer t(e, 1);
-    drlgx_launch_slam(S, e->stream, LaunchSel{base0, S.n_envs, nullptr, nullptr, 0});
+    drlgx_launch_slam(S, e->stream, LaunchSel{base0, S.n_envs, nullptr, nullptr, 0}, pbe);
   }
   // candidates beyond the rollout capacity are processed in successive waves over the same rollout instances
   for (int c0 = 0; c0 < n_cand; c0 += S.n_roll) {
@@ -492,7 +520,8 @@ int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
     }
     for (int a = 0; a < S.A_max; ++a) {
       LaunchSel sel{roll0, nc, nullptr, na, a};
-      if (e->fused && !e->per_stage) {
+      const int pb = std::min(pbe + a + 1, S.P_max);
+      if (drlgx_step_fusable(S, pb) && !e->per_stage) {
         ScopedTimer t(e, 5);
         drlgx_launch_step(S, e->stream, sel, act, S.A_max * 3, 1);
         continue;
@@ -503,7 +532,7 @@ int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
       }
       {
         ScopedTimer t(e, 1);
-        drlgx_launch_slam(S, e->stream, sel);
+        drlgx_launch_slam(S, e->stream, sel, pb);
       }
       {
         ScopedTimer t(e, 2);
@@ -772,6 +801,7 @@ int drlgx_snapshot(drlgx_engine *e, int slot) {
   ScopedTimer t(e, 3);
   drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr, 0,
                     2 * S.n_envs + S.n_roll + slot * S.n_envs, 0);
+  e->snap_pbound[slot] = e->pbound;
   return check_launch(e);
 }
 
@@ -781,6 +811,7 @@ int drlgx_restore(drlgx_engine *e, int slot) {
   ScopedTimer t(e, 3);
   drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr,
                     2 * S.n_envs + S.n_roll + slot * S.n_envs, 0, 0);
+  e->pbound = e->snap_pbound[slot];
   return check_launch(e);
 }
 

@@ -386,6 +386,11 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   // fast path: rows padded by 2 doubles against LDS bank conflicts
   const int Tn = (na + 15) / 16, N = 16 * Tn, ld = FT > 0 ? N + 2 : N;
   const int ntiles = Tn * (Tn + 1) / 2;
+  if ((FT > 0 && Tn > FT) || (FT == 0 && NTW > 0 && ntiles > NTW * kWaves)) {
+    // more poses than this variant was launched for (the host's bound was wrong): flag it, touch nothing
+    if (tid == 0) atomicMin(S.status, DRLGX_E_CAPACITY);
+    return;
+  }
   DRLGX_PROF(S, 0);
 
   // ---- LDS carve: small arrays first, then the dense system; overflow goes to the HBM workspace ----
@@ -1023,8 +1028,9 @@ bool drlgx_slam_in_lds(int P_max, int L_max, int M_max) {
   return kslam::slam_dim(P_max) <= nf && kslam::slam_small_bytes_n(nf, P_max, L_max, M_max, true) + nf * (nf + 2) * 8 <= (size_t)kslam::kLdsBudget;
 }
 
-void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
-  const int Tn = (int)(kslam::slam_dim(S.P_max) / 16), ntiles = Tn * (Tn + 1) / 2;
+void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p_bound) {
+  const int Pb = p_bound < S.P_max ? p_bound : S.P_max;
+  const int Tn = (int)(kslam::slam_dim(Pb) / 16), ntiles = Tn * (Tn + 1) / 2;
   static bool attr_set = false;
   if (!attr_set) {
     const void *fns[] = {reinterpret_cast<const void *>(&kslam::k_slam<true, 1, kslam::kFastTiles>),
@@ -1034,7 +1040,7 @@ void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
     for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kslam::kLdsBudget);
     attr_set = true;
   }
-  if (drlgx_slam_in_lds(S.P_max, S.L_max, S.M_max)) {
+  if (drlgx_slam_in_lds(Pb, S.L_max, S.M_max)) {
     // fast path: the kernel always works on the full 128 x 128 capacity; whatever LDS is left holds the factor records
     hipLaunchKernelGGL((kslam::k_slam<true, 1, kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
   } else {

@@ -36,9 +36,9 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
 
 }  // namespace kstep
 
-bool drlgx_step_fusable(const DrlgxState &S) {
+bool drlgx_step_fusable(const DrlgxState &S, int p_bound) {
   int chunk = 0;
-  return drlgx_slam_in_lds(S.P_max, S.L_max, S.M_max) && drlgx_map_lds_bytes(S, &chunk) <= (size_t)kslam::kLdsBudget &&
+  return drlgx_slam_in_lds(p_bound < S.P_max ? p_bound : S.P_max, S.L_max, S.M_max) && drlgx_map_lds_bytes(S, &chunk) <= (size_t)kslam::kLdsBudget &&
          (size_t)(2 * DRLGX_MT_STRIDE * 4 + (2 * S.LG + 2) * 8 + S.LG * 4) <= (size_t)kslam::kLdsBudget;
 }
 

@@ -48,8 +48,9 @@ class VecExplorationEnv(object):
         self.n_envs = n_envs
         self.test = test
         if max_poses is None:
-            # a 40 m map is explored in ~35-45 poses between resets; the SLAM kernel keeps the whole
-            # information matrix in LDS up to 43 poses (csrc/k_slam.hip) and in HBM workspace up to 86
+            # a 40 m map is explored in ~35-45 poses between resets. The capacity costs memory only: the engine picks
+            # the SLAM kernel per launch from the trajectories' current length (fused LDS-resident step up to 42
+            # poses, HBM/L2-workspace variants beyond; csrc/k_slam.hip), refreshed at every status check
             max_poses = 86
         self.cfg = default_config(map_size, num_landmarks=num_landmarks, algorithm=algorithm, max_poses=max_poses)
         if n_rollouts is None:
