@@ -382,9 +382,12 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   const int n_old_p = cnt[C_NEWP], n_old_l = cnt[C_NEWL];
   const int count = cnt[C_ISAM] + 1;
   const int np = 3 * P, na = np + 1;
-  // padded to 16x16 MFMA tiles; row np holds the rhs (its column and all pad rows / columns stay zero)
-  // fast path: rows padded by 2 doubles against LDS bank conflicts
-  const int Tn = (na + 15) / 16, N = 16 * Tn, ld = FT > 0 ? N + 2 : N;
+  // padded to 16x16 MFMA tiles; row np holds the rhs (its column and all pad rows / columns stay zero).  Only the lower
+  // triangle is ever addressed: the fast path packs it (row i at i (i + 1) / 2: half the LDS of the square, which keeps
+  // the factor records on chip for ~700 factors instead of ~230), the workspace variants keep the square
+  const int Tn = (na + 15) / 16, N = 16 * Tn, ld = N;
+  auto AT = [&](int i, int j) -> int { return FT > 0 ? i * (i + 1) / 2 + j : i * ld + j; };
+  const size_t a_doubles = FT > 0 ? max((size_t)N * (N + 1) / 2, (size_t)48 * N + 1280) : (size_t)N * ld;
   const int ntiles = Tn * (Tn + 1) / 2;
   if ((FT > 0 && Tn > FT) || (FT == 0 && NTW > 0 && ntiles > NTW * kWaves)) {
     // more poses than this variant was launched for (the host's bound was wrong): flag it, touch nothing
@@ -411,7 +414,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   double *A;
   if (kLds) {
     // (the fast path reuses this region for its sweep panels: 48 N + 1280 doubles)
-    A = reinterpret_cast<double *>(smem_raw + off); off += (FT > 0 ? max((size_t)N * ld, (size_t)48 * N + 1280) : (size_t)N * ld) * 8;
+    A = reinterpret_cast<double *>(smem_raw + off); off += a_doubles * 8;
   } else {
     A = wsd; wsd += (size_t)(3 * S.P_max + 16) * (3 * S.P_max + 16);
   }
@@ -462,7 +465,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   // ---- 2. clear the system; factor tables (factors are appended in pose order: contiguous ranges) ----
   {
     double2 *A2 = reinterpret_cast<double2 *>(A);
-    const int n2 = N * ld / 2;
+    const int n2 = (int)((FT > 0 ? (size_t)N * (N + 1) / 2 : (size_t)N * ld) / 2);  // (N is a multiple of 16: even)
     for (int e = tid; e < n2; e += kThreads) A2[e] = make_double2(0.0, 0.0);
   }
   for (int e = tid; e < L * P; e += kThreads) obs[e] = 0;
@@ -560,7 +563,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
       }
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c)
-          A[(3 * (i + 1) + r) * ld + 3 * i + c] =
+          A[AT((3 * (i + 1) + r), 3 * i + c)] =
               Hl[r] * wo[0] * J1[c] + Hl[3 + r] * wo[1] * J1[3 + c] + Hl[6 + r] * wo[2] * J1[6 + c];
     }
     for (int m = mstart[i]; m < mstart[i + 1]; ++m) {  // own bearing-range factors
@@ -571,8 +574,8 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
       }
     }
     for (int r = 0; r < 3; ++r) {
-      for (int c = 0; c <= r; ++c) A[(3 * i + r) * ld + 3 * i + c] = B[r * 3 + c];
-      A[np * ld + 3 * i + r] = -g[r];  // rhs lives in the augmented row
+      for (int c = 0; c <= r; ++c) A[AT((3 * i + r), 3 * i + c)] = B[r * 3 + c];
+      A[AT(np, 3 * i + r)] = -g[r];  // rhs lives in the augmented row
     }
   }
   __syncthreads();
@@ -620,7 +623,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
         for (int r = 0; r < 3; ++r)
           for (int c = 0; c < 3; ++c) {
             if (p == q && c > r) continue;
-            A[(3 * p + r) * ld + 3 * q + c] -= acc[r * 3 + c];
+            A[AT((3 * p + r), 3 * q + c)] -= acc[r * 3 + c];
           }
     }
     for (int p = (tid + kThreads / 2) % kThreads; p < P; p += kThreads) {  // rhs_p -= sum_m G_m eta_j (idle waves)
@@ -631,9 +634,9 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
         s1 += g[2] * lb[6] + g[3] * lb[7];
         s2 += g[4] * lb[6] + g[5] * lb[7];
       }
-      A[np * ld + 3 * p + 0] -= s0;
-      A[np * ld + 3 * p + 1] -= s1;
-      A[np * ld + 3 * p + 2] -= s2;
+      A[AT(np, 3 * p + 0)] -= s0;
+      A[AT(np, 3 * p + 1)] -= s1;
+      A[AT(np, 3 * p + 2)] -= s2;
     }
   }
   __syncthreads();
@@ -643,7 +646,13 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // tile rows r and FT-1-r share a SIMD (waves w and w+4): lower-triangle MFMA work is balanced across the SIMDs
-    const int trow = wv < FT / 2 ? wv : (FT - 1) - (wv - FT / 2);
+    int trow = wv < FT / 2 ? wv : (FT - 1) - (wv - FT / 2);
+    if (Tn == FT) {
+      // no idle tile row: the wave of row 0 (one tile of update work) also inverts the diagonal tiles, and its SIMD
+      // partner takes the next lightest row, so that the inversion chain competes with the fewest MFMAs:
+      // SIMD pairs (0, 1), (2, FT-1), (3, FT-2), ...
+      trow = wv == 0 ? 0 : wv == FT / 2 ? 1 : wv < FT / 2 ? wv + 1 : FT + FT / 2 - wv;
+    }
     SweepCtx x{trow, lane, lane & 15, lane >> 4, np, N, trow < Tn, trow == (Tn < FT ? FT - 1 : 0), bad, (S.prof && blockIdx.x == 0 && lane == 0) ? S.prof + 24 + 5 * wv : nullptr};
     v4d acc[FT];
 #pragma unroll
@@ -651,7 +660,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * x.I + x.lr + 4 * r, j = 16 * u + x.lc;
-        acc[u][r] = (i < N && j < N) ? A[max(i, j) * ld + min(i, j)] : 0.0;
+        acc[u][r] = (i < N && j < N) ? A[AT(max(i, j), min(i, j))] : 0.0;
       }
     __syncthreads();  // every tile is in registers: the LDS region of A now holds the sweep panels
     Sw16 Lp;
@@ -690,7 +699,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * x.I + x.lr + 4 * r, j = 16 * u + x.lc;
-        if (j <= i && i < N) A[i * ld + j] = acc[u][r];
+        if (j <= i && i < N) A[AT(i, j)] = acc[u][r];
       }
     }
   } else if constexpr (NTW == 0) {
@@ -705,12 +714,12 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
       const int k0 = 4 * g, KI = k0 >> 4, kc = k0 & 15, rg = kc >> 2;
       for (int e = tid; e < 4 * N; e += kThreads) {
         const int c = e / N, i = e - c * N, kk = k0 + c;
-        vb[e] = (kk < np) ? A[max(i, kk) * ld + min(i, kk)] : 0.0;
+        vb[e] = (kk < np) ? A[AT(max(i, kk), min(i, kk))] : 0.0;
       }
       if (wave == 0) {
         if (lane < 16) {
           const int r = k0 + (lane >> 2), c = k0 + (lane & 3);
-          eb[16 + lane] = (max(r, c) < N) ? A[max(r, c) * ld + min(r, c)] : 0.0;
+          eb[16 + lane] = (max(r, c) < N) ? A[AT(max(r, c), min(r, c))] : 0.0;
         }
         wave_sync();
         pivot_inverse_from(np, k0, eb + 16, eb, bad, lane);
@@ -730,7 +739,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * I + lr + 4 * r, j = 16 * J + lc;
-          acc[r] = A[max(i, j) * ld + min(i, j)];
+          acc[r] = A[AT(max(i, j), min(i, j))];
         }
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(nwb[lr * N + 16 * I + lc], vb[lr * N + 16 * J + lc], acc, 0, 0, 0);
         if (J == KI) {  // pivot columns: A_iK <- A_iK D^-1 = -nW (diagonal tile: rows at/below the pivot)
@@ -760,7 +769,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * I + lr + 4 * r, j = 16 * J + lc;
-          if (j <= i) A[i * ld + j] = acc[r];
+          if (j <= i) A[AT(i, j)] = acc[r];
         }
         for (int q = 0; q < kWaves; ++q) {
           if (++J > I) { ++I; J = 0; }
@@ -799,7 +808,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * ib + lr + 4 * r, j = 16 * jb + lc;
-        acc[u][r] = live[u] ? A[max(i, j) * ld + min(i, j)] : 0.0;
+        acc[u][r] = live[u] ? A[AT(max(i, j), min(i, j))] : 0.0;
       }
     }
     const int G = (np + 3) >> 2;
@@ -904,13 +913,13 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * tI[u] + lr + 4 * r, j = 16 * tJ[u] + lc;
-        if (j <= i) A[i * ld + j] = acc[u][r];
+        if (j <= i) A[AT(i, j)] = acc[u][r];
       }
     }
   }
   __syncthreads();
   DRLGX_PROF(S, 5);
-  for (int k = tid; k < np; k += kThreads) d_pose[k] = A[np * ld + k];
+  for (int k = tid; k < np; k += kThreads) d_pose[k] = A[AT(np, k)];
   // ---- 6. landmark marginals: rec[6..9] <- G_m^T ( sum_{m' of the same landmark} Sigma[p_m][p_m'] G_m' ) ----
   for (int m = tid; m < M; m += kThreads) {
     const int j = ml[m], p = mp[m];
@@ -922,7 +931,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
         double s0 = 0, s1 = 0;
         for (int c = 0; c < 3; ++c) {
           const int ra = 3 * p + r, cb = 3 * q + c;
-          const double sg = -((ra >= cb) ? A[ra * ld + cb] : A[cb * ld + ra]);
+          const double sg = -((ra >= cb) ? A[AT(ra, cb)] : A[AT(cb, ra)]);
           s0 += sg * gq[c * 2];
           s1 += sg * gq[c * 2 + 1];
         }
@@ -950,7 +959,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
       const int m1 = obs[j * P + p];
       const double *g = rec + (size_t)REC * (m1 - 1);
       c00 += g[6]; c01 += g[7]; c10 += g[8]; c11 += g[9];
-      const double dp0 = A[np * ld + 3 * p], dp1 = A[np * ld + 3 * p + 1], dp2 = A[np * ld + 3 * p + 2];
+      const double dp0 = A[AT(np, 3 * p)], dp1 = A[AT(np, 3 * p + 1)], dp2 = A[AT(np, 3 * p + 2)];
       dx -= g[0] * dp0 + g[2] * dp1 + g[4] * dp2;
       dy -= g[1] * dp0 + g[3] * dp1 + g[5] * dp2;
     }
@@ -972,10 +981,10 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   for (int i = (tid + kThreads / 2) % kThreads; i < P; i += kThreads) {
     const int k0 = 3 * i;
     const Pose t{thp[4 * i], thp[4 * i + 1], thp[4 * i + 2], thp[4 * i + 3]};
-    const Pose e = compose(t, make_pose(A[np * ld + k0], A[np * ld + k0 + 1], A[np * ld + k0 + 2]));
+    const Pose e = compose(t, make_pose(A[AT(np, k0)], A[AT(np, k0 + 1)], A[AT(np, k0 + 2)]));
     est_pose[4 * i] = e.x; est_pose[4 * i + 1] = e.y; est_pose[4 * i + 2] = e.c; est_pose[4 * i + 3] = e.s;
-    const double c00 = -A[k0 * ld + k0], c10 = -A[(k0 + 1) * ld + k0], c11 = -A[(k0 + 1) * ld + k0 + 1];
-    const double c20 = -A[(k0 + 2) * ld + k0], c21 = -A[(k0 + 2) * ld + k0 + 1], c22 = -A[(k0 + 2) * ld + k0 + 2];
+    const double c00 = -A[AT(k0, k0)], c10 = -A[AT((k0 + 1), k0)], c11 = -A[AT((k0 + 1), k0 + 1)];
+    const double c20 = -A[AT((k0 + 2), k0)], c21 = -A[AT((k0 + 2), k0 + 1)], c22 = -A[AT((k0 + 2), k0 + 2)];
     pose_tr[i] = c00 + c11 + c22;
     LLT3 llt(c00, c10, c20, c11, c21, c22);
     double x0, x1, x2;
@@ -1025,7 +1034,8 @@ size_t drlgx_slam_lds_bytes(int P_max, int L_max, int M_max) {
 // true when k_slam keeps the dense system in LDS (the fast path); otherwise the engine must provide the HBM workspace
 bool drlgx_slam_in_lds(int P_max, int L_max, int M_max) {
   const size_t nf = 16 * kslam::kFastTiles;
-  return kslam::slam_dim(P_max) <= nf && kslam::slam_small_bytes_n(nf, P_max, L_max, M_max, true) + nf * (nf + 2) * 8 <= (size_t)kslam::kLdsBudget;
+  return kslam::slam_dim(P_max) <= nf && kslam::slam_small_bytes_n(nf, P_max, L_max, M_max, true) +
+                                              std::max(nf * (nf + 1) / 2, 48 * nf + 1280) * 8 <= (size_t)kslam::kLdsBudget;
 }
 
 void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p_bound) {
