@@ -861,15 +861,19 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
       // ---- phase C: every tile A_IJ += nW_I V_J^T (one MFMA each, operands fetched up front so the MFMAs issue back
       //      to back), then the exact values of the pivot rows / columns; the owner of the next pivot's diagonal tile
       //      inverts that block right away (off the other waves' critical path) ----
-      double aop[NTW], bop[NTW];
+      constexpr int CH = NTW > 10 ? 5 : NTW;  // operand batch (all at once would spill at 20 tiles per wave)
 #pragma unroll
-      for (int u = 0; u < NTW; ++u) {
-        aop[u] = live[u] ? nwb[lr * N + 16 * tI[u] + lc] : 0.0;
-        bop[u] = live[u] ? vb[lr * N + 16 * tJ[u] + lc] : 0.0;
+      for (int u0 = 0; u0 < NTW; u0 += CH) {
+        double aop[CH], bop[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          aop[u] = live[u0 + u] ? nwb[lr * N + 16 * tI[u0 + u] + lc] : 0.0;
+          bop[u] = live[u0 + u] ? vb[lr * N + 16 * tJ[u0 + u] + lc] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+          if (live[u0 + u]) acc[u0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[u], bop[u], acc[u0 + u], 0, 0, 0);
       }
-#pragma unroll
-      for (int u = 0; u < NTW; ++u)
-        if (live[u]) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[u], bop[u], acc[u], 0, 0, 0);
       const int k1 = k0 + 4, KI1 = k1 >> 4;
 #pragma unroll
       for (int u = 0; u < NTW; ++u) {

@@ -1,0 +1,37 @@
+"""Dev tool: k_slam phase breakdown (block 0) at a given pose count / capacity (loop workload of bench_vs_poses.py)."""
+import math, os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from drl_graph_exploration_amd import default_config
+from drl_graph_exploration_amd.engine import Engine
+
+cap, poses = int(sys.argv[1]), int(sys.argv[2])
+n = 256
+cfg = default_config(bench.MAP, num_landmarks=bench.NUM_LM, max_poses=cap, max_landmarks=100, max_factors=14 * cap, max_snapshots=1)
+eng = Engine(cfg, n, 0, 0)
+rng = np.random.RandomState(0)
+starts = np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-3, 3, n)], 1)
+eng.reset(np.arange(n), np.arange(n), starts=starts)
+loop = [(2, 0, 0)] * 3 + [(0, 0, math.pi / 2)] + [(2, 0, 0)] * 2 + [(0.7, 0, 0.4)]
+odoms = [torch.tensor([a] * n, dtype=torch.float64, device=eng.device) for a in loop]
+for s in range(poses - 1):
+    eng.step(odoms[s % len(loop)])
+assert eng.status() == 0
+eng.snapshot(0)
+out = (C.c_int64 * 64)()
+eng.L.drlgx_debug_phase_clocks_host(eng.h, 1, None)
+eng.timing_enable(2)
+acc = np.zeros(64); k = 0
+for it in range(12):
+    eng.restore(0); eng.step(odoms[(poses - 1) % len(loop)])
+    eng.L.drlgx_debug_phase_clocks_host(eng.h, 1, out)
+    if it >= 4:
+        acc += np.array(out[:], dtype=np.float64); k += 1
+a = acc / k
+names = {1: "relin+clear+tables", 2: "landmark+pose blocks", 3: "G", 4: "Schur", 5: "sweeps", 6: "landmark partials", 7: "outputs"}
+print("capacity %d, %d -> %d poses; k_slam phases (us, block 0):" % (cap, poses, poses + 1))
+for i in range(1, 8):
+    print("  %-24s %8.2f" % (names[i], (a[i] - a[i - 1]) / 100.0))
+print("  total %.2f" % ((a[7] - a[0]) / 100.0))
