@@ -484,9 +484,17 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
     linearize_br(thp + 4 * p, thl + 2 * j, meas_br[2 * m], meas_br[2 * m + 1], rec + (size_t)REC * m);
   }
   __syncthreads();
-  if (tid == 0)
-    for (int p = P - 1; p >= 0; --p)
-      if (mstart[p] == M) mstart[p] = mstart[p + 1];  // poses without factors: empty range
+  {
+    // poses without factors get the empty range [next pose's start, same): first assigned start at or after p
+    int v = M;
+    if (tid < P) {
+      int q = tid;
+      v = mstart[q];
+      while (v == M && q < P) v = mstart[++q];  // mstart[P] = M
+    }
+    __syncthreads();
+    if (tid < P) mstart[tid] = v;
+  }
   __syncthreads();
   DRLGX_PROF(S, 1);
   // ---- 3. block assembly.  first waves: one thread per landmark; following waves: one thread per pose ----
