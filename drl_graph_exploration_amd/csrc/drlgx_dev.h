@@ -101,6 +101,13 @@ struct LaunchSel {
   const uint8_t *active;   // [n] or null
   const int32_t *n_act;    // [n] or null: instance active iff act_idx < n_act[i]
   int act_idx;
+  // look-ahead rollouts: the virtual map is a pure function of the SLAM state (both rebuilds start from the untouched
+  // map), and only the utility after the LAST action enters the reward, so the map stage runs for an instance only
+  // when act_idx is its last action
+  int map_last_only = 0;
+  __device__ __forceinline__ bool map_on(int i) const {
+    return !(map_last_only && n_act) || act_idx == n_act[i] - 1;
+  }
   __device__ __forceinline__ bool on(int i) const {
     if (active && !active[i]) return false;
     if (n_act && act_idx >= n_act[i]) return false;

@@ -520,6 +520,7 @@ int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
     }
     for (int a = 0; a < S.A_max; ++a) {
       LaunchSel sel{roll0, nc, nullptr, na, a};
+      sel.map_last_only = 1;
       const int pb = std::min(pbe + a + 1, S.P_max);
       if (drlgx_step_fusable(S, pb) && !e->per_stage) {
         ScopedTimer t(e, 5);

@@ -162,10 +162,11 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bi = blockIdx.x;
-  if (!sel.on(bi)) return;
+  if (!sel.on(bi) || !sel.map_on(bi)) return;
   const int inst = sel.base + bi;
   const int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
-  if (cnt[C_FLAG]) return;
+  // a rejected move leaves the belief as it was: nothing to rebuild, unless this is the one rebuild of a rollout
+  if (cnt[C_FLAG] && !sel.map_last_only) return;
   const drlgx_config &cfg = S.cfg;
   const int P = cnt[C_P], L = cnt[C_L];
   const int V = S.V, cols = S.cols, rows = S.rows, W = S.win, W2 = W * W;
