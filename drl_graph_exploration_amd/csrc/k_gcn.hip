@@ -45,10 +45,11 @@ __global__ void k_degree(int E, const int64_t *ei, int *cnt_dst, int *cnt_src) {
   atomicAdd(&cnt_dst[c], 1);
   atomicAdd(&cnt_src[r], 1);
 }
-// exclusive scan of two count arrays (single block; N is a few 10^4)
-__global__ void k_scan2(int n, const int *a, int *pa, const int *b, int *pb) {
-  __shared__ int part[2][1024];
-  const int t = threadIdx.x, nt = blockDim.x;
+// exclusive scan of two count arrays (single block of 1024 threads; N is a few 10^4): per-thread chunk sums, a
+// shuffle scan inside each wave, a shuffle scan of the 16 wave totals, then the chunks are rewritten
+__global__ __launch_bounds__(1024) void k_scan2(int n, const int *a, int *pa, const int *b, int *pb) {
+  __shared__ int wtot[2][16];
+  const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
   const int chunk = (n + nt - 1) / nt;
   const int i0 = t * chunk, i1 = min(n, i0 + chunk);
   int sa = 0, sb = 0;
@@ -56,25 +57,41 @@ __global__ void k_scan2(int n, const int *a, int *pa, const int *b, int *pb) {
     sa += a[i];
     sb += b[i];
   }
-  part[0][t] = sa;
-  part[1][t] = sb;
-  __syncthreads();
-  if (t == 0) {
-    int ra = 0, rb = 0;
-    for (int k = 0; k < nt; ++k) {
-      int x = part[0][k];
-      part[0][k] = ra;
-      ra += x;
-      x = part[1][k];
-      part[1][k] = rb;
-      rb += x;
+  int xa = sa, xb = sb;  // inclusive scan over the wave
+  for (int off = 1; off < 64; off <<= 1) {
+    const int ya = __shfl_up(xa, off), yb = __shfl_up(xb, off);
+    if (lane >= off) {
+      xa += ya;
+      xb += yb;
     }
-    pa[n] = ra;
-    pb[n] = rb;
+  }
+  if (lane == 63) {
+    wtot[0][wave] = xa;
+    wtot[1][wave] = xb;
   }
   __syncthreads();
-  sa = part[0][t];
-  sb = part[1][t];
+  if (wave == 0) {
+    int va = lane < 16 ? wtot[0][lane] : 0, vb = lane < 16 ? wtot[1][lane] : 0;
+    const int ia = va, ib = vb;
+    for (int off = 1; off < 16; off <<= 1) {
+      const int ya = __shfl_up(va, off), yb = __shfl_up(vb, off);
+      if (lane >= off) {
+        va += ya;
+        vb += yb;
+      }
+    }
+    if (lane < 16) {
+      wtot[0][lane] = va - ia;  // exclusive
+      wtot[1][lane] = vb - ib;
+    }
+    if (lane == 15) {
+      pa[n] = va;
+      pb[n] = vb;
+    }
+  }
+  __syncthreads();
+  sa = wtot[0][wave] + xa - sa;  // exclusive prefix of this thread's chunk
+  sb = wtot[1][wave] + xb - sb;
   for (int i = i0; i < i1; ++i) {
     pa[i] = sa;
     sa += a[i];
@@ -91,10 +108,13 @@ __global__ void k_csr_fill(int E, const int64_t *ei, const int *ptr_dst, int *cu
   eid_dst[ptr_dst[c] + atomicAdd(&cur_dst[c], 1)] = e;
   eid_src[ptr_src[r] + atomicAdd(&cur_src[r], 1)] = e;
 }
-// sort each CSR row by edge id (rows are short) -> deterministic summation order
-__global__ void k_csr_sort(int N, const int *ptr, int *eid) {
+// sort each CSR row by edge id (rows are short) -> deterministic summation order; both CSRs in one launch
+__global__ void k_csr_sort(int N, const int *ptr0, int *eid0, const int *ptr1, int *eid1) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+  if (n >= 2 * N) return;
+  const int *ptr = n < N ? ptr0 : ptr1;
+  int *eid = n < N ? eid0 : eid1;
+  if (n >= N) n -= N;
   const int a = ptr[n], b = ptr[n + 1];
   for (int i = a + 1; i < b; ++i) {
     int v = eid[i], j = i - 1;
@@ -114,11 +134,18 @@ __global__ void k_degree_sum(int N, const float *ew, const int *ptr_src, const i
   for (int i = ptr_src[n]; i < ptr_src[n + 1]; ++i) s += ew[eid_src[i]];
   deg[n] = s + 2.0f;
 }
-// resolve (neighbour, normalised weight) per CSR slot.  dis = deg^-1/2 (inf -> 0).
-__global__ void k_csr_finish(int N, int E, const int64_t *ei, const float *ew, const float *deg, const int *ptr, const int *eid,
-                             int *nbr, float *wn, int by_dst) {
+// resolve (neighbour, normalised weight) per CSR slot, for the by-destination CSR (threads < N) and the by-source one.
+// dis = deg^-1/2 (inf -> 0).
+__global__ void k_csr_finish(int N, int E, const int64_t *ei, const float *ew, const float *deg, const int *ptr_dst,
+                             const int *eid_dst, int *nbr_dst, float *wn_dst, const int *ptr_src, const int *eid_src, int *nbr_src,
+                             float *wn_src) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+  if (n >= 2 * N) return;
+  const bool by_dst = n < N;
+  const int *ptr = by_dst ? ptr_dst : ptr_src, *eid = by_dst ? eid_dst : eid_src;
+  int *nbr = by_dst ? nbr_dst : nbr_src;
+  float *wn = by_dst ? wn_dst : wn_src;
+  if (!by_dst) n -= N;
   for (int i = ptr[n]; i < ptr[n + 1]; ++i) {
     const int e = eid[i];
     const int r = (int)ei[e], c = (int)ei[(size_t)E + e];
@@ -521,7 +548,7 @@ __global__ __launch_bounds__(256) void k_colsum_part(int N, int C, const float *
 struct GcnWs {
   float *deg, *wn_dst, *wn_src, *AX, *H1, *AH1, *H2, *T0, *T1, *part;
   int *cnt_dst, *cnt_src, *ptr_dst, *ptr_src, *cur_dst, *cur_src, *eid_dst, *eid_src, *nbr_dst, *nbr_src;
-  size_t part_floats;
+  size_t part_floats, counters_bytes;
 };
 
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -551,12 +578,13 @@ size_t carve(GcnWs *w, char *base, int N, int E, int hidden, int out_dim) {
   takef(w ? &w->T1 : &df, NH);
   takef(w ? &w->part : &df, part);
   if (w) w->part_floats = part;
-  takei(w ? &w->cnt_dst : &di, N + 1);
+  takei(w ? &w->cnt_dst : &di, N + 1);  // the four counters are contiguous: one memset (see build_graph)
   takei(w ? &w->cnt_src : &di, N + 1);
-  takei(w ? &w->ptr_dst : &di, N + 1);
-  takei(w ? &w->ptr_src : &di, N + 1);
   takei(w ? &w->cur_dst : &di, N + 1);
   takei(w ? &w->cur_src : &di, N + 1);
+  if (w) w->counters_bytes = off - ((char *)w->cnt_dst - base);
+  takei(w ? &w->ptr_dst : &di, N + 1);
+  takei(w ? &w->ptr_src : &di, N + 1);
   takei(w ? &w->eid_dst : &di, E);
   takei(w ? &w->eid_src : &di, E);
   takei(w ? &w->nbr_dst : &di, E);
@@ -639,22 +667,18 @@ void colsum(hipStream_t st, const GcnWs &w, int N, int C, const float *X, float 
 }
 
 void build_graph(hipStream_t st, const GcnWs &w, int N, int E, const int64_t *ei, const float *ew) {
-  hipMemsetAsync(w.cnt_dst, 0, (size_t)(N + 1) * 4, st);
-  hipMemsetAsync(w.cnt_src, 0, (size_t)(N + 1) * 4, st);
-  hipMemsetAsync(w.cur_dst, 0, (size_t)(N + 1) * 4, st);
-  hipMemsetAsync(w.cur_src, 0, (size_t)(N + 1) * 4, st);
+  hipMemsetAsync(w.cnt_dst, 0, w.counters_bytes, st);  // cnt_dst, cnt_src, cur_dst, cur_src
   if (E > 0) hipLaunchKernelGGL(k_degree, dim3((E + 255) / 256), dim3(256), 0, st, E, ei, w.cnt_dst, w.cnt_src);
   hipLaunchKernelGGL(k_scan2, dim3(1), dim3(1024), 0, st, N, w.cnt_dst, w.ptr_dst, w.cnt_src, w.ptr_src);
   if (E > 0) {
     hipLaunchKernelGGL(k_csr_fill, dim3((E + 255) / 256), dim3(256), 0, st, E, ei, w.ptr_dst, w.cur_dst, w.eid_dst, w.ptr_src,
                        w.cur_src, w.eid_src);
   }
-  const dim3 gn((N + 127) / 128), bn(128);
-  hipLaunchKernelGGL(k_csr_sort, gn, bn, 0, st, N, w.ptr_dst, w.eid_dst);
-  hipLaunchKernelGGL(k_csr_sort, gn, bn, 0, st, N, w.ptr_src, w.eid_src);
+  const dim3 gn((N + 127) / 128), g2((2 * N + 127) / 128), bn(128);
+  hipLaunchKernelGGL(k_csr_sort, g2, bn, 0, st, N, w.ptr_dst, w.eid_dst, w.ptr_src, w.eid_src);
   hipLaunchKernelGGL(k_degree_sum, gn, bn, 0, st, N, ew, w.ptr_src, w.eid_src, w.deg);
-  hipLaunchKernelGGL(k_csr_finish, gn, bn, 0, st, N, E, ei, ew, w.deg, w.ptr_dst, w.eid_dst, w.nbr_dst, w.wn_dst, 1);
-  hipLaunchKernelGGL(k_csr_finish, gn, bn, 0, st, N, E, ei, ew, w.deg, w.ptr_src, w.eid_src, w.nbr_src, w.wn_src, 0);
+  hipLaunchKernelGGL(k_csr_finish, g2, bn, 0, st, N, E, ei, ew, w.deg, w.ptr_dst, w.eid_dst, w.nbr_dst, w.wn_dst, w.ptr_src,
+                     w.eid_src, w.nbr_src, w.wn_src);
 }
 
 }  // namespace
