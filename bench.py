@@ -197,10 +197,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # DRLGX_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a box with fewer GPUs than ranks
+    # (ranks then share devices); the measured configuration is one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get("DRLGX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
