@@ -35,3 +35,8 @@ print("capacity %d, %d -> %d poses; k_slam phases (us, block 0):" % (cap, poses,
 for i in range(1, 8):
     print("  %-24s %8.2f" % (names[i], (a[i] - a[i - 1]) / 100.0))
 print("  total %.2f" % ((a[7] - a[0]) / 100.0))
+last = np.array(out[:], dtype=np.int64)
+t0 = min(last[24 + 5 * w] for w in range(8))
+for w in range(8):
+    b5 = last[24 + 5 * w: 29 + 5 * w] - t0
+    print("  wave %d (block step K=3): start %5d  P done %5d  W done %5d  barrier2 passed %5d  end %5d" % (w, b5[0], b5[1], b5[2], b5[3], b5[4]))
