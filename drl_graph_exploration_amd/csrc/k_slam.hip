@@ -329,6 +329,51 @@ __device__ __forceinline__ void sweep16_all(const SweepCtx &x, const Sw16 &L, v4
     for (unsigned long long _m = (mk)[_w]; _m; _m &= _m - 1)                  \
       if (const int p = 64 * _w + __ffsll((long long)_m) - 1; true)
 
+// the part of a block step that overwrites instead of updating: tile column K takes -W, the pivot rows -(W)^T, the pivot
+// block E_K (masked rows / columns excepted); see sweep16_block
+__device__ __forceinline__ void tile_replace16(int I, int J, int K, int np, int lc, int lr, const double *wt, const double *einv,
+                                               v4d &acc) {
+  const int kb = 16 * K;
+  if (I > K && J == K) {  // A_IK <- A_IK D^-1 (masked columns: W = 0)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = -wt[(16 * I + lr + 4 * r) * 16 + ks16(lc)];
+  }
+  if (I == K) {
+    if (J < K) {  // pivot rows: A_KJ <- -(W_J)^T; rows >= np (rhs, pads) keep the regular update
+      double tt[4];
+      ld4(wt + (16 * J + lc) * 16 + lr * 4, tt);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = (kb + lr + 4 * r < np) ? -tt[r] : acc[r];
+    } else {  // pivot block <- E_K; masked rows / columns take -W like any other row
+      double ee[4], tt[4];
+      ld4(einv + lc * 16 + lr * 4, ee);
+      ld4(wt + (16 * K + lc) * 16 + lr * 4, tt);
+      const bool colact = kb + lc < np;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool rowact = kb + lr + 4 * r < np;
+        const double wv = wt[(16 * K + lr + 4 * r) * 16 + ks16(lc)];
+        acc[r] = rowact ? (colact ? ee[r] : -tt[r]) : (colact ? -wv : acc[r]);
+      }
+    }
+  }
+}
+
+// One lower tile (I, J) of block step K of the 16-wide symmetric sweep, for the variants that do not keep a whole tile row
+// per wave: the same update / replacement rules as sweep16_block, from the LDS panels PAN (pivot column), WT = PAN E_K
+// and E_K.  acc: accumulator layout (row lr + 4 r, column lc of the tile; diagonal tiles fully symmetric).
+__device__ __forceinline__ void tile_step16(int I, int J, int K, int np, int lc, int lr, const double *pan, const double *wt,
+                                            const double *einv, v4d &acc) {
+  const int kb = 16 * K;
+  const bool has_mask = np < kb + 16;
+  if ((I != K || has_mask) && (J != K || I == K)) {
+    double aW[4], bP[4];
+    ld4(wt + (16 * I + lc) * 16 + lr * 4, aW);
+    ld4(pan + (16 * J + lc) * 16 + lr * 4, bP);
+    acc = mfma4(aW, bP, acc);
+  }
+  tile_replace16(I, J, K, np, lc, lr, wt, einv, acc);
+}
 // E = -D^-1 of the 4x4 SPD pivot block at index q0i, read from `dscr` (16 doubles, row major, lower triangle valid), by
 // 2x2 block inversion (two reciprocals on the critical path instead of four; indices >= np act as identity); every
 // lane computes it redundantly, lanes 0-15 write `eout` (16 doubles, row major).
@@ -389,7 +434,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   auto AT = [&](int i, int j) -> int { return FT > 0 ? i * (i + 1) / 2 + j : i * ld + j; };
   const size_t a_doubles = FT > 0 ? max((size_t)N * (N + 1) / 2, (size_t)48 * N + 1280) : (size_t)N * ld;
   const int ntiles = Tn * (Tn + 1) / 2;
-  if ((FT > 0 && Tn > FT) || (FT == 0 && NTW > 0 && ntiles > NTW * kWaves)) {
+  if ((FT > 0 && Tn > FT) || (FT == 0 && NTW > 0 && ntiles > NTW * kWaves) || (FT < 0 && ntiles > NTW * (kWaves - 1))) {
     // more poses than this variant was launched for (the host's bound was wrong): flag it, touch nothing
     if (tid == 0) atomicMin(S.status, DRLGX_E_CAPACITY);
     return;
@@ -408,7 +453,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   // poses observing each landmark as bit masks (P <= 128): the per-landmark loops visit only those poses
   unsigned long long *lmask = reinterpret_cast<unsigned long long *>(smem_raw + off); off += (size_t)L * 16;
   off = (off + 31) & ~(size_t)31;
-  double *Vb = reinterpret_cast<double *>(smem_raw + off); off += (size_t)(FT > 0 ? 0 : 2 * (8 * N + 32)) * 8;  // sweep panels of the triangular path (the fast path
+  double *Vb = reinterpret_cast<double *>(smem_raw + off); off += (size_t)(FT > 0 ? 0 : FT < 0 ? 32 * N + 1280 : NTW < 0 ? 32 * N + 256 : 2 * (8 * N + 32)) * 8;  // sweep panels of the triangular path (the fast path
                                                                                    // keeps its panels in the dead matrix region)
   double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
   double *A;
@@ -710,6 +755,87 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
         if (j <= i && i < N) A[AT(i, j)] = acc[u][r];
       }
     }
+  } else if constexpr (NTW < 0) {
+    // ---- 5d. the 16-wide block steps of the fast path with the tiles left in the HBM/L2 workspace (43 .. 127 poses).
+    //      Per step K: the pivot column panel PAN (all N rows, from the lower triangle and its mirror) and E_K = -D_K^-1
+    //      (in-register inversion of the current diagonal tile by wave 0) -> W_I = PAN_I E_K for every tile row -> every
+    //      lower tile is loaded, updated / replaced exactly as sweep16_block does it, and stored.  Three barriers per
+    //      16 pivots instead of two per 4; the MFMA work per tile is 4 chained 16x16x4 products instead of 1.
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lc = lane & 15, lr = lane >> 4;
+    double *pan = Vb, *wt = Vb + 16 * N, *einv = Vb + 32 * N;
+    const SweepCtx x{0, lane, lc, lr, np, N, true, false, bad, nullptr};
+    for (int K = 0; 16 * K < np; ++K) {
+      const int kb = 16 * K;
+      // P: PAN[i][c] = A_sym[i][kb + c] (0 for pivot indices >= np); rows above the block come from its transpose
+      for (int e = tid; e < 16 * kb; e += kThreads) {
+        const int c = e / kb, i = e - c * kb, kk = kb + c;
+        pan[i * 16 + ks16(c)] = (kk < np) ? A[kk * ld + i] : 0.0;
+      }
+      for (int e = tid; e < 16 * (N - kb); e += kThreads) {
+        const int i = kb + (e >> 4), c = e & 15, kk = kb + c;
+        pan[i * 16 + ks16(c)] = (kk < np) ? A[max(i, kk) * ld + min(i, kk)] : 0.0;
+      }
+      if (wave == 0) {
+        v4d d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = kb + lr + 4 * r, j = kb + lc;
+          d[r] = A[max(i, j) * ld + min(i, j)];
+        }
+        inv16(x, K, d);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) einv[(lr + 4 * r) * 16 + ks16(lc)] = d[r];
+      }
+      __syncthreads();
+      // W_I = PAN_I E_K
+      for (int I = wave; I < Tn; I += kWaves) {
+        double aP[4], eB[4];
+        ld4(pan + (16 * I + lc) * 16 + lr * 4, aP);
+        ld4(einv + lc * 16 + lr * 4, eB);
+        v4d w = {0.0, 0.0, 0.0, 0.0};
+        w = mfma4(aP, eB, w);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wt[(16 * I + lr + 4 * r) * 16 + ks16(lc)] = w[r];
+      }
+      __syncthreads();
+      // U: tile t = wave, wave + kWaves, ... in row-major lower-triangle order, four tiles in flight per wave (the
+      // matrices of all instances do not fit the L2: a tile load is an HBM / MALL round trip)
+      constexpr int NB = 4;
+      int I = 0, J = 0;
+      for (int t = 0; t < wave; ++t) {
+        if (++J > I) { ++I; J = 0; }
+      }
+      for (int t = wave; t < ntiles; t += NB * kWaves) {
+        v4d acc[NB];
+        int bI[NB], bJ[NB];
+#pragma unroll
+        for (int b2 = 0; b2 < NB; ++b2) {
+          bI[b2] = I;
+          bJ[b2] = J;
+          const bool ok = t + b2 * kWaves < ntiles;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * I + lr + 4 * r, j = 16 * J + lc;
+            acc[b2][r] = ok ? A[max(i, j) * ld + min(i, j)] : 0.0;
+          }
+          for (int q = 0; q < kWaves; ++q) {
+            if (++J > I) { ++I; J = 0; }
+          }
+        }
+#pragma unroll
+        for (int b2 = 0; b2 < NB; ++b2) {
+          if (t + b2 * kWaves >= ntiles) continue;
+          tile_step16(bI[b2], bJ[b2], K, np, lc, lr, pan, wt, einv, acc[b2]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * bI[b2] + lr + 4 * r, j = 16 * bJ[b2] + lc;
+            if (j <= i) A[i * ld + j] = acc[b2][r];
+          }
+        }
+      }
+      __syncthreads();
+    }
   } else if constexpr (NTW == 0) {
     // ---- 5c. the 4-wide sweeps of 5b with the tiles left in the HBM/L2 workspace (any capacity up to 127 poses;
     //      config 5's ~120-pose graphs).  Per sweep g: panel v[c][i] and E_g = -D_g^-1 straight from memory, nW = V E,
@@ -785,25 +911,24 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
       }
       __syncthreads();
     }
-  } else
-  // ---- 5b. block symmetric sweep with 4-wide pivot groups on the fp64 matrix cores ----
-  // The lower triangle (+ full diagonal tiles) of the N x N system lives in v_mfma_f64_16x16x4_f64 accumulator tiles
-  // (C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg), NTW tiles per wave, for all sweeps.  Sweep g pivots on
-  // indices K = [4g, 4g+4) (those >= np - the rhs row and the pads - are masked out of the pivot):
-  //   panel   v[c][i] = A[max(i,k0+c)][min(i,k0+c)]  -> LDS, double buffered: ONE barrier per sweep
-  //   E = -D^-1 of the 4x4 pivot block by LDL^T (redundantly in every lane, broadcast LDS reads)
-  //   every tile: A_IJ += (V_I E) V_J^T, one MFMA (A operand = row k of V_I E, B operand = V_J^T)
-  //   then the entries in pivot rows / columns are overwritten with their exact sweep values.
-  {
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave-uniform tile bookkeeping (SGPRs)
+  } else if constexpr (FT < 0) {
+    // ---- 5e. 16-wide block steps with the lower tiles in registers: waves 0 .. kWaves-2 hold NTW tiles each (tile
+    //      t = wave + (kWaves - 1) u), no global memory inside the sweeps; the last wave is the E-wave of the fast path:
+    //      while the others run U of step K it forms D'_{K+1} = D_{K+1} + W_{K+1} PAN_{K+1}^T from the panels and inverts
+    //      it in registers (one inv16 call site: a copy per unrolled tile slot does not stay in the instruction cache).
+    constexpr int TW = kWaves - 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lc = lane & 15, lr = lane >> 4;
+    const bool ewave = wave == TW;
+    double *pan = Vb, *wt = Vb + 16 * N, *einv0 = Vb + 32 * N, *dscr = einv0 + 512, *es = dscr + 256;
+    const SweepCtx x{0, lane, lc, lr, np, N, true, ewave, bad, nullptr};
     v4d acc[NTW];
     int tI[NTW], tJ[NTW];
     bool live[NTW];
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
-      const int t = wave + kWaves * u;
-      live[u] = t < ntiles;
+      const int t = wave + TW * u;
+      live[u] = !ewave && t < ntiles;
       int ib = 0, jb = 0;
       if (live[u]) {
         ib = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
@@ -816,116 +941,94 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * ib + lr + 4 * r, j = 16 * jb + lc;
-        acc[u][r] = live[u] ? A[AT(max(i, j), min(i, j))] : 0.0;
+        acc[u][r] = live[u] ? A[max(i, j) * ld + min(i, j)] : 0.0;
       }
     }
-    const int G = (np + 3) >> 2;
-    // E_g = -D_g^-1 of the 4x4 SPD pivot block of group g, by the wave that holds the diagonal tile, from its
-    // accumulators via a 16-double LDS scratch (2x2 block inversion: two reciprocals on the critical path instead of
-    // four; indices >= np act as identity).  Written to `eout` (16 doubles, row major).
-    auto pivot_inverse = [&](int gq, const v4d &t, double *dscr, double *eout) {
-      const int q0i = 4 * gq, qc = q0i & 15, qr = qc >> 2;
-      const double x = sel4(qr, t[0], t[1], t[2], t[3]);   // rows q0i + lr, column 16 KI + lc
-      if ((unsigned)(lc - qc) < 4u) dscr[4 * lr + (lc - qc)] = x;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      pivot_inverse_from(np, q0i, dscr, eout, bad, lane);
-    };
-    // E_0 before the first sweep
+    // E_0 from the first diagonal tile (tile 0 = wave 0, slot 0)
+    if (wave == 0) {
 #pragma unroll
-    for (int u = 0; u < NTW; ++u)
-      if (live[u] && tI[u] == 0 && tJ[u] == 0) pivot_inverse(0, acc[u], Vb + 8 * N + 16, Vb + 8 * N);
-    for (int g = 0; g < G; ++g) {
-      const int k0 = 4 * g, KI = k0 >> 4, kc = k0 & 15, rg = kc >> 2;
-      double *vb = Vb + (size_t)(g & 1) * (8 * N + 32);  // planes 0-3: v, planes 4-7: nW = v E, then E (16) + scratch (16)
-      double *nwb = vb + 4 * N;
-      const double *eb = vb + 8 * N;
-      // ---- phase A: publish the pivot panel v[c][i] = A[max(i,k0+c)][min(i,k0+c)] ----
-#pragma unroll
-      for (int u = 0; u < NTW; ++u) {
-        if (!live[u]) continue;
-        if (tJ[u] == KI && (unsigned)(lc - kc) < 4u) {  // pivot columns, rows at or below the pivot index
-          const int c = lc - kc, kk = k0 + c;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * tI[u] + lr + 4 * r;
-            if (i >= kk) vb[c * N + i] = (kk < np) ? acc[u][r] : 0.0;
-          }
-        }
-        if (tI[u] == KI) {  // pivot rows, columns left of the pivot index (transposed part)
-          const int kk = k0 + lr, j = 16 * tJ[u] + lc;
-          const double x = sel4(rg, acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
-          if (j < kk) vb[lr * N + j] = (kk < np) ? x : 0.0;
-        }
-      }
-      __syncthreads();
-      // ---- phase B: nW = V E (4 planes; E_g was produced during the previous sweep) ----
-      for (int e = tid; e < 4 * N; e += kThreads) {
-        const int k = e / N, i = e - k * N;
-        nwb[e] = fma(vb[3 * N + i], eb[12 + k], fma(vb[2 * N + i], eb[8 + k], fma(vb[N + i], eb[4 + k], vb[i] * eb[k])));
-      }
-      __syncthreads();
-      // ---- phase C: every tile A_IJ += nW_I V_J^T (one MFMA each, operands fetched up front so the MFMAs issue back
-      //      to back), then the exact values of the pivot rows / columns; the owner of the next pivot's diagonal tile
-      //      inverts that block right away (off the other waves' critical path) ----
-      constexpr int CH = NTW > 10 ? 5 : NTW;  // operand batch (all at once would spill at 20 tiles per wave)
-#pragma unroll
-      for (int u0 = 0; u0 < NTW; u0 += CH) {
-        double aop[CH], bop[CH];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          aop[u] = live[u0 + u] ? nwb[lr * N + 16 * tI[u0 + u] + lc] : 0.0;
-          bop[u] = live[u0 + u] ? vb[lr * N + 16 * tJ[u0 + u] + lc] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < CH; ++u)
-          if (live[u0 + u]) acc[u0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[u], bop[u], acc[u0 + u], 0, 0, 0);
-      }
-      const int k1 = k0 + 4, KI1 = k1 >> 4;
-#pragma unroll
-      for (int u = 0; u < NTW; ++u) {
-        if (!live[u]) continue;
-        const int I = tI[u], J = tJ[u];
-        if (J == KI) {  // tile holds the pivot columns: A_iK <- A_iK D^-1 = -nW (diagonal tile: rows at/below the pivot)
-          const int c = lc - kc;
-          const bool mine = (unsigned)c < 4u && k0 + c < np;
-          const int cc = mine ? c : 0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (I == KI && r < rg) continue;
-            const double val = -nwb[cc * N + 16 * I + lr + 4 * r];
-            if (mine) acc[u][r] = val;
-          }
-          if (I == KI) {  // the pivot block itself (rows k0 + lr live in reg rg): A_KK <- -D^-1
-            const double pv = eb[4 * lr + cc];
-            const bool pm = mine && k0 + lr < np;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[u][r] = (pm && r == rg) ? pv : acc[u][r];  // (selects: a switch over vector inserts miscompiled)
-          }
-        }
-        if (I == KI) {  // pivot rows: A_Kj <- (A_jK D^-1)^T for the columns left of the pivot
-          const int j = 16 * J + lc;
-          const double val = -nwb[lr * N + j];
-          const bool pm = j < k0 && k0 + lr < np;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[u][r] = (pm && r == rg) ? val : acc[u][r];
-        }
-        if (g + 1 < G && I == KI1 && J == KI1) {
-          double *nb = Vb + (size_t)((g + 1) & 1) * (8 * N + 32) + 8 * N;
-          pivot_inverse(g + 1, acc[u], nb + 16, nb);
-        }
-      }
+      for (int r = 0; r < 4; ++r) dscr[4 * lane + r] = acc[0][r];
     }
     __syncthreads();
-    // write the tiles back: lower triangle = -S^-1, row np = delta_p
+    if (ewave) {
+      double t4[4];
+      ld4(dscr + 4 * lane, t4);
+      v4d d = {t4[0], t4[1], t4[2], t4[3]};
+      inv16(x, 0, d);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) einv0[(lr + 4 * r) * 16 + ks16(lc)] = d[r];
+    }
+    __syncthreads();
+    for (int K = 0; 16 * K < np; ++K) {
+      const int kb = 16 * K;
+      const bool have_next = kb + 16 < np;
+      double *einv = einv0 + 256 * (K & 1), *enext = einv0 + 256 * ((K + 1) & 1);
+      // P: publish the pivot column panel from the tiles of column K and (transposed) of row K; the owner of the next
+      // diagonal tile dumps its current values for the look-ahead
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) {
+        if (!live[u]) continue;
+        if (tJ[u] == K) {
+          const bool colact = kb + lc < np;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pan[(16 * tI[u] + lr + 4 * r) * 16 + ks16(lc)] = colact ? acc[u][r] : 0.0;
+        } else if (tI[u] == K) {  // tJ < K: PAN[16 J + lc][c = lr + 4 r] = A[kb + lr + 4 r][16 J + lc]
+          double *o = pan + (16 * tJ[u] + lc) * 16 + lr * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (kb + lr + 4 * r < np) ? acc[u][r] : 0.0;
+        }
+        if (have_next && tI[u] == K + 1 && tJ[u] == K + 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dscr[4 * lane + r] = acc[u][r];
+        }
+      }
+      __syncthreads();
+      v4d dn = {0.0, 0.0, 0.0, 0.0};
+      if (!ewave) {
+        for (int I = wave; I < Tn; I += TW) {  // W_I = PAN_I E_K
+          double aP[4], eB[4];
+          ld4(pan + (16 * I + lc) * 16 + lr * 4, aP);
+          ld4(einv + lc * 16 + lr * 4, eB);
+          v4d w = {0.0, 0.0, 0.0, 0.0};
+          w = mfma4(aP, eB, w);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) wt[(16 * I + lr + 4 * r) * 16 + ks16(lc)] = w[r];
+        }
+      } else if (have_next) {  // look-ahead: D'_{K+1} (the E-wave forms W_{K+1} itself)
+        double aP[4], eB[4], aW[4], t4[4];
+        ld4(pan + (16 * (K + 1) + lc) * 16 + lr * 4, aP);  // also the B operand of the update (PAN_{K+1}^T)
+        ld4(einv + lc * 16 + lr * 4, eB);
+        v4d w1 = {0.0, 0.0, 0.0, 0.0};
+        w1 = mfma4(aP, eB, w1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) es[(lr + 4 * r) * 16 + ks16(lc)] = w1[r];  // accumulator -> A-operand layout
+        wave_lds_sync();
+        ld4(es + lc * 16 + lr * 4, aW);
+        ld4(dscr + 4 * lane, t4);
+        dn = v4d{t4[0], t4[1], t4[2], t4[3]};
+        dn = mfma4(aW, aP, dn);
+      }
+      __syncthreads();
+      if (ewave) {
+        if (have_next) {
+          inv16(x, K + 1, dn);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) enext[(lr + 4 * r) * 16 + ks16(lc)] = dn[r];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < NTW; ++u)
+          if (live[u]) tile_step16(tI[u], tJ[u], K, np, lc, lr, pan, wt, einv, acc[u]);
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
       if (!live[u]) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * tI[u] + lr + 4 * r, j = 16 * tJ[u] + lc;
-        if (j <= i) A[AT(i, j)] = acc[u][r];
+        if (j <= i) A[i * ld + j] = acc[u][r];
       }
     }
   }
@@ -1034,6 +1137,11 @@ size_t slam_small_bytes_n(size_t N, int P_max, int L_max, int M_max, bool fast) 
 size_t slam_small_bytes(int P_max, int L_max, int M_max) {
   return slam_small_bytes_n(slam_dim(P_max), P_max, L_max, M_max, false);
 }
+// the streamed 16-wide variant: PAN and WT panels [N][16] + E
+size_t slam_small_bytes_s16(int P_max, int L_max, int M_max) {
+  const size_t N = slam_dim(P_max);
+  return slam_small_bytes_n(N, P_max, L_max, M_max, true) + (32 * N + 1280) * 8;
+}
 constexpr int kFastTiles = 8;  // fast path: N = 128 (<= 42 poses), system + panels in LDS
 
 }  // namespace kslam
@@ -1056,8 +1164,9 @@ void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p
   static bool attr_set = false;
   if (!attr_set) {
     const void *fns[] = {reinterpret_cast<const void *>(&kslam::k_slam<true, 1, kslam::kFastTiles>),
-                         reinterpret_cast<const void *>(&kslam::k_slam<false, 10, 0>),
-                         reinterpret_cast<const void *>(&kslam::k_slam<false, 20, 0>),
+                         reinterpret_cast<const void *>(&kslam::k_slam<false, 10, -1>),
+                         reinterpret_cast<const void *>(&kslam::k_slam<false, 20, -1>),
+                         reinterpret_cast<const void *>(&kslam::k_slam<false, -1, 0>),
                          reinterpret_cast<const void *>(&kslam::k_slam<false, 0, 0>)};
     for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kslam::kLdsBudget);
     attr_set = true;
@@ -1065,21 +1174,26 @@ void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p
   if (drlgx_slam_in_lds(Pb, S.L_max, S.M_max)) {
     // fast path: the kernel always works on the full 128 x 128 capacity; whatever LDS is left holds the factor records
     hipLaunchKernelGGL((kslam::k_slam<true, 1, kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
-  } else {
-    // dense system in the HBM/L2 workspace, triangular tile scheme; accumulator tiles in registers
-    // (<= 58 poses: 10 tiles per wave, <= 86 poses: 20 tiles per wave) or, beyond that, streamed per sweep (<= 127 poses:
-    // the per-landmark pose masks are 128 bits)
-    const size_t small = kslam::slam_small_bytes(S.P_max, S.L_max, S.M_max);
-    if (small > (size_t)kslam::kLdsBudget || S.P_max > 127) {
-      (void)hipMemsetAsync(S.status, 0xff, sizeof(int), st);  // capacity beyond this kernel: flag an error (-1)
-      return;
-    }
-    if (ntiles <= 10 * kslam::kWaves)
-      hipLaunchKernelGGL((kslam::k_slam<false, 10, 0>), dim3(sel.n), dim3(kslam::kThreads), small, st, S, sel, (int)small);
-    else if (ntiles <= 20 * kslam::kWaves)
-      hipLaunchKernelGGL((kslam::k_slam<false, 20, 0>), dim3(sel.n), dim3(kslam::kThreads), small, st, S, sel, (int)small);
-    else
-      hipLaunchKernelGGL((kslam::k_slam<false, 0, 0>), dim3(sel.n), dim3(kslam::kThreads), small, st, S, sel, (int)small);
+    return;
   }
+  // dense system in the HBM/L2 workspace, 16-wide block steps: lower tiles in registers (seven tile waves + the
+  // inverting wave: <= 58 poses with 10 tiles per wave, <= 85 with 20) or streamed per step (<= 127 poses: the
+  // per-landmark pose masks are 128 bits); 4-wide streamed sweeps when the 16-wide panels do not fit the LDS next to
+  // unusually large landmark / factor capacities
+  const size_t small4 = kslam::slam_small_bytes(S.P_max, S.L_max, S.M_max);
+  const size_t small16 = kslam::slam_small_bytes_s16(S.P_max, S.L_max, S.M_max);
+  if (S.P_max > 127 || small4 > (size_t)kslam::kLdsBudget) {
+    (void)hipMemsetAsync(S.status, 0xff, sizeof(int), st);  // capacity beyond these kernels: flag an error (-1)
+    return;
+  }
+  const dim3 grid(sel.n), block(kslam::kThreads);
+  if (small16 > (size_t)kslam::kLdsBudget)
+    hipLaunchKernelGGL((kslam::k_slam<false, 0, 0>), grid, block, small4, st, S, sel, (int)small4);
+  else if (ntiles <= 10 * (kslam::kWaves - 1))
+    hipLaunchKernelGGL((kslam::k_slam<false, 10, -1>), grid, block, small16, st, S, sel, (int)small16);
+  else if (ntiles <= 20 * (kslam::kWaves - 1))
+    hipLaunchKernelGGL((kslam::k_slam<false, 20, -1>), grid, block, small16, st, S, sel, (int)small16);
+  else
+    hipLaunchKernelGGL((kslam::k_slam<false, -1, 0>), grid, block, small16, st, S, sel, (int)small16);
 }
 #pragma clang fp contract(off)

@@ -9,7 +9,9 @@ from drl_graph_exploration_amd.engine import Engine
 
 cap, poses = int(sys.argv[1]), int(sys.argv[2])
 n = 256
-cfg = default_config(bench.MAP, num_landmarks=bench.NUM_LM, max_poses=cap, max_landmarks=100, max_factors=14 * cap, max_snapshots=1)
+MAP, NLM = int(os.environ.get("PP_MAP", bench.MAP)), int(os.environ.get("PP_LM", bench.NUM_LM))
+cfg = default_config(MAP, num_landmarks=NLM, max_poses=cap, max_landmarks=128 if NLM > 100 else 100,
+                     max_factors=(30 if NLM > 100 else 14) * cap, max_snapshots=1)
 eng = Engine(cfg, n, 0, 0)
 rng = np.random.RandomState(0)
 starts = np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-3, 3, n)], 1)
@@ -34,7 +36,7 @@ names = {1: "relin+clear+tables", 2: "landmark+pose blocks", 3: "G", 4: "Schur",
 print("capacity %d, %d -> %d poses; k_slam phases (us, block 0):" % (cap, poses, poses + 1))
 for i in range(1, 8):
     print("  %-24s %8.2f" % (names[i], (a[i] - a[i - 1]) / 100.0))
-print("  total %.2f" % ((a[7] - a[0]) / 100.0))
+print("  total %.2f" % ((a[7] - a[0]) / 100.0)); print("  16-wide register sweeps (us, summed over steps): publish+invert %.2f, W %.2f, U %.2f" % (a[8] / 100.0, a[9] / 100.0, a[10] / 100.0))
 last = np.array(out[:], dtype=np.int64)
 t0 = min(last[24 + 5 * w] for w in range(8))
 for w in range(8):

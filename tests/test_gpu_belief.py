@@ -277,12 +277,12 @@ def test_fused_step_kernel_equals_stage_kernels():
     staged.close()
 
 
-@pytest.mark.parametrize("max_poses", [43, 60, 86, 127])
+@pytest.mark.parametrize("max_poses", [43, 58, 60, 85, 86, 127])
 def test_larger_capacities_use_other_kernel_variants(max_poses, monkeypatch):
-    """Beyond 42 poses the dense system of k_slam moves from LDS to the HBM/L2 workspace (one register tile per thread
-    up to 58 poses, two up to 86, tiles streamed per sweep up to 127): same results. The engine picks the variant per
-    launch from its bound on the pose counts; DRLGX_VARIANT_BY_CAPACITY=1 makes it pick by `max_poses`, so that a short
-    trajectory exercises each variant."""
+    """Beyond 42 poses the dense system of k_slam moves from LDS to the HBM/L2 workspace (16-wide block steps with the
+    lower tiles in registers, 10 per wave up to 58 poses and 20 up to 85, streamed per step up to 127): same results.
+    The engine picks the variant per launch from its bound on the pose counts; DRLGX_VARIANT_BY_CAPACITY=1 makes it pick
+    by `max_poses`, so that a short trajectory exercises each variant."""
     monkeypatch.setenv("DRLGX_VARIANT_BY_CAPACITY", "1")
     n = 3
     eng, cfg = make_engine(n, max_poses=max_poses)
@@ -301,12 +301,12 @@ def test_larger_capacities_use_other_kernel_variants(max_poses, monkeypatch):
 
 
 def test_variant_follows_the_trajectory_length():
-    """One engine with an 86-pose capacity over an 84-pose trajectory: the steps run on the fused fast kernel up to 42
-    poses, then on the 10- and 20-tile register variants - selected per launch from the host's pose-count bound (exact
+    """One engine with a 90-pose capacity over an 88-pose trajectory: the steps run on the fused fast kernel up to 42
+    poses, then on the 10- and 20-tile register variants and (86 poses up) the streamed one - selected per launch from the host's pose-count bound (exact
     after every status check, +1 per step in between) - and agree with the oracle throughout; timing spans tell which
     kernel ran."""
     n = 2
-    eng, cfg = make_engine(n, max_poses=86)
+    eng, cfg = make_engine(n, max_poses=90)
     ocfg = O.default_config(MAP)
     starts = np.array([[-7.3183, -6.2718, 0.1234], [3.1, 4.7, 2.2]])
     sims = [O.OracleSim(ocfg, lo, lo, start=tuple(starts[lo])) for lo in range(n)]
@@ -314,13 +314,13 @@ def test_variant_follows_the_trajectory_length():
     loop = [(2, 0, 0)] * 3 + [(0, 0, math.pi / 2)] + [(2, 0, 0)] * 2 + [(0.7, 0, 0.4)]
     eng.timing_enable(True)
     fused_steps = {}
-    for s in range(83):
+    for s in range(87):
         act = loop[s % len(loop)]
         eng.timing_read()
         eng.step(torch.tensor([act] * n, dtype=torch.float64, device=eng.device))
         for sim in sims:
             sim.simulate(act)
-        if s % 10 == 9 or s in (40, 41, 42, 57, 58, 82):
+        if s % 10 == 9 or s in (40, 41, 42, 56, 57, 83, 84, 86):
             tm = eng.timing_read()
             fused_steps[s] = tm["step"][1] == 1
             assert eng.status() == 0  # also refreshes the bound
@@ -328,7 +328,7 @@ def test_variant_follows_the_trajectory_length():
                 assert eng.counts(i)["poses"] == s + 2
                 compare_state(eng, i, sims[i], "env %d step %d" % (i, s), mask_knife_edge=True)
     # poses after step s = s + 2: the fused LDS kernel serves up to 42 poses
-    assert fused_steps[39] and fused_steps[40] and not fused_steps[41] and not fused_steps[82]
+    assert fused_steps[39] and fused_steps[40] and not fused_steps[41] and not fused_steps[86]
     eng.close()
 
 
