@@ -300,6 +300,29 @@ def test_larger_capacities_use_other_kernel_variants(max_poses, monkeypatch):
     eng.close()
 
 
+def test_lds_hungry_capacities_fall_back_to_the_4wide_streamed_sweeps(monkeypatch):
+    """With landmark / factor capacities so large that the 16-wide panels no longer fit the LDS next to the per-instance
+    tables (100 poses, 400 landmarks, 9 000 factors: 166 KB), k_slam falls back to 4-wide streamed sweeps: same results."""
+    from drl_graph_exploration_amd import default_config
+    from drl_graph_exploration_amd.engine import Engine
+    monkeypatch.setenv("DRLGX_VARIANT_BY_CAPACITY", "1")
+    n = 2
+    cfg = default_config(MAP, max_poses=100, max_landmarks=400, max_factors=9000)
+    eng = Engine(cfg, n, 0)
+    ocfg = O.default_config(MAP)
+    starts = generic_starts(n)
+    sims = [O.OracleSim(ocfg, lo, lo, start=tuple(starts[lo])) for lo in range(n)]
+    eng.reset(np.arange(n), np.arange(n), starts=starts)
+    for act in SCRIPT[:12]:
+        eng.step(torch.tensor([act] * n, dtype=torch.float64, device=eng.device))
+        for sim in sims:
+            sim.simulate(act)
+    assert eng.status() == 0
+    for i in range(n):
+        compare_state(eng, i, sims[i], "4-wide fallback env %d" % i)
+    eng.close()
+
+
 def test_variant_follows_the_trajectory_length():
     """One engine with a 90-pose capacity over an 88-pose trajectory: the steps run on the fused fast kernel up to 42
     poses, then on the 10- and 20-tile register variants and (86 poses up) the streamed one - selected per launch from the host's pose-count bound (exact
