@@ -1189,11 +1189,12 @@ void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p
   const dim3 grid(sel.n), block(kslam::kThreads);
   if (small16 > (size_t)kslam::kLdsBudget)
     hipLaunchKernelGGL((kslam::k_slam<false, 0, 0>), grid, block, small4, st, S, sel, (int)small4);
+  // (the whole LDS is requested: what the panels and tables leave free holds the factor records and the observation table)
   else if (ntiles <= 10 * (kslam::kWaves - 1))
-    hipLaunchKernelGGL((kslam::k_slam<false, 10, -1>), grid, block, small16, st, S, sel, (int)small16);
+    hipLaunchKernelGGL((kslam::k_slam<false, 10, -1>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
   else if (ntiles <= 20 * (kslam::kWaves - 1))
-    hipLaunchKernelGGL((kslam::k_slam<false, 20, -1>), grid, block, small16, st, S, sel, (int)small16);
+    hipLaunchKernelGGL((kslam::k_slam<false, 20, -1>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
   else
-    hipLaunchKernelGGL((kslam::k_slam<false, -1, 0>), grid, block, small16, st, S, sel, (int)small16);
+    hipLaunchKernelGGL((kslam::k_slam<false, -1, 0>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
 }
 #pragma clang fp contract(off)
