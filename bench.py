@@ -47,10 +47,11 @@ def algorithmic_bytes(P, L, M, V):
     return {"map": cov + occ, "slam": slam, "sim": sim}
 
 
-def make_engine(device_index, seed0):
+def make_engine(device_index, seed0, max_poses=41):
     from drl_graph_exploration_amd import default_config
     from drl_graph_exploration_amd.engine import Engine
-    cfg = default_config(MAP, num_landmarks=NUM_LM, max_poses=41, max_landmarks=100, max_factors=512, max_snapshots=1)
+    cfg = default_config(MAP, num_landmarks=NUM_LM, max_poses=max_poses, max_landmarks=100, max_factors=12 * max_poses + 20,
+                         max_snapshots=1)
     eng = Engine(cfg, N_ENVS, 2048, device=device_index)  # 2048 rollout instances for the look-ahead waves
     ids = np.arange(N_ENVS)
     eng.reset(ids, seed0 + ids, los=seed0 + ids)
@@ -110,6 +111,10 @@ def policy_bench(eng, dev, iters=10):
 
     torch.manual_seed(0)
     model = GCN().to(dev)
+    # the look-ahead appends up to max_actions poses to the 37-pose trajectories: its own engine with room for them
+    # (the kernels are picked per launch from the actual trajectory lengths, not from this capacity)
+    eng.close()
+    eng, _ = make_engine(dev.index or 0, 0, max_poses=64)
     eng.restore(0)
     out = {}
     g = eng.graph()
@@ -124,7 +129,9 @@ def policy_bench(eng, dev, iters=10):
     out["graph_export_ms"] = timed(lambda: eng.graph()) * 1e3
     acts, nact = eng.line_plan(cand_env, goals)
     out["line_plan_ms"] = timed(lambda: eng.line_plan(cand_env, goals)) * 1e3
-    out["lookahead_ms"] = timed(lambda: eng.lookahead(cand_env, acts, nact), n=3) * 1e3
+    out["lookahead_ms"] = timed(lambda: eng.lookahead(cand_env, acts, nact, max_n_actions=int(nact.max())), n=3) * 1e3
+    eng.check_status()  # no rollout ran out of capacity
+    out["rollout_steps"] = int(nact.sum())
     with torch.no_grad():
         t_f = timed(lambda: model(data, 0.0))
     flops_f = 2.0 * N * (5 * 1000 + 1000 * 1000 + 1000) + 2.0 * 2 * (E + N) * 1000  # GEMMs + two aggregations
@@ -152,6 +159,7 @@ def policy_bench(eng, dev, iters=10):
     out["train_step_TFLOPs"] = flops_t / t_t / 1e12
     out["mfma_f32_peak_TFLOPs"] = MFMA_F32_PEAK_TFLOPS
     out["gcn_forward_frac_mfma_peak"] = out["gcn_forward_TFLOPs"] / MFMA_F32_PEAK_TFLOPS
+    eng.close()
     return out
 
 

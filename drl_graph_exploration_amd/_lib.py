@@ -24,7 +24,7 @@ def lib_path():
 SYMBOLS = [
     "drlgx_create", "drlgx_destroy", "drlgx_set_stream", "drlgx_synchronize", "drlgx_strerror", "drlgx_last_error",
     "drlgx_status_host", "drlgx_reset_host", "drlgx_step", "drlgx_utility", "drlgx_uncertainty_em", "drlgx_explored",
-    "drlgx_line_plan", "drlgx_lookahead", "drlgx_graph_capacity", "drlgx_graph", "drlgx_get_counts_host", "drlgx_counts",
+    "drlgx_line_plan", "drlgx_lookahead", "drlgx_lookahead_bounded", "drlgx_graph_capacity", "drlgx_graph", "drlgx_get_counts_host", "drlgx_counts",
     "drlgx_get_poses_host", "drlgx_get_landmarks_host", "drlgx_get_cov_traces_host", "drlgx_vm_shape",
     "drlgx_get_virtual_map_host", "drlgx_get_ground_truth_host", "drlgx_get_adjacency_host", "drlgx_get_factors_host",
     "drlgx_get_landmark_order_host", "drlgx_snapshot", "drlgx_restore", "drlgx_timing_enable",
@@ -62,6 +62,7 @@ def lib():
     L.drlgx_explored.argtypes = [vp, vp]
     L.drlgx_line_plan.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.drlgx_lookahead.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.drlgx_lookahead_bounded.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp]
     L.drlgx_graph_capacity.argtypes = [vp, ip, ip, ip]
     L.drlgx_graph.argtypes = [vp] + [vp] * 8
     L.drlgx_get_counts_host.argtypes = [vp, C.c_int, ip]

@@ -491,7 +491,15 @@ int drlgx_line_plan(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
 
 int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *actions_dev,
                     const int32_t *n_actions_dev, double *rewards_dev) {
-  if (!e || n_cand < 0 || !cand_env_dev || !actions_dev || !n_actions_dev || !rewards_dev) return DRLGX_E_INVALID;
+  if (!e) return DRLGX_E_INVALID;
+  return drlgx_lookahead_bounded(e, n_cand, cand_env_dev, actions_dev, n_actions_dev, e->S.A_max, rewards_dev);
+}
+
+int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *actions_dev,
+                            const int32_t *n_actions_dev, int max_n_actions, double *rewards_dev) {
+  if (!e || n_cand < 0 || !cand_env_dev || !actions_dev || !n_actions_dev || !rewards_dev || max_n_actions < 1 ||
+      max_n_actions > e->S.A_max)
+    return DRLGX_E_INVALID;
   if (n_cand == 0) return DRLGX_OK;
   if (e->S.n_roll < 1) return DRLGX_E_CAPACITY;
   const DrlgxState &S = e->S;
@@ -518,7 +526,7 @@ int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
       drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, nc, ce, nullptr, base0, roll0, 3);
       drlgx_launch_fix_rollouts(S, e->stream, nc, ce, roll0);
     }
-    for (int a = 0; a < S.A_max; ++a) {
+    for (int a = 0; a < max_n_actions; ++a) {
       LaunchSel sel{roll0, nc, nullptr, na, a};
       sel.map_last_only = 1;
       const int pb = std::min(pbe + a + 1, S.P_max);

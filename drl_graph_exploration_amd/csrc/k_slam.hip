@@ -12,8 +12,9 @@
 //      (v_mfma_f64_16x16x4_f64): the lower triangle lives in 16 x 16 accumulator tiles in registers for the whole
 //      factorisation; afterwards the triangle holds -S^-1 (every pose marginal and cross block) and the augmented row
 //      holds delta_p.  Fast path (<= 42 poses, everything in LDS): 16-wide block pivots, one tile row per wave, the next
-//      diagonal tile inverted in registers by an otherwise idle wave (sweep16_block).  Larger capacities (<= 86 poses,
-//      system in an HBM/L2 workspace): 4-wide pivots over triangular tiles (phase 5 in the kernel).
+//      diagonal tile inverted in registers by an otherwise idle wave (sweep16_block).  Larger systems (<= 127 poses,
+//      dense matrix in an HBM/L2 workspace): the same block steps per lower tile (tile_step16), tiles in registers up
+//      to 85 poses (5e) or streamed per step (5d); 4-wide streamed sweeps (5c) when the 16-wide panels do not fit.
 //   5. landmark deltas and 2x2 landmark marginals by back-substitution through G = Lambda_pl Lambda_ll^-1
 //   6. estimates theta (+) delta, information blocks (3x3 LLT inverse / 2x2 inverse), traces
 // Per-landmark loops walk a bit mask of the observing poses.  LDS: the padded system + per-factor records when they
@@ -50,9 +51,6 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return r;
 }
 
-__device__ __forceinline__ double sel4(unsigned k, double a, double b, double c, double d) {
-  return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d));
-}
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kWaves = kThreads / 64;
 
@@ -453,8 +451,9 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   // poses observing each landmark as bit masks (P <= 128): the per-landmark loops visit only those poses
   unsigned long long *lmask = reinterpret_cast<unsigned long long *>(smem_raw + off); off += (size_t)L * 16;
   off = (off + 31) & ~(size_t)31;
-  double *Vb = reinterpret_cast<double *>(smem_raw + off); off += (size_t)(FT > 0 ? 0 : FT < 0 ? 32 * N + 1280 : NTW < 0 ? 32 * N + 256 : 2 * (8 * N + 32)) * 8;  // sweep panels of the triangular path (the fast path
-                                                                                   // keeps its panels in the dead matrix region)
+  // sweep panels of the workspace variants (the fast path keeps its panels in the dead matrix region)
+  double *Vb = reinterpret_cast<double *>(smem_raw + off);
+  off += (size_t)(FT > 0 ? 0 : FT < 0 ? 32 * N + 1280 : NTW < 0 ? 32 * N + 256 : 2 * (8 * N + 32)) * 8;
   double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
   double *A;
   if (kLds) {
@@ -837,9 +836,11 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
       __syncthreads();
     }
   } else if constexpr (NTW == 0) {
-    // ---- 5c. the 4-wide sweeps of 5b with the tiles left in the HBM/L2 workspace (any capacity up to 127 poses;
-    //      config 5's ~120-pose graphs).  Per sweep g: panel v[c][i] and E_g = -D_g^-1 straight from memory, nW = V E,
-    //      then every tile is loaded, updated by one MFMA, patched on the pivot rows / columns and stored back.
+    // ---- 5c. fallback: symmetric sweeps with 4-wide pivot groups, tiles left in the HBM/L2 workspace (needs only
+    //      16 N + 64 doubles of LDS panels).  Sweep g pivots on indices [4g, 4g+4) (those >= np - the rhs row and the
+    //      pads - are masked out): panel v[c][i] = A[max(i,k0+c)][min(i,k0+c)] and E_g = -D_g^-1 straight from memory,
+    //      nW = V E, then every tile is loaded, updated by one MFMA (A_IJ += nW_I V_J^T), patched with the exact sweep
+    //      values on the pivot rows / columns and stored back.
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lc = lane & 15, lr = lane >> 4;
     const int G = (np + 3) >> 2;

@@ -106,10 +106,16 @@ class Engine(object):
         self._chk(self.L.drlgx_line_plan(self.h, n, _p(cand_env), _p(goals), _p(actions), _p(n_act)))
         return actions, n_act
 
-    def lookahead(self, cand_env, actions, n_actions):
+    def lookahead(self, cand_env, actions, n_actions, max_n_actions=None):
+        """Look-ahead rewards; `max_n_actions` (host int >= every n_actions[i]) skips the launches of the action indices
+        no plan reaches (None: all cfg.max_actions indices are launched)."""
         n = cand_env.numel()
         rewards = torch.empty(n, dtype=torch.float64, device=self.device)
-        self._chk(self.L.drlgx_lookahead(self.h, n, _p(cand_env), _p(actions), _p(n_actions), _p(rewards)))
+        if max_n_actions is None:
+            self._chk(self.L.drlgx_lookahead(self.h, n, _p(cand_env), _p(actions), _p(n_actions), _p(rewards)))
+        else:
+            self._chk(self.L.drlgx_lookahead_bounded(self.h, n, _p(cand_env), _p(actions), _p(n_actions), int(max_n_actions),
+                                                     _p(rewards)))
         return rewards
 
     def graph(self):

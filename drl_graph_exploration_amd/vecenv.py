@@ -143,7 +143,8 @@ class VecExplorationEnv(object):
         """Look-ahead reward per candidate, normalised per env like exploration_env.py:151-161:
         nearest frontier is the arg-max -> interp to [-1, 0], loop_clo False; else [-1, 1], loop_clo True."""
         actions, n_act = all_actions if all_actions is not None else (self._actions, self._n_act)
-        raw = self.engine.lookahead(self._cand_env, actions, n_act)
+        kmax = max(int(n_act.max().item()), 1) if n_act.numel() else 1  # host bound: unreached action indices are not launched
+        raw = self.engine.lookahead(self._cand_env, actions, n_act, max_n_actions=kmax)
         r, self.loop_clo = normalise_rewards(raw, self._cand_env.long(), self._cand_first, self.n_envs)
         return (r, raw) if return_raw else r
 

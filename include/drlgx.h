@@ -129,6 +129,12 @@ int drlgx_line_plan(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
 int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *actions_dev,
                     const int32_t *n_actions_dev, double *rewards_dev);
 
+/* drlgx_lookahead with a host-side bound on the plan lengths: max_n_actions >= every n_actions_dev[i] (the caller
+ * usually knows it from stepping the chosen plan; 0 < max_n_actions <= max_actions).  Action indices beyond it are
+ * not launched at all (drlgx_lookahead launches all max_actions of them and lets the workgroups exit). */
+int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *actions_dev,
+                            const int32_t *n_actions_dev, int max_n_actions, double *rewards_dev);
+
 /* ---- graph export for the policy (a14-a17) --------------------------------------------------- */
 
 /* ExplorationEnv.frontier + graph_matrix (scripts/envs/exploration_env.py:196-348) on top of

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import bench
-eng, cfg = bench.make_engine(0, 0)
+eng, cfg = bench.make_engine(0, 0, max_poses=64)
 dev = eng.device
 eng.restore(0)
 g = eng.graph()
@@ -27,4 +27,4 @@ eng.timing_enable(True); eng.timing_read()
 for _ in range(5):
     eng.lookahead(cand_env, acts, nact)
 tm = eng.timing_read()
-print({k: (round(v[0] / 5, 3), v[1] // 5) for k, v in tm.items() if v[1]})
+print({k: (round(v[0] / 5, 3), v[1] // 5) for k, v in tm.items() if v[1]}); eng.check_status()
