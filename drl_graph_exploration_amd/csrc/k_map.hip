@@ -184,6 +184,8 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
   int *lmc = pskip + S.P_max;                         // [V] estimated landmarks per cell
   uint8_t *ltr = reinterpret_cast<uint8_t *>(lmc + V);  // [DRLGX_LO_TAB][4] ladder transitions
   double *lpv = scratch + kWaves;                      // [DRLGX_LO_TAB] ladder state -> cell probability
+  int *pcount = reinterpret_cast<int *>(ltr + 4 * DRLGX_LO_TAB);  // number of (pose, cell) pairs in range (phase A)
+  unsigned short *plist = reinterpret_cast<unsigned short *>(pcount + 1);  // [chunk * 64] their pair indices
   double *prob = S.vm_prob + (size_t)inst * V;
   double *ixx = S.vm_info + ((size_t)inst * 3 + 0) * V, *ixy = S.vm_info + ((size_t)inst * 3 + 1) * V,
          *iyy = S.vm_info + ((size_t)inst * 3 + 2) * V;
@@ -269,29 +271,51 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
         mask[v] = 0ull;
         omask[v] = 0ull;
       }
+      if (tid == 0) *pcount = 0;
       __syncthreads();
-      for (int e = tid; e < nc * W2; e += kThreads) {  // (pose, window cell) pairs spread evenly over the threads
-        const int pl = e / W2, widx = e - pl * W2;
-        const int p = c0 + pl;
-        if (!pskip[p]) {
-          const int wr = widx / W, wc = widx - wr * W;
-          const int row = worg[2 * p] + wr, col = worg[2 * p + 1] + wc;
-          if (row >= 0 && row < rows && col >= 0 && col < cols) {
-            const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
-            const P2 pt{(col + 0.5) * cfg.resolution + cfg.map_min_x, (row + 0.5) * cfg.resolution + cfg.map_min_y};
-            const double dx = ps.x - pt.x, dy = ps.y - pt.y;
-            // KDTreeR2::queryRadiusNeighbors / OccupancyMap range test: sqrt(d2) < max_range, exactly; then the field of view
-            if (dx * dx + dy * dy < S.r2_max_lt && in_fov(S, ps, pt)) {
-              const bool in_bbox = !use_bbox || !(row < bbox[4 * p] || row > bbox[4 * p + 1] || col < bbox[4 * p + 2] || col > bbox[4 * p + 3]);
-              if (in_bbox) atomicOr(&omask[row * cols + col], 1ull << pl);  // OccupancyMap::update visits this cell
-              double a, b, d;
-              if (predict_cell<false>(S, ps, sl + 9 * p, pt, a, b, d)) {
-                double *o = stage + ((size_t)pl * 64 + widx) * 3;
-                o[0] = a; o[1] = b; o[2] = d;
-                atomicOr(&mask[row * cols + col], 1ull << pl);
-              }
+      // (pose, window cell) pairs: a cheap pass keeps the ones in range and in the field of view (~45 % of the window)
+      // in a compact list, so that the EKF push-through below runs on full waves
+      for (int e0 = 0; e0 < nc * W2; e0 += kThreads) {
+        const int e = e0 + tid;
+        bool valid = false;
+        if (e < nc * W2) {
+          const int pl = e / W2, widx = e - pl * W2;
+          const int p = c0 + pl;
+          if (!pskip[p]) {
+            const int wr = widx / W, wc = widx - wr * W;
+            const int row = worg[2 * p] + wr, col = worg[2 * p + 1] + wc;
+            if (row >= 0 && row < rows && col >= 0 && col < cols) {
+              const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
+              const P2 pt{(col + 0.5) * cfg.resolution + cfg.map_min_x, (row + 0.5) * cfg.resolution + cfg.map_min_y};
+              const double dx = ps.x - pt.x, dy = ps.y - pt.y;
+              // KDTreeR2::queryRadiusNeighbors / OccupancyMap range test: sqrt(d2) < max_range, exactly; then the field of view
+              valid = dx * dx + dy * dy < S.r2_max_lt && in_fov(S, ps, pt);
             }
           }
+        }
+        const unsigned long long bal = __ballot(valid);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(pcount, __popcll(bal));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (valid) plist[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)e;
+      }
+      __syncthreads();
+      const int npairs = *pcount;
+      for (int k = tid; k < npairs; k += kThreads) {
+        const int e = plist[k];
+        const int pl = e / W2, widx = e - pl * W2;
+        const int p = c0 + pl;
+        const int wr = widx / W, wc = widx - wr * W;
+        const int row = worg[2 * p] + wr, col = worg[2 * p + 1] + wc;
+        const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
+        const P2 pt{(col + 0.5) * cfg.resolution + cfg.map_min_x, (row + 0.5) * cfg.resolution + cfg.map_min_y};
+        const bool in_bbox = !use_bbox || !(row < bbox[4 * p] || row > bbox[4 * p + 1] || col < bbox[4 * p + 2] || col > bbox[4 * p + 3]);
+        if (in_bbox) atomicOr(&omask[row * cols + col], 1ull << pl);  // OccupancyMap::update visits this cell
+        double a, b, d;
+        if (predict_cell<false>(S, ps, sl + 9 * p, pt, a, b, d)) {
+          double *o = stage + ((size_t)pl * 64 + widx) * 3;
+          o[0] = a; o[1] = b; o[2] = d;
+          atomicOr(&mask[row * cols + col], 1ull << pl);
         }
       }
       __syncthreads();
@@ -441,7 +465,7 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
 
 static size_t map_lds_bytes(const DrlgxState &S, int chunk) {
   size_t d = (size_t)S.P_max * 19 + (size_t)chunk * 64 * 3 + 2 * (size_t)S.V + kmap::kWaves + DRLGX_LO_TAB;  // + two u64 masks per cell
-  size_t i = (size_t)S.P_max * 7 + (size_t)S.V + DRLGX_LO_TAB;
+  size_t i = (size_t)S.P_max * 7 + (size_t)S.V + DRLGX_LO_TAB + 1 + (size_t)chunk * 32;  // (+ pair counter, pair list)
   return d * sizeof(double) + i * sizeof(int) + 16;
 }
 
