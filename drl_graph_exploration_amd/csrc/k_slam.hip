@@ -429,8 +429,12 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   // triangle is ever addressed: the fast path packs it (row i at i (i + 1) / 2: half the LDS of the square, which keeps
   // the factor records on chip for ~700 factors instead of ~230), the workspace variants keep the square
   const int Tn = (na + 15) / 16, N = 16 * Tn, ld = N;
-  auto AT = [&](int i, int j) -> int { return FT > 0 ? i * (i + 1) / 2 + j : i * ld + j; };
-  const size_t a_doubles = FT > 0 ? max((size_t)N * (N + 1) / 2, (size_t)48 * N + 1280) : (size_t)N * ld;
+  constexpr bool kPacked = FT > 0 || (kLds && FT < 0);  // LDS-resident system: packed lower triangle
+  auto AT = [&](int i, int j) -> int { return kPacked ? i * (i + 1) / 2 + j : i * ld + j; };
+  // (the LDS-resident variants reuse the matrix region for their sweep panels while the tiles are in registers)
+  const size_t a_doubles = FT > 0   ? max((size_t)N * (N + 1) / 2, (size_t)48 * N + 1280)
+                           : kPacked ? max((size_t)N * (N + 1) / 2, (size_t)32 * N + 1280)
+                                     : (size_t)N * ld;
   const int ntiles = Tn * (Tn + 1) / 2;
   if ((FT > 0 && Tn > FT) || (FT == 0 && NTW > 0 && ntiles > NTW * kWaves) || (FT < 0 && ntiles > NTW * (kWaves - 1))) {
     // more poses than this variant was launched for (the host's bound was wrong): flag it, touch nothing
@@ -453,7 +457,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   off = (off + 31) & ~(size_t)31;
   // sweep panels of the workspace variants (the fast path keeps its panels in the dead matrix region)
   double *Vb = reinterpret_cast<double *>(smem_raw + off);
-  off += (size_t)(FT > 0 ? 0 : FT < 0 ? 32 * N + 1280 : NTW < 0 ? 32 * N + 256 : 2 * (8 * N + 32)) * 8;
+  off += (size_t)(kPacked ? 0 : FT < 0 ? 32 * N + 1280 : NTW < 0 ? 32 * N + 256 : 2 * (8 * N + 32)) * 8;
   double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
   double *A;
   if (kLds) {
@@ -509,7 +513,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   // ---- 2. clear the system; factor tables (factors are appended in pose order: contiguous ranges) ----
   {
     double2 *A2 = reinterpret_cast<double2 *>(A);
-    const int n2 = (int)((FT > 0 ? (size_t)N * (N + 1) / 2 : (size_t)N * ld) / 2);  // (N is a multiple of 16: even)
+    const int n2 = (int)((kPacked ? (size_t)N * (N + 1) / 2 : (size_t)N * ld) / 2);  // (N is a multiple of 16: even)
     for (int e = tid; e < n2; e += kThreads) A2[e] = make_double2(0.0, 0.0);
   }
   for (int e = tid; e < L * P; e += kThreads) obs[e] = 0;
@@ -921,7 +925,8 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lc = lane & 15, lr = lane >> 4;
     const bool ewave = wave == TW;
-    double *pan = Vb, *wt = Vb + 16 * N, *einv0 = Vb + 32 * N, *dscr = einv0 + 512, *es = dscr + 256;
+    double *pbase = kLds ? A : Vb;  // LDS-resident system: the matrix region is dead while the tiles are in registers
+    double *pan = pbase, *wt = pbase + 16 * N, *einv0 = pbase + 32 * N, *dscr = einv0 + 512, *es = dscr + 256;
     const SweepCtx x{0, lane, lc, lr, np, N, true, ewave, bad, nullptr};
     v4d acc[NTW];
     int tI[NTW], tJ[NTW];
@@ -942,9 +947,10 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * ib + lr + 4 * r, j = 16 * jb + lc;
-        acc[u][r] = live[u] ? A[max(i, j) * ld + min(i, j)] : 0.0;
+        acc[u][r] = live[u] ? A[AT(max(i, j), min(i, j))] : 0.0;
       }
     }
+    if (kLds) __syncthreads();  // every tile is in registers before the panels overwrite the matrix region
     // E_0 from the first diagonal tile (tile 0 = wave 0, slot 0)
     if (wave == 0) {
 #pragma unroll
@@ -1029,7 +1035,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * tI[u] + lr + 4 * r, j = 16 * tJ[u] + lc;
-        if (j <= i) A[i * ld + j] = acc[u][r];
+        if (j <= i) A[AT(i, j)] = acc[u][r];
       }
     }
   }
@@ -1166,6 +1172,7 @@ void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p
   if (!attr_set) {
     const void *fns[] = {reinterpret_cast<const void *>(&kslam::k_slam<true, 1, kslam::kFastTiles>),
                          reinterpret_cast<const void *>(&kslam::k_slam<false, 10, -1>),
+                         reinterpret_cast<const void *>(&kslam::k_slam<true, 10, -1>),
                          reinterpret_cast<const void *>(&kslam::k_slam<false, 20, -1>),
                          reinterpret_cast<const void *>(&kslam::k_slam<false, -1, 0>),
                          reinterpret_cast<const void *>(&kslam::k_slam<false, 0, 0>)};
@@ -1191,6 +1198,11 @@ void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p
   if (small16 > (size_t)kslam::kLdsBudget)
     hipLaunchKernelGGL((kslam::k_slam<false, 0, 0>), grid, block, small4, st, S, sel, (int)small4);
   // (the whole LDS is requested: what the panels and tables leave free holds the factor records and the observation table)
+  else if (ntiles <= 10 * (kslam::kWaves - 1) && kslam::slam_small_bytes_n(16 * Tn, S.P_max, S.L_max, S.M_max, true) +
+                                                       std::max((size_t)(16 * Tn) * (16 * Tn + 1) / 2, (size_t)32 * 16 * Tn + 1280) * 8 <=
+                                                   (size_t)kslam::kLdsBudget)
+    // up to ~52 poses the packed system itself fits the LDS next to the tables (panels alias it during the sweeps)
+    hipLaunchKernelGGL((kslam::k_slam<true, 10, -1>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
   else if (ntiles <= 10 * (kslam::kWaves - 1))
     hipLaunchKernelGGL((kslam::k_slam<false, 10, -1>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
   else if (ntiles <= 20 * (kslam::kWaves - 1))
