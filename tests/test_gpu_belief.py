@@ -355,6 +355,34 @@ def test_variant_follows_the_trajectory_length():
     eng.close()
 
 
+def test_random_walk_soak_32_envs():
+    """32 environments driven by independent random action sequences (turns, full and partial forward moves, a few
+    out-of-bounds requests) for 46 steps - through every tile count of the fast path and into the register-tile variant -
+    against one oracle instance each; full state comparison at the end and at two intermediate steps."""
+    n, steps = 32, 46
+    eng, cfg = make_engine(n, max_poses=60)
+    ocfg = O.default_config(MAP)
+    rng = np.random.RandomState(20260927)
+    starts = np.stack([rng.uniform(-14, 14, n), rng.uniform(-14, 14, n), rng.uniform(-3.1, 3.1, n)], 1)
+    sims = [O.OracleSim(ocfg, 100 + i, 100 + i, start=tuple(starts[i])) for i in range(n)]
+    eng.reset(np.arange(n), 100 + np.arange(n), starts=starts)
+    menu = [(2.0, 0.0, 0.0), (1.3, 0.0, 0.0), (0.0, 0.0, 0.9), (0.0, 0.0, -1.4), (0.6, 0.0, 0.3), (2.0, 0.0, 0.0), (1.0, 1.0, math.pi / 2),
+            (75.0, 0.0, 0.0)]  # the last one is rejected by the bounds check of SS2D.simulate
+    for s in range(steps):
+        pick = rng.randint(0, len(menu), n)
+        pick[rng.rand(n) < 0.5] = 0  # mostly forward moves, so that the trajectories spread out
+        acts = np.array([menu[k] for k in pick])
+        eng.step(torch.tensor(acts, dtype=torch.float64, device=eng.device))
+        for i, sim in enumerate(sims):
+            sim.simulate(tuple(acts[i]))
+        if s in (17, 33, steps - 1):
+            assert eng.status() == 0
+            for i in range(n):
+                compare_state(eng, i, sims[i], "soak env %d step %d" % (i, s), mask_knife_edge=True)
+    assert max(eng.counts(i)["poses"] for i in range(n)) >= 40
+    eng.close()
+
+
 def test_config5_scale_120_pose_graphs():
     """BASELINE config 5 scale: 50 m map, 500 landmarks, graphs grown to ~115 poses / ~100 landmarks (dense pose
     system n = 3 P + 1 > 340: k_slam streams its tiles from the HBM/L2 workspace, k_map works in pose chunks)."""
