@@ -203,6 +203,45 @@ def test_lookahead_rewards_match_oracle():
     eng.close()
 
 
+def test_lookahead_across_kernel_variants():
+    """Look-ahead from 39-pose trajectories with plans of up to 9 actions: the rollouts start on the fused LDS kernel and
+    cross to the register-tile SLAM variant at 43 poses (per-launch variant selection, virtual map rebuilt only at a
+    rollout's last action, bounded launch count): rewards against the oracle's simulations_reward."""
+    n = 4
+    eng, cfg = make_engine(n, n_roll=16, max_poses=60)
+    ocfg = O.default_config(MAP)
+    starts = np.array([[-7.3183, -6.2718, 0.1234], [3.1, 4.7, 2.2], [6.4, -8.1, -1.0], [-2.2, 9.3, 0.4]])
+    sims = [O.OracleSim(ocfg, lo, lo, start=tuple(starts[lo])) for lo in range(n)]
+    eng.reset(np.arange(n), np.arange(n), starts=starts)
+    loop = [(2, 0, 0)] * 3 + [(0, 0, math.pi / 2)] + [(2, 0, 0)] * 2 + [(0.7, 0, 0.4)]
+    for s in range(38):
+        act = loop[s % len(loop)]
+        eng.step(torch.tensor([act] * n, dtype=torch.float64, device=eng.device))
+        for sim in sims:
+            sim.simulate(act)
+    assert eng.status() == 0 and eng.counts(0)["poses"] == 39
+    cand_env, goals = [], []
+    for i in range(n):
+        xyt, _ = sims[i].poses()
+        for dx, dy in ((9.0, 7.0), (-11.0, 3.0), (1.5, -2.5)):  # 6, 6-7 and 2-3 actions
+            cand_env.append(i)
+            goals.append((xyt[-1, 0] + dx, xyt[-1, 1] + dy))
+    ce = torch.tensor(cand_env, dtype=torch.int32, device=eng.device)
+    gl = torch.tensor(goals, dtype=torch.float64, device=eng.device)
+    actions, n_act = eng.line_plan(ce, gl)
+    acts_h, n_h = actions.cpu().numpy(), n_act.cpu().numpy()
+    assert n_h.max() >= 6  # 39 + 6 > 42
+    rewards = eng.lookahead(ce, actions, n_act, max_n_actions=int(n_h.max())).cpu().numpy()
+    assert eng.status() == 0
+    for c, i in enumerate(cand_env):
+        want = sims[i].simulations_reward(acts_h[c, :n_h[c]])
+        assert rewards[c] == pytest.approx(want, abs=1e-6), (c, i, n_h[c])
+    np.testing.assert_array_equal(rewards, eng.lookahead(ce, actions, n_act).cpu().numpy())  # unbounded entry point
+    for i in range(n):
+        compare_state(eng, i, sims[i], "after lookahead env %d" % i, mask_knife_edge=True)
+    eng.close()
+
+
 def test_snapshot_restore_roundtrip():
     n = 3
     eng, cfg = make_engine(n)
