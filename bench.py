@@ -163,6 +163,35 @@ def policy_bench(eng, dev, iters=10):
     return out
 
 
+def dqn_loop_bench(device_index, n_envs=256, iters=8):
+    """BASELINE config 2 as a secondary figure: wall-clock rate of the whole DQN loop (`DeepQ.running`: graph export,
+    look-ahead rewards of every frontier, policy forward, env step, replay, one 64-graph train step per vector step,
+    episode resets), in the reference's unit - RL iterations (decisions) per second."""
+    import tempfile
+    from drl_graph_exploration_amd.networks import GCN
+    from drl_graph_exploration_amd.policy import DeepQ
+    from drl_graph_exploration_amd.vecenv import VecExplorationEnv
+    dev = torch.device("cuda", device_index)
+    torch.manual_seed(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        dq = DeepQ("bench/", "GCN", data_root=tmp)
+        dq.OBSERVE, dq.epoch = n_envs, n_envs * 3  # warm-up: 3 vector steps, training from the 2nd
+        pol, tgt = GCN().to(dev), GCN().to(dev)
+        tgt.load_state_dict(pol.state_dict())
+        env = VecExplorationEnv(MAP, n_envs, env_index=0, test=True, device=device_index)  # (construction is not timed)
+        dq.running(pol, tgt, test=True, env=env)
+        dq.epoch = n_envs * iters
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dq.running(pol, tgt, test=True, env=env)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        env.close()
+    return {"workload": "DeepQ.running, %d envs in lock-step, 40 m map, one train step (64 graphs) per vector step" % n_envs,
+            "ms_per_vector_step": dt / iters * 1e3, "rl_iterations_per_sec": n_envs * iters / dt,
+            "reference_published": "~3.8 RL iterations/s (A2C+GCN, authors' PC; BASELINE.md) - other hardware, reported beside"}
+
+
 def config5_bench(device_index, n_envs=256, warm=108, timed=8):
     """BASELINE config 5 scale as a secondary figure: 50 m map, 500 landmarks, graphs grown by a fixed motion loop to
     ~110 poses / ~95 landmarks (k_slam's tile-streaming variant, k_map in pose chunks); per-stage kernels."""
@@ -327,6 +356,7 @@ def main():
         if not args.no_policy:
             out["policy_path"] = policy_bench(eng, dev)
             out["config5_scale"] = config5_bench(local_rank)
+            out["dqn_loop"] = dqn_loop_bench(local_rank)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu_thread"] = (out["value"] / world) / out["cpu_baseline"]["value"]

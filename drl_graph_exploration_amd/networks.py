@@ -170,6 +170,10 @@ class GraphData(object):
     def __init__(self, x, edge_index, edge_attr, batch=None):
         self.x, self.edge_index, self.edge_attr, self.batch = x, edge_index, edge_attr, batch
 
+    @property
+    def num_nodes(self):
+        return self.x.shape[0]
+
     def to(self, device):
         self.x = self.x.to(device)
         self.edge_index = self.edge_index.to(device)
@@ -181,12 +185,52 @@ class GraphData(object):
     @staticmethod
     def collate(items):
         """torch_geometric DataLoader/Batch semantics: concatenate, offset edge_index by cumulative node counts."""
-        xs, eis, eas, bs = [], [], [], []
+        xs, eis, eas, counts = [], [], [], []
         off = 0
-        for g, d in enumerate(items):
-            xs.append(d.x)
-            eis.append(d.edge_index + off)
+        for d in items:
+            x = d.x
+            n = x.shape[0]
+            xs.append(x)
+            # a GraphSlice keeps the batch-global node ids of the export it was cut from: one shift does both offsets
+            eis.append(d.edge_index_global + (off - d.node0) if isinstance(d, GraphSlice) else d.edge_index + off)
             eas.append(d.edge_attr)
-            bs.append(torch.full((d.x.shape[0],), g, dtype=torch.long, device=d.x.device))
-            off += d.x.shape[0]
-        return GraphData(torch.cat(xs), torch.cat(eis, dim=1), torch.cat(eas), torch.cat(bs))
+            counts.append(n)
+            off += n
+        dev = xs[0].device
+        batch = torch.repeat_interleave(torch.arange(len(items), device=dev), torch.tensor(counts, device=dev))
+        return GraphData(torch.cat(xs), torch.cat(eis, dim=1), torch.cat(eas), batch)
+
+
+class GraphSlice(object):
+    """One env's graph as lazy VIEWS into the engine's batched export (no copies, no kernels and no tensor objects until
+    it is used): what a replay transition holds.  Same duck type as GraphData; `edge_index` (local node ids) is
+    materialised on access."""
+
+    __slots__ = ("g", "node0", "node1", "edge0", "edge1", "batch")
+
+    def __init__(self, g, n0, n1, e0, e1):
+        self.g, self.node0, self.node1, self.edge0, self.edge1, self.batch = g, int(n0), int(n1), int(e0), int(e1), None
+
+    @property
+    def num_nodes(self):
+        return self.node1 - self.node0
+
+    @property
+    def x(self):
+        return self.g["x"][self.node0:self.node1]
+
+    @property
+    def edge_attr(self):
+        return self.g["edge_attr"][self.edge0:self.edge1]
+
+    @property
+    def edge_index_global(self):
+        return self.g["edge_index"][:, self.edge0:self.edge1]
+
+    @property
+    def edge_index(self):
+        return self.edge_index_global - self.node0
+
+    def to(self, device):
+        x = self.x
+        return self if x.device == torch.device(device) else GraphData(x, self.edge_index, self.edge_attr).to(device)

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .networks import GraphData
+from .networks import GraphData, GraphSlice
 from .vecenv import VecExplorationEnv
 
 
@@ -87,7 +87,7 @@ class DeepQ(object):
         ids — what policy.py:211-232 builds from the dense (A, X) pair."""
         n0, n1 = int(g["node_off_h"][i]), int(g["node_off_h"][i + 1])
         e0, e1 = int(g["edge_off_h"][i]), int(g["edge_off_h"][i + 1])
-        return GraphData(g["x"][n0:n1].clone(), g["edge_index"][:, e0:e1] - n0, g["edge_attr"][e0:e1].clone())
+        return GraphSlice(g, n0, n1, e0, e1)  # views: the replay buffer keeps the export alive, nothing is copied
 
     @staticmethod
     def _host_offsets(g):
@@ -128,8 +128,8 @@ class DeepQ(object):
         s_j1 = GraphData.collate([d[3] for d in minibatch])
         with torch.no_grad():
             q1 = self.test(s_j1, 0.0, device, target_net).view(-1)
-        n_j = torch.tensor([d[0].x.shape[0] for d in minibatch], device=device)
-        n_j1 = torch.tensor([d[3].x.shape[0] for d in minibatch], device=device)
+        n_j = torch.tensor([d[0].num_nodes for d in minibatch], device=device)
+        n_j1 = torch.tensor([d[3].num_nodes for d in minibatch], device=device)
         fro1 = torch.tensor([d[5] for d in minibatch], device=device)
         a_loc = torch.tensor([d[1] for d in minibatch], device=device)
         r = torch.tensor([d[2] for d in minibatch], dtype=torch.float32, device=device)
@@ -413,7 +413,7 @@ class A2C(object):
                 for i in range(n_envs):  # trajectory-major, as the reference's DataLoader over one env's buffer
                     for t in range(T):
                         st, al, _, _, fro, v = self.buffer[t]
-                        n_nodes = st[i].x.shape[0]
+                        n_nodes = st[i].num_nodes
                         a = np.zeros(n_nodes, dtype=np.float32)
                         a[al[i]] = 1.0
                         m = np.zeros(n_nodes, dtype=bool)
