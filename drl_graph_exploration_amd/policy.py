@@ -165,12 +165,13 @@ class DeepQ(object):
         broadcast_parameters(policy_net)
         optimizer = torch.optim.Adam(policy_net.parameters(), lr=1e-5)
         temp_reward_data, temp_loss_data, rows = [], [], []
+        recent = deque(self.total_reward[-1000:].tolist(), maxlen=1000)  # average reward window (policy.py:201-203)
 
         g = self._host_offsets(env.graph_matrix())
+        s_t = [self.data_process(g, i) for i in range(n_envs)]
         while temp_i < self.epoch:
             if self.epsilon > self.FINAL_EPSILON and self.step_t > self.OBSERVE:
                 self.epsilon -= n_envs * (self.INITIAL_EPSILON - self.FINAL_EPSILON) / self.EXPLORE
-            s_t = [self.data_process(g, i) for i in range(n_envs)]
             env.actions_all_goals()
             rewards = env.rewards_all_goals()
             cand_env, cand_node, cand_first = env.candidates
@@ -204,12 +205,12 @@ class DeepQ(object):
                 env.reset(np.nonzero(done_h)[0])
             g1 = self._host_offsets(env.graph_matrix())
             nfr1 = g1["n_frontier"].cpu().numpy()
+            s_t1 = [self.data_process(g1, i) for i in range(n_envs)]  # also the next iteration's s_t
             for i in range(n_envs):
-                self.buffer.append((s_t[i], int(a_loc[i]), float(r_h[i]), self.data_process(g1, i),
-                                    bool(current_done[i] or done_h[i]), int(nfr1[i])))
+                self.buffer.append((s_t[i], int(a_loc[i]), float(r_h[i]), s_t1[i], bool(current_done[i] or done_h[i]), int(nfr1[i])))
                 if len(self.buffer) > self.REPLAY_MEMORY:
                     self.buffer.popleft()
-            g = g1
+            g, s_t = g1, s_t1
             self.step_t += n_envs
             temp_i += n_envs
 
@@ -223,10 +224,11 @@ class DeepQ(object):
                 print("TIMESTEP", self.step_t, "/ EPSILON", self.epsilon, "/ Q_MAX %e" % float(readout.max()),
                       "/ EXPLORED", float(env.status().mean()), "/ REWARD", float(r_h.mean()))
             rows.extend([self.step_t, float(x)] for x in r_h)
-            self.total_reward = np.append(self.total_reward, r_h)
+            recent.extend(float(x) for x in r_h)
             if self.step_t > 1000 and (self.step_t // n_envs) % max(100 // n_envs, 1) == 0:
-                temp_reward_data.append([self.step_t, float(np.average(self.total_reward[-1000:]))])
+                temp_reward_data.append([self.step_t, float(np.average(recent))])
 
+        self.total_reward = np.append(self.total_reward, np.array([r[1] for r in rows]))
         np.savetxt(os.path.join(self.object_path, "temp_reward.csv"), np.array(temp_reward_data).reshape(-1, 2), delimiter=",")
         np.savetxt(os.path.join(self.object_path, "temp_loss.csv"), np.array(temp_loss_data).reshape(-1, 2), delimiter=",")
         with open(os.path.join(self.reward_data_path, "reward_data.csv"), "a", newline="") as f:
