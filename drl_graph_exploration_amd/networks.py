@@ -15,7 +15,6 @@ import ctypes as C
 import math
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 
