@@ -144,6 +144,8 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   if (cfg->max_poses < 2 || cfg->max_landmarks < 1 || cfg->max_factors < 1 || cfg->num_landmarks < 0 ||
       cfg->max_actions < 1 || cfg->num_samples < 1 || !(cfg->resolution > 0))
     return DRLGX_E_INVALID;
+  // kernel limits: per-landmark pose masks of 128 bits (k_slam); 16-bit pose / landmark / factor indices in LDS tables
+  if (cfg->max_poses > 127 || cfg->max_landmarks > 65535 || cfg->max_factors > 65535) return DRLGX_E_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DRLGX_E_NODEVICE;
   drlgx_engine *e = new drlgx_engine();

@@ -59,7 +59,7 @@ typedef struct drlgx_config {
   double angle_weight, distance_weight0, distance_weight1, occupancy_threshold, max_edge_length;
   int32_t algorithm; /* DRLGX_ALG_* */
   /* capacities (new: the reference grows std::vectors) */
-  int32_t max_poses;     /* P_max per instance  */
+  int32_t max_poses;     /* P_max per instance (2 .. 127) */
   int32_t max_landmarks; /* L_max observed landmarks per instance */
   int32_t max_factors;   /* M_max bearing-range factors per instance */
   int32_t max_actions;   /* A_max actions per look-ahead candidate */

@@ -38,9 +38,12 @@ def test_error_strings_and_create_without_device():
     L = _lib.lib()
     for code in (0, -1, -2, -3, -4, -5):
         assert len(L.drlgx_strerror(code)) > 0
+    h = C.c_void_p()
+    # argument validation comes before the device: capacities beyond the kernels' index widths are refused
+    assert L.drlgx_create(C.byref(default_config(40, max_poses=128)), 4, 0, 0, C.byref(h)) == -1 and not h.value
+    assert L.drlgx_create(C.byref(default_config(40, max_poses=1)), 4, 0, 0, C.byref(h)) == -1 and not h.value
     if torch.cuda.is_available():
         pytest.skip("needs a box without a GPU")
-    h = C.c_void_p()
     rc = L.drlgx_create(C.byref(default_config(40)), 4, 0, 0, C.byref(h))
     assert rc in (-2, -4) and not h.value  # fails loudly: no CPU fallback
     from drl_graph_exploration_amd.engine import Engine
