@@ -207,7 +207,10 @@ def _worker(rank, world, port, q):
     m(x).pow(2).sum().backward()
     local = [p.grad.clone() for p in m.parameters()]
     allreduce_gradients(m)
-    q.put((rank, [p.detach().clone() for p in m.parameters()], local, [p.grad.clone() for p in m.parameters()]))
+    # numpy copies, pickled by value: tensors would travel as shared-memory file descriptors, which the parent can no
+    # longer receive once this process has exited
+    q.put((rank, [p.detach().numpy().copy() for p in m.parameters()], [g.numpy().copy() for g in local],
+           [p.grad.numpy().copy() for p in m.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -224,7 +227,7 @@ def test_gradient_allreduce_gloo_world_size_2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, w0, l0, g0), (_, w1, l1, g1) = res
+    (_, w0, l0, g0), (_, w1, l1, g1) = [(r, *[[torch.from_numpy(a) for a in part] for part in parts]) for r, *parts in res]
     for a, b in zip(w0, w1):
         assert torch.equal(a, b)  # broadcast made the replicas identical
     for a, b, x, y in zip(g0, g1, l0, l1):
