@@ -1,5 +1,6 @@
+"""Dev tool: cProfile of DeepQ.running over a vectorised env (host-side cost of the training loop)."""
 import os, sys, tempfile, time, cProfile, pstats
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from drl_graph_exploration_amd.networks import GCN
 from drl_graph_exploration_amd.policy import DeepQ
