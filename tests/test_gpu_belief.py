@@ -394,12 +394,13 @@ def test_variant_follows_the_trajectory_length():
     eng.close()
 
 
-def test_random_walk_soak_32_envs():
-    """32 environments driven by independent random action sequences (turns, full and partial forward moves, a few
-    out-of-bounds requests) for 46 steps - through every tile count of the fast path and into the register-tile variant -
-    against one oracle instance each; full state comparison at the end and at two intermediate steps."""
-    n, steps = 32, 46
-    eng, cfg = make_engine(n, max_poses=60)
+@pytest.mark.parametrize("n,steps,cap,checks", [(32, 46, 60, (17, 33, 45)), (6, 104, 110, (50, 70, 90, 103))])
+def test_random_walk_soak(n, steps, cap, checks):
+    """Environments driven by independent random action sequences (turns, full and partial forward moves, a few
+    out-of-bounds requests) against one oracle instance each, full state comparison at several steps: 32 envs x 46 steps
+    (every tile count of the fast path, into the register-tile variant) and 6 envs x 104 steps (register tiles with 10 and
+    20 tiles per wave, streamed tiles)."""
+    eng, cfg = make_engine(n, max_poses=cap)
     ocfg = O.default_config(MAP)
     rng = np.random.RandomState(20260927)
     starts = np.stack([rng.uniform(-14, 14, n), rng.uniform(-14, 14, n), rng.uniform(-3.1, 3.1, n)], 1)
@@ -414,11 +415,11 @@ def test_random_walk_soak_32_envs():
         eng.step(torch.tensor(acts, dtype=torch.float64, device=eng.device))
         for i, sim in enumerate(sims):
             sim.simulate(tuple(acts[i]))
-        if s in (17, 33, steps - 1):
+        if s in checks:
             assert eng.status() == 0
             for i in range(n):
                 compare_state(eng, i, sims[i], "soak env %d step %d" % (i, s), mask_knife_edge=True)
-    assert max(eng.counts(i)["poses"] for i in range(n)) >= 40
+    assert max(eng.counts(i)["poses"] for i in range(n)) >= (40 if cap == 60 else 88)
     eng.close()
 
 
