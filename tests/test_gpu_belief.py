@@ -116,6 +116,40 @@ def test_reset_and_scripted_steps_match_oracle():
     eng.close()
 
 
+def test_config0_single_env_small_map():
+    """BASELINE configs[0]: ONE environment, 20 m map (V = 900 virtual cells), 30 landmarks - the reference's own
+    CPU-runnable case: scripted steps, utility, explored fraction, line plans and look-ahead rewards against the oracle."""
+    from drl_graph_exploration_amd import default_config
+    from drl_graph_exploration_amd.engine import Engine
+    cfg = default_config(20, num_landmarks=30, max_poses=41)
+    eng = Engine(cfg, 1, 8)
+    assert eng.rows * eng.cols == 900
+    ocfg = O.default_config(20, num_landmarks=30)
+    start = (1.3183, -2.2718, 0.6234)
+    sim = O.OracleSim(ocfg, 5, 5, start=start)
+    eng.reset(np.array([0]), np.array([5]), starts=np.array([start]))
+    assert float(eng.utility().cpu()[0]) == 2.0 * 900
+    for s, act in enumerate(SCRIPT[:14]):
+        eng.step(torch.tensor([act], dtype=torch.float64, device=eng.device))
+        sim.simulate(act)
+        assert eng.status() == 0
+        compare_state(eng, 0, sim, "config-0 step %d" % s)
+        assert float(eng.utility().cpu()[0]) == pytest.approx(sim.calculate_utility(0.0), rel=1e-9)
+        assert float(eng.explored().cpu()[0]) == sim.explored()
+    xyt, _ = sim.poses()
+    goals = [(xyt[-1, 0] + 3.0, xyt[-1, 1] - 2.0), (xyt[-1, 0] - 4.5, xyt[-1, 1] + 1.0)]
+    ce = torch.zeros(2, dtype=torch.int32, device=eng.device)
+    actions, n_act = eng.line_plan(ce, torch.tensor(goals, dtype=torch.float64, device=eng.device))
+    acts_h, n_h = actions.cpu().numpy(), n_act.cpu().numpy()
+    rewards = eng.lookahead(ce, actions, n_act).cpu().numpy()
+    for c, g in enumerate(goals):
+        oa = sim.line_plan(g)
+        assert n_h[c] == len(oa)
+        np.testing.assert_allclose(acts_h[c, :len(oa)], oa, atol=1e-9)
+        assert rewards[c] == pytest.approx(sim.simulations_reward(acts_h[c, :n_h[c]]), abs=1e-6)
+    eng.close()
+
+
 def test_reference_integer_start_poses():
     """The reference's own start poses (pyss2d.py:89-95) are integers: when the early trajectory is pure
     dead reckoning the 4 x (1,1,pi/2) reset loop returns to the start and four cells sit EXACTLY at
