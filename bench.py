@@ -91,6 +91,46 @@ def cpu_baseline(budget_s=12.0):
             "host_cores_available": os.cpu_count()}
 
 
+def _cpu_worker(args):
+    """One process of the all-cores CPU figure: the single-thread measurement on its own seeded env."""
+    lo, budget_s = args
+    from oracle import oracle as O
+    ocfg = O.default_config(MAP, num_landmarks=NUM_LM)
+    s = O.OracleSim(ocfg, lo, lo)
+    for act in WARM_SCRIPT:
+        s.simulate(act)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        s.clone().simulate(STEP_ACTION)
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(budget_s=6.0, max_procs=64):
+    """the same oracle with independent environments sharded over host processes (the CPU
+    analogue of the env-parallel GPU path), every process timing its own clone-and-step loop.  Plain subprocesses with a
+    timeout: a failure yields an error entry, never a hung benchmark."""
+    import subprocess
+    procs = max(1, min(max_procs, (os.cpu_count() or 1)))
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
+    kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(lo), str(budget_s)], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for lo in range(procs)]
+    rate, ok = 0.0, 0
+    deadline = time.time() + budget_s + 90.0
+    for k in kids:
+        try:
+            out, _ = k.communicate(timeout=max(1.0, deadline - time.time()))
+            n, t = out.strip().split()[-2:]
+            rate += float(n) / float(t)
+            ok += 1
+        except Exception:  # noqa: BLE001 - timeout, crash or unparsable output: skip this process
+            k.kill()
+    if ok == 0:
+        return {"error": "no CPU worker finished"}
+    return {"value": rate, "unit": "env-steps/sec", "cores": ok, "kind": "port",
+            "sample": "%d processes x %.0f s of clone-and-step on one seeded env each (36 poses), oracle/drlgx_oracle.cpp -O3" % (ok, budget_s)}
+
+
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector rate
 
 
@@ -222,6 +262,10 @@ def config5_bench(device_index, n_envs=256, warm=108, timed=8):
 
 
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--cpu-worker":  # child of cpu_baseline_all_cores
+        n, t = _cpu_worker((int(sys.argv[2]), float(sys.argv[3])))
+        print(n, t)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -360,6 +404,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu_thread"] = (out["value"] / world) / out["cpu_baseline"]["value"]
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
         print(json.dumps(out))
     eng.close()
     if dist is not None:
