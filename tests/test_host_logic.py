@@ -256,3 +256,13 @@ def test_a2c_costs_and_returns(tmp_path):
     out = A2C.discounted_returns(r, term, np.array([10.0, 20.0]), 0.9)
     # env 0: t2 = 0 + .9*10 = 9; t1 terminal = 2; t0 = 1 + .9*2 = 2.8;  env 1: t2 = 3 + 18 = 21; t1 = -1 + 18.9; t0 = .5 + .9*17.9
     np.testing.assert_allclose(out, [[2.8, 0.5 + 0.9 * 17.9], [2.0, 17.9], [9.0, 21.0]], rtol=1e-12)
+
+
+def test_bench_cpu_worker_subprocess():
+    """bench.py's all-cores CPU baseline launches `bench.py --cpu-worker <seed> <seconds>` children: one of them, here."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", "3", "0.3"], capture_output=True,
+                         text=True, timeout=300, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+    assert out.returncode == 0, out.stderr[-500:]
+    n, t = out.stdout.strip().split()[-2:]
+    assert int(n) >= 1 and 0.3 <= float(t) < 30.0
