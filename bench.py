@@ -397,11 +397,12 @@ def main():
                        "envs_per_gpu": N_ENVS, "map_size": MAP, "num_landmarks": NUM_LM, "parallelism": "env-sharded x%d" % world},
             "roofline": roofline, "kernels": kernels, "event_pair_overhead_us": ev_over_us,
         }
-        if not args.no_policy:
+        # the secondary sections and the CPU baselines belong to the N = 1 line only (driver contract)
+        if not args.no_policy and world == 1:
             out["policy_path"] = policy_bench(eng, dev)
             out["config5_scale"] = config5_bench(local_rank)
             out["dqn_loop"] = dqn_loop_bench(local_rank)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu_thread"] = (out["value"] / world) / out["cpu_baseline"]["value"]
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
