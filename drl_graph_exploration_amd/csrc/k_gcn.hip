@@ -27,14 +27,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------------
 // graph normalisation + CSR
 // ------------------------------------------------------------------------------------------------
-__global__ void k_fill_f32(float *p, float v, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
-__global__ void k_fill_i32(int *p, int v, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
 // in/out degree counts for the two CSRs (the weighted degree is summed later in edge order: float atomics here would
 // make deg - and through the ReLU gates the whole forward/backward - depend on the arrival order)
 __global__ void k_degree(int E, const int64_t *ei, int *cnt_dst, int *cnt_src) {
