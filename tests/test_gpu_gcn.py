@@ -138,3 +138,57 @@ def test_policy_and_value_heads():
     (probs.log().sum() + v.sum()).backward()
     for p in list(pol.parameters()) + list(val.parameters()):
         assert p.grad is not None and torch.isfinite(p.grad).all()
+
+
+def test_a2c_heads_and_losses_match_torch_reference(monkeypatch, tmp_path):
+    """PolicyGCN / ValueGCN (Networks.py:31-70) and the A2C losses (policy.py:452-497) through the HIP trunk, against the
+    plain-torch float64 restatement with the same (fixed) dropout mask: head outputs and the gradients of the combined
+    loss with respect to every parameter of both networks."""
+    import drl_graph_exploration_amd.networks as NW
+    from drl_graph_exploration_amd.networks import PolicyGCN, ValueGCN, GraphData
+    from drl_graph_exploration_amd.policy import A2C
+    dev = torch.device("cuda", 0)
+    n_graphs = 5
+    x, ei, ea, batch = random_batch(n_graphs, 4242, dev)
+    N = x.shape[0]
+    sel = x[:, 4] > 0
+    for g in range(n_graphs):
+        sel[int((batch == g).nonzero()[0])] = True  # every graph has a candidate
+    torch.manual_seed(3)
+    fixed = (torch.rand(N, 1000, device=dev) >= 0.5).float() * 2.0  # F.dropout(x) with p = 0.5, frozen for the comparison
+    monkeypatch.setattr(NW, "_dropout_mask", lambda n, hidden, p, device: fixed)
+    pol, val = PolicyGCN().to(dev), ValueGCN().to(dev)
+    data = GraphData(x, ei, ea, batch)
+    a2c = A2C("t/", data_root=str(tmp_path))
+    a2c.nstep = n_graphs
+    # one chosen frontier node per graph, advantages and returns
+    action = torch.zeros(N, device=dev)
+    adv = torch.zeros(N, device=dev)
+    gsel = torch.Generator().manual_seed(1)
+    for g in range(n_graphs):
+        idx = (sel & (batch == g)).nonzero().view(-1)
+        pick = int(idx[int(torch.randint(0, idx.numel(), (1,), generator=gsel))])
+        action[pick] = 1.0
+        adv[pick] = float(torch.randn(1, generator=gsel))
+    ret = torch.randn(n_graphs, generator=gsel).to(dev)
+
+    def losses(probs, values):
+        return a2c.policy_cost(probs + 1e-35, adv.to(probs.dtype), action.to(probs.dtype), sel) \
+            - a2c.entropy_loss(probs + 1e-35) * a2c.ent_coef + a2c.value_cost(values, ret.to(values.dtype)) * a2c.vf_coef
+
+    probs, values = pol(data, sel, batch=batch), val(data, sel, batch=batch)
+    losses(probs, values).backward()
+    # float64 torch reference with the same parameters and mask
+    pp = {k: v.detach().double().clone().requires_grad_(True) for k, v in pol.state_dict().items()}
+    pv = {k: v.detach().double().clone().requires_grad_(True) for k, v in val.state_dict().items()}
+    rprobs = gcn_ref.policy_gcn_forward(pp, x.double(), ei, ea.double(), sel, batch, n_graphs, fixed.double())
+    rvalues = gcn_ref.value_gcn_forward(pv, x.double(), ei, ea.double(), batch, n_graphs, fixed.double())
+    assert rel_err(probs.double(), rprobs) < 1e-5 and rel_err(values.double(), rvalues) < 1e-5
+    sums = torch.zeros(n_graphs, device=dev).index_add_(0, batch[sel], probs.detach())
+    assert torch.allclose(sums, torch.ones(n_graphs, device=dev), atol=1e-5)
+    losses(rprobs, rvalues).backward()
+    for model, ref in ((pol, pp), (val, pv)):
+        for k, p in model.named_parameters():
+            g, r = p.grad.double(), ref[k].grad
+            # (the actor's output bias has an exactly zero gradient - softmax is shift invariant: absolute floor)
+            assert float((g - r).norm()) < 2e-4 * float(r.norm()) + 1e-6, k
