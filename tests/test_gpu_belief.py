@@ -276,6 +276,46 @@ def test_lookahead_across_kernel_variants():
     eng.close()
 
 
+def test_lookahead_soak_random_states_and_goals():
+    """Look-ahead rewards for random goals from 12 randomly driven environments (25 steps each, different graph sizes):
+    line plans exact to 1e-9, rewards to 1e-6 against the oracle; more candidates (48) than rollout instances (20)."""
+    n = 12
+    eng, cfg = make_engine(n, n_roll=20, max_poses=60)
+    ocfg = O.default_config(MAP)
+    rng = np.random.RandomState(77)
+    starts = np.stack([rng.uniform(-12, 12, n), rng.uniform(-12, 12, n), rng.uniform(-3.1, 3.1, n)], 1)
+    sims = [O.OracleSim(ocfg, 300 + i, 300 + i, start=tuple(starts[i])) for i in range(n)]
+    eng.reset(np.arange(n), 300 + np.arange(n), starts=starts)
+    menu = [(2.0, 0.0, 0.0), (1.3, 0.0, 0.0), (0.0, 0.0, 0.9), (0.0, 0.0, -1.4), (0.6, 0.0, 0.3), (1.0, 1.0, math.pi / 2)]
+    for s in range(25):
+        pick = rng.randint(0, len(menu), n)
+        pick[rng.rand(n) < 0.5] = 0
+        acts = np.array([menu[k] for k in pick])
+        eng.step(torch.tensor(acts, dtype=torch.float64, device=eng.device))
+        for i, sim in enumerate(sims):
+            sim.simulate(tuple(acts[i]))
+    assert eng.status() == 0
+    cand_env, goals = [], []
+    for i in range(n):
+        xyt, _ = sims[i].poses()
+        for _ in range(4):
+            r, th = rng.uniform(1.0, 13.0), rng.uniform(-math.pi, math.pi)
+            cand_env.append(i)
+            goals.append((xyt[-1, 0] + r * math.cos(th), xyt[-1, 1] + r * math.sin(th)))
+    ce = torch.tensor(cand_env, dtype=torch.int32, device=eng.device)
+    gl = torch.tensor(goals, dtype=torch.float64, device=eng.device)
+    actions, n_act = eng.line_plan(ce, gl)
+    acts_h, n_h = actions.cpu().numpy(), n_act.cpu().numpy()
+    rewards = eng.lookahead(ce, actions, n_act, max_n_actions=int(n_h.max())).cpu().numpy()
+    assert eng.status() == 0
+    for c, (i, g) in enumerate(zip(cand_env, goals)):
+        oa = sims[i].line_plan(g)
+        assert n_h[c] == len(oa)
+        np.testing.assert_allclose(acts_h[c, :len(oa)], oa, atol=1e-9)
+        assert rewards[c] == pytest.approx(sims[i].simulations_reward(acts_h[c, :n_h[c]]), abs=1e-6), (c, i, n_h[c])
+    eng.close()
+
+
 def test_snapshot_restore_roundtrip():
     n = 3
     eng, cfg = make_engine(n)
