@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <vector>
 #include <cmath>
+using namespace kslam;
 
 __global__ void k_inv16(const double *Din, double *Eout, long long *cyc, int np, int reps) {
   __shared__ int bad[2];
