@@ -23,7 +23,7 @@ def lib_path():
 # every symbol declared in include/drlgx.h
 SYMBOLS = [
     "drlgx_create", "drlgx_destroy", "drlgx_set_stream", "drlgx_synchronize", "drlgx_strerror", "drlgx_last_error",
-    "drlgx_status_host", "drlgx_reset_host", "drlgx_step", "drlgx_utility", "drlgx_uncertainty_em", "drlgx_explored",
+    "drlgx_status_host", "drlgx_reset_host", "drlgx_step", "drlgx_utility", "drlgx_uncertainty_em", "drlgx_explored", "drlgx_metrics", "drlgx_cov_array",
     "drlgx_line_plan", "drlgx_lookahead", "drlgx_lookahead_bounded", "drlgx_graph_capacity", "drlgx_graph", "drlgx_get_counts_host", "drlgx_counts",
     "drlgx_get_poses_host", "drlgx_get_landmarks_host", "drlgx_get_cov_traces_host", "drlgx_vm_shape",
     "drlgx_get_virtual_map_host", "drlgx_get_ground_truth_host", "drlgx_get_adjacency_host", "drlgx_get_factors_host",
@@ -60,6 +60,8 @@ def lib():
     L.drlgx_utility.argtypes = [vp, vp, vp]
     L.drlgx_uncertainty_em.argtypes = [vp, C.c_int, vp]
     L.drlgx_explored.argtypes = [vp, vp]
+    L.drlgx_metrics.argtypes = [vp, C.c_double, vp]
+    L.drlgx_cov_array.argtypes = [vp, vp, vp]
     L.drlgx_line_plan.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.drlgx_lookahead.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.drlgx_lookahead_bounded.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp]

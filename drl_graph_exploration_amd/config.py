@@ -34,8 +34,12 @@ def _rot2_theta(th):
 
 
 def default_config(map_size=40, num_landmarks=None, algorithm=0, max_poses=41, max_landmarks=None,
-                   max_factors=None, max_actions=24, max_snapshots=1):
-    """exploration_env.ini + ExplorationEnv.reset overrides + read_map_params(ext=20)."""
+                   max_factors=None, max_actions=None, max_snapshots=1):
+    """exploration_env.ini + ExplorationEnv.reset overrides + read_map_params(ext=20).
+
+    Capacities (engine-side, no counterpart in the reference): max_poses per trajectory (any value the LDS tables of
+    k_slam_arrow hold, a few hundred), max_landmarks <= 127, max_actions = the longest line plan the map can produce
+    (1-2 rotations + floor(d / max_edge_length) + 1 translations with d <= the diagonal of the vehicle's box)."""
     c = DrlgxConfig()
     c.bearing_noise = _rot2_theta(math.radians(0.5))
     c.range_noise = 0.02
@@ -64,8 +68,13 @@ def default_config(map_size=40, num_landmarks=None, algorithm=0, max_poses=41, m
     c.max_edge_length = 2.0
     c.algorithm = algorithm
     c.max_poses = max_poses
-    c.max_landmarks = max(1, min(c.num_landmarks, 128) if max_landmarks is None else max_landmarks)
+    c.max_landmarks = max(1, min(c.num_landmarks, 127) if max_landmarks is None else max_landmarks)
     c.max_factors = max_factors if max_factors is not None else max(64, 12 * max_poses)
+    if max_actions is None:
+        # start poses and frontiers lie in the padded box the start pose is drawn from / the unpadded box respectively
+        # (SURVEY.md App. C.2): the diagonal of the larger one bounds every plan
+        span = max(map_size, map_size / 2 + 20.0)
+        max_actions = int(math.ceil(math.hypot(span, span) / c.max_edge_length)) + 3
     c.max_actions = max_actions
     c.max_snapshots = max_snapshots
     return c

@@ -520,6 +520,15 @@ __device__ inline double rng_uniform_real(MtStream &s, double lo, double hi, int
   return (hi - lo) * mt_canonical(s, lane) + lo;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set it once per (call site, device)
+inline void drlgx_ensure_lds_attr(bool (&done)[32], const void *const *fns, int n, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+  if (done[dev]) return;
+  for (int i = 0; i < n; ++i) (void)hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done[dev] = true;
+}
+
 // ---- launchers implemented in the kernel translation units ------------------------------------
 struct DrlgxField;
 void drlgx_launch_reset(const DrlgxState &S, hipStream_t st, int n, const int32_t *env_ids_dev, const uint32_t *seeds_dev,
@@ -541,10 +550,13 @@ void drlgx_launch_fix_rollouts(const DrlgxState &S, hipStream_t st, int n_cand, 
 void drlgx_launch_rewards(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0,
                           double *rewards);
 void drlgx_launch_utility(const DrlgxState &S, hipStream_t st, const double *dist, double *out, int mode);
+void drlgx_launch_metrics(const DrlgxState &S, hipStream_t st, double sigma0, double *out);
+void drlgx_launch_cov_array(const DrlgxState &S, hipStream_t st, double *length, double *angle);
 void drlgx_launch_line_plan(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, const double *goal,
                             double *actions, int32_t *n_actions);
-size_t drlgx_slam_lds_bytes(int P_max, int L_max, int M_max);
-bool drlgx_slam_in_lds(int P_max, int L_max, int M_max);
+bool drlgx_slam_in_lds(int P_max, int L_max, int M_max);       // the fused LDS-resident kernel serves up to P_max poses
+bool drlgx_slam_capacity_ok(int P_max, int L_max, int M_max);  // capacities the SLAM kernels can serve at all
+size_t drlgx_slam_ws_doubles(int P_max, int L_max, int M_max);  // HBM workspace per instance (doubles)
 void drlgx_launch_graph(const DrlgxState &S, hipStream_t st, int *gi, int gi_stride, int32_t *node_off, int32_t *edge_off,
                         float *x, int64_t *edge_index, float *edge_attr, int32_t *n_frontier, double *frontier_xy,
                         int32_t *nearest_node, int max_frontier);

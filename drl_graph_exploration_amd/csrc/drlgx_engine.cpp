@@ -61,6 +61,12 @@ struct drlgx_engine {
   std::string last_error;
 };
 
+// every entry point makes the engine's device current (a process may drive several engines on several devices)
+#define DRLGX_ENTER(e)                          \
+  do {                                          \
+    if (e) (void)hipSetDevice((e)->device);     \
+  } while (0)
+
 namespace {
 
 template <typename T>
@@ -144,8 +150,10 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   if (cfg->max_poses < 2 || cfg->max_landmarks < 1 || cfg->max_factors < 1 || cfg->num_landmarks < 0 ||
       cfg->max_actions < 1 || cfg->num_samples < 1 || !(cfg->resolution > 0))
     return DRLGX_E_INVALID;
-  // kernel limits: per-landmark pose masks of 128 bits (k_slam); 16-bit pose / landmark / factor indices in LDS tables
-  if (cfg->max_poses > 127 || cfg->max_landmarks > 65535 || cfg->max_factors > 65535) return DRLGX_E_INVALID;
+  // kernel limits: 16-bit pose / landmark / factor indices in LDS tables; the landmark system of k_slam_arrow (<= 127
+  // landmarks) and its per-pose tables must fit the LDS
+  if (cfg->max_poses > 65535 || cfg->max_landmarks > 65535 || cfg->max_factors > 65534) return DRLGX_E_INVALID;
+  if (!drlgx_slam_capacity_ok(cfg->max_poses, cfg->max_landmarks, cfg->max_factors)) return DRLGX_E_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DRLGX_E_NODEVICE;
   drlgx_engine *e = new drlgx_engine();
@@ -338,11 +346,8 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   TRY(field_alloc(e, &S.gt_lm, (size_t)S.LG * 2, 2));  // rollouts read their parent's landmarks
   // SLAM workspace (not copied between instances)
   {
-    // k_slam overflow workspace: per-factor G (6) + partials (4) + the landmark x pose table, and — only when
-    // the dense system does not fit the 160 KB LDS — the padded (3P+4)^2 system and its 3-column panel
-    const bool lds = drlgx_slam_in_lds(S.P_max, S.L_max, S.M_max);
-    const size_t nd = 3 * P + 16;  // >= 16 * ceil((3P + 1) / 16)
-    S.slam_ws_stride = M * 12 + (L * P * 2 + 7) / 8 + 16 + (lds ? 0 : nd * nd);
+    // k_slam workspace (k_slam.hip: drlgx_slam_ws_doubles)
+    S.slam_ws_stride = drlgx_slam_ws_doubles(S.P_max, S.L_max, S.M_max);
     S.slam_iws_stride = 2;
     TRY(dev_alloc(e, &S.slam_ws, S.slam_ws_stride * (size_t)S.n_inst));
     TRY(dev_alloc(e, &S.slam_iws, S.slam_iws_stride * (size_t)S.n_inst));
@@ -366,6 +371,7 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
 }
 
 int drlgx_destroy(drlgx_engine *e) {
+  DRLGX_ENTER(e);
   if (!e) return DRLGX_E_INVALID;
   hipSetDevice(e->device);
   hipDeviceSynchronize();
@@ -381,13 +387,17 @@ int drlgx_destroy(drlgx_engine *e) {
 }
 
 int drlgx_set_stream(drlgx_engine *e, void *hip_stream) {
+  DRLGX_ENTER(e);
   if (!e) return DRLGX_E_INVALID;
-  hipStreamSynchronize(e->stream);
-  e->stream = (hip_stream == reinterpret_cast<void *>(-1)) ? e->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
+  hipStream_t s = (hip_stream == reinterpret_cast<void *>(-1)) ? e->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
+  if (s == e->stream) return DRLGX_OK;  // cheap when nothing changes: callers re-bind before every call
+  hipStreamSynchronize(e->stream);      // work already queued on the old stream is ordered before the new one's
+  e->stream = s;
   return DRLGX_OK;
 }
 
 int drlgx_synchronize(drlgx_engine *e) {
+  DRLGX_ENTER(e);
   if (!e) return DRLGX_E_INVALID;
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return DRLGX_OK;
@@ -401,6 +411,7 @@ static int max_bound(const drlgx_engine *e) {
 }
 
 int drlgx_status_host(drlgx_engine *e) {
+  DRLGX_ENTER(e);
   if (!e) return DRLGX_E_INVALID;
   int st = 0;
   // the same synchronisation refreshes the host's pose-count bounds with the exact device values
@@ -414,6 +425,7 @@ int drlgx_status_host(drlgx_engine *e) {
 }
 
 int drlgx_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint32_t *seeds, const double *start) {
+  DRLGX_ENTER(e);
   if (!e || n <= 0 || n > e->S.n_envs || !env_ids || !seeds || !start) return DRLGX_E_INVALID;
   std::vector<uint8_t> mask(e->S.n_envs, 0);
   for (int i = 0; i < n; ++i) {
@@ -439,6 +451,7 @@ int drlgx_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint3
 }
 
 int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_dev) {
+  DRLGX_ENTER(e);
   if (!e || !odom_dev) return DRLGX_E_INVALID;
   LaunchSel sel{0, e->S.n_envs, active_dev, nullptr, 0};
   const int pb = std::min(max_bound(e) + 1, e->S.P_max);
@@ -468,23 +481,40 @@ int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_de
 }
 
 int drlgx_utility(drlgx_engine *e, const double *dist_dev, double *out_dev) {
+  DRLGX_ENTER(e);
   if (!e || !out_dev) return DRLGX_E_INVALID;
   drlgx_launch_utility(e->S, e->stream, dist_dev, out_dev, 0);
   return check_launch(e);
 }
 int drlgx_uncertainty_em(drlgx_engine *e, int algorithm, double *out_dev) {
+  DRLGX_ENTER(e);
   if (!e || !out_dev || (algorithm != DRLGX_ALG_EM_AOPT && algorithm != DRLGX_ALG_EM_DOPT)) return DRLGX_E_INVALID;
   drlgx_launch_utility(e->S, e->stream, nullptr, out_dev, algorithm == DRLGX_ALG_EM_DOPT ? 3 : 2);
   return check_launch(e);
 }
 int drlgx_explored(drlgx_engine *e, double *out_dev) {
+  DRLGX_ENTER(e);
   if (!e || !out_dev) return DRLGX_E_INVALID;
   drlgx_launch_utility(e->S, e->stream, nullptr, out_dev, 1);
   return check_launch(e);
 }
 
+int drlgx_metrics(drlgx_engine *e, double sigma0, double *out_dev) {
+  DRLGX_ENTER(e);
+  if (!e || !out_dev) return DRLGX_E_INVALID;
+  drlgx_launch_metrics(e->S, e->stream, sigma0, out_dev);
+  return check_launch(e);
+}
+int drlgx_cov_array(drlgx_engine *e, double *length_dev, double *angle_dev) {
+  DRLGX_ENTER(e);
+  if (!e || !length_dev || !angle_dev) return DRLGX_E_INVALID;
+  drlgx_launch_cov_array(e->S, e->stream, length_dev, angle_dev);
+  return check_launch(e);
+}
+
 int drlgx_line_plan(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *goal_dev,
                     double *actions_dev, int32_t *n_actions_dev) {
+  DRLGX_ENTER(e);
   if (!e || n_cand < 0 || !cand_env_dev || !goal_dev || !actions_dev || !n_actions_dev) return DRLGX_E_INVALID;
   if (n_cand == 0) return DRLGX_OK;
   drlgx_launch_line_plan(e->S, e->stream, n_cand, cand_env_dev, goal_dev, actions_dev, n_actions_dev);
@@ -493,12 +523,14 @@ int drlgx_line_plan(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
 
 int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *actions_dev,
                     const int32_t *n_actions_dev, double *rewards_dev) {
+  DRLGX_ENTER(e);
   if (!e) return DRLGX_E_INVALID;
   return drlgx_lookahead_bounded(e, n_cand, cand_env_dev, actions_dev, n_actions_dev, e->S.A_max, rewards_dev);
 }
 
 int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *actions_dev,
                             const int32_t *n_actions_dev, int max_n_actions, double *rewards_dev) {
+  DRLGX_ENTER(e);
   if (!e || n_cand < 0 || !cand_env_dev || !actions_dev || !n_actions_dev || !rewards_dev || max_n_actions < 1 ||
       max_n_actions > e->S.A_max)
     return DRLGX_E_INVALID;
@@ -567,6 +599,7 @@ int drlgx_graph_capacity(const drlgx_engine *e, int *max_nodes, int *max_edges, 
 
 int drlgx_graph(drlgx_engine *e, int32_t *node_off_dev, int32_t *edge_off_dev, float *x_dev, int64_t *edge_index_dev,
                 float *edge_attr_dev, int32_t *n_frontier_dev, double *frontier_xy_dev, int32_t *nearest_frontier_node_dev) {
+  DRLGX_ENTER(e);
   if (!e || !node_off_dev || !edge_off_dev || !x_dev || !edge_index_dev || !edge_attr_dev || !n_frontier_dev ||
       !frontier_xy_dev || !nearest_frontier_node_dev)
     return DRLGX_E_INVALID;
@@ -584,6 +617,7 @@ static int fetch(drlgx_engine *e, void *dst, const void *src, size_t bytes) {
 #define INST_OK(e, inst) ((e) && (inst) >= 0 && (inst) < (e)->S.n_inst)
 
 int drlgx_get_counts_host(drlgx_engine *e, int inst, int32_t out[5]) {
+  DRLGX_ENTER(e);
   if (!INST_OK(e, inst) || !out) return DRLGX_E_INVALID;
   int c[DRLGX_CNT_STRIDE];
   int r = fetch(e, c, e->S.cnt + (size_t)inst * DRLGX_CNT_STRIDE, sizeof(c));
@@ -594,6 +628,7 @@ int drlgx_get_counts_host(drlgx_engine *e, int inst, int32_t out[5]) {
 }
 
 int drlgx_counts(drlgx_engine *e, int32_t *counts_dev) {
+  DRLGX_ENTER(e);
   if (!e || !counts_dev) return DRLGX_E_INVALID;
   HIPCHK(e, hipMemcpy2DAsync(counts_dev, 5 * sizeof(int32_t), e->S.cnt, DRLGX_CNT_STRIDE * sizeof(int32_t), 5 * sizeof(int32_t),
                              (size_t)e->S.n_envs, hipMemcpyDeviceToDevice, e->stream));
@@ -601,6 +636,7 @@ int drlgx_counts(drlgx_engine *e, int32_t *counts_dev) {
 }
 
 int drlgx_get_poses_host(drlgx_engine *e, int inst, double *xytheta, double *information) {
+  DRLGX_ENTER(e);
   int32_t c[5];
   int r = drlgx_get_counts_host(e, inst, c);
   if (r) return r;
@@ -640,6 +676,7 @@ static int sorted_slots(drlgx_engine *e, int inst, int L, std::vector<int> &keys
 }
 
 int drlgx_get_landmarks_host(drlgx_engine *e, int inst, int32_t *keys, double *xy, double *information) {
+  DRLGX_ENTER(e);
   int32_t c[5];
   int r = drlgx_get_counts_host(e, inst, c);
   if (r) return r;
@@ -669,6 +706,7 @@ int drlgx_get_landmarks_host(drlgx_engine *e, int inst, int32_t *keys, double *x
 }
 
 int drlgx_get_cov_traces_host(drlgx_engine *e, int inst, double *lm_trace, double *pose_trace) {
+  DRLGX_ENTER(e);
   int32_t c[5];
   int r = drlgx_get_counts_host(e, inst, c);
   if (r) return r;
@@ -696,6 +734,7 @@ int drlgx_vm_shape(const drlgx_engine *e, int *rows, int *cols) {
 
 int drlgx_get_virtual_map_host(drlgx_engine *e, int inst, double *prob, double *info, double *cov_trace,
                                uint8_t *updated) {
+  DRLGX_ENTER(e);
   if (!INST_OK(e, inst)) return DRLGX_E_INVALID;
   const DrlgxState &S = e->S;
   const size_t V = S.V;
@@ -715,6 +754,7 @@ int drlgx_get_virtual_map_host(drlgx_engine *e, int inst, double *prob, double *
 }
 
 int drlgx_get_ground_truth_host(drlgx_engine *e, int inst, double *vehicle_xytheta, double *landmarks_xy) {
+  DRLGX_ENTER(e);
   if (!INST_OK(e, inst)) return DRLGX_E_INVALID;
   const DrlgxState &S = e->S;
   double gp[4];
@@ -735,6 +775,7 @@ int drlgx_get_ground_truth_host(drlgx_engine *e, int inst, double *vehicle_xythe
 }
 
 int drlgx_get_factors_host(drlgx_engine *e, int inst, int32_t *pose, int32_t *key, double *bearing, double *range) {
+  DRLGX_ENTER(e);
   int32_t c[5];
   int r = drlgx_get_counts_host(e, inst, c);
   if (r) return r;
@@ -758,6 +799,7 @@ int drlgx_get_factors_host(drlgx_engine *e, int inst, int32_t *pose, int32_t *ke
 
 // SLAM2D::adjacency_degree_get (SLAM2D.cpp:198-273) assembled from the exported factor list.
 int drlgx_get_adjacency_host(drlgx_engine *e, int inst, double *adjacency, double *features) {
+  DRLGX_ENTER(e);
   int32_t c[5];
   int r = drlgx_get_counts_host(e, inst, c);
   if (r) return r;
@@ -807,6 +849,7 @@ int drlgx_get_landmark_order_host(const drlgx_engine *e, int32_t *order) {
 // ---- snapshots ---------------------------------------------------------------------------------
 // Snapshots are extra instances in the same HBM arrays: one copy kernel moves every field.
 int drlgx_snapshot(drlgx_engine *e, int slot) {
+  DRLGX_ENTER(e);
   if (!e || slot < 0 || slot >= e->S.cfg.max_snapshots) return DRLGX_E_INVALID;
   const DrlgxState &S = e->S;
   ScopedTimer t(e, 3);
@@ -817,6 +860,7 @@ int drlgx_snapshot(drlgx_engine *e, int slot) {
 }
 
 int drlgx_restore(drlgx_engine *e, int slot) {
+  DRLGX_ENTER(e);
   if (!e || slot < 0 || slot >= e->S.cfg.max_snapshots) return DRLGX_E_INVALID;
   const DrlgxState &S = e->S;
   ScopedTimer t(e, 3);
@@ -828,6 +872,7 @@ int drlgx_restore(drlgx_engine *e, int slot) {
 
 // ---- development aid: in-kernel phase stamps of block 0 ------------------------------------------
 int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]) {
+  DRLGX_ENTER(e);
   if (!e) return DRLGX_E_INVALID;
   HIPCHK(e, hipStreamSynchronize(e->stream));
   if (out && e->S.prof) HIPCHK(e, hipMemcpy(out, e->S.prof, 64 * sizeof(long long), hipMemcpyDeviceToHost));
@@ -845,6 +890,7 @@ int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]) {
 
 // ---- timing ------------------------------------------------------------------------------------
 int drlgx_timing_enable(drlgx_engine *e, int on) {
+  DRLGX_ENTER(e);
   if (!e) return DRLGX_E_INVALID;
   e->timing = on != 0;
   e->per_stage = on == 2;
@@ -852,6 +898,7 @@ int drlgx_timing_enable(drlgx_engine *e, int on) {
 }
 
 int drlgx_timing_read_host(drlgx_engine *e, double ms[DRLGX_N_TIMERS], int64_t launches[DRLGX_N_TIMERS]) {
+  DRLGX_ENTER(e);
   if (!e) return DRLGX_E_INVALID;
   HIPCHK(e, hipStreamSynchronize(e->stream));
   for (auto &sp : e->spans) {

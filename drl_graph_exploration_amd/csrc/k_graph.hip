@@ -385,12 +385,9 @@ void drlgx_launch_graph(const DrlgxState &S, hipStream_t st, int *gi, int gi_str
   GraphBufs G{gi, gi_stride};
   const size_t lds_a = ((S.V + 15) & ~15) + (size_t)(kT + 4) * 4 + (size_t)((S.V + 3) & ~3) * 2 + (size_t)(S.L_max + 2) * 4;
   const size_t lds_c = (((size_t)S.L_max * S.P_max * 2 + 15) & ~(size_t)15) + (size_t)(2 * S.L_max + S.P_max + 4) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_graph_build), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_graph_emit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static bool attr_set[32] = {false};
+  const void *fns[] = {reinterpret_cast<const void *>(&k_graph_build), reinterpret_cast<const void *>(&k_graph_emit)};
+  drlgx_ensure_lds_attr(attr_set, fns, 2, 160 * 1024);
   hipLaunchKernelGGL(k_graph_build, dim3(S.n_envs), dim3(kT), lds_a, st, S, G);
   hipLaunchKernelGGL(k_graph_scan, dim3(1), dim3(1024), 0, st, S, G, node_off, edge_off);
   hipLaunchKernelGGL(k_graph_emit, dim3(S.n_envs), dim3(kT), lds_c, st, S, G, node_off, edge_off, x, edge_index, edge_attr,

@@ -486,10 +486,8 @@ void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
   }
   int chunk = 0;
   const size_t lds = drlgx_map_lds_bytes(S, &chunk);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmap::k_map), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static bool attr_set[32] = {false};
+  const void *fns[] = {reinterpret_cast<const void *>(&kmap::k_map)};
+  drlgx_ensure_lds_attr(attr_set, fns, 1, 160 * 1024);
   hipLaunchKernelGGL(kmap::k_map, dim3(sel.n), dim3(kmap::kThreads), lds, st, S, sel, rebuild, chunk);
 }

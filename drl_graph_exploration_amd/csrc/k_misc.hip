@@ -154,8 +154,79 @@ __global__ void k_line_plan(DrlgxState S, int n_cand, const int32_t *cand_env, c
   if (n > S.A_max) atomicMin(S.status, DRLGX_E_CAPACITY);
 }
 
+// The metric trio of the reference's evaluation script, one 256-thread workgroup per environment:
+//   out[3 e + 0] landmark error   (exploration_env.py:170-177): (sum_j |gt[key_j] - est_j| + sigma0 (n_gt - L)) / n_gt
+//   out[3 e + 1] map entropy      (scripts/test.py:61-74): -sum_v p ln p + 0.5 ln(0.5) (V - interior cells)
+//   out[3 e + 2] max localisation uncertainty (exploration_env.py:190-194): max over the poses of tr(marginal covariance)
+__global__ __launch_bounds__(256) void k_metrics(DrlgxState S, double sigma0, double *out) {
+  __shared__ double red[3][4];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const int *cnt = S.cnt + (size_t)e * DRLGX_CNT_STRIDE;
+  const int P = cnt[C_P], L = cnt[C_L];
+  const double *gt = S.gt_lm + (size_t)S.parent[e] * S.LG * 2;
+  const double *el = S.est_lm + (size_t)e * S.L_max * 2;
+  const int *key = S.lm_key + (size_t)e * S.L_max;
+  double err = 0, ent = 0, mx = 0;
+  for (int j = tid; j < L; j += 256) {
+    const double dx = gt[2 * key[j]] - el[2 * j], dy = gt[2 * key[j] + 1] - el[2 * j + 1];
+    err += sqrt(dx * dx + dy * dy);
+  }
+  const double *prob = S.vm_prob + (size_t)e * S.V;
+  for (int v = tid; v < S.V; v += 256) ent += prob[v] * log(prob[v]);
+  const double *ptr = S.pose_tr + (size_t)e * S.P_max;
+  for (int i = tid; i < P; i += 256) mx = fmax(mx, ptr[i]);
+  for (int o = 32; o > 0; o >>= 1) {
+    err += __shfl_down(err, o);
+    ent += __shfl_down(ent, o);
+    mx = fmax(mx, __shfl_down(mx, o));
+  }
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = err;
+    red[1][tid >> 6] = ent;
+    red[2][tid >> 6] = mx;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int n_gt = S.cfg.num_landmarks;
+    const double es = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const double hs = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    out[3 * e] = (es + sigma0 * (n_gt - L)) / n_gt;
+    out[3 * e + 1] = -hs + 0.5 * log(0.5) * (double)(S.V - S.count_explored);
+    out[3 * e + 2] = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
+  }
+}
+
+// VirtualMap::toCovArray (VirtualMap.cpp:140-151): per cell the larger eigenvalue of the 2x2 covariance (its square
+// root clipped at sigma0) and the direction of its eigenvector.  Eigen's SelfAdjointEigenSolver returns a rotation
+// (cos > 0) with the columns sorted by eigenvalue, so the eigenvector's sign is fixed by: x component > 0 when the
+// larger eigenvalue belongs to the first axis, y component > 0 otherwise (recalled from Eigen; used for rendering only).
+__global__ __launch_bounds__(256) void k_cov_array(DrlgxState S, double *length, double *angle) {
+  const int e = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= S.V) return;
+  const double *inf = S.vm_info + (size_t)e * 3 * S.V;
+  double a, b, d;
+  inv2_llt_s(inf[v], inf[S.V + v], inf[2 * S.V + v], a, b, d);  // covariance()
+  const double half = 0.5 * (a - d), r = sqrt(half * half + b * b);
+  const double lmax = 0.5 * (a + d) + r;
+  double vx, vy;
+  if (a >= d) {  // (lmax - d, b) is parallel to the eigenvector and its x component is >= 0
+    vx = half + r; vy = b;
+    if (vx == 0.0 && vy == 0.0) { vx = 1.0; vy = 0.0; }
+  } else {       // (b, lmax - a): y component >= 0
+    vx = b; vy = r - half;
+  }
+  length[(size_t)e * S.V + v] = fmin(sqrt(lmax), S.cfg.sigma0);
+  angle[(size_t)e * S.V + v] = atan2(vy, vx);
+}
+
 }  // namespace
 
+void drlgx_launch_metrics(const DrlgxState &S, hipStream_t st, double sigma0, double *out) {
+  hipLaunchKernelGGL(k_metrics, dim3(S.n_envs), dim3(256), 0, st, S, sigma0, out);
+}
+void drlgx_launch_cov_array(const DrlgxState &S, hipStream_t st, double *length, double *angle) {
+  hipLaunchKernelGGL(k_cov_array, dim3((S.V + 255) / 256, S.n_envs), dim3(256), 0, st, S, length, angle);
+}
 void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
                        const int32_t *dst, int src_off, int dst_off, int skip_mask) {
   hipLaunchKernelGGL(k_copy_instances, dim3(n, n_fields), dim3(256), 0, st, fields_dev, n_fields, src, dst, src_off,

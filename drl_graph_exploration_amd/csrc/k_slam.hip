@@ -321,9 +321,9 @@ __device__ __forceinline__ void sweep16_all(const SweepCtx &x, const Sw16 &L, v4
   }
 }
 
-// iterate the poses p (ascending) whose bit is set in the two-word mask at `mk`
-#define FOR_EACH_OBSERVING_POSE(mk, p)                                         \
-  for (int _w = 0; _w < 2; ++_w)                                              \
+// iterate the poses p (ascending) whose bit is set in the W-word mask at `mk`
+#define FOR_EACH_OBSERVING_POSE(mk, W, p)                                      \
+  for (int _w = 0; _w < (W); ++_w)                                            \
     for (unsigned long long _m = (mk)[_w]; _m; _m &= _m - 1)                  \
       if (const int p = 64 * _w + __ffsll((long long)_m) - 1; true)
 
@@ -411,294 +411,83 @@ __device__ __forceinline__ void pivot_inverse_from(int np, int q0i, const double
       }
 }
 
-template <bool kLds, int NTW, int FT>
-__device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &sel, int lds_bytes) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int tid = threadIdx.x;
-  const int bi = blockIdx.x;
-  if (!sel.on(bi)) return;
-  const int inst = sel.base + bi;
-  int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
-  if (cnt[C_FLAG]) return;
+// Pose i's diagonal block B (3x3, full) and gradient g of the prior / odometry / own bearing-range factors linearised at
+// thp, and - for i + 1 < P - the block O = (i + 1, i) of the odometry factor i (SLAM2D.cpp:44-89; records: linearize_br)
+__device__ __forceinline__ void pose_block(const DrlgxState &S, int inst, const double *thp, const double *rec, const int *mstart,
+                                           int i, int P, double wb, double wr, double *B, double *g, double *O) {
   const drlgx_config &cfg = S.cfg;
-  const int P = cnt[C_P], L = cnt[C_L], M = cnt[C_M];
-  const int n_old_p = cnt[C_NEWP], n_old_l = cnt[C_NEWL];
-  const int count = cnt[C_ISAM] + 1;
-  const int np = 3 * P, na = np + 1;
-  // padded to 16x16 MFMA tiles; row np holds the rhs (its column and all pad rows / columns stay zero).  Only the lower
-  // triangle is ever addressed: the fast path packs it (row i at i (i + 1) / 2: half the LDS of the square, which keeps
-  // the factor records on chip for ~700 factors instead of ~230), the workspace variants keep the square
-  const int Tn = (na + 15) / 16, N = 16 * Tn, ld = N;
-  constexpr bool kPacked = FT > 0 || (kLds && FT < 0);  // LDS-resident system: packed lower triangle
-  auto AT = [&](int i, int j) -> int { return kPacked ? i * (i + 1) / 2 + j : i * ld + j; };
-  // (the LDS-resident variants reuse the matrix region for their sweep panels while the tiles are in registers)
-  const size_t a_doubles = FT > 0   ? max((size_t)N * (N + 1) / 2, (size_t)48 * N + 1280)
-                           : kPacked ? max((size_t)N * (N + 1) / 2, (size_t)32 * N + 1280)
-                                     : (size_t)N * ld;
-  const int ntiles = Tn * (Tn + 1) / 2;
-  if ((FT > 0 && Tn > FT) || (FT == 0 && NTW > 0 && ntiles > NTW * kWaves) || (FT < 0 && ntiles > NTW * (kWaves - 1))) {
-    // more poses than this variant was launched for (the host's bound was wrong): flag it, touch nothing
-    if (tid == 0) atomicMin(S.status, DRLGX_E_CAPACITY);
-    return;
-  }
-  DRLGX_PROF(S, 0);
-
-  // ---- LDS carve: small arrays first, then the dense system; overflow goes to the HBM workspace ----
-  size_t off = 0;
-  double *thp = reinterpret_cast<double *>(smem_raw + off); off += up8((size_t)P * 4 * 8);
-  double *thl = reinterpret_cast<double *>(smem_raw + off); off += up8((size_t)L * 2 * 8);
-  double *lamb = reinterpret_cast<double *>(smem_raw + off); off += up8((size_t)L * 8 * 8);
-  int *mstart = reinterpret_cast<int *>(smem_raw + off); off += up8((size_t)(P + 2) * 4);
-  unsigned short *mp = reinterpret_cast<unsigned short *>(smem_raw + off); off += up8((size_t)M * 2);
-  unsigned short *ml = reinterpret_cast<unsigned short *>(smem_raw + off); off += up8((size_t)M * 2);
-  int *bad = reinterpret_cast<int *>(smem_raw + off); off += 8;
-  // poses observing each landmark as bit masks (P <= 128): the per-landmark loops visit only those poses
-  unsigned long long *lmask = reinterpret_cast<unsigned long long *>(smem_raw + off); off += (size_t)L * 16;
-  off = (off + 31) & ~(size_t)31;
-  // sweep panels of the workspace variants (the fast path keeps its panels in the dead matrix region)
-  double *Vb = reinterpret_cast<double *>(smem_raw + off);
-  off += (size_t)(kPacked ? 0 : FT < 0 ? 32 * N + 1280 : NTW < 0 ? 32 * N + 256 : 2 * (8 * N + 32)) * 8;
-  double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
-  double *A;
-  if (kLds) {
-    // (the fast path reuses this region for its sweep panels: 48 N + 1280 doubles)
-    A = reinterpret_cast<double *>(smem_raw + off); off += a_doubles * 8;
-  } else {
-    A = wsd; wsd += (size_t)(3 * S.P_max + 16) * (3 * S.P_max + 16);
-  }
-  // per-factor records and the landmark x pose observation table: LDS if they fit
-  const size_t big = (size_t)M * REC * 8 + up8((size_t)L * P * 2);
-  double *rec;
-  unsigned short *obs;
-  if (off + big <= (size_t)lds_bytes) {
-    rec = reinterpret_cast<double *>(smem_raw + off); off += (size_t)M * REC * 8;
-    obs = reinterpret_cast<unsigned short *>(smem_raw + off);
-  } else {
-    rec = wsd; wsd += (size_t)S.M_max * REC;
-    obs = reinterpret_cast<unsigned short *>(wsd);
-  }
-  double *th_pose = S.th_pose + (size_t)inst * S.P_max * 4;
-  double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
-  double *th_lm = S.th_lm + (size_t)inst * S.L_max * 2;
-  double *d_lm = S.d_lm + (size_t)inst * S.L_max * 2;
-  const int *meas_pose = S.meas_pose + (size_t)inst * S.M_max;
-  const int *meas_lm = S.meas_lm + (size_t)inst * S.M_max;
-  const double *meas_br = S.meas_br + (size_t)inst * S.M_max * 2;
-
-  // ---- 1. relinearisation policy (gtsam ISAM2: relinearizeSkip 10, relinearizeThreshold 0.1);
-  //         theta (+ folded delta) is staged in LDS ----
-  const bool relin = (count % 10 == 0);
-  for (int i = tid; i < P; i += kThreads) {
-    Pose t{th_pose[4 * i], th_pose[4 * i + 1], th_pose[4 * i + 2], th_pose[4 * i + 3]};
-    if (relin && i < n_old_p) {
-      const double a = fabs(d_pose[3 * i]), b = fabs(d_pose[3 * i + 1]), c = fabs(d_pose[3 * i + 2]);
-      if (fmax(a, fmax(b, c)) >= 0.1) {
-        t = compose(t, make_pose(d_pose[3 * i], d_pose[3 * i + 1], d_pose[3 * i + 2]));
-        th_pose[4 * i] = t.x; th_pose[4 * i + 1] = t.y; th_pose[4 * i + 2] = t.c; th_pose[4 * i + 3] = t.s;
-      }
-    }
-    thp[4 * i] = t.x; thp[4 * i + 1] = t.y; thp[4 * i + 2] = t.c; thp[4 * i + 3] = t.s;
-  }
-  for (int j = tid; j < L; j += kThreads) {
-    double x = th_lm[2 * j], y = th_lm[2 * j + 1];
-    if (relin && j < n_old_l && fmax(fabs(d_lm[2 * j]), fabs(d_lm[2 * j + 1])) >= 0.1) {
-      x += d_lm[2 * j];
-      y += d_lm[2 * j + 1];
-      th_lm[2 * j] = x;
-      th_lm[2 * j + 1] = y;
-    }
-    thl[2 * j] = x;
-    thl[2 * j + 1] = y;
-  }
-  // ---- 2. clear the system; factor tables (factors are appended in pose order: contiguous ranges) ----
-  {
-    double2 *A2 = reinterpret_cast<double2 *>(A);
-    const int n2 = (int)((kPacked ? (size_t)N * (N + 1) / 2 : (size_t)N * ld) / 2);  // (N is a multiple of 16: even)
-    for (int e = tid; e < n2; e += kThreads) A2[e] = make_double2(0.0, 0.0);
-  }
-  for (int e = tid; e < L * P; e += kThreads) obs[e] = 0;
-  for (int e = tid; e < 2 * L; e += kThreads) lmask[e] = 0ull;
-  for (int e = tid; e <= P; e += kThreads) mstart[e] = M;
-  if (tid == 0) bad[0] = 0;
-  __syncthreads();
-  // one thread per factor: tables + the (expensive) linearisation, once
-  for (int m = tid; m < M; m += kThreads) {
-    const int p = meas_pose[m], j = meas_lm[m];
-    mp[m] = (unsigned short)p;
-    ml[m] = (unsigned short)j;
-    if (m == 0 || meas_pose[m - 1] != p) mstart[p] = m;
-    obs[j * P + p] = (unsigned short)(m + 1);
-    atomicOr(&lmask[2 * j + (p >> 6)], 1ull << (p & 63));
-    linearize_br(thp + 4 * p, thl + 2 * j, meas_br[2 * m], meas_br[2 * m + 1], rec + (size_t)REC * m);
-  }
-  __syncthreads();
-  {
-    // poses without factors get the empty range [next pose's start, same): first assigned start at or after p
-    int v = M;
-    if (tid < P) {
-      int q = tid;
-      v = mstart[q];
-      while (v == M && q < P) v = mstart[++q];  // mstart[P] = M
-    }
-    __syncthreads();
-    if (tid < P) mstart[tid] = v;
-  }
-  __syncthreads();
-  DRLGX_PROF(S, 1);
-  // ---- 3. block assembly.  first waves: one thread per landmark; following waves: one thread per pose ----
-  const double wb = 1.0 / (cfg.bearing_noise * cfg.bearing_noise), wr = 1.0 / (cfg.range_noise * cfg.range_noise);
-  const int pose_t0 = ((L + 63) & ~63) % kThreads;  // poses start on a fresh wave so both roles overlap
-  for (int j = tid; j < L; j += kThreads) {
-    double a = 0, b = 0, d = 0, g0 = 0, g1 = 0;
-    FOR_EACH_OBSERVING_POSE(lmask + 2 * j, p) {
-      const int m1 = obs[j * P + p];
-      const double *r = rec + (size_t)REC * (m1 - 1);
-      a += r[6] * wb * r[6] + r[8] * wr * r[8];
-      b += r[6] * wb * r[7] + r[8] * wr * r[9];
-      d += r[7] * wb * r[7] + r[9] * wr * r[9];
-      g0 += r[6] * wb * r[10] + r[8] * wr * r[11];
-      g1 += r[7] * wb * r[10] + r[9] * wr * r[11];
-    }
-    const double id = 1.0 / (a * d - b * b);
-    double *lb = lamb + 8 * j;
-    lb[0] = a; lb[1] = b; lb[2] = d;
-    lb[3] = d * id; lb[4] = -b * id; lb[5] = a * id;  // Lambda_jj^-1
-    lb[6] = -g0; lb[7] = -g1;                           // eta_j
-  }
-  for (int i = (tid - pose_t0 + kThreads) % kThreads; i < P; i += kThreads) {
-    double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // A_ii (symmetric, full)
-    double g[3] = {0, 0, 0};
-    const Pose ti{thp[4 * i], thp[4 * i + 1], thp[4 * i + 2], thp[4 * i + 3]};
-    if (i == 0) {  // prior (SLAM2D.cpp:44-57): e = Local(prior, x0), J = diag(R_h^T, 1), W = information
-      const double *pr = S.prior + (size_t)inst * DRLGX_PRIOR_STRIDE;
-      const Pose h = between(Pose{pr[0], pr[1], pr[2], pr[3]}, ti, nullptr);
-      const double e[3] = {h.x, h.y, theta_of(h)};
-      const double J[9] = {h.c, h.s, 0, -h.s, h.c, 0, 0, 0, 1};
-      const double *W = pr + 4;
-      double WJ[9], We[3];
-      for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) WJ[r * 3 + c] = W[r * 3] * J[c] + W[r * 3 + 1] * J[3 + c] + W[r * 3 + 2] * J[6 + c];
-        We[r] = W[r * 3] * e[0] + W[r * 3 + 1] * e[1] + W[r * 3 + 2] * e[2];
-      }
-      for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) B[r * 3 + c] += J[r] * WJ[c] + J[3 + r] * WJ[3 + c] + J[6 + r] * WJ[6 + c];
-        g[r] += J[r] * We[0] + J[3 + r] * We[1] + J[6 + r] * We[2];
-      }
-    }
-    const double wo[3] = {1.0 / (cfg.translation_noise * cfg.translation_noise),
-                          1.0 / (cfg.translation_noise * cfg.translation_noise),
-                          1.0 / (cfg.rotation_noise * cfg.rotation_noise)};
-    if (i > 0) {  // odometry factor i-1 seen from its second key: J2 = Hlocal (SLAM2D.cpp:59-89)
-      const double *oo = S.odo + ((size_t)inst * S.P_max + (i - 1)) * 4;
-      const Pose tm{thp[4 * (i - 1)], thp[4 * (i - 1) + 1], thp[4 * (i - 1) + 2], thp[4 * (i - 1) + 3]};
-      const Pose hx = between(tm, ti, nullptr);
-      const Pose h = between(Pose{oo[0], oo[1], oo[2], oo[3]}, hx, nullptr);
-      const double e[3] = {h.x, h.y, theta_of(h)};
-      const double J2[9] = {h.c, h.s, 0, -h.s, h.c, 0, 0, 0, 1};
-      for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c)
-          B[r * 3 + c] += J2[r] * wo[0] * J2[c] + J2[3 + r] * wo[1] * J2[3 + c] + J2[6 + r] * wo[2] * J2[6 + c];
-        g[r] += J2[r] * wo[0] * e[0] + J2[3 + r] * wo[1] * e[1] + J2[6 + r] * wo[2] * e[2];
-      }
-    }
-    if (i + 1 < P) {  // odometry factor i from its first key: J1 = Hlocal * H1; also block (i+1, i) = J2^T W J1
-      const double *oo = S.odo + ((size_t)inst * S.P_max + i) * 4;
-      const Pose tn{thp[4 * (i + 1)], thp[4 * (i + 1) + 1], thp[4 * (i + 1) + 2], thp[4 * (i + 1) + 3]};
-      double H1[9];
-      const Pose hx = between(ti, tn, H1);
-      const Pose h = between(Pose{oo[0], oo[1], oo[2], oo[3]}, hx, nullptr);
-      const double e[3] = {h.x, h.y, theta_of(h)};
-      const double Hl[9] = {h.c, h.s, 0, -h.s, h.c, 0, 0, 0, 1};
-      double J1[9];
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) J1[r * 3 + c] = Hl[r * 3] * H1[c] + Hl[r * 3 + 1] * H1[3 + c] + Hl[r * 3 + 2] * H1[6 + c];
-      for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c)
-          B[r * 3 + c] += J1[r] * wo[0] * J1[c] + J1[3 + r] * wo[1] * J1[3 + c] + J1[6 + r] * wo[2] * J1[6 + c];
-        g[r] += J1[r] * wo[0] * e[0] + J1[3 + r] * wo[1] * e[1] + J1[6 + r] * wo[2] * e[2];
-      }
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c)
-          A[AT((3 * (i + 1) + r), 3 * i + c)] =
-              Hl[r] * wo[0] * J1[c] + Hl[3 + r] * wo[1] * J1[3 + c] + Hl[6 + r] * wo[2] * J1[6 + c];
-    }
-    for (int m = mstart[i]; m < mstart[i + 1]; ++m) {  // own bearing-range factors
-      const double *l = rec + (size_t)REC * m;
-      for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) B[r * 3 + c] += l[r] * wb * l[c] + l[3 + r] * wr * l[3 + c];
-        g[r] += l[r] * wb * l[10] + l[3 + r] * wr * l[11];
-      }
+  for (int k = 0; k < 9; ++k) B[k] = 0.0;
+  for (int k = 0; k < 3; ++k) g[k] = 0.0;
+  const Pose ti{thp[4 * i], thp[4 * i + 1], thp[4 * i + 2], thp[4 * i + 3]};
+  if (i == 0) {  // prior (SLAM2D.cpp:44-57): e = Local(prior, x0), J = diag(R_h^T, 1), W = information
+    const double *pr = S.prior + (size_t)inst * DRLGX_PRIOR_STRIDE;
+    const Pose h = between(Pose{pr[0], pr[1], pr[2], pr[3]}, ti, nullptr);
+    const double e[3] = {h.x, h.y, theta_of(h)};
+    const double J[9] = {h.c, h.s, 0, -h.s, h.c, 0, 0, 0, 1};
+    const double *W = pr + 4;
+    double WJ[9], We[3];
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) WJ[r * 3 + c] = W[r * 3] * J[c] + W[r * 3 + 1] * J[3 + c] + W[r * 3 + 2] * J[6 + c];
+      We[r] = W[r * 3] * e[0] + W[r * 3 + 1] * e[1] + W[r * 3 + 2] * e[2];
     }
     for (int r = 0; r < 3; ++r) {
-      for (int c = 0; c <= r; ++c) A[AT((3 * i + r), 3 * i + c)] = B[r * 3 + c];
-      A[AT(np, 3 * i + r)] = -g[r];  // rhs lives in the augmented row
+      for (int c = 0; c < 3; ++c) B[r * 3 + c] += J[r] * WJ[c] + J[3 + r] * WJ[3 + c] + J[6 + r] * WJ[6 + c];
+      g[r] += J[r] * We[0] + J[3 + r] * We[1] + J[6 + r] * We[2];
     }
   }
-  __syncthreads();
-  DRLGX_PROF(S, 2);
-  // ---- 4. landmark elimination: rec[0..5] <- G_m = Lambda_pl Lambda_ll^-1 (3x2) ----
-  for (int m = tid; m < M; m += kThreads) {
-    double *l = rec + (size_t)REC * m;
-    const double *lb = lamb + 8 * ml[m];
-    double g[6];
+  const double wo[3] = {1.0 / (cfg.translation_noise * cfg.translation_noise),
+                        1.0 / (cfg.translation_noise * cfg.translation_noise),
+                        1.0 / (cfg.rotation_noise * cfg.rotation_noise)};
+  if (i > 0) {  // odometry factor i-1 seen from its second key: J2 = Hlocal (SLAM2D.cpp:59-89)
+    const double *oo = S.odo + ((size_t)inst * S.P_max + (i - 1)) * 4;
+    const Pose tm{thp[4 * (i - 1)], thp[4 * (i - 1) + 1], thp[4 * (i - 1) + 2], thp[4 * (i - 1) + 3]};
+    const Pose hx = between(tm, ti, nullptr);
+    const Pose h = between(Pose{oo[0], oo[1], oo[2], oo[3]}, hx, nullptr);
+    const double e[3] = {h.x, h.y, theta_of(h)};
+    const double J2[9] = {h.c, h.s, 0, -h.s, h.c, 0, 0, 0, 1};
     for (int r = 0; r < 3; ++r) {
-      const double b0 = l[r] * wb * l[6] + l[3 + r] * wr * l[8];
-      const double b1 = l[r] * wb * l[7] + l[3 + r] * wr * l[9];
-      g[r * 2 + 0] = b0 * lb[3] + b1 * lb[4];
-      g[r * 2 + 1] = b0 * lb[4] + b1 * lb[5];
+      for (int c = 0; c < 3; ++c)
+        B[r * 3 + c] += J2[r] * wo[0] * J2[c] + J2[3 + r] * wo[1] * J2[3 + c] + J2[6 + r] * wo[2] * J2[6 + c];
+      g[r] += J2[r] * wo[0] * e[0] + J2[3 + r] * wo[1] * e[1] + J2[6 + r] * wo[2] * e[2];
     }
-    for (int k = 0; k < 6; ++k) l[k] = g[k];
   }
-  __syncthreads();
-  DRLGX_PROF(S, 3);
-  //      Schur complement: S_pq -= sum_j G_m Lambda_jj G_mq^T   (Lambda_pl = G Lambda_jj)
+  if (i + 1 < P) {  // odometry factor i from its first key: J1 = Hlocal * H1; also block (i+1, i) = J2^T W J1
+    const double *oo = S.odo + ((size_t)inst * S.P_max + i) * 4;
+    const Pose tn{thp[4 * (i + 1)], thp[4 * (i + 1) + 1], thp[4 * (i + 1) + 2], thp[4 * (i + 1) + 3]};
+    double H1[9];
+    const Pose hx = between(ti, tn, H1);
+    const Pose h = between(Pose{oo[0], oo[1], oo[2], oo[3]}, hx, nullptr);
+    const double e[3] = {h.x, h.y, theta_of(h)};
+    const double Hl[9] = {h.c, h.s, 0, -h.s, h.c, 0, 0, 0, 1};
+    double J1[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) J1[r * 3 + c] = Hl[r * 3] * H1[c] + Hl[r * 3 + 1] * H1[3 + c] + Hl[r * 3 + 2] * H1[6 + c];
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c)
+        B[r * 3 + c] += J1[r] * wo[0] * J1[c] + J1[3 + r] * wo[1] * J1[3 + c] + J1[6 + r] * wo[2] * J1[6 + c];
+      g[r] += J1[r] * wo[0] * e[0] + J1[3 + r] * wo[1] * e[1] + J1[6 + r] * wo[2] * e[2];
+    }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        O[r * 3 + c] = Hl[r] * wo[0] * J1[c] + Hl[3 + r] * wo[1] * J1[3 + c] + Hl[6 + r] * wo[2] * J1[6 + c];
+  }
+  for (int m = mstart[i]; m < mstart[i + 1]; ++m) {  // own bearing-range factors
+    const double *l = rec + (size_t)REC * m;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) B[r * 3 + c] += l[r] * wb * l[c] + l[3 + r] * wr * l[3 + c];
+      g[r] += l[r] * wb * l[10] + l[3 + r] * wr * l[11];
+    }
+  }
+}
+
+// Symmetric Gauss-Jordan sweep of the packed lower triangle `A` (LDS, row i at i (i + 1) / 2, N = 16 Tn <= 16 FT rows; the
+// region must hold max(N (N + 1) / 2, 48 N + 1280) doubles: the sweep panels alias it while the tiles are in registers) on
+// the pivots [0, np); rows >= np (the rhs row np, pads) are carried along.  Afterwards A holds -A_pp^-1 and row np the
+// solution.  All kThreads threads of the workgroup call it (block barriers inside).
+template <int FT>
+__device__ __forceinline__ void sweep_packed_fast(const DrlgxState &S, double *A, int np, int N, int Tn, int *bad, int tid) {
+  auto AT = [&](int i, int j) -> int { return i * (i + 1) / 2 + j; };
   {
-    const int npairs = P * (P + 1) / 2;
-    for (int e = tid; e < npairs; e += kThreads) {
-      int p = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
-      while ((p + 1) * (p + 2) / 2 <= e) ++p;
-      while (p * (p + 1) / 2 > e) --p;
-      const int q = e - p * (p + 1) / 2;
-      double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      bool any = false;
-      for (int m = mstart[p]; m < mstart[p + 1]; ++m) {
-        const int j = ml[m];
-        const int mq1 = obs[j * P + q];
-        if (!mq1) continue;
-        any = true;
-        const double *g = rec + (size_t)REC * m, *gq = rec + (size_t)REC * (mq1 - 1), *lb = lamb + 8 * j;
-        double h[6];  // G_m Lambda_jj  (3x2)
-        for (int r = 0; r < 3; ++r) {
-          h[r * 2 + 0] = g[r * 2] * lb[0] + g[r * 2 + 1] * lb[1];
-          h[r * 2 + 1] = g[r * 2] * lb[1] + g[r * 2 + 1] * lb[2];
-        }
-        for (int r = 0; r < 3; ++r)
-          for (int c = 0; c < 3; ++c) acc[r * 3 + c] += h[r * 2] * gq[c * 2] + h[r * 2 + 1] * gq[c * 2 + 1];
-      }
-      if (any)
-        for (int r = 0; r < 3; ++r)
-          for (int c = 0; c < 3; ++c) {
-            if (p == q && c > r) continue;
-            A[AT((3 * p + r), 3 * q + c)] -= acc[r * 3 + c];
-          }
-    }
-    for (int p = (tid + kThreads / 2) % kThreads; p < P; p += kThreads) {  // rhs_p -= sum_m G_m eta_j (idle waves)
-      double s0 = 0, s1 = 0, s2 = 0;
-      for (int m = mstart[p]; m < mstart[p + 1]; ++m) {
-        const double *g = rec + (size_t)REC * m, *lb = lamb + 8 * ml[m];
-        s0 += g[0] * lb[6] + g[1] * lb[7];
-        s1 += g[2] * lb[6] + g[3] * lb[7];
-        s2 += g[4] * lb[6] + g[5] * lb[7];
-      }
-      A[AT(np, 3 * p + 0)] -= s0;
-      A[AT(np, 3 * p + 1)] -= s1;
-      A[AT(np, 3 * p + 2)] -= s2;
-    }
-  }
-  __syncthreads();
-  DRLGX_PROF(S, 4);
-  if constexpr (FT > 0) {
-    // ---- 5a. fast path: full symmetric storage, one tile row per wave (see sweep_block) ----
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // tile rows r and FT-1-r share a SIMD (waves w and w+4): lower-triangle MFMA work is balanced across the SIMDs
@@ -758,174 +547,22 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
         if (j <= i && i < N) A[AT(i, j)] = acc[u][r];
       }
     }
-  } else if constexpr (NTW < 0) {
-    // ---- 5d. the 16-wide block steps of the fast path with the tiles left in the HBM/L2 workspace (43 .. 127 poses).
-    //      Per step K: the pivot column panel PAN (all N rows, from the lower triangle and its mirror) and E_K = -D_K^-1
-    //      (in-register inversion of the current diagonal tile by wave 0) -> W_I = PAN_I E_K for every tile row -> every
-    //      lower tile is loaded, updated / replaced exactly as sweep16_block does it, and stored.  Three barriers per
-    //      16 pivots instead of two per 4; the MFMA work per tile is 4 chained 16x16x4 products instead of 1.
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int lc = lane & 15, lr = lane >> 4;
-    double *pan = Vb, *wt = Vb + 16 * N, *einv = Vb + 32 * N;
-    const SweepCtx x{0, lane, lc, lr, np, N, true, false, bad, nullptr};
-    for (int K = 0; 16 * K < np; ++K) {
-      const int kb = 16 * K;
-      // P: PAN[i][c] = A_sym[i][kb + c] (0 for pivot indices >= np); rows above the block come from its transpose
-      for (int e = tid; e < 16 * kb; e += kThreads) {
-        const int c = e / kb, i = e - c * kb, kk = kb + c;
-        pan[i * 16 + ks16(c)] = (kk < np) ? A[kk * ld + i] : 0.0;
-      }
-      for (int e = tid; e < 16 * (N - kb); e += kThreads) {
-        const int i = kb + (e >> 4), c = e & 15, kk = kb + c;
-        pan[i * 16 + ks16(c)] = (kk < np) ? A[max(i, kk) * ld + min(i, kk)] : 0.0;
-      }
-      if (wave == 0) {
-        v4d d;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = kb + lr + 4 * r, j = kb + lc;
-          d[r] = A[max(i, j) * ld + min(i, j)];
-        }
-        inv16(x, K, d);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) einv[(lr + 4 * r) * 16 + ks16(lc)] = d[r];
-      }
-      __syncthreads();
-      // W_I = PAN_I E_K
-      for (int I = wave; I < Tn; I += kWaves) {
-        double aP[4], eB[4];
-        ld4(pan + (16 * I + lc) * 16 + lr * 4, aP);
-        ld4(einv + lc * 16 + lr * 4, eB);
-        v4d w = {0.0, 0.0, 0.0, 0.0};
-        w = mfma4(aP, eB, w);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wt[(16 * I + lr + 4 * r) * 16 + ks16(lc)] = w[r];
-      }
-      __syncthreads();
-      // U: tile t = wave, wave + kWaves, ... in row-major lower-triangle order, four tiles in flight per wave (the
-      // matrices of all instances do not fit the L2: a tile load is an HBM / MALL round trip)
-      constexpr int NB = 4;
-      int I = 0, J = 0;
-      for (int t = 0; t < wave; ++t) {
-        if (++J > I) { ++I; J = 0; }
-      }
-      for (int t = wave; t < ntiles; t += NB * kWaves) {
-        v4d acc[NB];
-        int bI[NB], bJ[NB];
-#pragma unroll
-        for (int b2 = 0; b2 < NB; ++b2) {
-          bI[b2] = I;
-          bJ[b2] = J;
-          const bool ok = t + b2 * kWaves < ntiles;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * I + lr + 4 * r, j = 16 * J + lc;
-            acc[b2][r] = ok ? A[max(i, j) * ld + min(i, j)] : 0.0;
-          }
-          for (int q = 0; q < kWaves; ++q) {
-            if (++J > I) { ++I; J = 0; }
-          }
-        }
-#pragma unroll
-        for (int b2 = 0; b2 < NB; ++b2) {
-          if (t + b2 * kWaves >= ntiles) continue;
-          tile_step16(bI[b2], bJ[b2], K, np, lc, lr, pan, wt, einv, acc[b2]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * bI[b2] + lr + 4 * r, j = 16 * bJ[b2] + lc;
-            if (j <= i) A[i * ld + j] = acc[b2][r];
-          }
-        }
-      }
-      __syncthreads();
-    }
-  } else if constexpr (NTW == 0) {
-    // ---- 5c. fallback: symmetric sweeps with 4-wide pivot groups, tiles left in the HBM/L2 workspace (needs only
-    //      16 N + 64 doubles of LDS panels).  Sweep g pivots on indices [4g, 4g+4) (those >= np - the rhs row and the
-    //      pads - are masked out): panel v[c][i] = A[max(i,k0+c)][min(i,k0+c)] and E_g = -D_g^-1 straight from memory,
-    //      nW = V E, then every tile is loaded, updated by one MFMA (A_IJ += nW_I V_J^T), patched with the exact sweep
-    //      values on the pivot rows / columns and stored back.
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int lc = lane & 15, lr = lane >> 4;
-    const int G = (np + 3) >> 2;
-    double *vb = Vb, *nwb = Vb + 4 * N, *eb = Vb + 8 * N;
-    for (int g = 0; g < G; ++g) {
-      const int k0 = 4 * g, KI = k0 >> 4, kc = k0 & 15, rg = kc >> 2;
-      for (int e = tid; e < 4 * N; e += kThreads) {
-        const int c = e / N, i = e - c * N, kk = k0 + c;
-        vb[e] = (kk < np) ? A[AT(max(i, kk), min(i, kk))] : 0.0;
-      }
-      if (wave == 0) {
-        if (lane < 16) {
-          const int r = k0 + (lane >> 2), c = k0 + (lane & 3);
-          eb[16 + lane] = (max(r, c) < N) ? A[AT(max(r, c), min(r, c))] : 0.0;
-        }
-        wave_sync();
-        pivot_inverse_from(np, k0, eb + 16, eb, bad, lane);
-      }
-      __syncthreads();
-      for (int e = tid; e < 4 * N; e += kThreads) {
-        const int k = e / N, i = e - k * N;
-        nwb[e] = fma(vb[3 * N + i], eb[12 + k], fma(vb[2 * N + i], eb[8 + k], fma(vb[N + i], eb[4 + k], vb[i] * eb[k])));
-      }
-      __syncthreads();
-      int I = 0, J = 0;  // tile t = wave, wave + kWaves, ... in row-major lower-triangle order
-      for (int t = 0; t < wave; ++t) {
-        if (++J > I) { ++I; J = 0; }
-      }
-      for (int t = wave; t < ntiles; t += kWaves) {
-        v4d acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 16 * I + lr + 4 * r, j = 16 * J + lc;
-          acc[r] = A[AT(max(i, j), min(i, j))];
-        }
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(nwb[lr * N + 16 * I + lc], vb[lr * N + 16 * J + lc], acc, 0, 0, 0);
-        if (J == KI) {  // pivot columns: A_iK <- A_iK D^-1 = -nW (diagonal tile: rows at/below the pivot)
-          const int c = lc - kc;
-          const bool mine = (unsigned)c < 4u && k0 + c < np;
-          const int cc = mine ? c : 0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (I == KI && r < rg) continue;
-            const double val = -nwb[cc * N + 16 * I + lr + 4 * r];
-            if (mine) acc[r] = val;
-          }
-          if (I == KI) {  // the pivot block itself: A_KK <- -D^-1
-            const double pv = eb[4 * lr + cc];
-            const bool pm = mine && k0 + lr < np;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = (pm && r == rg) ? pv : acc[r];
-          }
-        }
-        if (I == KI) {  // pivot rows: A_Kj <- (A_jK D^-1)^T for the columns left of the pivot
-          const int j = 16 * J + lc;
-          const double val = -nwb[lr * N + j];
-          const bool pm = j < k0 && k0 + lr < np;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = (pm && r == rg) ? val : acc[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 16 * I + lr + 4 * r, j = 16 * J + lc;
-          if (j <= i) A[AT(i, j)] = acc[r];
-        }
-        for (int q = 0; q < kWaves; ++q) {
-          if (++J > I) { ++I; J = 0; }
-        }
-      }
-      __syncthreads();
-    }
-  } else if constexpr (FT < 0) {
-    // ---- 5e. 16-wide block steps with the lower tiles in registers: waves 0 .. kWaves-2 hold NTW tiles each (tile
-    //      t = wave + (kWaves - 1) u), no global memory inside the sweeps; the last wave is the E-wave of the fast path:
-    //      while the others run U of step K it forms D'_{K+1} = D_{K+1} + W_{K+1} PAN_{K+1}^T from the panels and inverts
-    //      it in registers (one inv16 call site: a copy per unrolled tile slot does not stay in the instruction cache).
+  }
+}
+
+// 16-wide block steps with the lower tiles in registers (see 5e in slam_body): `A` is the packed lower triangle in LDS
+// (kPackedA, the panels `pbase` may alias it: every tile is in registers before the first panel is written) or the square
+// matrix with leading dimension N in the HBM/L2 workspace (panels `pbase` in LDS, 32 N + 1280 doubles).
+template <bool kPackedA, int NTW>
+__device__ __forceinline__ void sweep_regtiles(double *A, double *pbase, int np, int N, int Tn, int ntiles, int *bad, int tid) {
+  const int ld = N;
+  auto AT = [&](int i, int j) -> int { return kPackedA ? i * (i + 1) / 2 + j : i * ld + j; };
+  constexpr bool kLds = kPackedA;
+  {
     constexpr int TW = kWaves - 1;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lc = lane & 15, lr = lane >> 4;
     const bool ewave = wave == TW;
-    double *pbase = kLds ? A : Vb;  // LDS-resident system: the matrix region is dead while the tiles are in registers
     double *pan = pbase, *wt = pbase + 16 * N, *einv0 = pbase + 32 * N, *dscr = einv0 + 512, *es = dscr + 256;
     const SweepCtx x{0, lane, lc, lr, np, N, true, ewave, bad, nullptr};
     v4d acc[NTW];
@@ -1039,6 +676,227 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
       }
     }
   }
+}
+
+// The fast path: <= 42 poses (N <= 16 FT = 128), the whole problem in LDS.  Longer trajectories: arrow_body (k_slam_arrow.hip).
+template <int FT>
+__device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &sel, int lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int bi = blockIdx.x;
+  if (!sel.on(bi)) return;
+  const int inst = sel.base + bi;
+  int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
+  if (cnt[C_FLAG]) return;
+  const drlgx_config &cfg = S.cfg;
+  const int P = cnt[C_P], L = cnt[C_L], M = cnt[C_M];
+  const int n_old_p = cnt[C_NEWP], n_old_l = cnt[C_NEWL];
+  const int count = cnt[C_ISAM] + 1;
+  const int np = 3 * P, na = np + 1;
+  // padded to 16x16 MFMA tiles; row np holds the rhs (its column and all pad rows / columns stay zero).  Only the lower
+  // triangle is ever addressed and it is stored packed (row i at i (i + 1) / 2: half the LDS of the square, which keeps
+  // the factor records on chip for ~700 factors instead of ~230)
+  const int Tn = (na + 15) / 16, N = 16 * Tn;
+  auto AT = [&](int i, int j) -> int { return i * (i + 1) / 2 + j; };
+  // (the matrix region is reused for the sweep panels while the tiles are in registers)
+  const size_t a_doubles = max((size_t)N * (N + 1) / 2, (size_t)48 * N + 1280);
+  if (Tn > FT) {
+    // more poses than this kernel was launched for (the host's bound was wrong): flag it, touch nothing
+    if (tid == 0) atomicMin(S.status, DRLGX_E_CAPACITY);
+    return;
+  }
+  DRLGX_PROF(S, 0);
+
+  // ---- LDS carve: small arrays first, then the dense system; overflow goes to the HBM workspace ----
+  size_t off = 0;
+  double *thp = reinterpret_cast<double *>(smem_raw + off); off += up8((size_t)P * 4 * 8);
+  double *thl = reinterpret_cast<double *>(smem_raw + off); off += up8((size_t)L * 2 * 8);
+  double *lamb = reinterpret_cast<double *>(smem_raw + off); off += up8((size_t)L * 8 * 8);
+  int *mstart = reinterpret_cast<int *>(smem_raw + off); off += up8((size_t)(P + 2) * 4);
+  unsigned short *mp = reinterpret_cast<unsigned short *>(smem_raw + off); off += up8((size_t)M * 2);
+  unsigned short *ml = reinterpret_cast<unsigned short *>(smem_raw + off); off += up8((size_t)M * 2);
+  int *bad = reinterpret_cast<int *>(smem_raw + off); off += 8;
+  // poses observing each landmark as bit masks (MW 64-bit words): the per-landmark loops visit only those poses
+  const int MW = (P + 63) >> 6;
+  unsigned long long *lmask = reinterpret_cast<unsigned long long *>(smem_raw + off); off += (size_t)L * MW * 8;
+  off = (off + 31) & ~(size_t)31;
+  double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
+  double *A = reinterpret_cast<double *>(smem_raw + off); off += a_doubles * 8;
+  // per-factor records and the landmark x pose observation table: LDS if they fit
+  const size_t big = (size_t)M * REC * 8 + up8((size_t)L * P * 2);
+  double *rec;
+  unsigned short *obs;
+  if (off + big <= (size_t)lds_bytes) {
+    rec = reinterpret_cast<double *>(smem_raw + off); off += (size_t)M * REC * 8;
+    obs = reinterpret_cast<unsigned short *>(smem_raw + off);
+  } else {
+    rec = wsd; wsd += (size_t)S.M_max * REC;
+    obs = reinterpret_cast<unsigned short *>(wsd);
+  }
+  double *th_pose = S.th_pose + (size_t)inst * S.P_max * 4;
+  double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
+  double *th_lm = S.th_lm + (size_t)inst * S.L_max * 2;
+  double *d_lm = S.d_lm + (size_t)inst * S.L_max * 2;
+  const int *meas_pose = S.meas_pose + (size_t)inst * S.M_max;
+  const int *meas_lm = S.meas_lm + (size_t)inst * S.M_max;
+  const double *meas_br = S.meas_br + (size_t)inst * S.M_max * 2;
+
+  // ---- 1. relinearisation policy (gtsam ISAM2: relinearizeSkip 10, relinearizeThreshold 0.1);
+  //         theta (+ folded delta) is staged in LDS ----
+  const bool relin = (count % 10 == 0);
+  for (int i = tid; i < P; i += kThreads) {
+    Pose t{th_pose[4 * i], th_pose[4 * i + 1], th_pose[4 * i + 2], th_pose[4 * i + 3]};
+    if (relin && i < n_old_p) {
+      const double a = fabs(d_pose[3 * i]), b = fabs(d_pose[3 * i + 1]), c = fabs(d_pose[3 * i + 2]);
+      if (fmax(a, fmax(b, c)) >= 0.1) {
+        t = compose(t, make_pose(d_pose[3 * i], d_pose[3 * i + 1], d_pose[3 * i + 2]));
+        th_pose[4 * i] = t.x; th_pose[4 * i + 1] = t.y; th_pose[4 * i + 2] = t.c; th_pose[4 * i + 3] = t.s;
+      }
+    }
+    thp[4 * i] = t.x; thp[4 * i + 1] = t.y; thp[4 * i + 2] = t.c; thp[4 * i + 3] = t.s;
+  }
+  for (int j = tid; j < L; j += kThreads) {
+    double x = th_lm[2 * j], y = th_lm[2 * j + 1];
+    if (relin && j < n_old_l && fmax(fabs(d_lm[2 * j]), fabs(d_lm[2 * j + 1])) >= 0.1) {
+      x += d_lm[2 * j];
+      y += d_lm[2 * j + 1];
+      th_lm[2 * j] = x;
+      th_lm[2 * j + 1] = y;
+    }
+    thl[2 * j] = x;
+    thl[2 * j + 1] = y;
+  }
+  // ---- 2. clear the system; factor tables (factors are appended in pose order: contiguous ranges) ----
+  {
+    double2 *A2 = reinterpret_cast<double2 *>(A);
+    const int n2 = (int)((size_t)N * (N + 1) / 2 / 2);  // (N is a multiple of 16: even)
+    for (int e = tid; e < n2; e += kThreads) A2[e] = make_double2(0.0, 0.0);
+  }
+  for (int e = tid; e < L * P; e += kThreads) obs[e] = 0;
+  for (int e = tid; e < MW * L; e += kThreads) lmask[e] = 0ull;
+  for (int e = tid; e <= P; e += kThreads) mstart[e] = M;
+  if (tid == 0) bad[0] = 0;
+  __syncthreads();
+  // one thread per factor: tables + the (expensive) linearisation, once
+  for (int m = tid; m < M; m += kThreads) {
+    const int p = meas_pose[m], j = meas_lm[m];
+    mp[m] = (unsigned short)p;
+    ml[m] = (unsigned short)j;
+    if (m == 0 || meas_pose[m - 1] != p) mstart[p] = m;
+    obs[j * P + p] = (unsigned short)(m + 1);
+    atomicOr(&lmask[MW * j + (p >> 6)], 1ull << (p & 63));
+    linearize_br(thp + 4 * p, thl + 2 * j, meas_br[2 * m], meas_br[2 * m + 1], rec + (size_t)REC * m);
+  }
+  __syncthreads();
+  {
+    // poses without factors get the empty range [next pose's start, same): first assigned start at or after p
+    int v = M;
+    if (tid < P) {
+      int q = tid;
+      v = mstart[q];
+      while (v == M && q < P) v = mstart[++q];  // mstart[P] = M
+    }
+    __syncthreads();
+    if (tid < P) mstart[tid] = v;
+  }
+  __syncthreads();
+  DRLGX_PROF(S, 1);
+  // ---- 3. block assembly.  first waves: one thread per landmark; following waves: one thread per pose ----
+  const double wb = 1.0 / (cfg.bearing_noise * cfg.bearing_noise), wr = 1.0 / (cfg.range_noise * cfg.range_noise);
+  const int pose_t0 = ((L + 63) & ~63) % kThreads;  // poses start on a fresh wave so both roles overlap
+  for (int j = tid; j < L; j += kThreads) {
+    double a = 0, b = 0, d = 0, g0 = 0, g1 = 0;
+    FOR_EACH_OBSERVING_POSE(lmask + MW * j, MW, p) {
+      const int m1 = obs[j * P + p];
+      const double *r = rec + (size_t)REC * (m1 - 1);
+      a += r[6] * wb * r[6] + r[8] * wr * r[8];
+      b += r[6] * wb * r[7] + r[8] * wr * r[9];
+      d += r[7] * wb * r[7] + r[9] * wr * r[9];
+      g0 += r[6] * wb * r[10] + r[8] * wr * r[11];
+      g1 += r[7] * wb * r[10] + r[9] * wr * r[11];
+    }
+    const double id = 1.0 / (a * d - b * b);
+    double *lb = lamb + 8 * j;
+    lb[0] = a; lb[1] = b; lb[2] = d;
+    lb[3] = d * id; lb[4] = -b * id; lb[5] = a * id;  // Lambda_jj^-1
+    lb[6] = -g0; lb[7] = -g1;                           // eta_j
+  }
+  for (int i = (tid - pose_t0 + kThreads) % kThreads; i < P; i += kThreads) {
+    double B[9], g[3], O[9];
+    pose_block(S, inst, thp, rec, mstart, i, P, wb, wr, B, g, O);
+    if (i + 1 < P)
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) A[AT((3 * (i + 1) + r), 3 * i + c)] = O[r * 3 + c];
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c <= r; ++c) A[AT((3 * i + r), 3 * i + c)] = B[r * 3 + c];
+      A[AT(np, 3 * i + r)] = -g[r];  // rhs lives in the augmented row
+    }
+  }
+  __syncthreads();
+  DRLGX_PROF(S, 2);
+  // ---- 4. landmark elimination: rec[0..5] <- G_m = Lambda_pl Lambda_ll^-1 (3x2) ----
+  for (int m = tid; m < M; m += kThreads) {
+    double *l = rec + (size_t)REC * m;
+    const double *lb = lamb + 8 * ml[m];
+    double g[6];
+    for (int r = 0; r < 3; ++r) {
+      const double b0 = l[r] * wb * l[6] + l[3 + r] * wr * l[8];
+      const double b1 = l[r] * wb * l[7] + l[3 + r] * wr * l[9];
+      g[r * 2 + 0] = b0 * lb[3] + b1 * lb[4];
+      g[r * 2 + 1] = b0 * lb[4] + b1 * lb[5];
+    }
+    for (int k = 0; k < 6; ++k) l[k] = g[k];
+  }
+  __syncthreads();
+  DRLGX_PROF(S, 3);
+  //      Schur complement: S_pq -= sum_j G_m Lambda_jj G_mq^T   (Lambda_pl = G Lambda_jj)
+  {
+    const int npairs = P * (P + 1) / 2;
+    for (int e = tid; e < npairs; e += kThreads) {
+      int p = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+      while ((p + 1) * (p + 2) / 2 <= e) ++p;
+      while (p * (p + 1) / 2 > e) --p;
+      const int q = e - p * (p + 1) / 2;
+      double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      bool any = false;
+      for (int m = mstart[p]; m < mstart[p + 1]; ++m) {
+        const int j = ml[m];
+        const int mq1 = obs[j * P + q];
+        if (!mq1) continue;
+        any = true;
+        const double *g = rec + (size_t)REC * m, *gq = rec + (size_t)REC * (mq1 - 1), *lb = lamb + 8 * j;
+        double h[6];  // G_m Lambda_jj  (3x2)
+        for (int r = 0; r < 3; ++r) {
+          h[r * 2 + 0] = g[r * 2] * lb[0] + g[r * 2 + 1] * lb[1];
+          h[r * 2 + 1] = g[r * 2] * lb[1] + g[r * 2 + 1] * lb[2];
+        }
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) acc[r * 3 + c] += h[r * 2] * gq[c * 2] + h[r * 2 + 1] * gq[c * 2 + 1];
+      }
+      if (any)
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) {
+            if (p == q && c > r) continue;
+            A[AT((3 * p + r), 3 * q + c)] -= acc[r * 3 + c];
+          }
+    }
+    for (int p = (tid + kThreads / 2) % kThreads; p < P; p += kThreads) {  // rhs_p -= sum_m G_m eta_j (idle waves)
+      double s0 = 0, s1 = 0, s2 = 0;
+      for (int m = mstart[p]; m < mstart[p + 1]; ++m) {
+        const double *g = rec + (size_t)REC * m, *lb = lamb + 8 * ml[m];
+        s0 += g[0] * lb[6] + g[1] * lb[7];
+        s1 += g[2] * lb[6] + g[3] * lb[7];
+        s2 += g[4] * lb[6] + g[5] * lb[7];
+      }
+      A[AT(np, 3 * p + 0)] -= s0;
+      A[AT(np, 3 * p + 1)] -= s1;
+      A[AT(np, 3 * p + 2)] -= s2;
+    }
+  }
+  __syncthreads();
+  DRLGX_PROF(S, 4);
+  // ---- 5. sweep: one tile row per wave (sweep_packed_fast) ----
+  sweep_packed_fast<FT>(S, A, np, N, Tn, bad, tid);
   __syncthreads();
   DRLGX_PROF(S, 5);
   for (int k = tid; k < np; k += kThreads) d_pose[k] = A[AT(np, k)];
@@ -1046,7 +904,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   for (int m = tid; m < M; m += kThreads) {
     const int j = ml[m], p = mp[m];
     double Wm[6] = {0, 0, 0, 0, 0, 0};
-    FOR_EACH_OBSERVING_POSE(lmask + 2 * j, q) {
+    FOR_EACH_OBSERVING_POSE(lmask + MW * j, MW, q) {
       const int mq1 = obs[j * P + q];
       const double *gq = rec + (size_t)REC * (mq1 - 1);
       for (int r = 0; r < 3; ++r) {
@@ -1077,7 +935,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
     double c00 = lb[3], c01 = lb[4], c10 = lb[4], c11 = lb[5];
     // delta_j = Lambda^-1 eta_j - sum_m G_m^T delta_p
     double dx = lb[3] * lb[6] + lb[4] * lb[7], dy = lb[4] * lb[6] + lb[5] * lb[7];
-    FOR_EACH_OBSERVING_POSE(lmask + 2 * j, p) {
+    FOR_EACH_OBSERVING_POSE(lmask + MW * j, MW, p) {
       const int m1 = obs[j * P + p];
       const double *g = rec + (size_t)REC * (m1 - 1);
       c00 += g[6]; c01 += g[7]; c10 += g[8]; c11 += g[9];
@@ -1127,87 +985,68 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   }
 }
 
-template <bool kLds, int NTW, int FT>
+template <int FT>
 __global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, int lds_bytes) {
-  slam_body<kLds, NTW, FT>(S, sel, lds_bytes);
+  slam_body<FT>(S, sel, lds_bytes);
 }
 
 constexpr int kLdsBudget = 160 * 1024;
+constexpr int kFastTiles = 8;       // fast path: N = 128 (<= 42 poses), system + panels in LDS
+constexpr int kFastTilesArrow = 8;  // arrow path: landmark system of <= 63 landmarks (N <= 128) packed in LDS
+constexpr int kArrowRegTiles = 20;  // ... beyond: up to 20 register tiles per wave (N <= 256, <= 127 landmarks)
 
-// LDS needed by the always-resident small arrays + panels for an N x N system
+#include "k_slam_arrow.hip"
+
+// LDS needed by the always-resident small arrays of the fast path
 size_t slam_dim(int P_max) { return 16 * (((size_t)3 * P_max + 1 + 15) / 16); }
-size_t slam_small_bytes_n(size_t N, int P_max, int L_max, int M_max, bool fast) {
-  const size_t panels = fast ? 0 : 2 * (8 * N + 32);  // the fast path keeps its panels in the (dead) matrix region
-  return (size_t)P_max * 32 + (size_t)L_max * 16 + (size_t)L_max * 64 + (size_t)L_max * 16 + (size_t)(P_max + 2) * 4 + (size_t)M_max * 4 +
-         panels * 8 + 128;
-}
 size_t slam_small_bytes(int P_max, int L_max, int M_max) {
-  return slam_small_bytes_n(slam_dim(P_max), P_max, L_max, M_max, false);
+  return (size_t)P_max * 32 + (size_t)L_max * 16 + (size_t)L_max * 64 + (size_t)L_max * 8 * ((P_max + 63) / 64) + (size_t)(P_max + 2) * 4 +
+         (size_t)M_max * 4 + 128;
 }
-// the streamed 16-wide variant: PAN and WT panels [N][16] + E
-size_t slam_small_bytes_s16(int P_max, int L_max, int M_max) {
-  const size_t N = slam_dim(P_max);
-  return slam_small_bytes_n(N, P_max, L_max, M_max, true) + (32 * N + 1280) * 8;
+// LDS the arrow path cannot do without at full capacity: tables + the packed landmark system or the panels of the
+// workspace variant (factor records and the observation table overflow to the workspace)
+size_t arrow_lds_bytes(int P_max, int L_max, int M_max) {
+  const size_t N = 16 * (((size_t)2 * L_max + 1 + 15) / 16);
+  const size_t sys = N <= 16 * kFastTilesArrow ? std::max(N * (N + 1) / 2, 48 * N + 1280) : 32 * N + 1280;
+  return arrow_small_bytes(P_max, L_max, M_max) + sys * 8 + 64;
 }
-constexpr int kFastTiles = 8;  // fast path: N = 128 (<= 42 poses), system + panels in LDS
 
 }  // namespace kslam
 
-size_t drlgx_slam_lds_bytes(int P_max, int L_max, int M_max) {
-  const size_t N = kslam::slam_dim(P_max);
-  return kslam::slam_small_bytes(P_max, L_max, M_max) + N * N * 8;
-}
-
-// true when k_slam keeps the dense system in LDS (the fast path); otherwise the engine must provide the HBM workspace
+// true when the fused LDS-resident kernel applies to trajectories of up to P_max poses
 bool drlgx_slam_in_lds(int P_max, int L_max, int M_max) {
   const size_t nf = 16 * kslam::kFastTiles;
-  return kslam::slam_dim(P_max) <= nf && kslam::slam_small_bytes_n(nf, P_max, L_max, M_max, true) +
-                                              std::max(nf * (nf + 1) / 2, 48 * nf + 1280) * 8 <= (size_t)kslam::kLdsBudget;
+  return kslam::slam_dim(P_max) <= nf &&
+         kslam::slam_small_bytes(P_max, L_max, M_max) + std::max(nf * (nf + 1) / 2, 48 * nf + 1280) * 8 <= (size_t)kslam::kLdsBudget;
+}
+// capacities the SLAM kernels can serve at all (checked by drlgx_create)
+bool drlgx_slam_capacity_ok(int P_max, int L_max, int M_max) {
+  const size_t N = 16 * (((size_t)2 * L_max + 1 + 15) / 16);
+  const size_t Tn = N / 16;
+  if (Tn > (size_t)kslam::kFastTilesArrow && Tn * (Tn + 1) / 2 > (size_t)kslam::kArrowRegTiles * (kslam::kWaves - 1)) return false;
+  return kslam::arrow_lds_bytes(P_max, L_max, M_max) <= (size_t)kslam::kLdsBudget && 2 * L_max + 1 <= kslam::kThreads;
+}
+// doubles of HBM workspace per instance: X (3 P x (2 L + 1), row stride rounded up to 4), the square landmark system of the
+// workspace variant, the factor records and the observation table when they do not fit the LDS
+size_t drlgx_slam_ws_doubles(int P_max, int L_max, int M_max) {
+  return (size_t)3 * P_max * (size_t)((2 * L_max + 1 + 3) & ~3) + (size_t)(2 * L_max + 17) * (2 * L_max + 17) + (size_t)M_max * kslam::REC +
+         ((size_t)L_max * P_max * 2 + 7) / 8 + 16;
 }
 
 void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p_bound) {
   const int Pb = p_bound < S.P_max ? p_bound : S.P_max;
-  const int Tn = (int)(kslam::slam_dim(Pb) / 16), ntiles = Tn * (Tn + 1) / 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const void *fns[] = {reinterpret_cast<const void *>(&kslam::k_slam<true, 1, kslam::kFastTiles>),
-                         reinterpret_cast<const void *>(&kslam::k_slam<false, 10, -1>),
-                         reinterpret_cast<const void *>(&kslam::k_slam<true, 10, -1>),
-                         reinterpret_cast<const void *>(&kslam::k_slam<false, 20, -1>),
-                         reinterpret_cast<const void *>(&kslam::k_slam<false, -1, 0>),
-                         reinterpret_cast<const void *>(&kslam::k_slam<false, 0, 0>)};
-    for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kslam::kLdsBudget);
-    attr_set = true;
-  }
-  if (drlgx_slam_in_lds(Pb, S.L_max, S.M_max)) {
-    // fast path: the kernel always works on the full 128 x 128 capacity; whatever LDS is left holds the factor records
-    hipLaunchKernelGGL((kslam::k_slam<true, 1, kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
-    return;
-  }
-  // dense system in the HBM/L2 workspace, 16-wide block steps: lower tiles in registers (seven tile waves + the
-  // inverting wave: <= 58 poses with 10 tiles per wave, <= 85 with 20) or streamed per step (<= 127 poses: the
-  // per-landmark pose masks are 128 bits); 4-wide streamed sweeps when the 16-wide panels do not fit the LDS next to
-  // unusually large landmark / factor capacities
-  const size_t small4 = kslam::slam_small_bytes(S.P_max, S.L_max, S.M_max);
-  const size_t small16 = kslam::slam_small_bytes_s16(S.P_max, S.L_max, S.M_max);
-  if (S.P_max > 127 || small4 > (size_t)kslam::kLdsBudget) {
-    (void)hipMemsetAsync(S.status, 0xff, sizeof(int), st);  // capacity beyond these kernels: flag an error (-1)
-    return;
-  }
+  static bool attr_set[32] = {false};
+  const void *fns[] = {reinterpret_cast<const void *>(&kslam::k_slam<kslam::kFastTiles>),
+                       reinterpret_cast<const void *>(&kslam::k_slam_arrow<0>),
+                       reinterpret_cast<const void *>(&kslam::k_slam_arrow<kslam::kArrowRegTiles>)};
+  drlgx_ensure_lds_attr(attr_set, fns, 3, kslam::kLdsBudget);
   const dim3 grid(sel.n), block(kslam::kThreads);
-  if (small16 > (size_t)kslam::kLdsBudget)
-    hipLaunchKernelGGL((kslam::k_slam<false, 0, 0>), grid, block, small4, st, S, sel, (int)small4);
-  // (the whole LDS is requested: what the panels and tables leave free holds the factor records and the observation table)
-  else if (ntiles <= 10 * (kslam::kWaves - 1) && kslam::slam_small_bytes_n(16 * Tn, S.P_max, S.L_max, S.M_max, true) +
-                                                       std::max((size_t)(16 * Tn) * (16 * Tn + 1) / 2, (size_t)32 * 16 * Tn + 1280) * 8 <=
-                                                   (size_t)kslam::kLdsBudget)
-    // up to ~52 poses the packed system itself fits the LDS next to the tables (panels alias it during the sweeps)
-    hipLaunchKernelGGL((kslam::k_slam<true, 10, -1>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
-  else if (ntiles <= 10 * (kslam::kWaves - 1))
-    hipLaunchKernelGGL((kslam::k_slam<false, 10, -1>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
-  else if (ntiles <= 20 * (kslam::kWaves - 1))
-    hipLaunchKernelGGL((kslam::k_slam<false, 20, -1>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
+  // (the whole LDS is requested: what the tables and the system leave free holds the factor records and the observation table)
+  if (drlgx_slam_in_lds(Pb, S.L_max, S.M_max))
+    hipLaunchKernelGGL((kslam::k_slam<kslam::kFastTiles>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
+  else if (2 * S.L_max + 1 <= 16 * kslam::kFastTilesArrow)  // landmark system always packed in LDS: no register-tile sweep compiled in
+    hipLaunchKernelGGL((kslam::k_slam_arrow<0>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
   else
-    hipLaunchKernelGGL((kslam::k_slam<false, -1, 0>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
+    hipLaunchKernelGGL((kslam::k_slam_arrow<kslam::kArrowRegTiles>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
 }
 #pragma clang fp contract(off)

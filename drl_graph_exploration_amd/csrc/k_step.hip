@@ -29,7 +29,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
     ksim::sim_step_body(S, sel, odom, odom_stride, n_measure, l0, l1, dyn, tid);
   }
   __syncthreads();
-  kslam::slam_body<true, 1, FT>(S, sel, lds_bytes);
+  kslam::slam_body<FT>(S, sel, lds_bytes);
   __syncthreads();
   kmap::map_body(S, sel, 1, map_chunk);
 }
@@ -45,12 +45,9 @@ bool drlgx_step_fusable(const DrlgxState &S, int p_bound) {
 void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure) {
   int chunk = 0;
   (void)drlgx_map_lds_bytes(S, &chunk);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kstep::k_step<kslam::kFastTiles>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kslam::kLdsBudget);
-    attr_set = true;
-  }
+  static bool attr_set[32] = {false};
+  const void *fns[] = {reinterpret_cast<const void *>(&kstep::k_step<kslam::kFastTiles>)};
+  drlgx_ensure_lds_attr(attr_set, fns, 1, kslam::kLdsBudget);
   hipLaunchKernelGGL((kstep::k_step<kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, odom,
                      odom_stride, n_measure, kslam::kLdsBudget, chunk);
 }

@@ -49,10 +49,13 @@ class Engine(object):
         _lib.check(rc, self.h)
 
     def use_torch_stream(self):
-        """Enqueue engine kernels on torch's current stream so tensors can be shared without syncs."""
-        with torch.cuda.device(self.device):
-            s = torch.cuda.current_stream().cuda_stream
-        self._chk(self.L.drlgx_set_stream(self.h, C.c_void_p(s)))
+        """Enqueue engine kernels on torch's current stream of the engine's device, so that tensors can be shared
+        without syncs.  Called before every call that enqueues work (cheap when the stream has not changed), so the
+        engine follows `with torch.cuda.stream(...)` blocks."""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != getattr(self, "_bound_stream", None):
+            self._chk(self.L.drlgx_set_stream(self.h, C.c_void_p(s)))
+            self._bound_stream = s
 
     def synchronize(self):
         self._chk(self.L.drlgx_synchronize(self.h))
@@ -69,6 +72,7 @@ class Engine(object):
     def reset(self, env_ids, seeds, starts=None, los=None):
         """SS2D.__init__ for the listed envs. starts: (n,3) x,y,theta; or `los` to use the reference's
         legacy numpy start-pose stream (pyss2d.py:89-95)."""
+        self.use_torch_stream()
         env_ids = np.ascontiguousarray(env_ids, dtype=np.int32)
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
         if starts is None:
@@ -80,25 +84,46 @@ class Engine(object):
 
     def step(self, odom, active=None):
         """SS2D.simulate(core=True) for all envs. odom: CUDA float64 [n_envs,3]; active: CUDA uint8 [n_envs]."""
+        self.use_torch_stream()
         assert odom.is_cuda and odom.dtype == torch.float64 and odom.is_contiguous()
         self._chk(self.L.drlgx_step(self.h, _p(odom), _p(active)))
 
     def utility(self, dist=None):
+        self.use_torch_stream()
         out = torch.empty(self.n_envs, dtype=torch.float64, device=self.device)
         self._chk(self.L.drlgx_utility(self.h, _p(dist), _p(out)))
         return out
 
     def uncertainty_em(self, algorithm):
+        self.use_torch_stream()
         out = torch.empty(self.n_envs, dtype=torch.float64, device=self.device)
         self._chk(self.L.drlgx_uncertainty_em(self.h, int(algorithm), _p(out)))
         return out
 
     def explored(self):
+        self.use_torch_stream()
         out = torch.empty(self.n_envs, dtype=torch.float64, device=self.device)
         self._chk(self.L.drlgx_explored(self.h, _p(out)))
         return out
 
+    def metrics(self, sigma0=1.0):
+        """[n_envs, 3] float64 CUDA tensor: landmark error, map entropy, max localisation uncertainty - the columns
+        scripts/test.py:136-142 writes per executed action."""
+        self.use_torch_stream()
+        out = torch.empty(self.n_envs, 3, dtype=torch.float64, device=self.device)
+        self._chk(self.L.drlgx_metrics(self.h, float(sigma0), _p(out)))
+        return out
+
+    def cov_array(self):
+        """VirtualMap.to_cov_array for every env: (length, angle) [n_envs, rows, cols] float64 CUDA tensors."""
+        self.use_torch_stream()
+        ln = torch.empty(self.n_envs, self.rows, self.cols, dtype=torch.float64, device=self.device)
+        an = torch.empty_like(ln)
+        self._chk(self.L.drlgx_cov_array(self.h, _p(ln), _p(an)))
+        return ln, an
+
     def line_plan(self, cand_env, goals):
+        self.use_torch_stream()
         n = cand_env.numel()
         A = self.cfg.max_actions
         actions = torch.zeros(n, A, 3, dtype=torch.float64, device=self.device)
@@ -109,6 +134,7 @@ class Engine(object):
     def lookahead(self, cand_env, actions, n_actions, max_n_actions=None):
         """Look-ahead rewards; `max_n_actions` (host int >= every n_actions[i]) skips the launches of the action indices
         no plan reaches (None: all cfg.max_actions indices are launched)."""
+        self.use_torch_stream()
         n = cand_env.numel()
         rewards = torch.empty(n, dtype=torch.float64, device=self.device)
         if max_n_actions is None:
@@ -123,6 +149,7 @@ class Engine(object):
         Returns a dict of CUDA tensors: x [N,5] f32, edge_index [2,E] i64, edge_attr [E] f32, node_off / edge_off
         [n_envs+1] i32, batch [N] i64, n_frontier [n_envs] i32, frontier_xy [n_envs,Fmax,2] f64,
         nearest_frontier_node [n_envs] i32 (local node id)."""
+        self.use_torch_stream()
         if not hasattr(self, "_gcap"):
             a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
             self._chk(self.L.drlgx_graph_capacity(self.h, C.byref(a), C.byref(b), C.byref(c)))
@@ -146,9 +173,11 @@ class Engine(object):
                     batch=batch, n_frontier=nfr, frontier_xy=fxy, nearest_frontier_node=near)
 
     def snapshot(self, slot=0):
+        self.use_torch_stream()
         self._chk(self.L.drlgx_snapshot(self.h, slot))
 
     def restore(self, slot=0):
+        self.use_torch_stream()
         self._chk(self.L.drlgx_restore(self.h, slot))
 
     def timing_enable(self, on=True):
@@ -170,6 +199,7 @@ class Engine(object):
 
     def counts_dev(self):
         """[n_envs, 5] int32 CUDA tensor: poses, landmarks, factors, step, isam update count (no sync)."""
+        self.use_torch_stream()
         out = torch.empty(self.n_envs, 5, dtype=torch.int32, device=self.device)
         self._chk(self.L.drlgx_counts(self.h, _p(out)))
         return out

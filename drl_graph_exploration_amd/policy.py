@@ -79,6 +79,9 @@ class DeepQ(object):
         self.epsilon = self.INITIAL_EPSILON
         self.temp_loss = 0
         self.total_reward = np.empty([0, 0])
+        self.target_window = "reference"  # or "aligned": see td_targets
+        # minibatch updates per vector step; None = one per environment step like the reference (n_envs per vector step)
+        self.updates_per_vector_step = None
 
     # ------------------------------------------------------------------ data
     @staticmethod
@@ -106,8 +109,10 @@ class DeepQ(object):
         data = data.to(device)
         optimizer.zero_grad()
         out = model(data, 0.5, batch=data.batch)
-        y = torch.as_tensor(y, dtype=out.dtype, device=device)
-        action = torch.as_tensor(action, dtype=out.dtype, device=device)
+        # the reference builds y / action as numpy float64 and `torch.tensor(y)` keeps that dtype: the product with
+        # the float32 read-out promotes, the loss is float64, the parameter gradients float32 (policy.py:241-248)
+        y = torch.as_tensor(y, dtype=torch.float64, device=device)
+        action = torch.as_tensor(action, dtype=torch.float64, device=device)
         loss = self.cost(out, y, action)
         self.temp_loss = loss.item()
         loss.backward()
@@ -122,31 +127,54 @@ class DeepQ(object):
         return model(data, prob)
 
     # ------------------------------------------------------------------ one mini-batch (policy.py:139-177)
+    def td_targets(self, minibatch, q1, device):
+        """(a_batch, y_batch) [sum of current-state nodes] float64 for a list of transitions
+        (s_j, local action node, reward, s_j1, terminal, fro_size1) and the target network's read-out `q1` over the
+        collated next states.
+
+        `self.target_window == "reference"` (default) restates the reference's loop literally (policy.py:154-175): the
+        read-out window of sample i is `q1[start_p : start_p + n_i][-fro1_i:]` with `start_p` advanced by the
+        CURRENT-state node counts n_i, although q1 is laid out by the next-state counts - so the window drifts away from
+        sample i's own next-state frontier nodes whenever graphs grew during the step (quirks are
+        restated, not fixed).  `"aligned"` reads the last fro1_i nodes of sample i's own next-state graph."""
+        n_j = torch.tensor([d[0].num_nodes for d in minibatch], device=device)
+        n_j1 = torch.tensor([d[3].num_nodes for d in minibatch], device=device)
+        fro1 = torch.tensor([d[5] for d in minibatch], device=device)
+        a_loc = torch.tensor([d[1] for d in minibatch], device=device)
+        r = torch.tensor([d[2] for d in minibatch], dtype=torch.float64, device=device)
+        term = torch.tensor([bool(d[4]) for d in minibatch], device=device)
+        off_j = torch.cumsum(n_j, 0) - n_j
+        n1_tot = int(q1.numel())
+        if self.target_window == "reference":
+            lo = off_j.clamp(max=n1_tot)                 # python slicing clips to the array
+            hi = (off_j + n_j).clamp(max=n1_tot)
+        else:
+            hi = torch.cumsum(n_j1, 0)
+            lo = hi - n_j1
+        lo = torch.maximum(lo, hi - fro1)                # [-fro1:] of the slice
+        if bool(((hi <= lo) & ~term).any()):
+            raise ValueError("zero-size array to reduction operation maximum which has no identity")  # as numpy would
+        pos = torch.arange(n1_tot, device=device)
+        # sample owning each position of q1 under the chosen windows (windows of different samples do not overlap)
+        seg = torch.searchsorted(hi, pos, right=True).clamp(max=len(minibatch) - 1)
+        inside = (pos >= lo[seg]) & (pos < hi[seg])
+        max_q = torch.full((len(minibatch),), -float("inf"), dtype=q1.dtype, device=device).scatter_reduce(
+            0, seg[inside], q1[inside], reduce="amax")
+        target = torch.where(term, r, r + self.GAMMA * max_q.to(torch.float64))
+        N = int(n_j.sum())
+        a_batch = torch.zeros(N, dtype=torch.float64, device=device)
+        y_batch = torch.zeros(N, dtype=torch.float64, device=device)
+        a_batch[off_j + a_loc] = 1.0
+        y_batch[off_j + a_loc] = target
+        return a_batch, y_batch
+
     def _train_minibatch(self, device, policy_net, target_net, optimizer):
         minibatch = random.sample(self.buffer, self.BATCH)
         s_j = GraphData.collate([d[0] for d in minibatch])
         s_j1 = GraphData.collate([d[3] for d in minibatch])
         with torch.no_grad():
             q1 = self.test(s_j1, 0.0, device, target_net).view(-1)
-        n_j = torch.tensor([d[0].num_nodes for d in minibatch], device=device)
-        n_j1 = torch.tensor([d[3].num_nodes for d in minibatch], device=device)
-        fro1 = torch.tensor([d[5] for d in minibatch], device=device)
-        a_loc = torch.tensor([d[1] for d in minibatch], device=device)
-        r = torch.tensor([d[2] for d in minibatch], dtype=torch.float32, device=device)
-        term = torch.tensor([bool(d[4]) for d in minibatch], device=device)
-        off_j = torch.cumsum(n_j, 0) - n_j
-        end_j1 = torch.cumsum(n_j1, 0)
-        # max over the last `fro1` (frontier) nodes of every next-state graph
-        node_g = s_j1.batch
-        is_fr = torch.arange(q1.numel(), device=device) >= (end_j1 - fro1)[node_g]
-        max_q = torch.full((len(minibatch),), -float("inf"), device=device).scatter_reduce(
-            0, node_g[is_fr], q1[is_fr], reduce="amax")
-        target = torch.where(term, r, r + self.GAMMA * max_q)
-        N = int(n_j.sum())
-        a_batch = torch.zeros(N, device=device)
-        y_batch = torch.zeros(N, device=device)
-        a_batch[off_j + a_loc] = 1.0
-        y_batch[off_j + a_loc] = target
+        a_batch, y_batch = self.td_targets(minibatch, q1, device)
         self.train(s_j, a_batch, y_batch, device, policy_net, optimizer)
 
     # ------------------------------------------------------------------ main loop (policy.py:60-208)
@@ -163,6 +191,7 @@ class DeepQ(object):
         policy_net, target_net = model, modelTarget
         target_net.eval()
         broadcast_parameters(policy_net)
+        broadcast_parameters(target_net)
         optimizer = torch.optim.Adam(policy_net.parameters(), lr=1e-5)
         temp_reward_data, temp_loss_data, rows = [], [], []
         recent = deque(self.total_reward[-1000:].tolist(), maxlen=1000)  # average reward window (policy.py:201-203)
@@ -199,25 +228,34 @@ class DeepQ(object):
             done_h = done.cpu().numpy()
             r_h = r_t.cpu().numpy()
 
-            # finished envs are re-created before the next graph export (`env = ExplorationEnv(...)` in the reference);
-            # their transition keeps the terminal flag, so the (unused) s_t1 may be the new env's first graph
-            if done_h.any():
-                env.reset(np.nonzero(done_h)[0])
+            # next state = the graph after the step, BEFORE a finished env is re-created (policy.py:127-133 store s_t1,
+            # then `env = ExplorationEnv(...)` at :185-189); envs that ran out of pose capacity are re-created too, but
+            # their transition stays non-terminal (VecExplorationEnv.truncated)
+            renew = done_h | env.truncated().cpu().numpy()
             g1 = self._host_offsets(env.graph_matrix())
             nfr1 = g1["n_frontier"].cpu().numpy()
-            s_t1 = [self.data_process(g1, i) for i in range(n_envs)]  # also the next iteration's s_t
+            s_t1 = [self.data_process(g1, i) for i in range(n_envs)]
             for i in range(n_envs):
-                self.buffer.append((s_t[i], int(a_loc[i]), float(r_h[i]), s_t1[i], bool(current_done[i] or done_h[i]), int(nfr1[i])))
+                self.buffer.append((s_t[i], int(a_loc[i]), float(r_h[i]), s_t1[i], bool(current_done[i]), int(nfr1[i])))
                 if len(self.buffer) > self.REPLAY_MEMORY:
                     self.buffer.popleft()
-            g, s_t = g1, s_t1
+            if renew.any():
+                env.reset(np.nonzero(renew)[0])
+                g1 = self._host_offsets(env.graph_matrix())
+                s_t1 = [self.data_process(g1, i) for i in range(n_envs)]
+            g, s_t = g1, s_t1  # the next iteration's s_t
             self.step_t += n_envs
             temp_i += n_envs
 
+            # the reference trains once per environment step (policy.py:137-178): n_envs mini-batches per vector step
+            # unless `updates_per_vector_step` says otherwise; the target network is refreshed when the env-step counter
+            # passes a multiple of TARGET_UPDATE
             if self.step_t > self.OBSERVE and len(self.buffer) >= self.BATCH:
-                if (self.step_t // n_envs) % max(int(self.TARGET_UPDATE // n_envs), 1) == 0:
+                n_upd = n_envs if self.updates_per_vector_step is None else int(self.updates_per_vector_step)
+                if self.step_t // self.TARGET_UPDATE > (self.step_t - n_envs) // self.TARGET_UPDATE:
                     target_net.load_state_dict(policy_net.state_dict())
-                self._train_minibatch(device, policy_net, target_net, optimizer)
+                for _ in range(n_upd):
+                    self._train_minibatch(device, policy_net, target_net, optimizer)
                 temp_loss_data.append([self.step_t, self.temp_loss])
 
             if log_every and (self.step_t // n_envs) % log_every == 0:
@@ -397,8 +435,10 @@ class A2C(object):
             done_h = done.cpu().numpy()
             r_h = r_t.cpu().numpy()
             val_h = val.cpu().numpy()
-            if done_h.any():
-                env.reset(np.nonzero(done_h)[0])
+            # envs out of pose capacity are re-created like finished ones, but stay non-terminal (VecExplorationEnv.truncated)
+            renew = done_h | env.truncated().cpu().numpy()
+            if renew.any():
+                env.reset(np.nonzero(renew)[0])
             g1 = self._host_offsets(env.graph_matrix())
             self.buffer.append((s_t, a_loc, r_h, current_done | done_h, nfr_h.copy(), val_h))
             self.step_t += n_envs

@@ -31,7 +31,7 @@ def load_config(path):
     return cp
 
 
-def config_from_ini(cp, max_poses=86, max_actions=24, max_snapshots=1):
+def config_from_ini(cp, max_poses=256, max_actions=None, max_snapshots=1):
     """The ini sections of pyss2d.py:10-55 + pyplanner2d.py:24-54 -> struct drlgx_config (plus the parameter objects)."""
     sp = ss2d.BearingRangeSensorModelParameter()
     sp.bearing_noise = math.radians(cp.getfloat("Sensor Model", "bearing_noise"))
@@ -77,8 +77,11 @@ def config_from_ini(cp, max_poses=86, max_actions=24, max_snapshots=1):
     c.angle_weight, c.distance_weight0, c.distance_weight1 = pp.angle_weight, pp.distance_weight0, pp.distance_weight1
     c.occupancy_threshold, c.max_edge_length, c.algorithm = pp.occupancy_threshold, pp.max_edge_length, int(pp.algorithm)
     c.max_poses = max_poses
-    c.max_landmarks = max(1, min(c.num_landmarks, 128))
+    c.max_landmarks = max(1, min(c.num_landmarks, 127))
     c.max_factors = max(64, 12 * max_poses)
+    if max_actions is None:  # the longest line plan the boxes allow (config.default_config)
+        span = max(ep.max_x - ep.min_x, ep.max_y - ep.min_y, (mp.max_x - mp.min_x) / 2, (mp.max_y - mp.min_y) / 2)
+        max_actions = int(math.ceil(math.hypot(span, span) / c.max_edge_length)) + 3
     c.max_actions, c.max_snapshots = max_actions, max_snapshots
     return c, dict(sensor=sp, control=cm, environment=ep, map=mp, virtual_map=vp, planner=pp)
 
@@ -185,7 +188,7 @@ class _Sim(object):
 class SS2D(object):
     """scripts/envs/pyss2d.py:56-330 (construction + simulate + getters)."""
 
-    def __init__(self, config, verbose=False, device=0, max_poses=86, start=None):
+    def __init__(self, config, verbose=False, device=0, max_poses=256, start=None):
         self._config = load_config(config) if isinstance(config, str) else config
         cfg, prm = config_from_ini(self._config, max_poses=max_poses)
         self._sensor_params, self._control_params = prm["sensor"], prm["control"]

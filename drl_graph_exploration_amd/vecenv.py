@@ -48,10 +48,11 @@ class VecExplorationEnv(object):
         self.n_envs = n_envs
         self.test = test
         if max_poses is None:
-            # a 40 m map is explored in ~35-45 poses between resets. The capacity costs memory only: the engine picks
-            # the SLAM kernel per launch from the trajectories' current length (fused LDS-resident step up to 42
-            # poses, HBM/L2-workspace variants beyond; csrc/k_slam.hip), refreshed at every status check
-            max_poses = 86
+            # the reference's own 40 m evaluation episodes take 96-197 primitive steps (data/test_result/40_DQN_GCN.csv)
+            # on top of the 5 poses of reset().  The capacity costs memory only: the engine picks the SLAM kernel per
+            # launch from the trajectories' current length (fused LDS-resident step up to 42 poses, the pose-chain
+            # ordered solve of csrc/k_slam_arrow.hip beyond), refreshed at every status check
+            max_poses = 256
         self.cfg = default_config(map_size, num_landmarks=num_landmarks, algorithm=algorithm, max_poses=max_poses)
         if n_rollouts is None:
             # one rollout instance per (env, frontier) candidate up to 4096; more candidates run in waves
@@ -173,14 +174,26 @@ class VecExplorationEnv(object):
         return self.engine.explored()
 
     def done(self):
-        """exploration_env.py:107-110 (`_done or step > max_steps or status() > 0.85`), plus one engine-side condition
-        the reference does not have: an env whose trajectory is within one plan (max_actions poses) of the engine's
-        pose capacity is reported done so that the caller resets it instead of overflowing (DRLGX_E_CAPACITY)."""
+        """exploration_env.py:107-110: `_done or step > max_steps or status() > 0.85` - the reference's terminal
+        condition and nothing else."""
         c = self.engine.counts_dev()
-        full = c[:, 0] + self.cfg.max_actions + 1 > self.cfg.max_poses
-        return (self.status() > 0.85) | (c[:, 3] > self._max_steps) | full
+        return (self.status() > 0.85) | (c[:, 3] > self._max_steps)
 
-    # ------------------------------------------------------------------ reporting (host, one env)
+    def truncated(self):
+        """Engine-side condition with no counterpart in the reference: envs whose trajectory is within one plan
+        (max_actions poses) of the pose capacity.  Callers reset them WITHOUT treating the transition as terminal
+        (the reference's episodes end on `explored > 0.85` only); with the default capacity of 256 poses this does not
+        occur on the reference's maps."""
+        c = self.engine.counts_dev()
+        return c[:, 0] + self.cfg.max_actions + 1 > self.cfg.max_poses
+
+    # ------------------------------------------------------------------ reporting
+    def metrics(self, sigma0=1.0):
+        """[n_envs, 3] float64 device tensor: get_landmark_error(), scripts/test.py's map_entropy(obs) and
+        max_uncertainty_of_trajectory() of every env (scripts/test.py:136-142), computed on the device."""
+        return self.engine.metrics(sigma0)
+
+    # (host, one env)
     def get_landmark_size(self, i):
         return self.engine.counts(int(i))["landmarks"]
 

@@ -111,6 +111,16 @@ int drlgx_uncertainty_em(drlgx_engine *e, int algorithm, double *out_dev);
 /* VirtualMap::explored (src/em_exploration/VirtualMap.cpp:47-59). out_dev: DEVICE double[n_envs]. */
 int drlgx_explored(drlgx_engine *e, double *out_dev);
 
+/* The metric trio of the reference's evaluation script (scripts/test.py:136-142) for every environment, on the device:
+ * out_dev: DEVICE double[n_envs*3] = landmark error (scripts/envs/exploration_env.py:170-177, with its sigma0 argument),
+ * map entropy (scripts/test.py:61-74; its per-map-size constant is 0.5 ln 0.5 x the number of padding cells),
+ * max localisation uncertainty = max_i tr(marginalCovariance(x_i)) (exploration_env.py:190-194). */
+int drlgx_metrics(drlgx_engine *e, double sigma0, double *out_dev);
+/* VirtualMap::toCovArray (src/SS2D.cpp:239, src/em_exploration/VirtualMap.cpp:140-151) for every environment:
+ * length_dev / angle_dev: DEVICE double[n_envs*rows*cols], row-major grids (min(sqrt(larger eigenvalue of the cell
+ * covariance), sigma0) and the direction of its eigenvector). */
+int drlgx_cov_array(drlgx_engine *e, double *length_dev, double *angle_dev);
+
 /* ---- planner calls used by the DRL loop ------------------------------------------------------ */
 
 /* EMPlanner2D::line_planner (Planner2D.cpp:937-1041), frontier-goal branch, for n_cand goals.

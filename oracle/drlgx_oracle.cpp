@@ -291,6 +291,11 @@ struct MeasFactor {
   double bearing, range;
 };
 
+// development knobs (scripts/dbg_*.py): relinearisation threshold / skip tried against the reference CSV
+static double g_relin_thr = 0.1;
+static int g_relin_skip = 10;
+static int g_relin_mode = 0;  // 0: variables with |delta|_inf >= threshold; 1: all variables if any one crosses it
+
 struct Isam {
   int count = 0;
   std::vector<Pose> th_pose;
@@ -319,9 +324,15 @@ struct Isam {
   // new variables/factors are appended by the caller before update()
   void update(int n_old_pose, int n_old_lm) {
     count++;
-    const bool relin = (count % 10 == 0);  // relinearizeSkip = 10 (offsets 1,2 and thresholds
+    const bool relin = (count % g_relin_skip == 0);  // relinearizeSkip = 10 (offsets 1,2 and thresholds
     // 0.05/0.01/0.001 were tried against the reference CSV pins and track it worse — DESIGN.md)
-    const double relin_thr = 0.1;  // relinearizeThreshold
+    double relin_thr = g_relin_thr;  // relinearizeThreshold = 0.1
+    if (relin && g_relin_mode == 1) {
+      double mx = 0;
+      for (int i = 0; i < 3 * n_old_pose; ++i) mx = std::max(mx, std::fabs(d_pose[i]));
+      for (int j = 0; j < 2 * n_old_lm; ++j) mx = std::max(mx, std::fabs(d_lm[j]));
+      if (mx >= relin_thr) relin_thr = -1.0;
+    }
     if (relin) {
       for (int i = 0; i < n_old_pose; ++i) {
         double m = std::max({std::fabs(d_pose[3 * i]), std::fabs(d_pose[3 * i + 1]), std::fabs(d_pose[3 * i + 2])});
@@ -1152,6 +1163,11 @@ void orc_get_factors(void *h, int *pose, int *key, double *bearing, double *rang
   }
 }
 // full state of the linearisation point (theta, delta) for parity checks of the SLAM kernel
+void orc_dev_set_relin(double thr, int skip, int mode) {
+  g_relin_thr = thr;
+  g_relin_skip = skip;
+  g_relin_mode = mode;
+}
 void orc_get_isam(void *h, double *th_pose /*P*3 x,y,theta*/, double *d_pose, double *th_lm /*slot order*/, double *d_lm,
                   int *count) {
   Env *e = (Env *)h;

@@ -390,12 +390,11 @@ def test_fused_step_kernel_equals_stage_kernels():
     staged.close()
 
 
-@pytest.mark.parametrize("max_poses", [43, 58, 60, 85, 86, 127])
-def test_larger_capacities_use_other_kernel_variants(max_poses, monkeypatch):
-    """Beyond 42 poses the dense system of k_slam moves from LDS to the HBM/L2 workspace (16-wide block steps with the
-    lower tiles in registers, 10 per wave up to 58 poses and 20 up to 85, streamed per step up to 127): same results.
-    The engine picks the variant per launch from its bound on the pose counts; DRLGX_VARIANT_BY_CAPACITY=1 makes it pick
-    by `max_poses`, so that a short trajectory exercises each variant."""
+@pytest.mark.parametrize("max_poses", [43, 86, 127, 200, 256])
+def test_larger_capacities_use_the_pose_chain_solver(max_poses, monkeypatch):
+    """Beyond 42 poses k_slam solves in the pose-chain-first order (csrc/k_slam_arrow.hip: block LDL^T of the odometry
+    chain, dense system on the landmarks only): same results.  The engine picks the kernel per launch from its bound on
+    the pose counts; DRLGX_VARIANT_BY_CAPACITY=1 makes it pick by `max_poses`, so that a short trajectory exercises it."""
     monkeypatch.setenv("DRLGX_VARIANT_BY_CAPACITY", "1")
     n = 3
     eng, cfg = make_engine(n, max_poses=max_poses)
@@ -403,44 +402,35 @@ def test_larger_capacities_use_other_kernel_variants(max_poses, monkeypatch):
     starts = generic_starts(n)
     sims = [O.OracleSim(ocfg, lo, lo, start=tuple(starts[lo])) for lo in range(n)]
     eng.reset(np.arange(n), np.arange(n), starts=starts)
+    for i in range(n):
+        compare_state(eng, i, sims[i], "chain solver, reset env %d" % i, check_vm=False)
     for s, act in enumerate(SCRIPT[:12]):
         eng.step(torch.tensor([act] * n, dtype=torch.float64, device=eng.device))
         for sim in sims:
             sim.simulate(act)
+        if s in (0, 5):
+            for i in range(n):
+                compare_state(eng, i, sims[i], "chain solver env %d step %d" % (i, s))
     assert eng.status() == 0
     for i in range(n):
-        compare_state(eng, i, sims[i], "hbm-ws env %d" % i)
+        compare_state(eng, i, sims[i], "chain solver env %d" % i)
     eng.close()
 
 
-def test_lds_hungry_capacities_fall_back_to_the_4wide_streamed_sweeps(monkeypatch):
-    """With landmark / factor capacities so large that the 16-wide panels no longer fit the LDS next to the per-instance
-    tables (100 poses, 400 landmarks, 9 000 factors: 166 KB), k_slam falls back to 4-wide streamed sweeps: same results."""
-    from drl_graph_exploration_amd import default_config
+def test_capacities_beyond_the_kernels_are_refused():
+    """More than 127 landmarks (the landmark system of the pose-chain solver is at most 256 x 256) or per-pose tables
+    beyond the LDS: drlgx_create says so instead of overrunning."""
+    from drl_graph_exploration_amd import _lib, default_config
     from drl_graph_exploration_amd.engine import Engine
-    monkeypatch.setenv("DRLGX_VARIANT_BY_CAPACITY", "1")
-    n = 2
-    cfg = default_config(MAP, max_poses=100, max_landmarks=400, max_factors=9000)
-    eng = Engine(cfg, n, 0)
-    ocfg = O.default_config(MAP)
-    starts = generic_starts(n)
-    sims = [O.OracleSim(ocfg, lo, lo, start=tuple(starts[lo])) for lo in range(n)]
-    eng.reset(np.arange(n), np.arange(n), starts=starts)
-    for act in SCRIPT[:12]:
-        eng.step(torch.tensor([act] * n, dtype=torch.float64, device=eng.device))
-        for sim in sims:
-            sim.simulate(act)
-    assert eng.status() == 0
-    for i in range(n):
-        compare_state(eng, i, sims[i], "4-wide fallback env %d" % i)
-    eng.close()
+    for kw in (dict(num_landmarks=400, max_landmarks=400), dict(max_poses=2000)):
+        with pytest.raises(_lib.DrlgxError):
+            Engine(default_config(MAP, **kw), 2, 0)
 
 
 def test_variant_follows_the_trajectory_length():
     """One engine with a 90-pose capacity over an 88-pose trajectory: the steps run on the fused fast kernel up to 42
-    poses, then on the 10- and 20-tile register variants and (86 poses up) the streamed one - selected per launch from the host's pose-count bound (exact
-    after every status check, +1 per step in between) - and agree with the oracle throughout; timing spans tell which
-    kernel ran."""
+    poses, then on the pose-chain solver - selected per launch from the host's pose-count bound (exact after every
+    status check, +1 per step in between) - and agree with the oracle throughout; timing spans tell which kernel ran."""
     n = 2
     eng, cfg = make_engine(n, max_poses=90)
     ocfg = O.default_config(MAP)
@@ -468,14 +458,17 @@ def test_variant_follows_the_trajectory_length():
     eng.close()
 
 
-@pytest.mark.parametrize("n,steps,cap,checks", [(32, 46, 60, (17, 33, 45)), (6, 104, 110, (50, 70, 90, 103))])
-def test_random_walk_soak(n, steps, cap, checks):
+@pytest.mark.parametrize("n,steps,cap,checks,num_lm", [(32, 46, 60, (17, 33, 45), None), (6, 104, 110, (50, 70, 90, 103), None),
+                                                       (4, 215, 256, (99, 150, 199, 214), None),
+                                                       (3, 180, 200, (60, 120, 179), 100)])
+def test_random_walk_soak(n, steps, cap, checks, num_lm):
     """Environments driven by independent random action sequences (turns, full and partial forward moves, a few
     out-of-bounds requests) against one oracle instance each, full state comparison at several steps: 32 envs x 46 steps
-    (every tile count of the fast path, into the register-tile variant) and 6 envs x 104 steps (register tiles with 10 and
-    20 tiles per wave, streamed tiles)."""
-    eng, cfg = make_engine(n, max_poses=cap)
-    ocfg = O.default_config(MAP)
+    (every tile count of the fast path, into the pose-chain solver), 6 envs x 104 steps, 4 envs x 215 steps (the length of
+    the reference's own evaluation episodes: 96-197 actions) and 3 envs x 180 steps among 100 landmarks (the landmark
+    system of the pose-chain solver grows past 63 landmarks: register-tile sweep from the workspace)."""
+    eng, cfg = make_engine(n, max_poses=cap, num_landmarks=num_lm)
+    ocfg = O.default_config(MAP, num_landmarks=num_lm)
     rng = np.random.RandomState(20260927)
     starts = np.stack([rng.uniform(-14, 14, n), rng.uniform(-14, 14, n), rng.uniform(-3.1, 3.1, n)], 1)
     sims = [O.OracleSim(ocfg, 100 + i, 100 + i, start=tuple(starts[i])) for i in range(n)]
@@ -493,17 +486,19 @@ def test_random_walk_soak(n, steps, cap, checks):
             assert eng.status() == 0
             for i in range(n):
                 compare_state(eng, i, sims[i], "soak env %d step %d" % (i, s), mask_knife_edge=True)
-    assert max(eng.counts(i)["poses"] for i in range(n)) >= (40 if cap == 60 else 88)
+    assert max(eng.counts(i)["poses"] for i in range(n)) >= {60: 40, 110: 88, 256: 180, 200: 150}[cap]
+    if num_lm == 100:
+        assert max(eng.counts(i)["landmarks"] for i in range(n)) >= 64
     eng.close()
 
 
 def test_config5_scale_120_pose_graphs():
-    """BASELINE config 5 scale: 50 m map, 500 landmarks, graphs grown to ~115 poses / ~100 landmarks (dense pose
-    system n = 3 P + 1 > 340: k_slam streams its tiles from the HBM/L2 workspace, k_map works in pose chunks)."""
+    """BASELINE config 5 scale: 50 m map, 500 landmarks, graphs grown to ~115 poses / ~100 landmarks (pose-chain solver
+    with a ~200 x 200 landmark system swept from the HBM/L2 workspace, k_map works in pose chunks)."""
     from drl_graph_exploration_amd import default_config
     from drl_graph_exploration_amd.engine import Engine
     n, msize = 2, 50
-    cfg = default_config(msize, num_landmarks=500, max_poses=120, max_landmarks=128, max_factors=3600)
+    cfg = default_config(msize, num_landmarks=500, max_poses=120, max_landmarks=127, max_factors=3600)
     eng = Engine(cfg, n, 0)
     ocfg = O.default_config(msize, num_landmarks=500)
     starts = np.array([[-7.3183, -6.2718, 0.1234], [3.1, 4.7, 2.2]])
@@ -515,7 +510,7 @@ def test_config5_scale_120_pose_graphs():
         eng.step(torch.tensor([act] * n, dtype=torch.float64, device=eng.device))
         for sim in sims:
             sim.simulate(act)
-        if s in (87, 113):  # 20-tile-per-wave register variant no longer fits from 87 poses on
+        if s in (87, 113):
             assert eng.status() == 0
             for i in range(n):
                 assert eng.counts(i)["poses"] == s + 2

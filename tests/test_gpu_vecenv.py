@@ -165,73 +165,20 @@ def test_a2c_running_smoke(tmp_path):
 # ---------------------------------------------------------------------------------------------------------------------
 # the reference's own golden data through the PRODUCT path: data/test_result/40_DQN_GCN.csv (fixture csv_pin.json)
 # ---------------------------------------------------------------------------------------------------------------------
-def _csv_entropy(obs):
-    """scripts/test.py:61-74 for map_size 40."""
-    return float(-(obs * np.log(obs)).sum() + 0.5 * np.log(0.5) * 1200)
-
-
-def _first_difference_is_knife_edge(seed, pin):
-    """Replay one seed through the engine and the oracle side by side. Returns the number of rows for which the two
-    were in the same state, after asserting that the first difference is a knife-edge event: occupancy cells at exactly
-    max_range / the FOV edge of a dead-reckoned pose, or an exact tie between two frontier cells (the reference's start
-    poses and cell centres are integers, so both occur structurally; 1 ulp of pose round-off decides them)."""
-    from drl_graph_exploration_amd.vecenv import VecExplorationEnv
-    env = VecExplorationEnv(MAP, 1, env_index=seed, test=True, max_poses=41)
-    ref = O.OracleEnv(MAP, seed)
-    assert int(env.env_index[0]) == ref.env_index
-    eng, row = env.engine, 0
-    try:
-        for choice in pin["choices"]:
-            g = env.graph_matrix()
-            acts, nact = env.actions_all_goals()
-            A, X, _, fro = ref.graph_matrix()
-            racts = ref.actions_all_goals()
-            ks = A.shape[0] - fro
-            first = int(env.candidates[2][0])
-            fe = g["frontier_xy"][0, :int(g["n_frontier"][0])].cpu().numpy()
-            fo = np.array(ref._frontier)
-            if fe.shape != fo.shape or not np.allclose(fe, fo, atol=1e-9):
-                # a different frontier list: must be an exact tie for some query point (vehicle or a landmark)
-                veh = ref.vehicle_position()
-                kp = ref._sim.key_points()
-                queries = [np.array(veh[:2])] + [np.array(kp[k]) for k in range(ref.get_landmark_size())]
-                cells = np.array(ref.all_frontiers)
-                tie = False
-                for q in queries:
-                    d = np.sort(np.sqrt(((cells - q) ** 2).sum(axis=1)))
-                    tie |= len(d) > 1 and d[1] - d[0] < 1e-9
-                assert tie, "seed %d: frontier lists differ without a tie" % seed
-                return row
-            a = acts[first + choice].cpu().numpy()
-            plan = racts[ks + choice]
-            assert int(nact[first + choice]) == len(plan) and np.allclose(a[:len(plan)], np.array(plan), atol=1e-9)
-            for k in range(len(plan)):
-                eng.step(torch.tensor(a[k:k + 1], device=env.device))
-                ref.step(plan[k])
-                sim = ref._sim
-                p, kk, _, _ = eng.factors(0)
-                op, ok, _, _ = sim.factors()
-                np.testing.assert_array_equal(p, op)
-                np.testing.assert_array_equal(kk, ok)
-                np.testing.assert_allclose(eng.poses(0)[0], sim.poses()[0], atol=1e-8)
-                prob, oprob = eng.virtual_map(0)[0], sim.virtual_map()[0]
-                if not np.array_equal(prob, oprob):
-                    knife = sim.knife_edge_cells(1e-9).reshape(prob.shape)
-                    assert knife[prob != oprob].all(), "seed %d: grids differ outside knife-edge cells" % seed
-                    return row
-                row += 1
-        return row
-    finally:
-        env.close()
-
-
 def test_hip_path_reproduces_reference_evaluation_csv(golden_dir):
-    """Every seed of the reference's shipped evaluation run (data/test_result/40_DQN_GCN.csv: per executed action the
-    landmark error, the map entropy and the largest pose-covariance trace) replayed through the product path in ONE
-    vectorised run: VecExplorationEnv (HIP belief step, graph export, line plans) + the HIP GCN with the shipped
-    MyModel.pt choosing the frontier. Tolerances as in the oracle's CPU pin (tests/test_oracle_csv_pin.py): 1e-4
-    relative on landmark error and trace, 5e-3 on the entropy. Seeds that leave the CSV must do so through a knife-edge
-    event (see _first_difference_is_knife_edge), and at least 80 % of the seeds must reproduce every row."""
+    """Every pinned row of the reference's shipped evaluation run (data/test_result/40_DQN_GCN.csv: per executed action
+    the landmark error, the map entropy and the largest pose-covariance trace; 2 273 rows over 44 seeds, one whole
+    179-action episode, five seeds beyond 90 actions) replayed through the product path in ONE vectorised run:
+    VecExplorationEnv (HIP belief step with the pose-chain solver beyond 42 poses, device metrics, graph export, line
+    plans) and the HIP GCN with the shipped MyModel.pt.
+
+    The engine executes the action lists the fixture pins (the reference's actions as inferred by the CPU oracle's
+    search, scripts/make_csv_pin_fixture.py), so the rows do not depend on knife-edge decisions of the replaying
+    implementation (a frontier tie, a cell at exactly max_range, a path length of exactly 4.0 m).  Tolerances as in the
+    oracle's CPU pin (tests/test_oracle_csv_pin.py): 1e-4 relative on landmark error and trace, 2e-2 on the entropy.
+    Beside that the product's own decisions are compared where they are well defined: its line plan to the pinned goal
+    (equal to the executed plan up to the documented remainder variants), its frontier list (contains the pinned goal)
+    and the HIP GCN's pick (the reference network's, on the decisions where the frontier lists agree)."""
     import json
     import os
     from drl_graph_exploration_amd.networks import GCN, GraphData
@@ -240,63 +187,108 @@ def test_hip_path_reproduces_reference_evaluation_csv(golden_dir):
     seeds = [int(k) for k, v in pins.items() if len(v["rows"]) >= 4]
     n = len(seeds)
     assert n >= 40
-    env = VecExplorationEnv(MAP, n, env_index=0, test=True, max_poses=41)
+    env = VecExplorationEnv(MAP, n, env_index=0, test=True, max_poses=256, n_rollouts=0)
     env.env_index = np.array(seeds, dtype=np.int64)
     env.reset()
     dev = env.device
+    A_max = env.cfg.max_actions
     model = GCN()
     model.load_state_dict(torch.load(os.path.join(golden_dir, "DQN_GCN_MyModel.pt"), map_location="cpu"))
     model.to(dev)
-    row, ok = [0] * n, [True] * n
-    gcn_same = gcn_all = 0
-    for d in range(max(len(pins[str(s)]["choices"]) for s in seeds)):
+    row = [0] * n
+    bad_rows = []
+    plan_same = plan_all = goal_in_frontier = gcn_same = gcn_all = 0
+    n_dec = max(len(pins[str(s)]["choices"]) for s in seeds)
+    for d in range(n_dec):
         g = env.graph_matrix()
         with torch.no_grad():
             q = model(GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"]), 0.0, batch=g["batch"]).view(-1).cpu().numpy()
         node_off, nfr = g["node_off"].cpu().numpy(), g["n_frontier"].cpu().numpy()
-        acts, nact = env.actions_all_goals()
-        first = env.candidates[2].cpu().numpy()
-        choice = np.zeros(n, dtype=np.int64)
-        live = np.zeros(n, dtype=bool)
+        fxy = g["frontier_xy"].cpu().numpy()
+        live = np.array([d < len(pins[str(s)]["choices"]) for s in seeds])
+        goals = np.zeros((n, 2))
+        acts = np.zeros((n, A_max, 3))
+        nact = np.zeros(n, dtype=np.int64)
         for i, s in enumerate(seeds):
+            if not live[i]:
+                continue
             pin = pins[str(s)]
-            if not ok[i] or d >= len(pin["choices"]):
+            goals[i] = pin["goals"][d]
+            pl = np.array(pin["plans"][d])
+            acts[i, :len(pl)] = pl
+            nact[i] = len(pl)
+            ch = pin["choices"][d]
+            fr = fxy[i, :nfr[i]]
+            hit = np.nonzero(np.all(np.abs(fr - goals[i]) < 1e-9, axis=1))[0]
+            goal_in_frontier += int(len(hit) > 0)
+            if isinstance(ch, int) and len(hit) and hit[0] == ch and pin["gcn_choices"][d] >= 0:
+                gcn_all += 1
+                gcn_same += int(np.argmax(q[node_off[i + 1] - nfr[i]:node_off[i + 1]])) == pin["gcn_choices"][d]
+        # the product's own line plan to the pinned goals
+        ce = torch.arange(n, dtype=torch.int32, device=dev)
+        pa, pn = env.engine.line_plan(ce, torch.as_tensor(goals, device=dev))
+        pa, pn = pa.cpu().numpy(), pn.cpu().numpy()
+        for i, s in enumerate(seeds):
+            if not live[i]:
                 continue
-            if pin["choices"][d] >= nfr[i]:
-                ok[i] = False
-                continue
-            gcn_all += 1
-            gcn_same += int(np.argmax(q[node_off[i + 1] - nfr[i]:node_off[i + 1]])) == pin["gcn_choices"][d]
-            choice[i], live[i] = pin["choices"][d], True
-        c = torch.as_tensor(first + choice, device=dev)
-        a = acts[c]
-        na = nact[c] * torch.as_tensor(live, device=dev).to(nact.dtype)
-        for k in range(int(na.max().item())):
+            ch = pins[str(s)]["choices"][d]
+            want = acts[i, :nact[i]]
+            mine = pa[i, :pn[i]]
+            if isinstance(ch, list) and isinstance(ch[0], str):  # remainder on the other side of a multiple of 2 m
+                mine = mine[:-1] if ch[0] == "no_tail" else np.concatenate([mine, np.zeros((1, 3))])
+            plan_all += 1
+            k = min(len(mine), len(want))
+            last_cut = pins[str(s)]["finished"] and d + 1 == len(pins[str(s)]["choices"])  # the reference stopped mid-plan
+            plan_same += int(np.allclose(mine[:k], want[:k], atol=1e-7) and
+                             (len(mine) == len(want) or (last_cut and len(want) < len(mine))))
+        a_dev = torch.as_tensor(acts, device=dev)
+        na = torch.as_tensor(nact, device=dev)
+        for k in range(int(nact.max())):
             active = (na > k).to(torch.uint8)
-            env.engine.step(a[:, k].contiguous(), active)
-            act_h = active.cpu().numpy()
+            env.engine.step(a_dev[:, k].contiguous(), active)
+            m = env.engine.metrics().cpu().numpy()
             for i, s in enumerate(seeds):
-                if not act_h[i] or not ok[i]:
+                if nact[i] <= k:
                     continue
-                rows = pins[str(s)]["rows"]
-                if row[i] >= len(rows):
-                    ok[i] = False
-                    continue
-                ref = np.array(rows[row[i]])
-                got = np.array([env.get_landmark_error(i), _csv_entropy(env.obs(i)), env.max_uncertainty_of_trajectory(i)])
-                rel = np.abs(got - ref) / np.abs(ref)
-                if rel[0] > 1e-4 or rel[2] > 1e-4 or rel[1] > 5e-3:
-                    ok[i] = False
-                else:
-                    row[i] += 1
+                ref = np.array(pins[str(s)]["rows"][row[i]])
+                rel = np.abs(m[i] - ref) / np.abs(ref)
+                if rel[0] > 1e-4 or rel[2] > 1e-4 or rel[1] > 2e-2:
+                    bad_rows.append((s, row[i], rel.tolist()))
+                row[i] += 1
         env._graph = None
     env.engine.check_status()
+    poses = env.engine.counts_dev()[:, 0].cpu().numpy()
     env.close()
-    full = [ok[i] and row[i] == len(pins[str(s)]["rows"]) for i, s in enumerate(seeds)]
-    assert sum(full) >= 0.8 * n, (sum(full), n)
-    assert gcn_same >= gcn_all - 4  # the HIP GCN picks the frontier the reference's network picked
-    for i, s in enumerate(seeds):
-        if not full[i]:
-            same = _first_difference_is_knife_edge(s, pins[str(s)])
-            # up to the knife-edge event the engine followed the oracle, hence (oracle pin) the CSV
-            assert row[i] >= min(same, len(pins[str(s)]["rows"])) - 1, (s, row[i], same)
+    total = sum(len(pins[str(s)]["rows"]) for s in seeds)
+    assert sum(row) == total and total >= 2000
+    assert poses.max() >= 180  # the whole 179-action episode ran on the device
+    assert not bad_rows, bad_rows[:5]
+    assert plan_same >= 0.97 * plan_all, (plan_same, plan_all)
+    assert goal_in_frontier >= 0.85 * plan_all, (goal_in_frontier, plan_all)
+    assert gcn_all >= 300 and gcn_same >= 0.97 * gcn_all, (gcn_same, gcn_all)
+
+
+def test_device_metrics_equal_the_host_getters():
+    """drlgx_metrics (landmark error, map entropy of scripts/test.py:61-74, max pose-covariance trace) against the same
+    quantities assembled on the host from the exported state, and against the oracle."""
+    from drl_graph_exploration_amd.vecenv import VecExplorationEnv
+    n = 5
+    env = VecExplorationEnv(MAP, n, env_index=3, test=True, max_poses=60, n_rollouts=0)
+    refs = [O.OracleEnv(MAP, 3 + i) for i in range(n)]
+    for act in [(2.0, 0.0, 0.0), (0.0, 0.0, 1.1), (2.0, 0.0, 0.0), (1.5, 0.0, 0.0)]:
+        env.engine.step(torch.tensor([act] * n, dtype=torch.float64, device=env.device))
+        for r in refs:
+            r.step(act)
+    m = env.metrics().cpu().numpy()
+    for i in range(n):
+        obs = env.obs(i)
+        host = [env.get_landmark_error(i), float(-(obs * np.log(obs)).sum() + 0.5 * np.log(0.5) * 1200),
+                env.max_uncertainty_of_trajectory(i)]
+        np.testing.assert_allclose(m[i], host, rtol=1e-12)
+        orc = [refs[i].get_landmark_error(), O.map_entropy(refs[i]._obs), refs[i].max_uncertainty_of_trajectory()]
+        np.testing.assert_allclose(m[i], orc, rtol=1e-8)
+    ln, an = env.engine.cov_array()
+    # VirtualMap.to_cov_array: untouched cells have covariance sigma0^2 I -> length sigma0; touched cells are tighter
+    ln = ln.cpu().numpy()
+    assert ln.shape == (n, 40, 40) and np.all(ln <= 1.0 + 1e-15) and (ln < 0.999).any() and np.isfinite(an.cpu().numpy()).all()
+    env.close()

@@ -39,8 +39,9 @@ def test_error_strings_and_create_without_device():
     for code in (0, -1, -2, -3, -4, -5):
         assert len(L.drlgx_strerror(code)) > 0
     h = C.c_void_p()
-    # argument validation comes before the device: capacities beyond the kernels' index widths are refused
-    assert L.drlgx_create(C.byref(default_config(40, max_poses=128)), 4, 0, 0, C.byref(h)) == -1 and not h.value
+    # argument validation comes before the device: capacities beyond what the SLAM kernels' LDS tables hold are refused
+    assert L.drlgx_create(C.byref(default_config(40, max_poses=4096)), 4, 0, 0, C.byref(h)) == -1 and not h.value
+    assert L.drlgx_create(C.byref(default_config(40, num_landmarks=200, max_landmarks=128)), 4, 0, 0, C.byref(h)) == -1
     assert L.drlgx_create(C.byref(default_config(40, max_poses=1)), 4, 0, 0, C.byref(h)) == -1 and not h.value
     if torch.cuda.is_available():
         pytest.skip("needs a box without a GPU")
@@ -140,19 +141,24 @@ class _TinyQ(torch.nn.Module):
 
 
 def test_dqn_targets_equal_reference_loop(tmp_path):
-    """DeepQ._train_minibatch builds the same (a_batch, y_batch) as policy.py:152-177's numpy loop."""
+    """DeepQ.td_targets builds the same (a_batch, y_batch) as the reference's numpy loop (policy.py:152-177), whose
+    literal restatement lives in oracle/dqn_ref.py - including its read-out window offsets by the CURRENT-state node
+    counts - in float64; the "aligned" variant reads each sample's own next-state frontier nodes."""
     import random
+    from oracle import dqn_ref
     from drl_graph_exploration_amd.networks import GraphData
     from drl_graph_exploration_amd.policy import DeepQ
     torch.manual_seed(0)
     rng = np.random.RandomState(1)
     dq = DeepQ("t/", "GCN", data_root=str(tmp_path))
     dq.BATCH = 8
+    assert dq.target_window == "reference"
 
     def graph(n):
         return GraphData(torch.randn(n, 5), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0))
     for _ in range(20):
-        n, n1 = int(rng.randint(4, 9)), int(rng.randint(4, 9))
+        n = int(rng.randint(4, 9))
+        n1 = n + int(rng.randint(0, 4))  # graphs grow during a step (new poses / landmarks)
         fro, fro1 = int(rng.randint(1, 4)), int(rng.randint(1, 4))
         a = n - fro + int(rng.randint(fro))
         dq.buffer.append((graph(n), a, float(rng.randn()), graph(n1), bool(rng.rand() < 0.3), fro1))
@@ -166,30 +172,43 @@ def test_dqn_targets_equal_reference_loop(tmp_path):
     dq._train_minibatch(torch.device("cpu"), pol, tgt, None)
     random.seed(5)
     minibatch = random.sample(dq.buffer, dq.BATCH)
-    q1 = tgt(GraphData.collate([d[3] for d in minibatch]), 0.0).view(-1).detach().numpy()
-    a_batch, y_batch, start_p = np.array([]), np.array([]), 0
+    q1 = tgt(GraphData.collate([d[3] for d in minibatch]), 0.0).detach().numpy()  # [N1, 1] float32 like the reference's
+    acts = []
     for d in minibatch:
-        node_space = d[0].x.shape[0]
-        act = np.zeros(node_space)
+        act = np.zeros(d[0].x.shape[0])
         act[d[1]] = 1
-        temp_y = np.zeros(node_space)
-        n1 = d[3].x.shape[0]
-        if d[4]:
-            temp_y[d[1]] = d[2]
-        else:
-            temp_y[d[1]] = d[2] + dq.GAMMA * np.max(q1[start_p:start_p + n1][-d[5]:])
-        start_p += n1  # (the reference advances by the s_t node count; the two agree only when graphs keep their size —
-        #                 indexing the next-state readout by the next-state sizes is the intended behaviour)
-        a_batch, y_batch = np.append(a_batch, act), np.append(y_batch, temp_y)
-    np.testing.assert_array_equal(captured["a"].numpy(), a_batch)
-    np.testing.assert_allclose(captured["y"].numpy(), y_batch, rtol=1e-6, atol=1e-6)
-    # and the loss / clamp / step path runs on a plain module
+        acts.append(act)
+    a_ref, y_ref = dqn_ref.reference_targets(acts, [d[2] for d in minibatch], [d[4] for d in minibatch],
+                                             [d[5] for d in minibatch], q1, dq.GAMMA)
+    assert captured["a"].dtype == torch.float64 and captured["y"].dtype == torch.float64
+    np.testing.assert_array_equal(captured["a"].numpy(), a_ref)
+    np.testing.assert_array_equal(captured["y"].numpy(), y_ref)  # same float64 arithmetic: bit-equal
+    # the windows really are the drifting ones: the aligned variant differs on this data and matches its own loop
+    dq.target_window = "aligned"
+    a_al, y_al = dq.td_targets(minibatch, torch.as_tensor(q1).view(-1), torch.device("cpu"))
+    y_exp, start = [], 0
+    for d in minibatch:
+        n, n1 = d[0].x.shape[0], d[3].x.shape[0]
+        t = np.zeros(n)
+        t[d[1]] = d[2] if d[4] else d[2] + dq.GAMMA * float(np.max(q1[start:start + n1][-d[5]:]))
+        start += n1
+        y_exp.append(t)
+    np.testing.assert_array_equal(y_al.numpy(), np.concatenate(y_exp))
+    assert not np.array_equal(y_al.numpy(), y_ref)
+    # loss in float64 (policy.py:246-248), clamp and step on a plain module
     dq2 = DeepQ("t2/", "GCN", data_root=str(tmp_path))
     opt = torch.optim.Adam(pol.parameters(), lr=1e-3)
     before = pol.lin.weight.detach().clone()
     dq2.BATCH = 8
+    pred = pol(captured["data"], 0.5).detach().numpy()
     dq2.train(captured["data"], captured["a"], captured["y"], torch.device("cpu"), pol, opt)
+    assert dq2.temp_loss == pytest.approx(dqn_ref.reference_cost(pred, y_ref, a_ref, 8), rel=1e-12)
     assert dq2.temp_loss > 0 and not torch.equal(before, pol.lin.weight.detach())
+    # an empty window is the reference's numpy error, not a silent value
+    small = [(graph(6), 5, 0.1, graph(2), False, 1), (graph(6), 5, 0.1, graph(2), False, 1)]
+    dq.target_window = "reference"
+    with pytest.raises(ValueError):
+        dq.td_targets(small, torch.zeros(4), torch.device("cpu"))
 
 
 def _worker(rank, world, port, q):
