@@ -1,5 +1,7 @@
-"""Dev tool: belief-step stage times as the trajectories grow (256 envs, 40 m map, 100 landmarks, 86-pose capacity)."""
-import math, os, sys
+"""Dev tool: belief-step stage times as the trajectories grow (256 envs, 40 m map).
+usage: bench_vs_poses.py [pose capacity = 206] [landmarks in the world = 100] [phases]
+With `phases`, the in-kernel phase stamps of block 0 of the SLAM kernel are printed too (k_slam_arrow beyond 42 poses)."""
+import ctypes as C, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -8,17 +10,23 @@ from drl_graph_exploration_amd import default_config
 from drl_graph_exploration_amd.engine import Engine
 
 n = 256
-cap = int(sys.argv[1]) if len(sys.argv) > 1 else 86
-cfg = default_config(bench.MAP, num_landmarks=bench.NUM_LM, max_poses=cap, max_landmarks=100, max_factors=14 * cap, max_snapshots=1)
+cap = int(sys.argv[1]) if len(sys.argv) > 1 else 206
+num_lm = int(sys.argv[2]) if len(sys.argv) > 2 else bench.NUM_LM
+phases = len(sys.argv) > 3
+cfg = default_config(bench.MAP, num_landmarks=num_lm, max_poses=cap, max_factors=14 * cap, max_snapshots=1)
 eng = Engine(cfg, n, 0, 0)
 rng = np.random.RandomState(0)
 starts = np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-3, 3, n)], 1)
 eng.reset(np.arange(n), np.arange(n), starts=starts)
 loop = [(2, 0, 0)] * 3 + [(0, 0, math.pi / 2)] + [(2, 0, 0)] * 2 + [(0.7, 0, 0.4)]
 odoms = [torch.tensor([a] * n, dtype=torch.float64, device=eng.device) for a in loop]
+names = ["relin+tables+linearise", "blocks", "chain LDL^T", "substitution + (T^-1)_ii", "landmark system", "sweep", "outputs"]
+out = (C.c_int64 * 64)()
+print("# %d envs, %d landmarks in the world, capacity %d poses" % (n, num_lm, cap))
 for s in range(cap - 3):
     eng.step(odoms[s % len(loop)])
-    if (s + 2) % 8 == 0 or s + 2 in (41, 42, 43, 58, 59) or (len(sys.argv) > 2 and s + 2 in range(30, 44)):
+    p = s + 2
+    if (p < 48 and p % 8 == 0) or p in (41, 42, 43) or (p >= 48 and p % 16 == 0) or p == cap - 2:
         assert eng.status() == 0
         eng.snapshot(0)
         eng.timing_enable(2)
@@ -36,10 +44,21 @@ for s in range(cap - 3):
             eng.step(odoms[(s + 1) % len(loop)])
         tf = eng.timing_read()
         eng.timing_enable(False)
+        extra = ""
+        if phases and p > 42:
+            eng.timing_enable(2)
+            eng.L.drlgx_debug_phase_clocks_host(eng.h, 1, None)
+            eng.restore(0)
+            eng.step(odoms[(s + 1) % len(loop)])
+            eng.L.drlgx_debug_phase_clocks_host(eng.h, 0, out)
+            eng.timing_enable(False)
+            a = np.array(out[:8], dtype=np.float64)
+            extra = " | block 0: " + ", ".join("%s %.1f" % (names[k], (a[k + 1] - a[k]) / 100.0) for k in range(7))
         eng.restore(0)
         c = eng.counts_dev().cpu().numpy()
         ov = tm["t7"][0] / tm["t7"][1] * 1e3
-        print("poses %3d -> %3d landmarks %.0f factors %.0f: sim %.1f slam %.1f map %.1f us%s" % (
-            s + 2, s + 3, c[:, 1].mean(), c[:, 2].mean(), tm["sim"][0] / tm["sim"][1] * 1e3 - ov, tm["slam"][0] / tm["slam"][1] * 1e3 - ov,
-            tm["map"][0] / tm["map"][1] * 1e3 - ov, (", fused %.1f us" % (tf["step"][0] / tf["step"][1] * 1e3 - ov)) if tf["step"][1] else ""))
+        print("poses %3d -> %3d landmarks %.0f (max %d) factors %.0f: sim %.1f slam %.1f map %.1f us%s%s" % (
+            p, p + 1, c[:, 1].mean(), c[:, 1].max(), c[:, 2].mean(), tm["sim"][0] / tm["sim"][1] * 1e3 - ov,
+            tm["slam"][0] / tm["slam"][1] * 1e3 - ov, tm["map"][0] / tm["map"][1] * 1e3 - ov,
+            (", fused %.1f us" % (tf["step"][0] / tf["step"][1] * 1e3 - ov)) if tf["step"][1] else "", extra), flush=True)
 eng.close()
