@@ -11,14 +11,24 @@
 // Eliminating the pose chain first leaves a dense system on the landmarks only ("arrowhead" / bordered block
 // tridiagonal): cost O(P L^2 + L^3) instead of O(P^3) for the landmark-first Schur complement of the fast path, which
 // is what the reference's own episodes need (100-200 poses, a handful of landmarks).  Selected inverse:
-//     X = T^-1 [B  eta_p]                     block LDL^T of T (chain recursion) + forward / backward substitution,
-//                                             one thread per column, the recurrence state in registers
+//     X = T^-1 [B  eta_p]                     block cyclic reduction of the chain (= nested dissection of the pose
+//                                             chain: log2 P levels, every level parallel over its poses x columns)
 //     C = Lambda_ll - B^T X_B                 landmark Schur complement, rhs eta_l - B^T x_eta
 //     [C r] -> -C^-1, delta_l                 the symmetric Gauss-Jordan sweep of the fast path (fp64 matrix cores)
 //     delta_p = x_eta - X_B delta_l
 //     Sigma_ll = C^-1 (its 2x2 diagonal blocks);  Sigma_ii = (T^-1)_ii + X_i C^-1 X_i^T   for every pose i,
-//     (T^-1)_ii by the backward recursion  (T^-1)_ii = D'_i^-1 + L_{i+1,i}^T (T^-1)_{i+1,i+1} L_{i+1,i}.
-// X (3P x (2L + 1)) and, beyond 63 landmarks, C live in the HBM/L2 workspace; everything else is in LDS.
+//     (T^-1)_ii by the Takahashi recursion over the same elimination tree (top level down, parallel per level).
+// X (3P x (2L + 1)), the selected-inverse blocks and, beyond 63 landmarks, C live in the HBM/L2 workspace; the chain
+// factors and the landmark tables are in LDS.
+//
+// Cyclic reduction.  Level l (stride s = 2^l) eliminates the poses i = s, 3s, 5s, ... from the poses that are multiples of
+// s; their neighbours i - s and i + s survive.  With A_i = T_{i,i-s} (coupling to the left neighbour at that level):
+//     E_i = D_i^-1,  GL_i = E_i A_i,  GR_i = E_i A_{i+s}^T                                      (eliminated i)
+//     D_j -= A_j GR_{j-s} + A_{j+s}^T GL_{j+s},  A_j <- -A_j GL_{j-s},
+//     b_j -= GR_{j-s}^T b_{j-s} + GL_{j+s}^T b_{j+s}                                           (surviving j)
+// and back down:  x_i = E_i b_i - GL_i x_{i-s} - GR_i x_{i+s};  Takahashi: S_{l,i} = -(S_ll GL_i^T + S_lr GR_i^T),
+// S_{r,i} = -(S_rl GL_i^T + S_rr GR_i^T), S_ii = E_i - GL_i S_{l,i} - GR_i S_{r,i}, where the cross block S_lr of the two
+// neighbours is the one stored by whichever of them is eliminated at the next level.
 
 // symmetric 3x3 (a00 a01 a02 a11 a12 a22) -> inverse in the same storage; returns the determinant's sign test
 __device__ __forceinline__ bool inv3s(const double *a, double *o) {
@@ -38,12 +48,38 @@ __device__ __forceinline__ double sym3(const double *a, int r, int c) {
   return a[idx[r * 3 + c]];
 }
 
+// ascending iteration over the set bits of a W-word mask, up to four at a time (so that the loads of four
+// observations can be issued before the first one is used)
+struct MaskIter {
+  const unsigned long long *mk;
+  int W, w;
+  unsigned long long m;
+  __device__ __forceinline__ MaskIter(const unsigned long long *mk_, int W_) : mk(mk_), W(W_), w(0), m(mk_[0]) {}
+  __device__ __forceinline__ int next4(int (&ip)[4]) {
+    int n = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      while (!m && w + 1 < W) m = mk[++w];
+      if (m) {
+        ip[u] = 64 * w + __ffsll((long long)m) - 1;
+        m &= m - 1;
+        n = u + 1;
+      } else {
+        ip[u] = ip[0];
+      }
+    }
+    return n;
+  }
+};
+
 // LDS bytes of the per-pose / per-landmark tables of arrow_body (without the landmark system, records and tables)
 __host__ __device__ inline size_t arrow_small_bytes(int P, int L, int M) {
   const size_t MW = (size_t)(P + 63) >> 6;
-  return (size_t)P * (4 + 6 + 9 + 3 + 6) * 8 + (size_t)L * (2 + 8) * 8 + (((size_t)(P + 2) * 4 + 7) & ~(size_t)7) +
-         2 * (((size_t)M * 2 + 7) & ~(size_t)7) + (size_t)L * MW * 8 + 64;
+  return (size_t)P * (4 + 6 + 9 + 9 + 9) * 8 + (size_t)L * (2 + 8) * 8 + (((size_t)(P + 2) * 4 + 7) & ~(size_t)7) +
+         (size_t)L * MW * 8 + 64;
 }
+
+constexpr int kSegLog = 3, kSeg = 1 << kSegLog;  // leaf segments of the chain: 7 interior poses between separators
 
 template <int NTW>
 __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel &sel, int lds_bytes) {
@@ -77,42 +113,53 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     return q;
   };
   double *thp = reinterpret_cast<double *>(take((size_t)P * 4 * 8));
-  double *Dd = reinterpret_cast<double *>(take((size_t)P * 6 * 8));   // D_i -> D'_i^-1 (symmetric)
-  double *Oo = reinterpret_cast<double *>(take((size_t)P * 9 * 8));   // T_{i+1,i} -> L_{i+1,i}
-  double *gp = reinterpret_cast<double *>(take((size_t)P * 3 * 8));   // eta_p = -g
-  double *Ti = reinterpret_cast<double *>(take((size_t)P * 6 * 8));   // (T^-1)_ii (symmetric)
+  double *Dd = reinterpret_cast<double *>(take((size_t)P * 6 * 8));   // D_i (symmetric) -> E_i = its inverse when i is eliminated
+  double *Al = reinterpret_cast<double *>(take((size_t)P * 9 * 8));   // A_i = T_{i,i-s}: coupling to the current left neighbour
+  double *GL = reinterpret_cast<double *>(take((size_t)P * 9 * 8));   // E_i A_i
+  double *GR = reinterpret_cast<double *>(take((size_t)P * 9 * 8));   // E_i A_{i+s}^T
   double *thl = reinterpret_cast<double *>(take((size_t)L * 2 * 8));
   double *lamb = reinterpret_cast<double *>(take((size_t)L * 8 * 8));
   int *mstart = reinterpret_cast<int *>(take((size_t)(P + 2) * 4));
-  unsigned short *mp = reinterpret_cast<unsigned short *>(take((size_t)M * 2));
-  unsigned short *ml = reinterpret_cast<unsigned short *>(take((size_t)M * 2));
   int *bad = reinterpret_cast<int *>(take(8));
   const int MW = (P + 63) >> 6;
   unsigned long long *lmask = reinterpret_cast<unsigned long long *>(take((size_t)L * MW * 8));
   off = (off + 31) & ~(size_t)31;
   double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
   double *X = wsd; wsd += (size_t)3 * S.P_max * (size_t)((2 * S.L_max + 1 + 3) & ~3);
-  double *A;       // landmark system: packed lower triangle in LDS, or square (ld = N) in the workspace
-  double *panels;  // sweep panels of the workspace variant
-  if (c_lds) {
-    A = reinterpret_cast<double *>(smem_raw + off);
-    off += max((size_t)N * (N + 1) / 2, (size_t)48 * N + 1280) * 8;
-    panels = nullptr;
-  } else {
-    A = wsd; wsd += (size_t)(2 * S.L_max + 17) * (2 * S.L_max + 17);
-    panels = reinterpret_cast<double *>(smem_raw + off);
-    off += ((size_t)32 * N + 1280) * 8;
-  }
-  auto AT = [&](int i, int j) -> int { return c_lds ? i * (i + 1) / 2 + j : i * N + j; };
-  const size_t big = (size_t)M * REC * 8 + up8((size_t)L * P * 2);
-  double *rec;
+  double *Ti = wsd; wsd += (size_t)6 * S.P_max;    // (T^-1)_ii, symmetric
+  double *Sl = wsd; wsd += (size_t)9 * S.P_max;    // (T^-1)_{i-s,i} at i's elimination level
+  double *Sr = wsd; wsd += (size_t)9 * S.P_max;    // (T^-1)_{i+s,i}
+  double *sepR = wsd; wsd += (size_t)(S.P_max / kSeg + 2) * 3 * (size_t)((2 * S.L_max + 1 + 3) & ~3);  // leaf -> right separator rhs
+  // the landmark x pose observation table: LDS when it fits
   unsigned short *obs;
-  if (off + big <= (size_t)lds_bytes) {
-    rec = reinterpret_cast<double *>(smem_raw + off); off += (size_t)M * REC * 8;
-    obs = reinterpret_cast<unsigned short *>(smem_raw + off);
+  double *rec_ws = wsd; wsd += (size_t)S.M_max * REC;
+  double *Aws = wsd; wsd += (size_t)(2 * S.L_max + 17) * (2 * S.L_max + 17);
+  const size_t sys_bytes = (c_lds ? max((size_t)N * (N + 1) / 2, (size_t)48 * N + 1280) : (size_t)32 * N + 1280) * 8;
+  if (off + sys_bytes + up8((size_t)L * P * 2) + 32 <= (size_t)lds_bytes) {
+    obs = reinterpret_cast<unsigned short *>(smem_raw + off); off += (up8((size_t)L * P * 2) + 31) & ~(size_t)31;
   } else {
-    rec = wsd; wsd += (size_t)S.M_max * REC;
     obs = reinterpret_cast<unsigned short *>(wsd);
+  }
+  // union region: during the chain solve the rhs rows of the separator poses (3 rows x ldx per separator), afterwards
+  // the landmark system (packed lower triangle + its sweep panels) or the panels of the workspace variant
+  const int nsep = (P + kSeg - 1) / kSeg;
+  const size_t xs_bytes = (size_t)nsep * 3 * ldx * 8;
+  double *U = reinterpret_cast<double *>(smem_raw + off);
+  const bool xs_lds = off + max(sys_bytes, xs_bytes) <= (size_t)lds_bytes;
+  off += xs_lds ? max(sys_bytes, xs_bytes) : sys_bytes;
+  double *A = c_lds ? U : Aws;          // landmark system: packed lower triangle in LDS, or square (ld = N) in the workspace
+  double *panels = c_lds ? nullptr : U;  // sweep panels of the workspace variant
+  auto AT = [&](int i, int j) -> int { return c_lds ? i * (i + 1) / 2 + j : i * N + j; };
+  // rhs rows of separator pose j (a multiple of kSeg), component r, column c:  SB[(j >> sshift) * 3 ldx + r ldx + c]
+  double *SB = xs_lds ? U : X;
+  const int sshift = xs_lds ? kSegLog : 0;
+  auto srow = [&](int j) -> double * { return SB + (size_t)(j >> sshift) * 3 * ldx; };
+  // per-factor records: LDS when they fit
+  double *rec;
+  if (off + (size_t)M * REC * 8 <= (size_t)lds_bytes) {
+    rec = reinterpret_cast<double *>(smem_raw + off); off += (size_t)M * REC * 8;
+  } else {
+    rec = rec_ws;
   }
   double *th_pose = S.th_pose + (size_t)inst * S.P_max * 4;
   double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
@@ -147,10 +194,6 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     thl[2 * j + 1] = y;
   }
   // ---- 2. tables + one linearisation per factor ----
-  {
-    const size_t nA = c_lds ? (size_t)N * (N + 1) / 2 : (size_t)N * N;
-    for (size_t e = tid; e < nA; e += kThreads) A[e] = 0.0;
-  }
   for (int e = tid; e < L * P; e += kThreads) obs[e] = 0;
   for (int e = tid; e < MW * L; e += kThreads) lmask[e] = 0ull;
   for (int e = tid; e <= P; e += kThreads) mstart[e] = M;
@@ -158,8 +201,6 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   __syncthreads();
   for (int m = tid; m < M; m += kThreads) {
     const int p = meas_pose[m], j = meas_lm[m];
-    mp[m] = (unsigned short)p;
-    ml[m] = (unsigned short)j;
     if (m == 0 || meas_pose[m - 1] != p) mstart[p] = m;
     obs[j * P + p] = (unsigned short)(m + 1);
     atomicOr(&lmask[MW * j + (p >> 6)], 1ull << (p & 63));
@@ -185,13 +226,28 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   const int pose_t0 = ((L + 63) & ~63) % kThreads;
   for (int j = tid; j < L; j += kThreads) {
     double a = 0, b = 0, d = 0, g0 = 0, g1 = 0;
-    FOR_EACH_OBSERVING_POSE(lmask + MW * j, MW, p) {
-      const double *r = rec + (size_t)REC * (obs[j * P + p] - 1);
-      a += r[6] * wb * r[6] + r[8] * wr * r[8];
-      b += r[6] * wb * r[7] + r[8] * wr * r[9];
-      d += r[7] * wb * r[7] + r[9] * wr * r[9];
-      g0 += r[6] * wb * r[10] + r[8] * wr * r[11];
-      g1 += r[7] * wb * r[10] + r[9] * wr * r[11];
+    MaskIter it(lmask + MW * j, MW);
+    for (;;) {
+      int ip[4];
+      const int n = it.next4(ip);
+      if (n == 0) break;
+      double2 rv[4][3];  // Jl (4) and e (2) of up to four observations, loaded together
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double2 *r2 = reinterpret_cast<const double2 *>(rec + (size_t)REC * (obs[j * P + ip[u]] - 1) + 6);
+        rv[u][0] = r2[0]; rv[u][1] = r2[1]; rv[u][2] = r2[2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u >= n) break;
+        const double r6 = rv[u][0].x, r7 = rv[u][0].y, r8 = rv[u][1].x, r9 = rv[u][1].y, r10 = rv[u][2].x, r11 = rv[u][2].y;
+        a += r6 * wb * r6 + r8 * wr * r8;
+        b += r6 * wb * r7 + r8 * wr * r9;
+        d += r7 * wb * r7 + r9 * wr * r9;
+        g0 += r6 * wb * r10 + r8 * wr * r11;
+        g1 += r7 * wb * r10 + r9 * wr * r11;
+      }
+      if (n < 4) break;
     }
     double *lb = lamb + 8 * j;
     lb[0] = a; lb[1] = b; lb[2] = d;
@@ -202,9 +258,9 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     pose_block(S, inst, thp, rec, mstart, i, P, wb, wr, B, g, O);
     double *dd = Dd + 6 * i;
     dd[0] = B[0]; dd[1] = B[3]; dd[2] = B[6]; dd[3] = B[4]; dd[4] = B[7]; dd[5] = B[8];
-    for (int r = 0; r < 3; ++r) gp[3 * i + r] = -g[r];
+    for (int r = 0; r < 3; ++r) X[(size_t)(3 * i + r) * ldx + np] = -g[r];  // eta_p: the rhs column of X
     if (i + 1 < P)
-      for (int k = 0; k < 9; ++k) Oo[9 * i + k] = O[k];
+      for (int k = 0; k < 9; ++k) Al[9 * (i + 1) + k] = O[k];  // T_{i+1,i}
   }
   __syncthreads();
   // ---- 4. B_m = Jx^T W Jl (3x2, row major) replaces Jx in the factor record ----
@@ -218,147 +274,438 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     for (int k = 0; k < 6; ++k) l[k] = bm[k];
   }
   DRLGX_PROF(S, 2);
-  // ---- 5. block LDL^T of the chain: D'_0 = D_0, L_{i+1,i} = T_{i+1,i} D'_i^-1, D'_{i+1} = D_{i+1} - L_{i+1,i} T_{i+1,i}^T
-  //         (sequential; every lane of wave 0 computes it, lane 0 stores).  Dd <- D'^-1, Oo <- L. ----
-  if (tid < 64) {
-    double dcur[6];
-    for (int k = 0; k < 6; ++k) dcur[k] = Dd[k];
-    bool ok = true;
-    for (int i = 0; i < P; ++i) {
-      double di[6];
-      ok = inv3s(dcur, di) && ok;
-      double lf[9], o[9];
-      if (i + 1 < P) {
-        for (int k = 0; k < 9; ++k) o[k] = Oo[9 * i + k];
-        for (int r = 0; r < 3; ++r)
-          for (int c = 0; c < 3; ++c)
-            lf[r * 3 + c] = o[r * 3] * sym3(di, 0, c) + o[r * 3 + 1] * sym3(di, 1, c) + o[r * 3 + 2] * sym3(di, 2, c);
-        const double *dn = Dd + 6 * (i + 1);
-        // D'_{i+1} = D_{i+1} - L T^T (symmetric)
-        dcur[0] = dn[0] - (lf[0] * o[0] + lf[1] * o[1] + lf[2] * o[2]);
-        dcur[1] = dn[1] - (lf[0] * o[3] + lf[1] * o[4] + lf[2] * o[5]);
-        dcur[2] = dn[2] - (lf[0] * o[6] + lf[1] * o[7] + lf[2] * o[8]);
-        dcur[3] = dn[3] - (lf[3] * o[3] + lf[4] * o[4] + lf[5] * o[5]);
-        dcur[4] = dn[4] - (lf[3] * o[6] + lf[4] * o[7] + lf[5] * o[8]);
-        dcur[5] = dn[5] - (lf[6] * o[6] + lf[7] * o[7] + lf[8] * o[8]);
+  __syncthreads();
+  // ---- 5. chain solve, leaves: the 7 poses between two separator poses (multiples of 8) are eliminated in order, each
+  //         against its successor and the segment's left separator l (fill).  One thread per segment:
+  //         E_i = D_i^-1, GL_i = E_i T_{i,l}, GR_i = E_i T_{n,i}^T (n = i + 1);  D_l -= T_{i,l}^T GL_i,  D_n -= T_{n,i} GR_i,
+  //         T_{n,l} = -T_{n,i} GL_i.  The two separators' diagonal updates go through scratch (GL / GR slots of l). ----
+  auto mat_ab = [](const double *a, const double *b, double *o) {  // o = a b (3x3 row major)
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) o[r * 3 + c] = a[r * 3] * b[c] + a[r * 3 + 1] * b[3 + c] + a[r * 3 + 2] * b[6 + c];
+  };
+  for (int g = tid; g < nsep; g += kThreads) {
+    const int l = g << kSegLog, nk = min(kSeg - 1, P - 1 - l);
+    double dl[6] = {0, 0, 0, 0, 0, 0}, dr[6] = {0, 0, 0, 0, 0, 0}, cl[9];
+    for (int q = 0; q < 9; ++q) cl[q] = nk > 0 ? Al[9 * (l + 1) + q] : 0.0;
+    for (int k = 1; k <= nk; ++k) {
+      const int i = l + k, n = i + 1;
+      const bool hn = n < P;
+      double e[6], glf[9], grf[9], cn[9];
+      if (!inv3s(Dd + 6 * i, e)) bad[0] = 1;
+      for (int q = 0; q < 6; ++q) Dd[6 * i + q] = e[q];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          glf[r * 3 + c] = sym3(e, r, 0) * cl[c] + sym3(e, r, 1) * cl[3 + c] + sym3(e, r, 2) * cl[6 + c];
+        }
+      for (int q = 0; q < 9; ++q) cn[q] = hn ? Al[9 * n + q] : 0.0;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+          grf[r * 3 + c] = sym3(e, r, 0) * cn[c * 3] + sym3(e, r, 1) * cn[c * 3 + 1] + sym3(e, r, 2) * cn[c * 3 + 2];
+      for (int q = 0; q < 9; ++q) {
+        GL[9 * i + q] = glf[q];
+        GR[9 * i + q] = grf[q];
       }
-      if (tid == 0) {
-        for (int k = 0; k < 6; ++k) Dd[6 * i + k] = di[k];
-        if (i + 1 < P)
-          for (int k = 0; k < 9; ++k) Oo[9 * i + k] = lf[k];
+      for (int r = 0, q = 0; r < 3; ++r)  // D_l -= T_{i,l}^T GL_i
+        for (int c = r; c < 3; ++c, ++q) dl[q] -= cl[r] * glf[c] + cl[3 + r] * glf[3 + c] + cl[6 + r] * glf[6 + c];
+      if (hn) {
+        double t[9], nc[9];
+        mat_ab(cn, grf, t);   // T_{n,i} E T_{n,i}^T
+        mat_ab(cn, glf, nc);  // T_{n,i} E T_{i,l}
+        if (k < kSeg - 1) {
+          double *dn = Dd + 6 * n;
+          dn[0] -= t[0]; dn[1] -= t[1]; dn[2] -= t[2]; dn[3] -= t[4]; dn[4] -= t[5]; dn[5] -= t[8];
+          for (int q = 0; q < 9; ++q) cl[q] = -nc[q];
+        } else {  // n is the right separator
+          dr[0] = -t[0]; dr[1] = -t[1]; dr[2] = -t[2]; dr[3] = -t[4]; dr[4] = -t[5]; dr[5] = -t[8];
+          for (int q = 0; q < 9; ++q) Al[9 * n + q] = -nc[q];  // T_{r,l}: the separator system's coupling
+        }
       }
     }
-    if (tid == 0 && !ok) bad[0] = 1;
+    for (int q = 0; q < 6; ++q) {
+      GL[9 * l + q] = dl[q];
+      GR[9 * l + q] = dr[q];
+    }
   }
   __syncthreads();
+  for (int g = tid; g < nsep; g += kThreads) {
+    const int l = g << kSegLog;
+    for (int q = 0; q < 6; ++q) Dd[6 * l + q] += GL[9 * l + q] + (g > 0 ? GR[9 * (l - kSeg) + q] : 0.0);
+  }
   DRLGX_PROF(S, 3);
-  // ---- 6. X = T^-1 [B eta_p]: one thread per column, forward then backward substitution with the state in
-  //         registers; the last wave runs the (T^-1)_ii recursion meanwhile ----
-  if (tid < ncol) {
-    const int c = tid;
-    const bool is_rhs = c == np;
-    const int j = c >> 1, a = c & 1;
+  // ---- 6. rhs columns [B eta_p] through the leaves: one thread per (segment, column), the segment's rows in registers;
+  //         y_i (the rhs at i's elimination) goes to X, the contributions to the two separators to the separator rows ----
+  auto rhs_of = [&](int i, int c, double &b0, double &b1, double &b2) {  // column c of [B eta_p] at pose i
+    if (c == np) {
+      b0 = X[(size_t)(3 * i) * ldx + np]; b1 = X[(size_t)(3 * i + 1) * ldx + np]; b2 = X[(size_t)(3 * i + 2) * ldx + np];
+    } else {
+      const int m1 = obs[(c >> 1) * P + i], a = c & 1;
+      const double *bm = rec + (size_t)REC * (m1 ? m1 - 1 : 0);
+      b0 = m1 ? bm[a] : 0.0; b1 = m1 ? bm[2 + a] : 0.0; b2 = m1 ? bm[4 + a] : 0.0;
+    }
+  };
+  for (int e = tid; e < nsep * ncol; e += kThreads) {
+    const int g = e / ncol, c = e - g * ncol;
+    const int l = g << kSegLog, nk = min(kSeg - 1, P - 1 - l);
+    double bk[kSeg][3];
+#pragma unroll
+    for (int k = 0; k < kSeg; ++k) {
+      bk[k][0] = bk[k][1] = bk[k][2] = 0.0;
+      if (k <= nk) rhs_of(l + k, c, bk[k][0], bk[k][1], bk[k][2]);
+    }
+    double d0 = bk[0][0], d1 = bk[0][1], d2 = bk[0][2];  // separator l: own value + the leaf's contributions
     double y0 = 0, y1 = 0, y2 = 0;
-    for (int i = 0; i < P; ++i) {
-      double b0, b1, b2;
-      if (is_rhs) {
-        b0 = gp[3 * i]; b1 = gp[3 * i + 1]; b2 = gp[3 * i + 2];
-      } else {
-        const int m1 = obs[j * P + i];
-        const double *bm = rec + (size_t)REC * (m1 ? m1 - 1 : 0);
-        b0 = m1 ? bm[a] : 0.0; b1 = m1 ? bm[2 + a] : 0.0; b2 = m1 ? bm[4 + a] : 0.0;
-      }
-      if (i > 0) {
-        const double *lf = Oo + 9 * (i - 1);
-        const double t0 = b0 - (lf[0] * y0 + lf[1] * y1 + lf[2] * y2);
-        const double t1 = b1 - (lf[3] * y0 + lf[4] * y1 + lf[5] * y2);
-        const double t2 = b2 - (lf[6] * y0 + lf[7] * y1 + lf[8] * y2);
-        y0 = t0; y1 = t1; y2 = t2;
-      } else {
-        y0 = b0; y1 = b1; y2 = b2;
-      }
-      X[(size_t)(3 * i) * ldx + c] = y0;
-      X[(size_t)(3 * i + 1) * ldx + c] = y1;
-      X[(size_t)(3 * i + 2) * ldx + c] = y2;
-    }
-    double x0 = 0, x1 = 0, x2 = 0;
-    for (int i = P - 1; i >= 0; --i) {
-      const double *di = Dd + 6 * i;
-      double t0 = di[0] * y0 + di[1] * y1 + di[2] * y2;
-      double t1 = di[1] * y0 + di[3] * y1 + di[4] * y2;
-      double t2 = di[2] * y0 + di[4] * y1 + di[5] * y2;
-      if (i + 1 < P) {
-        const double *lf = Oo + 9 * i;  // L_{i+1,i}^T x_{i+1}
-        t0 -= lf[0] * x0 + lf[3] * x1 + lf[6] * x2;
-        t1 -= lf[1] * x0 + lf[4] * x1 + lf[7] * x2;
-        t2 -= lf[2] * x0 + lf[5] * x1 + lf[8] * x2;
-      }
-      x0 = t0; x1 = t1; x2 = t2;
-      X[(size_t)(3 * i) * ldx + c] = x0;
-      X[(size_t)(3 * i + 1) * ldx + c] = x1;
-      X[(size_t)(3 * i + 2) * ldx + c] = x2;
-      if (i > 0) {  // this thread's own forward values of the previous pose
-        y0 = X[(size_t)(3 * i - 3) * ldx + c];
-        y1 = X[(size_t)(3 * i - 2) * ldx + c];
-        y2 = X[(size_t)(3 * i - 1) * ldx + c];
+#pragma unroll
+    for (int k = 1; k < kSeg; ++k) {
+      if (k <= nk) {
+        const int i = l + k;
+        if (k > 1) {  // b_i -= GR_{i-1}^T y_{i-1}
+          const double *g2 = GR + 9 * (i - 1);
+          bk[k][0] -= g2[0] * y0 + g2[3] * y1 + g2[6] * y2;
+          bk[k][1] -= g2[1] * y0 + g2[4] * y1 + g2[7] * y2;
+          bk[k][2] -= g2[2] * y0 + g2[5] * y1 + g2[8] * y2;
+        }
+        y0 = bk[k][0]; y1 = bk[k][1]; y2 = bk[k][2];
+        X[(size_t)(3 * i) * ldx + c] = y0;
+        X[(size_t)(3 * i + 1) * ldx + c] = y1;
+        X[(size_t)(3 * i + 2) * ldx + c] = y2;
+        const double *g1 = GL + 9 * i;  // b_l -= GL_i^T y_i
+        d0 -= g1[0] * y0 + g1[3] * y1 + g1[6] * y2;
+        d1 -= g1[1] * y0 + g1[4] * y1 + g1[7] * y2;
+        d2 -= g1[2] * y0 + g1[5] * y1 + g1[8] * y2;
       }
     }
-  } else if (tid >= kThreads - 64) {
-    // (T^-1)_ii = D'_i^-1 + L_{i+1,i}^T (T^-1)_{i+1,i+1} L_{i+1,i}, from the last pose backwards
-    double t[6];
-    for (int k = 0; k < 6; ++k) t[k] = Dd[6 * (P - 1) + k];
-    if (tid == kThreads - 64)
-      for (int k = 0; k < 6; ++k) Ti[6 * (P - 1) + k] = t[k];
-    for (int i = P - 2; i >= 0; --i) {
-      const double *lf = Oo + 9 * i, *di = Dd + 6 * i;
-      double w[9];  // W = (T^-1)_{i+1,i+1} L
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) w[r * 3 + c] = sym3(t, r, 0) * lf[c] + sym3(t, r, 1) * lf[3 + c] + sym3(t, r, 2) * lf[6 + c];
-      double n[6];
-      n[0] = di[0] + lf[0] * w[0] + lf[3] * w[3] + lf[6] * w[6];
-      n[1] = di[1] + lf[0] * w[1] + lf[3] * w[4] + lf[6] * w[7];
-      n[2] = di[2] + lf[0] * w[2] + lf[3] * w[5] + lf[6] * w[8];
-      n[3] = di[3] + lf[1] * w[1] + lf[4] * w[4] + lf[7] * w[7];
-      n[4] = di[4] + lf[1] * w[2] + lf[4] * w[5] + lf[7] * w[8];
-      n[5] = di[5] + lf[2] * w[2] + lf[5] * w[5] + lf[8] * w[8];
-      for (int k = 0; k < 6; ++k) t[k] = n[k];
-      if (tid == kThreads - 64)
-        for (int k = 0; k < 6; ++k) Ti[6 * i + k] = t[k];
+    double *sl = srow(l) + c;
+    sl[0] = d0; sl[ldx] = d1; sl[2 * ldx] = d2;
+    if (l + kSeg < P) {  // contribution to the right separator: added by the next loop (one writer per element)
+      const double *g2 = GR + 9 * (l + kSeg - 1);
+      double *pr = sepR + (size_t)g * 3 * ldx + c;
+      pr[0] = -(g2[0] * y0 + g2[3] * y1 + g2[6] * y2);
+      pr[ldx] = -(g2[1] * y0 + g2[4] * y1 + g2[7] * y2);
+      pr[2 * ldx] = -(g2[2] * y0 + g2[5] * y1 + g2[8] * y2);
     }
+  }
+  __syncthreads();
+  for (int e = tid; e < (nsep - 1) * ncol; e += kThreads) {  // separator g + 1 += its left leaf's contribution
+    const int g = e / ncol, c = e - g * ncol;
+    const double *pr = sepR + (size_t)g * 3 * ldx + c;
+    double *sr = srow((g + 1) << kSegLog) + c;
+    sr[0] += pr[0]; sr[ldx] += pr[ldx]; sr[2 * ldx] += pr[2 * ldx];
   }
   __syncthreads();
   DRLGX_PROF(S, 4);
-  // ---- 7. landmark system [C r]: rows 2j, 2j+1 at column c (lower triangle + the rhs column) ----
-  for (int e = tid; e < L * ncol; e += kThreads) {
-    const int j = e / ncol, c = e - j * ncol;
-    if (c != np && c > 2 * j + 1) continue;
-    double a0 = 0, a1 = 0;
-    FOR_EACH_OBSERVING_POSE(lmask + MW * j, MW, i) {
-      const double *bm = rec + (size_t)REC * (obs[j * P + i] - 1);
-      const double x0 = X[(size_t)(3 * i) * ldx + c], x1 = X[(size_t)(3 * i + 1) * ldx + c], x2 = X[(size_t)(3 * i + 2) * ldx + c];
-      a0 += bm[0] * x0 + bm[2] * x1 + bm[4] * x2;
-      a1 += bm[1] * x0 + bm[3] * x1 + bm[5] * x2;
+  // ---- ... cyclic reduction of the separator system (strides 8, 16, ...), its rhs rows in LDS: down ----
+  for (int s = kSeg; s < P; s <<= 1) {
+    // eliminated poses i = s, 3s, ...: E_i, GL_i, GR_i
+    for (int k = tid; (2 * k + 1) * s < P; k += kThreads) {
+      const int i = (2 * k + 1) * s;
+      double e[6];
+      if (!inv3s(Dd + 6 * i, e)) bad[0] = 1;
+      for (int q = 0; q < 6; ++q) Dd[6 * i + q] = e[q];
+      const double *ai = Al + 9 * i;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) GL[9 * i + r * 3 + c] = sym3(e, r, 0) * ai[c] + sym3(e, r, 1) * ai[3 + c] + sym3(e, r, 2) * ai[6 + c];
+      const bool hr = i + s < P;
+      const double *ar = Al + 9 * (hr ? i + s : i);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)  // E A_{i+s}^T
+          GR[9 * i + r * 3 + c] = hr ? sym3(e, r, 0) * ar[c * 3] + sym3(e, r, 1) * ar[c * 3 + 1] + sym3(e, r, 2) * ar[c * 3 + 2] : 0.0;
     }
-    const double *lb = lamb + 8 * j;
-    if (c == np) {
-      A[AT(np, 2 * j)] = lb[6] - a0;
-      A[AT(np, 2 * j + 1)] = lb[7] - a1;
-    } else {
-      const bool own = (c >> 1) == j;
-      const double l0 = own ? ((c & 1) ? lb[1] : lb[0]) : 0.0, l1 = own ? ((c & 1) ? lb[2] : lb[1]) : 0.0;
-      if (c <= 2 * j) A[AT(2 * j, c)] = l0 - a0;
-      A[AT(2 * j + 1, c)] = l1 - a1;
+    __syncthreads();
+    // surviving poses j = 0, 2s, 4s, ...: diagonal block, coupling to j - 2s
+    for (int k = tid; 2 * k * s < P; k += kThreads) {
+      const int j = 2 * k * s;
+      double d[6];
+      for (int q = 0; q < 6; ++q) d[q] = Dd[6 * j + q];
+      if (j >= s) {  // left eliminated neighbour i1 = j - s:  D_j -= A_j GR_i1,  A_j <- -A_j GL_i1
+        const double *aj = Al + 9 * j, *gr = GR + 9 * (j - s), *gl = GL + 9 * (j - s);
+        double t[9], na[9];
+        mat_ab(aj, gr, t);
+        mat_ab(aj, gl, na);
+        d[0] -= t[0]; d[1] -= t[1]; d[2] -= t[2]; d[3] -= t[4]; d[4] -= t[5]; d[5] -= t[8];
+        for (int q = 0; q < 9; ++q) Al[9 * j + q] = -na[q];
+      }
+      if (j + s < P) {  // right eliminated neighbour i2 = j + s:  D_j -= A_i2^T GL_i2
+        const double *a2 = Al + 9 * (j + s), *gl = GL + 9 * (j + s);
+        for (int r = 0, q = 0; r < 3; ++r)
+          for (int c = r; c < 3; ++c, ++q) d[q] -= a2[r] * gl[c] + a2[3 + r] * gl[3 + c] + a2[6 + r] * gl[6 + c];
+      }
+      for (int q = 0; q < 6; ++q) Dd[6 * j + q] = d[q];
+    }
+    // ... and their rhs rows: b_j -= GR_i1^T b_i1 + GL_i2^T b_i2
+    {
+      const int nsurv = (P - 1) / (2 * s) + 1;
+      for (int e = tid; e < nsurv * ncol; e += kThreads) {
+        const int k = e / ncol, c = e - k * ncol, j = 2 * k * s;
+        double *bj = srow(j) + c;
+        double b0 = bj[0], b1 = bj[ldx], b2 = bj[2 * ldx];
+        if (j >= s) {
+          const double *g = GR + 9 * (j - s), *bi = srow(j - s) + c;
+          const double v0 = bi[0], v1 = bi[ldx], v2 = bi[2 * ldx];
+          b0 -= g[0] * v0 + g[3] * v1 + g[6] * v2;
+          b1 -= g[1] * v0 + g[4] * v1 + g[7] * v2;
+          b2 -= g[2] * v0 + g[5] * v1 + g[8] * v2;
+        }
+        if (j + s < P) {
+          const double *g = GL + 9 * (j + s), *bi = srow(j + s) + c;
+          const double v0 = bi[0], v1 = bi[ldx], v2 = bi[2 * ldx];
+          b0 -= g[0] * v0 + g[3] * v1 + g[6] * v2;
+          b1 -= g[1] * v0 + g[4] * v1 + g[7] * v2;
+          b2 -= g[2] * v0 + g[5] * v1 + g[8] * v2;
+        }
+        bj[0] = b0; bj[ldx] = b1; bj[2 * ldx] = b2;
+      }
+    }
+    __syncthreads();
+  }
+  // root (pose 0): E_0, x_0 = E_0 b_0, (T^-1)_00 = E_0
+  if (tid == 0) {
+    double e[6];
+    if (!inv3s(Dd, e)) bad[0] = 1;
+    for (int q = 0; q < 6; ++q) {
+      Dd[q] = e[q];
+      Ti[q] = e[q];
     }
   }
   __syncthreads();
+  for (int c = tid; c < ncol; c += kThreads) {
+    double *b = srow(0) + c;
+    const double v0 = b[0], v1 = b[ldx], v2 = b[2 * ldx];
+    b[0] = Dd[0] * v0 + Dd[1] * v1 + Dd[2] * v2;
+    b[ldx] = Dd[1] * v0 + Dd[3] * v1 + Dd[4] * v2;
+    b[2 * ldx] = Dd[2] * v0 + Dd[4] * v1 + Dd[5] * v2;
+  }
+  __syncthreads();
+  // ---- ... and back up: separator solutions and the selected inverse, level by level ----
+  auto ld_sym = [](const double *t, double *o) {
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[1]; o[4] = t[3]; o[5] = t[4]; o[6] = t[2]; o[7] = t[4]; o[8] = t[5];
+  };
+  // S_lr (row l, column r) of two poses adjacent at stride 2s: stored by the one that is eliminated at that stride
+  auto cross_lr = [&](int l, int r, int s, double *slr) {
+    if ((l / (2 * s)) & 1) {  // l: its right neighbour at stride 2s is r:  Sr[l] = S_{r,l}
+      const double *t = Sr + 9 * l;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) slr[a * 3 + b] = t[b * 3 + a];
+    } else {                  // r: its left neighbour at stride 2s is l:   Sl[r] = S_{l,r}
+      const double *t = Sl + 9 * r;
+      for (int q = 0; q < 9; ++q) slr[q] = t[q];
+    }
+  };
+  // Takahashi step of pose i with neighbours (l, n):  S_{l,i} = -(S_ll GL^T + S_ln GR^T),  S_{n,i} = -(S_nl GL^T + S_nn GR^T),
+  // S_ii = E_i - GL S_{l,i} - GR S_{n,i}
+  auto takahashi = [&](int i, const double *sll, const double *snn, const double *sln, double *sli, double *sni, double *sii) {
+    const double *gl = GL + 9 * i, *gr = GR + 9 * i, *e = Dd + 6 * i;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        double v = 0, w = 0;
+        for (int q = 0; q < 3; ++q) {
+          v += sll[a * 3 + q] * gl[b * 3 + q] + sln[a * 3 + q] * gr[b * 3 + q];
+          w += sln[q * 3 + a] * gl[b * 3 + q] + snn[a * 3 + q] * gr[b * 3 + q];
+        }
+        sli[a * 3 + b] = -v;
+        sni[a * 3 + b] = -w;
+      }
+    for (int a = 0, q = 0; a < 3; ++a)
+      for (int b = a; b < 3; ++b, ++q) {
+        double v = e[q];
+        for (int t = 0; t < 3; ++t) v -= gl[a * 3 + t] * sli[t * 3 + b] + gr[a * 3 + t] * sni[t * 3 + b];
+        sii[q] = v;
+      }
+  };
+  {
+    int s_top = kSeg;
+    while (2 * s_top < P) s_top <<= 1;
+    for (int s = (P > kSeg) ? s_top : 0; s >= kSeg; s >>= 1) {
+      const int nel = (P - 1 - s) / (2 * s) + 1;  // eliminated poses of this level: s, 3s, ... < P
+      for (int k = tid; k < nel; k += kThreads) {
+        const int i = (2 * k + 1) * s, l = i - s, r = i + s;
+        const bool hr = r < P;
+        double sll[9], srr[9], slr[9], sli[9], sri[9];
+        ld_sym(Ti + 6 * l, sll);
+        for (int q = 0; q < 9; ++q) srr[q] = slr[q] = 0.0;
+        if (hr) {
+          ld_sym(Ti + 6 * r, srr);
+          cross_lr(l, r, s, slr);
+        }
+        takahashi(i, sll, srr, slr, sli, sri, Ti + 6 * i);
+        for (int q = 0; q < 9; ++q) {
+          Sl[9 * i + q] = sli[q];
+          Sr[9 * i + q] = sri[q];
+        }
+      }
+      // solutions x_i = E_i b_i - GL_i x_l - GR_i x_r, one thread per (pose, column)
+      for (int e = tid; e < nel * ncol; e += kThreads) {
+        const int k = e / ncol, c = e - k * ncol, i = (2 * k + 1) * s;
+        double *bi = srow(i) + c;
+        const double *ei = Dd + 6 * i, *gl = GL + 9 * i, *gr = GR + 9 * i;
+        const double v0 = bi[0], v1 = bi[ldx], v2 = bi[2 * ldx];
+        double x0 = ei[0] * v0 + ei[1] * v1 + ei[2] * v2;
+        double x1 = ei[1] * v0 + ei[3] * v1 + ei[4] * v2;
+        double x2 = ei[2] * v0 + ei[4] * v1 + ei[5] * v2;
+        {
+          const double *xl = srow(i - s) + c;
+          const double l0 = xl[0], l1 = xl[ldx], l2 = xl[2 * ldx];
+          x0 -= gl[0] * l0 + gl[1] * l1 + gl[2] * l2;
+          x1 -= gl[3] * l0 + gl[4] * l1 + gl[5] * l2;
+          x2 -= gl[6] * l0 + gl[7] * l1 + gl[8] * l2;
+        }
+        if (i + s < P) {
+          const double *xr = srow(i + s) + c;
+          const double r0 = xr[0], r1 = xr[ldx], r2 = xr[2 * ldx];
+          x0 -= gr[0] * r0 + gr[1] * r1 + gr[2] * r2;
+          x1 -= gr[3] * r0 + gr[4] * r1 + gr[5] * r2;
+          x2 -= gr[6] * r0 + gr[7] * r1 + gr[8] * r2;
+        }
+        bi[0] = x0; bi[ldx] = x1; bi[2 * ldx] = x2;
+      }
+      __syncthreads();
+    }
+  }
   DRLGX_PROF(S, 5);
+  // ---- ... leaves: selected inverse (one thread per segment, last interior pose first) and solutions (one thread per
+  //         (segment, column): x_i = E_i y_i - GL_i x_l - GR_i x_{i+1}); the separators' solutions go to X too ----
+  for (int g = tid; g < nsep; g += kThreads) {
+    const int l = g << kSegLog, nk = min(kSeg - 1, P - 1 - l), r = l + kSeg;
+    if (nk > 0) {
+      double sll[9], snn[9], sln[9], sli[9], sni[9], sii[6];
+      ld_sym(Ti + 6 * l, sll);
+      for (int q = 0; q < 9; ++q) snn[q] = sln[q] = 0.0;
+      if (r < P) {
+        ld_sym(Ti + 6 * r, snn);
+        cross_lr(l, r, kSeg >> 1, sln);
+      }
+      for (int k = nk; k >= 1; --k) {
+        const int i = l + k;
+        takahashi(i, sll, snn, sln, sli, sni, sii);
+        for (int q = 0; q < 6; ++q) Ti[6 * i + q] = sii[q];
+        ld_sym(sii, snn);                           // the next pose down has this one as its successor
+        for (int q = 0; q < 9; ++q) sln[q] = sli[q];
+      }
+    }
+  }
+  for (int e = tid; e < nsep * ncol; e += kThreads) {
+    const int g = e / ncol, c = e - g * ncol;
+    const int l = g << kSegLog, nk = min(kSeg - 1, P - 1 - l);
+    double yk[kSeg][3];
+#pragma unroll
+    for (int k = 1; k < kSeg; ++k) {
+      const bool ok = k <= nk;
+      const double *yp = X + (size_t)(3 * (ok ? l + k : l)) * ldx + c;
+      yk[k][0] = ok ? yp[0] : 0.0; yk[k][1] = ok ? yp[ldx] : 0.0; yk[k][2] = ok ? yp[2 * ldx] : 0.0;
+    }
+    const double *xlp = srow(l) + c;
+    const double xl0 = xlp[0], xl1 = xlp[ldx], xl2 = xlp[2 * ldx];
+    double n0 = 0, n1 = 0, n2 = 0;  // solution of the successor (the right separator for the last interior pose)
+    if (l + kSeg < P) {
+      const double *xrp = srow(l + kSeg) + c;
+      n0 = xrp[0]; n1 = xrp[ldx]; n2 = xrp[2 * ldx];
+    }
+    X[(size_t)(3 * l) * ldx + c] = xl0;
+    X[(size_t)(3 * l + 1) * ldx + c] = xl1;
+    X[(size_t)(3 * l + 2) * ldx + c] = xl2;
+#pragma unroll
+    for (int k = kSeg - 1; k >= 1; --k) {
+      if (k <= nk) {
+        const int i = l + k;
+        const double *ei = Dd + 6 * i, *gl = GL + 9 * i, *gr = GR + 9 * i;
+        const double v0 = yk[k][0], v1 = yk[k][1], v2 = yk[k][2];
+        const double x0 = ei[0] * v0 + ei[1] * v1 + ei[2] * v2 - (gl[0] * xl0 + gl[1] * xl1 + gl[2] * xl2) - (gr[0] * n0 + gr[1] * n1 + gr[2] * n2);
+        const double x1 = ei[1] * v0 + ei[3] * v1 + ei[4] * v2 - (gl[3] * xl0 + gl[4] * xl1 + gl[5] * xl2) - (gr[3] * n0 + gr[4] * n1 + gr[5] * n2);
+        const double x2 = ei[2] * v0 + ei[4] * v1 + ei[5] * v2 - (gl[6] * xl0 + gl[7] * xl1 + gl[8] * xl2) - (gr[6] * n0 + gr[7] * n1 + gr[8] * n2);
+        X[(size_t)(3 * i) * ldx + c] = x0;
+        X[(size_t)(3 * i + 1) * ldx + c] = x1;
+        X[(size_t)(3 * i + 2) * ldx + c] = x2;
+        n0 = x0; n1 = x1; n2 = x2;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const size_t nA = c_lds ? (size_t)N * (N + 1) / 2 : (size_t)N * N;
+    for (size_t e = tid; e < nA; e += kThreads) A[e] = 0.0;  // (the region held the separator rows until here)
+  }
+  __syncthreads();
+  DRLGX_PROF(S, 10);
+  // ---- 7. landmark system [C r]: rows 2j, 2j+1 at column c (lower triangle + the rhs column) ----
+  {
+    // one thread per (landmark, 4 columns): the observing poses are visited in ascending order, four at a time with
+    // all their loads (32-byte rows of X, the factor's B block) issued before the first use - X lives in L2 / HBM
+    const int nq = ldx >> 2, q_rhs = np >> 2;
+    for (int e = tid; e < L * nq; e += kThreads) {
+      const int j = e / nq, q = e - j * nq, c0 = 4 * q;
+      if (c0 > 2 * j + 1 && q != q_rhs) continue;
+      double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+      int w = 0;
+      unsigned long long m = lmask[MW * j];
+      bool more = true;
+      while (more) {
+        int ip[4];
+        int n = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          while (!m && w + 1 < MW) m = lmask[MW * j + (++w)];
+          if (m) {
+            ip[u] = 64 * w + __ffsll((long long)m) - 1;
+            m &= m - 1;
+            n = u + 1;
+          } else {
+            ip[u] = ip[0];
+          }
+        }
+        if (n == 0) break;
+        more = n == 4;
+        double2 xv[4][3][2];
+        double bm[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = (u < n) ? ip[u] : ip[0];
+          const double *xr = X + (size_t)(3 * i) * ldx + c0;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            xv[u][r][0] = *reinterpret_cast<const double2 *>(xr + (size_t)r * ldx);
+            xv[u][r][1] = *reinterpret_cast<const double2 *>(xr + (size_t)r * ldx + 2);
+          }
+          const double *bp = rec + (size_t)REC * (obs[j * P + i] - 1);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) bm[u][k] = bp[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (u >= n) break;
+          const double x0[4] = {xv[u][0][0].x, xv[u][0][0].y, xv[u][0][1].x, xv[u][0][1].y};
+          const double x1[4] = {xv[u][1][0].x, xv[u][1][0].y, xv[u][1][1].x, xv[u][1][1].y};
+          const double x2[4] = {xv[u][2][0].x, xv[u][2][0].y, xv[u][2][1].x, xv[u][2][1].y};
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            a0[cc] += bm[u][0] * x0[cc] + bm[u][2] * x1[cc] + bm[u][4] * x2[cc];
+            a1[cc] += bm[u][1] * x0[cc] + bm[u][3] * x1[cc] + bm[u][5] * x2[cc];
+          }
+        }
+      }
+      const double *lb = lamb + 8 * j;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = c0 + cc;
+        if (c == np) {
+          A[AT(np, 2 * j)] = lb[6] - a0[cc];
+          A[AT(np, 2 * j + 1)] = lb[7] - a1[cc];
+        } else if (c < np && c <= 2 * j + 1) {
+          const bool own = (c >> 1) == j;
+          const double l0 = own ? ((c & 1) ? lb[1] : lb[0]) : 0.0, l1 = own ? ((c & 1) ? lb[2] : lb[1]) : 0.0;
+          if (c <= 2 * j) A[AT(2 * j, c)] = l0 - a0[cc];
+          A[AT(2 * j + 1, c)] = l1 - a1[cc];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  DRLGX_PROF(S, 6);
   // ---- 8. sweep: A <- -C^-1 (lower triangle), row np <- delta_l ----
   if (c_lds)
     sweep_packed_fast<kFastTilesArrow>(S, A, np, N, Tn, bad, tid);
   else if constexpr (NTW > 0)
     sweep_regtiles<false, NTW>(A, panels, np, N, Tn, ntiles, bad, tid);
   __syncthreads();
-  DRLGX_PROF(S, 6);
+  DRLGX_PROF(S, 7);
   // ---- 9. landmark outputs ----
   double *est_lm = S.est_lm + (size_t)inst * S.L_max * 2;
   double *lm_info = S.lm_info + (size_t)inst * S.L_max * 3;
@@ -376,62 +723,138 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     lm_info[3 * j + 1] = -cs * id;
     lm_info[3 * j + 2] = c00 * id;
   }
-  // ---- 10. pose outputs: delta_p = x_eta - X_B delta_l; Sigma_ii = (T^-1)_ii + X_i C^-1 X_i^T.  One 16-lane row per
-  //          pose: lane l handles the columns c = l, l + 16, ...; partial sums reduced over the row in a fixed order ----
+  DRLGX_PROF(S, 8);
+  // ---- 10. pose outputs: delta_p = x_eta - X_B delta_l; Sigma_ii = (T^-1)_ii + X_i C^-1 X_i^T.
+  //      Z = X_B [-C^-1 | delta_l] on the fp64 matrix cores (one wave per 16 rows of X, tiles of 16 columns, the
+  //      A operand = 32-byte rows of X from L2 / HBM, the B operand from the swept system), then per row the products
+  //      with the three X rows of its pose, reduced over the 16 lanes of an accumulator row in a fixed order ----
   double *est_pose = S.est_pose + (size_t)inst * S.P_max * 4;
   double *pose_info = S.pose_info + (size_t)inst * S.P_max * 6;
   double *pose_tr = S.pose_tr + (size_t)inst * S.P_max;
+  double *Sc = Sl;  // [3P][3]: rows of X_i (-C^-1) X_i^T   (the Takahashi cross blocks are dead by now)
+  double *dz = Sr;  // [3P]:    X_B delta_l
   {
-    const int sub = tid & 15, grp = tid >> 4, ngrp = kThreads / 16;
-    for (int i = grp; i < P; i += ngrp) {
-      const double *x0r = X + (size_t)(3 * i) * ldx, *x1r = x0r + ldx, *x2r = x1r + ldx;
-      double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // dp0 dp1 dp2, then the 6 entries of X_i (-C^-1) X_i^T
-      for (int c = sub; c < np; c += 16) {
-        // z_r = sum_k X_i[r][k] (-C^-1)[k][c]
-        double z0 = 0, z1 = 0, z2 = 0;
-        for (int k = 0; k < np; ++k) {
-          const double m = A[AT(max(k, c), min(k, c))];
-          z0 += x0r[k] * m;
-          z1 += x1r[k] * m;
-          z2 += x2r[k] * m;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lc = lane & 15, lr = lane >> 4;
+    const int nrows = 3 * P, nrt = (nrows + 15) / 16, nK = (np + 15) / 16;
+    for (int I = wave; I < nrt; I += kWaves) {
+      const int arow = 16 * I + lc;
+      const double *xa = X + (size_t)(arow < nrows ? arow : 0) * ldx;
+      const bool arow_ok = arow < nrows;
+      // the A operand of the whole tile row (its 16 x np panel of X) is loaded once: every load is in flight before the
+      // first matrix instruction (up to 8 column chunks = 127 landmark columns: the LDS-resident systems; beyond that
+      // the chunks are reloaded per column tile)
+      constexpr int kPanel = 8;
+      double pan[kPanel][4];
+      const bool panel = nK <= kPanel;
+      if (panel) {
+#pragma unroll
+        for (int K = 0; K < kPanel; ++K)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int k = 16 * K + 4 * lr + t;
+            pan[K][t] = (k < np && arow_ok) ? xa[k] : 0.0;
+          }
+      }
+      double sp[4][3];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sp[r][0] = sp[r][1] = sp[r][2] = 0.0;
+      for (int J = 0; J < Tn; ++J) {
+        const int c = 16 * J + lc;
+        // the three X rows of each accumulator row's pose at this lane's column (epilogue), issued before the products
+        double xe[4][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + lr + 4 * r;
+          const bool ok = row < nrows && c < np;
+          const double *xb = X + (size_t)(ok ? 3 * (row / 3) : 0) * ldx + (ok ? c : 0);
+          xe[r][0] = ok ? xb[0] : 0.0;
+          xe[r][1] = ok ? xb[ldx] : 0.0;
+          xe[r][2] = ok ? xb[2 * ldx] : 0.0;
         }
-        const double xc0 = x0r[c], xc1 = x1r[c], xc2 = x2r[c], dl = A[AT(np, c)];
-        s[0] += xc0 * dl; s[1] += xc1 * dl; s[2] += xc2 * dl;
-        s[3] += z0 * xc0; s[4] += z0 * xc1; s[5] += z0 * xc2;
-        s[6] += z1 * xc1; s[7] += z1 * xc2; s[8] += z2 * xc2;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        if (panel) {
+#pragma unroll
+          for (int K = 0; K < kPanel; ++K) {
+            if (K < nK) {
+              double bv[4];
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const int k = 16 * K + 4 * lr + t;
+                bv[t] = (k < np && c <= np) ? A[AT(max(k, c), min(k, c))] : 0.0;
+              }
+              acc = mfma4(pan[K], bv, acc);
+            }
+          }
+        } else {
+          for (int K = 0; K < nK; ++K) {
+            const int k0 = 16 * K + 4 * lr;
+            double av[4], bv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int k = k0 + t;
+              const bool kin = k < np;
+              av[t] = (kin && arow_ok) ? xa[k] : 0.0;
+              bv[t] = (kin && c <= np) ? A[AT(max(k, c), min(k, c))] : 0.0;
+            }
+            acc = mfma4(av, bv, acc);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + lr + 4 * r;
+          sp[r][0] += acc[r] * xe[r][0];  // (zeros outside the matrix)
+          sp[r][1] += acc[r] * xe[r][1];
+          sp[r][2] += acc[r] * xe[r][2];
+          if (row < nrows && c == np) dz[row] = acc[r];
+        }
       }
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        double v = s[k];
-        v += __shfl_xor(v, 8, 16);
-        v += __shfl_xor(v, 4, 16);
-        v += __shfl_xor(v, 2, 16);
-        v += __shfl_xor(v, 1, 16);
-        s[k] = v;
-      }
-      if (sub == 0) {
-        const double dp0 = x0r[np] - s[0], dp1 = x1r[np] - s[1], dp2 = x2r[np] - s[2];
-        d_pose[3 * i] = dp0; d_pose[3 * i + 1] = dp1; d_pose[3 * i + 2] = dp2;
-        const Pose t{thp[4 * i], thp[4 * i + 1], thp[4 * i + 2], thp[4 * i + 3]};
-        const Pose e = compose(t, make_pose(dp0, dp1, dp2));
-        est_pose[4 * i] = e.x; est_pose[4 * i + 1] = e.y; est_pose[4 * i + 2] = e.c; est_pose[4 * i + 3] = e.s;
-        const double *ti = Ti + 6 * i;
-        const double c00 = ti[0] - s[3], c10 = ti[1] - s[4], c20 = ti[2] - s[5];
-        const double c11 = ti[3] - s[6], c21 = ti[4] - s[7], c22 = ti[5] - s[8];
-        pose_tr[i] = c00 + c11 + c22;
-        LLT3 llt(c00, c10, c20, c11, c21, c22);  // information = inverse(covariance) by LLT (SLAM2D.cpp:395-408)
-        double q0, q1, q2;
-        double *pi = pose_info + 6 * i;
-        llt.solve(1, 0, 0, q0, q1, q2);
-        pi[0] = q0; pi[1] = q1; pi[2] = q2;
-        llt.solve(0, 1, 0, q0, q1, q2);
-        pi[3] = q1; pi[4] = q2;
-        llt.solve(0, 0, 1, q0, q1, q2);
-        pi[5] = q2;
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b3 = 0; b3 < 3; ++b3) {
+          double v = sp[r][b3];
+          v += __shfl_xor(v, 8, 16);
+          v += __shfl_xor(v, 4, 16);
+          v += __shfl_xor(v, 2, 16);
+          v += __shfl_xor(v, 1, 16);
+          sp[r][b3] = v;
+        }
+      if (lc == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + lr + 4 * r;
+          if (row < nrows) {
+            Sc[3 * row] = sp[r][0];
+            Sc[3 * row + 1] = sp[r][1];
+            Sc[3 * row + 2] = sp[r][2];
+          }
+        }
       }
     }
   }
-  DRLGX_PROF(S, 7);
+  __syncthreads();
+  for (int i = tid; i < P; i += kThreads) {
+    const double dp0 = X[(size_t)(3 * i) * ldx + np] - dz[3 * i], dp1 = X[(size_t)(3 * i + 1) * ldx + np] - dz[3 * i + 1],
+                 dp2 = X[(size_t)(3 * i + 2) * ldx + np] - dz[3 * i + 2];
+    d_pose[3 * i] = dp0; d_pose[3 * i + 1] = dp1; d_pose[3 * i + 2] = dp2;
+    const Pose t{thp[4 * i], thp[4 * i + 1], thp[4 * i + 2], thp[4 * i + 3]};
+    const Pose e = compose(t, make_pose(dp0, dp1, dp2));
+    est_pose[4 * i] = e.x; est_pose[4 * i + 1] = e.y; est_pose[4 * i + 2] = e.c; est_pose[4 * i + 3] = e.s;
+    const double *ti = Ti + 6 * i, *sc = Sc + 9 * i;  // sc[3 a + b] = (X_i (-C^-1) X_i^T)[a][b]: symmetric up to round-off
+    const double c00 = ti[0] - sc[0], c10 = ti[1] - 0.5 * (sc[1] + sc[3]), c20 = ti[2] - 0.5 * (sc[2] + sc[6]);
+    const double c11 = ti[3] - sc[4], c21 = ti[4] - 0.5 * (sc[5] + sc[7]), c22 = ti[5] - sc[8];
+    pose_tr[i] = c00 + c11 + c22;
+    LLT3 llt(c00, c10, c20, c11, c21, c22);  // information = inverse(covariance) by LLT (SLAM2D.cpp:395-408)
+    double q0, q1, q2;
+    double *pi = pose_info + 6 * i;
+    llt.solve(1, 0, 0, q0, q1, q2);
+    pi[0] = q0; pi[1] = q1; pi[2] = q2;
+    llt.solve(0, 1, 0, q0, q1, q2);
+    pi[3] = q1; pi[4] = q2;
+    llt.solve(0, 0, 1, q0, q1, q2);
+    pi[5] = q2;
+  }
+  DRLGX_PROF(S, 9);
   if (tid == 0) {
     cnt[C_ISAM] = count;
     cnt[C_NEWP] = P;

@@ -20,7 +20,8 @@ starts = np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform
 eng.reset(np.arange(n), np.arange(n), starts=starts)
 loop = [(2, 0, 0)] * 3 + [(0, 0, math.pi / 2)] + [(2, 0, 0)] * 2 + [(0.7, 0, 0.4)]
 odoms = [torch.tensor([a] * n, dtype=torch.float64, device=eng.device) for a in loop]
-names = ["relin+tables+linearise", "blocks", "chain LDL^T", "substitution + (T^-1)_ii", "landmark system", "sweep", "outputs"]
+names = ["tables+linearise", "blocks", "leaf factor", "leaf rhs down", "separator CR", "leaf up + selinv", "landmark system", "sweep", "lm out", "pose out"]
+order = [0, 1, 2, 3, 4, 5, 10, 6, 7, 8, 9]  # stamp slots in program order
 out = (C.c_int64 * 64)()
 print("# %d envs, %d landmarks in the world, capacity %d poses" % (n, num_lm, cap))
 for s in range(cap - 3):
@@ -52,8 +53,8 @@ for s in range(cap - 3):
             eng.step(odoms[(s + 1) % len(loop)])
             eng.L.drlgx_debug_phase_clocks_host(eng.h, 0, out)
             eng.timing_enable(False)
-            a = np.array(out[:8], dtype=np.float64)
-            extra = " | block 0: " + ", ".join("%s %.1f" % (names[k], (a[k + 1] - a[k]) / 100.0) for k in range(7))
+            a = np.array(out[:11], dtype=np.float64)[order]
+            extra = " | block 0: " + ", ".join("%s %.1f" % (names[k], (a[k + 1] - a[k]) / 100.0) for k in range(10))
         eng.restore(0)
         c = eng.counts_dev().cpu().numpy()
         ov = tm["t7"][0] / tm["t7"][1] * 1e3
