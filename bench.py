@@ -10,7 +10,11 @@ reductions) for all 256 envs, starting from the snapshot (the device-side restor
 region so the graph size stays at the quoted ~64 nodes).  All inputs are resident in HBM.
 
 Multi-GPU: one process per GPU (torch.distributed / RCCL), independent environments per rank, no
-data-path collective (weak scaling); time = max over ranks.
+data-path collective in the belief step (weak scaling); time = max over ranks.  `--gpus N` without a launcher
+re-executes itself under `torch.distributed.run` with N ranks; under a launcher WORLD_SIZE must equal --gpus.
+The only exchange of the path is the policy gradient: the `train_allreduce` section of the same line times the
+64-graph DQN step with the flat gradient all-reduce (RCCL over xGMI), the collective alone, and the belief steps
+sustained while that training runs on a second stream (BASELINE.json configs[3]).
 
 Output: ONE JSON line on rank 0 (see the driver contract), with `roofline` for the time-dominant
 kernel (per-kernel HIP-event timing on the engine stream), `kernels` for all three and
@@ -205,8 +209,9 @@ def policy_bench(eng, dev, iters=10):
 
 def dqn_loop_bench(device_index, n_envs=256, iters=8):
     """BASELINE config 2 as a secondary figure: wall-clock rate of the whole DQN loop (`DeepQ.running`: graph export,
-    look-ahead rewards of every frontier, policy forward, env step, replay, one 64-graph train step per vector step,
-    episode resets), in the reference's unit - RL iterations (decisions) per second."""
+    look-ahead rewards of every frontier, policy forward, env step, replay, one 64-graph train step per ENVIRONMENT step
+    like the reference - n_envs per vector step -, episode resets), in the reference's unit - RL iterations (decisions)
+    per second."""
     import tempfile
     from drl_graph_exploration_amd.networks import GCN
     from drl_graph_exploration_amd.policy import DeepQ
@@ -227,17 +232,17 @@ def dqn_loop_bench(device_index, n_envs=256, iters=8):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         env.close()
-    return {"workload": "DeepQ.running, %d envs in lock-step, 40 m map, one train step (64 graphs) per vector step" % n_envs,
+    return {"workload": "DeepQ.running, %d envs in lock-step, 40 m map, one train step (64 graphs) per environment step" % n_envs,
             "ms_per_vector_step": dt / iters * 1e3, "rl_iterations_per_sec": n_envs * iters / dt,
             "reference_published": "~3.8 RL iterations/s (A2C+GCN, authors' PC; BASELINE.md) - other hardware, reported beside"}
 
 
 def config5_bench(device_index, n_envs=256, warm=108, timed=8):
     """BASELINE config 5 scale as a secondary figure: 50 m map, 500 landmarks, graphs grown by a fixed motion loop to
-    ~110 poses / ~95 landmarks (k_slam's tile-streaming variant, k_map in pose chunks); per-stage kernels."""
+    ~110 poses / ~95 landmarks (k_slam_arrow with a ~200 x 200 landmark system, k_map in pose chunks); per-stage kernels."""
     from drl_graph_exploration_amd import default_config
     from drl_graph_exploration_amd.engine import Engine
-    cfg = default_config(50, num_landmarks=500, max_poses=127, max_landmarks=128, max_factors=3800)
+    cfg = default_config(50, num_landmarks=500, max_poses=127, max_landmarks=127, max_factors=3800)
     eng = Engine(cfg, n_envs, 0, device_index)
     rng = np.random.RandomState(0)
     starts = np.stack([rng.uniform(-12, 12, n_envs), rng.uniform(-12, 12, n_envs), rng.uniform(-3, 3, n_envs)], 1)
@@ -261,6 +266,100 @@ def config5_bench(device_index, n_envs=256, warm=108, timed=8):
             "env_steps_per_sec": n_envs / dt}
 
 
+def csrc_digest():
+    """sha1 over the kernel sources: ties a PMC traffic file to the tree it was measured on (no .git on the GPU box)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "drl_graph_exploration_amd", "csrc", "*.h*")) +
+                    glob.glob(os.path.join(ROOT, "drl_graph_exploration_amd", "csrc", "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def spawn_command(args_list, n):
+    """The launcher the driver itself uses for N > 1 (one rank per GPU, rendezvous on 127.0.0.1)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(args_list)
+
+
+def train_allreduce_bench(eng, dev, dist, world, iters=20, env_steps_per_iter=8):
+    """BASELINE.json configs[3]: the exchange step of the path.  Every rank runs the reference's DQN update on a 64-graph
+    batch of its own environments (GCN forward + backward through the HIP kernels, ONE flat all-reduce of the 1 008 001
+    gradient elements over RCCL, element-wise clamp, Adam).  Three bracketed timings (barrier + synchronize on both
+    sides, max over ranks): the train step, the collective alone, and train steps on a second stream while the belief
+    steps keep running on the engine's stream (the overlap SURVEY.md section 5 asks for)."""
+    from drl_graph_exploration_amd.networks import GCN, GraphData
+    from drl_graph_exploration_amd.policy import allreduce_gradients, broadcast_parameters
+    torch.manual_seed(0)
+    model = GCN().to(dev)
+    broadcast_parameters(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-5)
+    eng.restore(0)
+    g = eng.graph()
+    n64, e64 = int(g["node_off"][64]), int(g["edge_off"][64])
+    d64 = GraphData(g["x"][:n64].clone(), g["edge_index"][:, :e64].clone(), g["edge_attr"][:e64].clone(), g["batch"][:n64].clone())
+    w = torch.randn(n64, 1, device=dev)
+    odom = torch.tensor([STEP_ACTION] * N_ENVS, dtype=torch.float64, device=dev)
+    n_param = sum(p.numel() for p in model.parameters())
+    flat = torch.zeros(n_param, dtype=torch.float32, device=dev)
+
+    def train_step():
+        opt.zero_grad()
+        q = model(d64, 0.5, batch=d64.batch)
+        ((q * w) ** 2).sum().div(64).backward()
+        allreduce_gradients(model)
+        for p_ in model.parameters():
+            p_.grad.data.clamp_(-0.5, 0.5)
+        opt.step()
+
+    def bracket(fn, n):
+        for _ in range(3):
+            fn()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / n
+
+    t_train = bracket(train_step, iters)
+    t_coll = bracket((lambda: dist.all_reduce(flat)) if dist is not None else (lambda: None), iters)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+
+    def overlapped():
+        with torch.cuda.stream(side):  # the trainer's stream; the engine stays on the current stream
+            train_step()
+        for _ in range(env_steps_per_iter):
+            eng.restore(0)
+            eng.step(odom)
+        torch.cuda.current_stream().wait_stream(side)
+    t_ov = bracket(overlapped, iters)
+    eng.check_status()
+    return {"workload": "configs[3]: per rank 256 envs + DQN update on 64 graphs (%d nodes), flat fp32 gradient all-reduce of %d "
+                        "elements (%.2f MB) per train step" % (n64, n_param, n_param * 4 / 1e6),
+            "ranks": world, "backend": (dist.get_backend() if dist is not None else "none"),
+            "train_step_ms": t_train * 1e3, "allreduce_ms": t_coll * 1e3 if dist is not None else 0.0,
+            "overlapped_iteration_ms": t_ov * 1e3, "env_steps_per_iteration": env_steps_per_iter * N_ENVS,
+            "env_steps_per_sec_while_training": env_steps_per_iter * N_ENVS * world / t_ov,
+            "train_steps_per_sec": world / t_ov}
+
+
 def main():
     if len(sys.argv) == 4 and sys.argv[1] == "--cpu-worker":  # child of cpu_baseline_all_cores
         n, t = _cpu_worker((int(sys.argv[2]), float(sys.argv[3])))
@@ -272,9 +371,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-policy", action="store_true", help="skip the secondary decision-path / GCN measurements")
+    ap.add_argument("--no-train", action="store_true", help="skip the DQN-update / gradient all-reduce section")
+    ap.add_argument("--print-launch", action="store_true", help="print the multi-rank launch command and exit")
     args = ap.parse_args()
-
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.print_launch):
+        # no launcher around us: become one (one rank per GPU, the command the driver uses for N > 1)
+        cmd = spawn_command([a for a in sys.argv[1:] if a != "--print-launch"], args.gpus)
+        if args.print_launch:
+            print(" ".join(cmd))
+            return
+        import subprocess
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -293,6 +405,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    if dist is not None:
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     eng, cfg = make_engine(local_rank, seed0=rank * N_ENVS)
     odom = torch.tensor([STEP_ACTION] * N_ENVS, dtype=torch.float64, device=dev)
     counts = [eng.counts(i) for i in range(0, N_ENVS, 16)]
@@ -337,6 +451,9 @@ def main():
         one_step()
     tm = eng.timing_read()
     eng.timing_enable(False)
+    train = None
+    if not args.no_train:  # every rank takes part: the section contains collectives
+        train = train_allreduce_bench(eng, dev, dist, world)
 
     if rank == 0:
         V = eng.rows * eng.cols
@@ -376,13 +493,18 @@ def main():
                     "frac": kernels[dom]["frac_hbm_peak"], "traffic": None,
                     "avg_us_per_launch": kernels[dom]["avg_us_per_launch"]}
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this same command (counters cannot be
-        # read in-process); profiles/r01_pmc_traffic.json holds the corrected per-kernel figures (scripts/rocpd_pmc.py)
+        # read in-process): profiles/pmc_traffic.json holds the corrected per-kernel figures (scripts/rocpd_pmc.py) and
+        # the digest of the kernel sources they were measured on - traffic is reported only when that is THIS tree
+        roofline["algorithmic_bytes_per_launch"] = kernels[dom]["algorithmic_bytes_per_launch"]
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pmc = json.load(f)["kernels"]
-            roofline["traffic"] = pmc[roofline["kernel"]]["hbm_traffic_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
-            roofline["algorithmic_bytes_per_launch"] = kernels[dom]["algorithmic_bytes_per_launch"]
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("csrc_sha1") == csrc_digest():
+                roofline["traffic"] = pmc["kernels"][roofline["kernel"]]["hbm_traffic_bytes_per_launch"]
+                roofline["traffic_source"] = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch), "
+                                              "measured on kernel sources sha1 %s = this tree" % pmc["csrc_sha1"][:12])
+            else:
+                roofline["traffic_source"] = "profiles/pmc_traffic.json is from other kernel sources (sha1 %s): not reported" % str(pmc.get("csrc_sha1"))[:12]
         except (OSError, KeyError, ValueError):
             pass
         total_steps = args.steps * N_ENVS * world
@@ -396,7 +518,11 @@ def main():
                                    % (P + 1 + L, P + 1, L, M),
                        "envs_per_gpu": N_ENVS, "map_size": MAP, "num_landmarks": NUM_LM, "parallelism": "env-sharded x%d" % world},
             "roofline": roofline, "kernels": kernels, "event_pair_overhead_us": ev_over_us,
+            "ranks_in_process_group": (dist.get_world_size() if dist is not None else 1),
+            "collective_backend": (dist.get_backend() if dist is not None else "none"),
         }
+        if train is not None:
+            out["train_allreduce"] = train
         # the secondary sections and the CPU baselines belong to the N = 1 line only (driver contract)
         if not args.no_policy and world == 1:
             out["policy_path"] = policy_bench(eng, dev)

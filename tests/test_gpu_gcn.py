@@ -192,3 +192,73 @@ def test_a2c_heads_and_losses_match_torch_reference(monkeypatch, tmp_path):
             g, r = p.grad.double(), ref[k].grad
             # (the actor's output bias has an exactly zero gradient - softmax is shift invariant: absolute floor)
             assert float((g - r).norm()) < 2e-4 * float(r.norm()) + 1e-6, k
+
+
+def test_dqn_minibatch_matches_float64_restatement(monkeypatch, tmp_path):
+    """One DQN update (scripts/policy.py:139-178, :234-253) through the product path - target network forward on the HIP
+    GCN, `DeepQ.td_targets` (the reference's read-out windows), float64 loss, HIP backward, element-wise clamp, Adam -
+    against the same update restated in float64 torch + the oracle's numpy target loop: y_batch, loss and the
+    parameters after the optimiser step."""
+    import random
+    import drl_graph_exploration_amd.networks as NW
+    from drl_graph_exploration_amd.networks import GCN, GraphData
+    from drl_graph_exploration_amd.policy import DeepQ
+    from oracle import dqn_ref
+    dev = torch.device("cuda", 0)
+    B = 8
+    gen = torch.Generator().manual_seed(7)
+    trans = []
+    for k in range(B):
+        x, ei, ea, _ = random_batch(1, 900 + k, dev, nmin=12, nmax=30)
+        x1, ei1, ea1, _ = random_batch(1, 1900 + k, dev, nmin=int(x.shape[0]), nmax=int(x.shape[0]) + 6)  # graphs grow
+        n, fro, fro1 = int(x.shape[0]), 1 + int(torch.randint(0, 4, (1,), generator=gen)), 1 + int(torch.randint(0, 4, (1,), generator=gen))
+        a = n - fro + int(torch.randint(0, fro, (1,), generator=gen))
+        trans.append((GraphData(x, ei, ea), a, float(torch.randn(1, generator=gen)), GraphData(x1, ei1, ea1), k % 3 == 0, fro1))
+    dq = DeepQ("t/", "GCN", data_root=str(tmp_path))
+    dq.BATCH = B
+    dq.buffer.extend(trans)
+    torch.manual_seed(11)
+    pol, tgt = GCN().to(dev), GCN().to(dev)
+    with torch.no_grad():
+        for m in (pol, tgt):  # biases away from zero so that every parameter sees a gradient
+            m.conv1.bias.normal_(0, 0.05); m.conv2.bias.normal_(0, 0.05); m.fully_con1.bias.normal_(0, 0.05)
+    p0 = {k: v.detach().double().clone() for k, v in pol.state_dict().items()}
+    pt = {k: v.detach().double().clone() for k, v in tgt.state_dict().items()}
+    N = sum(t[0].num_nodes for t in trans)
+    fixed = (torch.rand(N, 1000, device=dev, generator=torch.Generator(device=dev).manual_seed(5)) >= 0.5).float() * 2.0
+    monkeypatch.setattr(NW, "_dropout_mask", lambda n, hidden, p, device: fixed if p > 0 else None)
+    monkeypatch.setattr(random, "sample", lambda buf, k: list(buf)[:k])  # the minibatch = the 8 transitions, in order
+    captured = {}
+    orig_train = dq.train
+
+    def spy(data, action, y, device, model, optimizer):
+        captured.update(a=action.clone(), y=y.clone())
+        return orig_train(data, action, y, device, model, optimizer)
+    dq.train = spy
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-3)
+    dq._train_minibatch(dev, pol, tgt, opt)
+    # ---- float64 restatement
+    s_j, s_j1 = GraphData.collate([t[0] for t in trans]), GraphData.collate([t[3] for t in trans])
+    q1 = gcn_ref.gcn_forward(pt, s_j1.x.double(), s_j1.edge_index, s_j1.edge_attr.double()).detach().cpu().numpy()
+    acts = []
+    for t in trans:
+        act = np.zeros(t[0].num_nodes)
+        act[t[1]] = 1
+        acts.append(act)
+    a_ref, y_ref = dqn_ref.reference_targets(acts, [t[2] for t in trans], [t[4] for t in trans], [t[5] for t in trans], q1, dq.GAMMA)
+    np.testing.assert_array_equal(captured["a"].cpu().numpy(), a_ref)
+    np.testing.assert_allclose(captured["y"].cpu().numpy(), y_ref, rtol=0, atol=2e-5)  # fp32 target network vs float64
+    pr = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+    out = gcn_ref.gcn_forward(pr, s_j.x.double(), s_j.edge_index, s_j.edge_attr.double(), fixed.double()).view(-1)
+    y_t, a_t = torch.as_tensor(y_ref, device=dev), torch.as_tensor(a_ref, device=dev)
+    loss = torch.pow(out * a_t - y_t, 2).sum() / B
+    assert dq.temp_loss == pytest.approx(float(loss.detach()), rel=2e-4)
+    loss.backward()
+    ref_opt = torch.optim.Adam([pr[k] for k in pr], lr=1e-3)
+    for k in pr:
+        pr[k].grad.clamp_(-dq.max_grad_norm, dq.max_grad_norm)
+    ref_opt.step()
+    for k, v in pol.state_dict().items():
+        # Adam's first step moves every parameter by lr * sign(grad) (up to eps): compare the step, not just the value
+        step, rstep = v.double() - p0[k], pr[k].detach() - p0[k]
+        assert float((step - rstep).abs().max()) < 2e-2 * 1e-3 + 1e-9, k

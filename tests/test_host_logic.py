@@ -285,3 +285,19 @@ def test_bench_cpu_worker_subprocess():
     assert out.returncode == 0, out.stderr[-500:]
     n, t = out.stdout.strip().split()[-2:]
     assert int(n) >= 1 and 0.3 <= float(t) < 30.0
+
+
+def test_bench_launch_contract():
+    """`bench.py --gpus N` without a launcher becomes its own launcher (one rank per GPU, 127.0.0.1 rendezvous - the
+    command the driver uses); under a launcher a WORLD_SIZE that differs from --gpus is an error, not a silent 1-rank run."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--print-launch"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    cmd = out.stdout.split()
+    assert "torch.distributed.run" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr
