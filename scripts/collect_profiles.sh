@@ -1,0 +1,25 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): rocprofv3 passes over the bench workload, summarised into gpurun_out/<tag>/.
+#   1. --kernel-trace --stats            -> kernel_stats.csv
+#   2. --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)  -> pmc_traffic.json (with the digest of the kernel sources)
+#   3. --pmc SQ_* (one pass, 8 SQ slots) + GRBM_GUI_ACTIVE     -> sq_counters.txt
+# usage: scripts/collect_profiles.sh <tag>     (counters are never combined with sys / hip / hsa tracing)
+set -u
+tag=${1:-r02}
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+BENCH="python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-policy --no-train"
+db() { find "$1" -name '*_results.db' | head -1; }
+rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -- $BENCH > $out/bench_under_rocprof.json 2> $out/rocprof_stats.err
+python scripts/rocpd_summary.py "$(db /tmp/prof_stats)" > $out/kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_fetch -- $BENCH > /dev/null 2> $out/rocprof_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_write -- $BENCH > /dev/null 2> $out/rocprof_write.err
+python scripts/rocpd_pmc.py "$(db /tmp/prof_fetch)" "$(db /tmp/prof_write)" > $out/pmc_traffic.json
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
+  --kernel-trace -d /tmp/prof_sq -- $BENCH > /dev/null 2> $out/rocprof_sq.err
+python scripts/pmc_sq_summary.py "$(db /tmp/prof_sq)" > $out/sq_counters.txt
+rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES \
+  --kernel-trace -d /tmp/prof_sq2 -- $BENCH > /dev/null 2> $out/rocprof_sq2.err
+python scripts/pmc_sq_summary.py "$(db /tmp/prof_sq2)" > $out/sq_counters2.txt
+ls -la $out

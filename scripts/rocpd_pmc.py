@@ -5,8 +5,11 @@ Units/corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; 
 read requests at 64 B, so it is doubled (the instance-copy kernel, whose byte count is known exactly - it reads what it
 writes - confirms the factor on this workload: 2 x 12860 KiB read vs 25244 KiB written)."""
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(path, counter):
@@ -17,7 +20,7 @@ def per_kernel(path, counter):
 
 
 def short(name):
-    for k in ("k_step", "k_slam", "k_map", "k_sim_step", "k_copy_instances", "k_reset"):
+    for k in ("k_step", "k_slam_arrow", "k_slam", "k_map", "k_sim_step", "k_copy_instances", "k_reset"):
         if k in name:
             return k
     return name
@@ -32,6 +35,7 @@ for name in fetch:
     f, w = fetch[name][1] * 1024.0, write[name][1] * 1024.0
     out[short(name)] = {"launches_sampled": fetch[name][0], "FETCH_SIZE_bytes_raw": f, "WRITE_SIZE_bytes": w,
                         "hbm_read_bytes_corrected": 2.0 * f, "hbm_traffic_bytes_per_launch": 2.0 * f + w}
-print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
+import bench  # noqa: E402  (csrc_digest: ties the figures to the kernel sources they were measured on)
+print(json.dumps({"csrc_sha1": bench.csrc_digest(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
                             "`python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-policy`",
                   "correction": "FETCH_SIZE x2 (gfx950), KiB -> bytes", "kernels": out}, indent=1))
