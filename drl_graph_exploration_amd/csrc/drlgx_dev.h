@@ -532,7 +532,12 @@ inline void drlgx_ensure_lds_attr(bool (&done)[32], const void *const *fns, int 
 // ---- launchers implemented in the kernel translation units ------------------------------------
 struct DrlgxField;
 void drlgx_launch_reset(const DrlgxState &S, hipStream_t st, int n, const int32_t *env_ids_dev, const uint32_t *seeds_dev,
-                        const double *start_dev);
+                        const double *start_dev, int first_measure = 1);
+// staged interface: mode 0 = move + addOdometry, mode 1 = one exporting measure (keys [n][LG], br [n][LG][2], count [n])
+void drlgx_launch_sim_stage(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int mode, int32_t *keys,
+                            double *br, int32_t *count);
+void drlgx_launch_add_measurements(const DrlgxState &S, hipStream_t st, LaunchSel sel, const int32_t *keys, const double *br,
+                                   const int32_t *count);
 void drlgx_launch_sim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride,
                       int n_measure);
 // p_bound: host-side upper bound of the pose count of every selected instance after this launch (<= P_max); it picks

@@ -480,6 +480,72 @@ int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_de
   return check_launch(e);
 }
 
+// ---- staged form of the belief step: one call per call of SS2D.__init__ / SS2D.simulate (scripts/envs/pyss2d.py) -------
+int drlgx_stage_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint32_t *seeds, const double *start) {
+  DRLGX_ENTER(e);
+  if (!e || n <= 0 || n > e->S.n_envs || !env_ids || !seeds || !start) return DRLGX_E_INVALID;
+  for (int i = 0; i < n; ++i)
+    if (env_ids[i] < 0 || env_ids[i] >= e->S.n_envs) return DRLGX_E_INVALID;
+  HIPCHK(e, hipMemcpyAsync(e->stage_i32, env_ids, n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->stage_u32, seeds, n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->stage_f64, start, n * 3 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemsetAsync(e->S.status, 0, sizeof(int), e->stream));
+  drlgx_launch_reset(e->S, e->stream, n, e->stage_i32, e->stage_u32, e->stage_f64, 0);
+  for (int i = 0; i < n; ++i) e->pbound[env_ids[i]] = 1;
+  int r = check_launch(e);
+  if (r) return r;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return DRLGX_OK;
+}
+int drlgx_stage_move(drlgx_engine *e, const double *odom_dev, const uint8_t *active_dev) {
+  DRLGX_ENTER(e);
+  if (!e || !odom_dev) return DRLGX_E_INVALID;
+  for (int &v : e->pbound) v = std::min(v + 1, e->S.P_max);
+  drlgx_launch_sim_stage(e->S, e->stream, LaunchSel{0, e->S.n_envs, active_dev, nullptr, 0}, odom_dev, 0, nullptr, nullptr, nullptr);
+  return check_launch(e);
+}
+int drlgx_stage_measure(drlgx_engine *e, const uint8_t *active_dev, int32_t *keys_dev, double *bearing_range_dev, int32_t *count_dev) {
+  DRLGX_ENTER(e);
+  if (!e || !keys_dev || !bearing_range_dev || !count_dev) return DRLGX_E_INVALID;
+  HIPCHK(e, hipMemsetAsync(count_dev, 0, sizeof(int32_t) * e->S.n_envs, e->stream));
+  drlgx_launch_sim_stage(e->S, e->stream, LaunchSel{0, e->S.n_envs, active_dev, nullptr, 0}, nullptr, 1, keys_dev, bearing_range_dev,
+                         count_dev);
+  return check_launch(e);
+}
+int drlgx_stage_add_measurements(drlgx_engine *e, const uint8_t *active_dev, const int32_t *keys_dev, const double *bearing_range_dev,
+                                 const int32_t *count_dev) {
+  DRLGX_ENTER(e);
+  if (!e || !keys_dev || !bearing_range_dev || !count_dev) return DRLGX_E_INVALID;
+  drlgx_launch_add_measurements(e->S, e->stream, LaunchSel{0, e->S.n_envs, active_dev, nullptr, 0}, keys_dev, bearing_range_dev, count_dev);
+  return check_launch(e);
+}
+int drlgx_stage_optimize(drlgx_engine *e, const uint8_t *active_dev) {
+  DRLGX_ENTER(e);
+  if (!e) return DRLGX_E_INVALID;
+  drlgx_launch_slam(e->S, e->stream, LaunchSel{0, e->S.n_envs, active_dev, nullptr, 0}, max_bound(e));
+  return check_launch(e);
+}
+int drlgx_stage_update_map(drlgx_engine *e, const uint8_t *active_dev, int rebuild) {
+  DRLGX_ENTER(e);
+  if (!e) return DRLGX_E_INVALID;
+  drlgx_launch_map(e->S, e->stream, LaunchSel{0, e->S.n_envs, active_dev, nullptr, rebuild ? 0 : -2});
+  return check_launch(e);
+}
+
+int drlgx_set_planner_parameter(drlgx_engine *e, double angle_weight, double distance_weight0, double distance_weight1,
+                                double occupancy_threshold, double max_edge_length, int algorithm) {
+  DRLGX_ENTER(e);
+  if (!e || !(max_edge_length > 0) || algorithm < 0 || algorithm > 3) return DRLGX_E_INVALID;
+  drlgx_config &c = e->S.cfg;  // (the state struct is passed to every launch by value: the next launch sees the new values)
+  c.angle_weight = angle_weight;
+  c.distance_weight0 = distance_weight0;
+  c.distance_weight1 = distance_weight1;
+  c.occupancy_threshold = occupancy_threshold;
+  c.max_edge_length = max_edge_length;
+  c.algorithm = algorithm;
+  return DRLGX_OK;
+}
+
 int drlgx_utility(drlgx_engine *e, const double *dist_dev, double *out_dev) {
   DRLGX_ENTER(e);
   if (!e || !out_dev) return DRLGX_E_INVALID;

@@ -51,12 +51,39 @@ __device__ inline int scan_in_range(SimCtx &c, int *inr) {
   wave_sync();
   return n_in;
 }
-__device__ inline void measure(SimCtx &c, bool record, double *nrm, const int *inr, int n_in) {
+// exp_*: the staged interface (drlgx_stage_measure) exports the valid measurements (key, bearing, range) in order instead
+// of appending them: Simulator2D::measure as the object-level API sees it
+__device__ inline void measure(SimCtx &c, bool record, double *nrm, const int *inr, int n_in, int32_t *exp_keys = nullptr,
+                               double *exp_br = nullptr, int32_t *exp_count = nullptr) {
   const DrlgxState &S = c.S;
   const drlgx_config &cfg = S.cfg;
   const double *gl = S.gt_lm + (size_t)S.parent[c.inst] * S.LG * 2;
   const unsigned long long below = (1ull << c.lane) - 1ull;
-  draw_normals(c.sensor, c.ns_sensor, 2 * n_in, nrm, c.lane, record);
+  draw_normals(c.sensor, c.ns_sensor, 2 * n_in, nrm, c.lane, record || exp_keys);
+  if (exp_keys) {
+    int n_out = 0;
+    for (int base = 0; base < n_in; base += 64) {
+      const int k = base + c.lane;
+      const bool v = k < n_in;
+      const int key = v ? inr[k] : 0;
+      const P2 lm{gl[2 * key], gl[2 * key + 1]};
+      const double bn = (v ? nrm[2 * k] : 0.0) * cfg.bearing_noise + 0.0;
+      const double rn = (v ? nrm[2 * k + 1] : 0.0) * cfg.range_noise + 0.0;
+      const double bearing = bearing_of<false>(c.veh, lm, nullptr, nullptr) + bn;
+      const double range = range_of<false>(c.veh, lm, nullptr, nullptr) + rn;
+      const bool ok = v && bearing < cfg.max_bearing && bearing > cfg.min_bearing && range < cfg.max_range && range > cfg.min_range;
+      const unsigned long long okm = __ballot(ok);
+      if (ok) {
+        const int f = n_out + __popcll(okm & below);
+        exp_keys[f] = key;
+        exp_br[2 * f] = bearing;
+        exp_br[2 * f + 1] = range;
+      }
+      n_out += __popcll(okm);
+    }
+    if (c.lane == 0) *exp_count = n_out;
+    return;
+  }
   if (!record) return;
   int *key_slot = S.key_slot + (size_t)c.inst * S.LG;
   for (int base = 0; base < n_in; base += 64) {
@@ -125,7 +152,7 @@ __device__ inline void store_ctx(SimCtx &c) {
 }
 
 // SS2D.__init__ (pyss2d.py:102-138): seed, vehicle, landmarks, prior, first measure.
-__global__ __launch_bounds__(64) void k_reset(DrlgxState S, const int32_t *env_ids, const uint32_t *seeds,
+__global__ __launch_bounds__(64) void k_reset(DrlgxState S, int first_measure, const int32_t *env_ids, const uint32_t *seeds,
                                               const double *start) {
   __shared__ uint32_t lds[3][DRLGX_MT_STRIDE];
   extern __shared__ double dyn[];  // nrm[2 LG + 2] doubles, inr[LG] ints
@@ -181,7 +208,7 @@ __global__ __launch_bounds__(64) void k_reset(DrlgxState S, const int32_t *env_i
   }
   __syncthreads();
   c.P = 1;
-  measure(c, true, nrm, inr, scan_in_range(c, inr));  // pyss2d.py:135 self.measure()
+  if (first_measure) measure(c, true, nrm, inr, scan_in_range(c, inr));  // pyss2d.py:135 self.measure()
   store_ctx(c);
   // VirtualMap::initialize (VirtualMap.cpp:318-362): prob 0.5, information I / sigma0^2
   const double i0 = 1.0 / pow(cfg.sigma0, 2);
@@ -196,8 +223,12 @@ __global__ __launch_bounds__(64) void k_reset(DrlgxState S, const int32_t *env_i
 
 // move + addOdometry + measure(s) + addMeasurement for one belief step, executed by ONE wave (lane = 0..63).
 // lds0 / lds1: 626 words each, dyn: (2 LG + 2) doubles + LG ints of LDS scratch.
+// kMove / exp_*: the staged interface runs the move (with addOdometry) and a single exporting measure() as separate
+// launches (drlgx_stage_move / drlgx_stage_measure); the fused step is <true> with n_measure = 2 and no export.
+template <bool kMove = true>
 __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchSel &sel, const double *odom, int odom_stride,
-                                              int n_measure, uint32_t *lds0, uint32_t *lds1, double *dyn, int lane) {
+                                              int n_measure, uint32_t *lds0, uint32_t *lds1, double *dyn, int lane,
+                                              int32_t *exp_keys = nullptr, double *exp_br = nullptr, int32_t *exp_count = nullptr) {
   uint32_t *lds[2] = {lds0, lds1};
   double *nrm = dyn;
   int *inr = reinterpret_cast<int *>(dyn + 2 * S.LG + 2);
@@ -206,15 +237,18 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
   const int inst = sel.base + i;
   const drlgx_config &cfg = S.cfg;
   int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
-  const double *od = odom + (size_t)i * odom_stride + (size_t)sel.act_idx * 3;
-  const double ox = od[0], oy = od[1], oth = od[2];
-  // SS2D.simulate bounds-checks the odometry increment against the map box (pyss2d.py:173-176)
-  if (!(cfg.map_min_x < ox && ox < cfg.map_max_x) || !(cfg.map_min_y < oy && oy < cfg.map_max_y)) {
-    if (lane == 0) cnt[C_FLAG] = 1;
-    return;
+  double ox = 0, oy = 0, oth = 0;
+  if constexpr (kMove) {
+    const double *od = odom + (size_t)i * odom_stride + (size_t)sel.act_idx * 3;
+    ox = od[0]; oy = od[1]; oth = od[2];
+    // SS2D.simulate bounds-checks the odometry increment against the map box (pyss2d.py:173-176)
+    if (!(cfg.map_min_x < ox && ox < cfg.map_max_x) || !(cfg.map_min_y < oy && oy < cfg.map_max_y)) {
+      if (lane == 0) cnt[C_FLAG] = 1;
+      return;
+    }
   }
   SimCtx c{S, inst, lane, {}, {}, {0, 0}, {0, 0}, {}, cnt[C_P], cnt[C_L], cnt[C_M], 0};
-  if (c.P >= S.P_max) {
+  if (kMove && c.P >= S.P_max) {
     if (lane == 0) {
       cnt[C_FLAG] = 1;
       atomicMin(S.status, DRLGX_E_CAPACITY);
@@ -227,8 +261,9 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
   c.ns_control = NormalState{S.nrm_saved[inst * 2 + 1], S.nrm_has[inst * 2 + 1]};
   const double *gp = S.gt_pose + (size_t)inst * 4;
   c.veh = Pose{gp[0], gp[1], gp[2], gp[3]};
-  const Pose odomP = make_pose(ox, oy, oth);
   DRLGX_PROF(S, 9);
+  if constexpr (kMove) {
+  const Pose odomP = make_pose(ox, oy, oth);
   // SimpleControlModel::evolve (Simulator2D.cpp:161-182)
   draw_normals(c.control, c.ns_control, 3, nrm, lane);
   const double xn = nrm[0] * cfg.translation_noise + 0.0;
@@ -255,12 +290,15 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
     S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST] += sqrt(ox * ox + oy * oy + cfg.angle_weight * (th * th));
   }
   wave_sync();  // lane 0's writes (initial guess of the new pose) are read by every lane below
-  DRLGX_PROF(S, 10);
   c.P += 1;
-  const int n_in = scan_in_range(c, inr);
-  for (int m = 0; m < n_measure; ++m) {
-    measure(c, m == n_measure - 1, nrm, inr, n_in);
-    DRLGX_PROF(S, 11 + m);
+  }
+  DRLGX_PROF(S, 10);
+  if (n_measure > 0) {
+    const int n_in = scan_in_range(c, inr);
+    for (int m = 0; m < n_measure; ++m) {
+      measure(c, m == n_measure - 1 && !exp_keys, nrm, inr, n_in, exp_keys, exp_br, exp_count);
+      DRLGX_PROF(S, 11 + m);
+    }
   }
   store_ctx(c);
   DRLGX_PROF(S, 13);
@@ -273,12 +311,81 @@ __global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, co
   sim_step_body(S, sel, odom, odom_stride, n_measure, lds[0], lds[1], dyn, threadIdx.x);
 }
 
+// drlgx_stage_move (mode 0): Simulator2D::move + SLAM2D::addOdometry.  drlgx_stage_measure (mode 1): one
+// Simulator2D::measure whose valid measurements are exported: keys [n][LG], br [n][LG][2], count [n].
+__global__ __launch_bounds__(64) void k_sim_stage(DrlgxState S, LaunchSel sel, const double *odom, int mode, int32_t *keys,
+                                                  double *br, int32_t *count) {
+  __shared__ uint32_t lds[2][DRLGX_MT_STRIDE];
+  extern __shared__ double dyn[];
+  const int i = blockIdx.x;
+  if (mode == 0)
+    sim_step_body<true>(S, sel, odom, 3, 0, lds[0], lds[1], dyn, threadIdx.x);
+  else
+    sim_step_body<false>(S, sel, nullptr, 0, 1, lds[0], lds[1], dyn, threadIdx.x, keys + (size_t)i * S.LG, br + (size_t)i * S.LG * 2,
+                         count + i);
+}
+
+// drlgx_stage_add_measurements: SLAM2D::addMeasurement (SLAM2D.cpp:103-124) of every listed (key, bearing, range) at the
+// newest pose, in list order (a key may repeat: the second one is no longer new).  Not a hot path: one lane per instance.
+__global__ void k_add_measurements(DrlgxState S, LaunchSel sel, const int32_t *keys, const double *br, const int32_t *count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sel.n || !sel.on(i)) return;
+  const int inst = sel.base + i;
+  int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
+  int P = cnt[C_P], L = cnt[C_L], M = cnt[C_M];
+  int *key_slot = S.key_slot + (size_t)inst * S.LG;
+  for (int k = 0; k < count[i]; ++k) {
+    const int key = keys[(size_t)i * S.LG + k];
+    const double bearing = br[((size_t)i * S.LG + k) * 2], range = br[((size_t)i * S.LG + k) * 2 + 1];
+    if (key < 0 || key >= S.cfg.num_landmarks) {
+      atomicMin(S.status, DRLGX_E_INVALID);
+      break;
+    }
+    int slot = key_slot[key];
+    if (slot < 0) {
+      if (L >= S.L_max) {
+        atomicMin(S.status, DRLGX_E_CAPACITY);
+        break;
+      }
+      slot = L++;
+      const double *tp = S.th_pose + ((size_t)inst * S.P_max + (P - 1)) * 4;
+      const P2 g = transform_from(Pose{tp[0], tp[1], tp[2], tp[3]}, P2{range * cos(bearing), range * sin(bearing)});
+      double *tl = S.th_lm + ((size_t)inst * S.L_max + slot) * 2;
+      tl[0] = g.x; tl[1] = g.y;
+      double *dl = S.d_lm + ((size_t)inst * S.L_max + slot) * 2;
+      dl[0] = 0; dl[1] = 0;
+      S.lm_key[(size_t)inst * S.L_max + slot] = key;
+      key_slot[key] = slot;
+    }
+    if (M >= S.M_max) {
+      atomicMin(S.status, DRLGX_E_CAPACITY);
+      break;
+    }
+    S.meas_pose[(size_t)inst * S.M_max + M] = P - 1;
+    S.meas_lm[(size_t)inst * S.M_max + M] = slot;
+    S.meas_br[((size_t)inst * S.M_max + M) * 2] = bearing;
+    S.meas_br[((size_t)inst * S.M_max + M) * 2 + 1] = range;
+    ++M;
+  }
+  cnt[C_L] = L;
+  cnt[C_M] = M;
+}
+
 }  // namespace ksim
 
-void drlgx_launch_reset(const DrlgxState &S, hipStream_t st, int n, const int32_t *env_ids_dev,
-                        const uint32_t *seeds_dev, const double *start_dev) {
+void drlgx_launch_sim_stage(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int mode, int32_t *keys,
+                            double *br, int32_t *count) {
   const size_t dyn = (size_t)(2 * S.LG + 2) * sizeof(double) + (size_t)S.LG * sizeof(int);
-  hipLaunchKernelGGL(ksim::k_reset, dim3(n), dim3(64), dyn, st, S, env_ids_dev, seeds_dev, start_dev);
+  hipLaunchKernelGGL(ksim::k_sim_stage, dim3(sel.n), dim3(64), dyn, st, S, sel, odom, mode, keys, br, count);
+}
+void drlgx_launch_add_measurements(const DrlgxState &S, hipStream_t st, LaunchSel sel, const int32_t *keys, const double *br,
+                                   const int32_t *count) {
+  hipLaunchKernelGGL(ksim::k_add_measurements, dim3((sel.n + 63) / 64), dim3(64), 0, st, S, sel, keys, br, count);
+}
+void drlgx_launch_reset(const DrlgxState &S, hipStream_t st, int n, const int32_t *env_ids_dev,
+                        const uint32_t *seeds_dev, const double *start_dev, int first_measure) {
+  const size_t dyn = (size_t)(2 * S.LG + 2) * sizeof(double) + (size_t)S.LG * sizeof(int);
+  hipLaunchKernelGGL(ksim::k_reset, dim3(n), dim3(64), dyn, st, S, first_measure, env_ids_dev, seeds_dev, start_dev);
 }
 void drlgx_launch_sim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride,
                       int n_measure) {

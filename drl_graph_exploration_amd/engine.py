@@ -88,6 +88,48 @@ class Engine(object):
         assert odom.is_cuda and odom.dtype == torch.float64 and odom.is_contiguous()
         self._chk(self.L.drlgx_step(self.h, _p(odom), _p(active)))
 
+    # ---- staged belief step (one call per call of the reference's SS2D.__init__ / SS2D.simulate)
+    def stage_reset(self, env_ids, seeds, starts):
+        env_ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        starts = np.ascontiguousarray(starts, dtype=np.float64)
+        self.use_torch_stream()
+        self._chk(self.L.drlgx_stage_reset_host(self.h, len(env_ids), env_ids.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                seeds.ctypes.data_as(C.POINTER(C.c_uint32)), starts.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def stage_move(self, odom, active=None):
+        self.use_torch_stream()
+        self._chk(self.L.drlgx_stage_move(self.h, _p(odom), _p(active)))
+
+    def stage_measure(self, active=None):
+        """One Simulator2D::measure per env: (keys [n, LG] i32, bearing_range [n, LG, 2] f64, count [n] i32)."""
+        self.use_torch_stream()
+        lg = max(self.cfg.num_landmarks, 1)
+        keys = torch.zeros(self.n_envs, lg, dtype=torch.int32, device=self.device)
+        br = torch.zeros(self.n_envs, lg, 2, dtype=torch.float64, device=self.device)
+        cnt = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
+        self._chk(self.L.drlgx_stage_measure(self.h, _p(active), _p(keys), _p(br), _p(cnt)))
+        return keys, br, cnt
+
+    def stage_add_measurements(self, keys, br, cnt, active=None):
+        self.use_torch_stream()
+        self._chk(self.L.drlgx_stage_add_measurements(self.h, _p(active), _p(keys), _p(br), _p(cnt)))
+
+    def stage_optimize(self, active=None):
+        self.use_torch_stream()
+        self._chk(self.L.drlgx_stage_optimize(self.h, _p(active)))
+
+    def stage_update_map(self, active=None, rebuild=True):
+        self.use_torch_stream()
+        self._chk(self.L.drlgx_stage_update_map(self.h, _p(active), int(bool(rebuild))))
+
+    def set_planner_parameter(self, angle_weight, distance_weight0, distance_weight1, occupancy_threshold, max_edge_length, algorithm):
+        self._chk(self.L.drlgx_set_planner_parameter(self.h, float(angle_weight), float(distance_weight0), float(distance_weight1),
+                                                     float(occupancy_threshold), float(max_edge_length), int(algorithm)))
+        for k, v in (("angle_weight", angle_weight), ("distance_weight0", distance_weight0), ("distance_weight1", distance_weight1),
+                     ("occupancy_threshold", occupancy_threshold), ("max_edge_length", max_edge_length), ("algorithm", int(algorithm))):
+            setattr(self.cfg, k, v)
+
     def utility(self, dist=None):
         self.use_torch_stream()
         out = torch.empty(self.n_envs, dtype=torch.float64, device=self.device)

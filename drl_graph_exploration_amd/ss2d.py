@@ -1,10 +1,21 @@
-"""`ss2d` — value types and parameter classes of the reference's pybind module (src/SS2D.cpp:18-258).
+"""`ss2d` — the module surface of the reference's first pybind module (src/SS2D.cpp:18-258) over the drlgx engine.
 
-Only the part of the module surface the DRL scripts touch is provided (SURVEY.md §8b "minimum export set"):
-Pose2 / Point2 / Rot2 with gtsam semantics, the four parameter classes with the same property names, and the belief-state
-value types returned by the engine-backed facades in `pyss2d.py` / `pyplanner2d.py`.  The per-object mutators of the
-reference (`SLAM2D.add_odometry`, `Simulator2D.move`, ...) are fused into one device step (`SS2D.simulate`); the facades
-expose them at that granularity.
+Value types (Pose2 / Point2 / Rot2 with gtsam semantics), the parameter classes with the reference's property names, and
+the classes with behaviour the reference's Python layer constructs and drives (scripts/envs/pyss2d.py:59-246):
+`Simulator2D`, `SLAM2D`, `VirtualMap`, `Environment` (+ the sensor / control model holders).  They are thin objects over
+ONE one-environment engine: every call of the reference's call sequence maps onto one staged C-ABI call
+(include/drlgx.h: drlgx_stage_*), e.g.
+
+    sim.move(odom, True) + slam.add_odometry(cs)         -> drlgx_stage_move
+    sim.measure()                                         -> drlgx_stage_measure          (values returned, nothing added)
+    slam.add_measurement(key, m) ... slam.optimize()      -> drlgx_stage_add_measurements + drlgx_stage_optimize
+    vm.update_probability(slam, sensor) / update_information(map, sensor) -> drlgx_stage_update_map
+
+The objects of one simulation find each other the way the reference's script wires them: a `Simulator2D` opens a session,
+the `SLAM2D` / `VirtualMap` constructed next join it, and the engine is created at `SLAM2D.add_prior` (the first call that
+needs every parameter).  The batched product path does not go through these classes (`VecExplorationEnv`); they exist so
+that code written against the reference's module keeps working, one environment at a time.  No CPU path: creating the
+engine without a HIP device raises.
 """
 import math
 
@@ -41,6 +52,7 @@ class Pose2(object):
     def __init__(self, x=0.0, y=0.0, theta=0.0):
         self.x, self.y = float(x), float(y)
         self._c, self._s = math.cos(theta), math.sin(theta)
+        self._theta_in = float(theta)  # (kept so that a start pose reaches the engine with the angle it was given)
 
     @property
     def theta(self):
@@ -48,6 +60,7 @@ class Pose2(object):
 
     def __mul__(self, o):
         r = Pose2()
+        del r._theta_in
         c, s = self._c * o._c - self._s * o._s, self._s * o._c + self._c * o._s
         if abs(c * c + s * s - 1.0) > 1e-9:
             n = math.sqrt(c * c + s * s)
@@ -129,11 +142,357 @@ class LandmarkBeliefState(object):
 
 
 class Measurement(object):
-    """BearingRangeSensorModel::Measurement (bearing, range)."""
+    """BearingRangeSensorModel::Measurement (bearing, range[, sigmas])."""
 
-    def __init__(self, bearing, range_):
+    def __init__(self, bearing, range_, sigmas=None):
         self.bearing, self.range = bearing, range_
+        self.sigmas = None if sigmas is None else np.asarray(sigmas, dtype=np.float64)
+        self.has_jacobian = False
 
     def transform_from(self, origin):
         q = Point2(self.range * math.cos(self.bearing), self.range * math.sin(self.bearing))
         return Point2(origin._c * q.x - origin._s * q.y + origin.x, origin._s * q.x + origin._c * q.y + origin.y)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# classes with behaviour (engine-backed)
+# ------------------------------------------------------------------------------------------------------------------
+class _Session(object):
+    """The objects of one simulation + their engine (created lazily at SLAM2D.add_prior)."""
+    current = None
+
+    def __init__(self):
+        self.sim = self.slam = self.vm = self.engine = None
+        self.planner_params = None
+        self.max_poses = 256
+
+    def require_engine(self):
+        if self.engine is None:
+            raise RuntimeError("the engine of this simulation is created by SLAM2D.add_prior (call order of pyss2d.SS2D.__init__)")
+        return self.engine
+
+    def materialise(self, prior_state):
+        import torch  # noqa: F401  (device memory)
+        from .config import DrlgxConfig
+        from .engine import Engine
+        from . import planner2d
+        sim, slam, vm = self.sim, self.slam, self.vm
+        if sim is None or sim._env_params is None:
+            raise RuntimeError("Simulator2D.random_landmarks must be called before SLAM2D.add_prior")
+        sp, cp, ep, mp = sim._sensor_params, sim._control_params, sim._env_params, slam._map_params
+        vp = vm._params if vm is not None else VirtualMapParameter(mp)
+        pp = self.planner_params or planner2d.EMPlannerParameter()
+        c = DrlgxConfig()
+        c.bearing_noise, c.range_noise = sp.bearing_noise, sp.range_noise
+        c.min_bearing, c.max_bearing, c.min_range, c.max_range = sp.min_bearing, sp.max_bearing, sp.min_range, sp.max_range
+        c.translation_noise, c.rotation_noise = cp.translation_noise, cp.rotation_noise
+        c.env_min_x, c.env_max_x, c.env_min_y, c.env_max_y, c.safe_distance = ep.min_x, ep.max_x, ep.min_y, ep.max_y, ep.safe_distance
+        c.map_min_x, c.map_max_x, c.map_min_y, c.map_max_y = mp.min_x, mp.max_x, mp.min_y, mp.max_y
+        c.resolution, c.sigma0, c.num_samples = vp.resolution, vp.sigma0, vp.num_samples
+        info = np.asarray(prior_state.information, dtype=np.float64)
+        if np.abs(info - np.diag(np.diag(info))).max() > 0:
+            raise NotImplementedError("the engine's prior is diagonal (sigma_x0, sigma_y0, sigma_theta0 of the ini file)")
+        c.sigma_x0, c.sigma_y0, c.sigma_theta0 = (1.0 / math.sqrt(info[k, k]) for k in range(3))
+        c.num_landmarks = sim._num_landmarks
+        c.angle_weight, c.distance_weight0, c.distance_weight1 = pp.angle_weight, pp.distance_weight0, pp.distance_weight1
+        c.occupancy_threshold, c.max_edge_length, c.algorithm = pp.occupancy_threshold, pp.max_edge_length, int(pp.algorithm)
+        c.max_poses = self.max_poses
+        c.max_landmarks = max(1, min(c.num_landmarks, 127))
+        c.max_factors = max(64, 12 * c.max_poses)
+        span = max(ep.max_x - ep.min_x, ep.max_y - ep.min_y, (mp.max_x - mp.min_x) / 2, (mp.max_y - mp.min_y) / 2)
+        c.max_actions = int(math.ceil(math.hypot(span, span) / c.max_edge_length)) + 3
+        c.max_snapshots = 1
+        self.engine = Engine(c, 1, max(c.max_landmarks, 1), sim._device)
+        p = prior_state.pose
+        if (abs(p.x - sim._start.x), abs(p.y - sim._start.y)) != (0.0, 0.0) or abs(_wrap(p.theta - sim._start.theta)) > 1e-15:
+            raise NotImplementedError("the prior pose is the simulator's initial vehicle pose (pyss2d.py:124-133)")
+        self.engine.stage_reset([0], [sim._seed], np.array([[p.x, p.y, getattr(p, "_theta_in", p.theta)]]))
+        self.engine.stage_update_map(rebuild=False)  # sums of the untouched map (a fresh VirtualMap)
+        self.engine.check_status()
+
+
+class BearingRangeSensorModel(object):
+    """Holder handed from `Simulator2D.sensor_model` to `VirtualMap.update_*` / `EMPlanner2D` (src/SS2D.cpp:83-88)."""
+
+    def __init__(self, parameter, seed=0, _session=None):
+        self.parameter, self._session = parameter, _session
+
+
+class SimpleControlModel(object):
+    def __init__(self, parameter, seed=0, _session=None):
+        self.parameter, self._session = parameter, _session
+
+
+class SimpleControlModelState(object):
+    """SimpleControlModel::ControlState (src/SS2D.cpp:98-106): what `Simulator2D.move` returns and `SLAM2D.add_odometry` takes."""
+
+    def __init__(self, pose=None, odom=None, sigmas=None):
+        self.pose, self.odom = pose or Pose2(), odom or Pose2()
+        self.sigmas = np.zeros(3) if sigmas is None else np.asarray(sigmas, dtype=np.float64)
+        self.has_jacobian = False
+
+
+class Environment(object):
+    """`Simulator2D.environment` (ground truth) / `SLAM2D.map` (estimates): the getters of src/SS2D.cpp:141-171."""
+
+    def __init__(self, session, truth, parameter=None):
+        self._ses, self._truth, self.parameter = session, truth, parameter
+
+    @property
+    def distance(self):
+        return None
+
+    def get_landmark_size(self):
+        e = self._ses.require_engine()
+        return e.cfg.num_landmarks if self._truth else e.counts(0)["landmarks"]
+
+    def get_trajectory_size(self):
+        return 1 if self._truth else self._ses.require_engine().counts(0)["poses"]
+
+    def iter_landmarks(self):
+        e = self._ses.require_engine()
+        if self._truth:
+            _, lms = e.ground_truth(0)
+            for k, p in enumerate(lms):
+                yield k, LandmarkBeliefState(Point2(*p))
+        else:
+            keys, xy, info = e.landmarks(0)
+            for k, p, i in zip(keys, xy, info):
+                yield int(k), LandmarkBeliefState(Point2(*p), i)
+
+    def get_landmark(self, key):
+        for k, l in self.iter_landmarks():
+            if k == key:
+                return l
+        raise KeyError(key)
+
+    def iter_trajectory(self):
+        e = self._ses.require_engine()
+        if self._truth:
+            veh, _ = e.ground_truth(0)
+            yield VehicleBeliefState(Pose2(*veh))
+            return
+        xyt, info = e.poses(0)
+        for p, i in zip(xyt, info):
+            yield VehicleBeliefState(Pose2(*p), i)
+
+    def get_vehicle(self, i):
+        return list(self.iter_trajectory())[i]
+
+    def get_current_vehicle(self):
+        e = self._ses.require_engine()
+        if self._truth:
+            return next(self.iter_trajectory())
+        xyt, info = e.poses(0)
+        return VehicleBeliefState(Pose2(*xyt[-1]), info[-1])
+
+
+class Simulator2D(object):
+    """src/SS2D.cpp:173-187.  `Simulator2D(sensor_params, control_params[, seed])`; opens a new simulation session."""
+
+    def __init__(self, sensor_params, control_params, seed=0, device=0):
+        self._ses = _Session.current = _Session()
+        self._ses.sim = self
+        self._sensor_params, self._control_params, self._seed, self._device = sensor_params, control_params, int(seed), device
+        self._start, self._env_params, self._num_landmarks = Pose2(), None, 0
+        self.sensor_model = BearingRangeSensorModel(sensor_params, seed, self._ses)
+        self.control_model = SimpleControlModel(control_params, seed, self._ses)
+        self.environment = Environment(self._ses, True)
+
+    def initialize_vehicle(self, pose):
+        if self._ses.engine is not None:
+            raise RuntimeError("initialize_vehicle after the simulation started")
+        self._start = pose
+
+    def random_landmarks(self, landmarks, num, env_params):
+        """Simulator2D::addLandmarks (Simulator2D.cpp:445-464): `num` landmarks sampled uniformly in the environment box,
+        >= 2 m from the vehicle.  Fixed landmark lists (the ini file's optional [Landmarks] section) are not supported."""
+        if len(landmarks):
+            raise NotImplementedError("explicit landmark lists: the engine samples its ground-truth landmarks on the device")
+        self._num_landmarks, self._env_params = int(num), env_params
+        self.environment.parameter = env_params
+
+    @property
+    def vehicle(self):
+        if self._ses.engine is None:
+            return self._start
+        return Pose2(*self._ses.engine.ground_truth(0)[0])
+
+    def move(self, odom, core=True):
+        """Simulator2D::move (Simulator2D.cpp:491-503) -> (collision flag, ControlState).  The SLAM side of the same step
+        (`SLAM2D.add_odometry(control_state)`) is part of the same staged call."""
+        import torch
+        e = self._ses.require_engine()
+        e.stage_move(torch.tensor([[odom.x, odom.y, odom.theta]], dtype=torch.float64, device=e.device))
+        cp = self._control_params
+        cs = SimpleControlModelState(self.vehicle, odom, (cp.translation_noise, cp.translation_noise, cp.rotation_noise))
+        self._ses.slam._pending_odometry = cs
+        return False, cs
+
+    def measure(self):
+        """Simulator2D::measure (Simulator2D.cpp:505-527): [(key, Measurement)] of the landmarks that pass the gates."""
+        e = self._ses.require_engine()
+        keys, br, cnt = e.stage_measure()
+        n = int(cnt[0])
+        keys, br = keys[0, :n].cpu().numpy(), br[0, :n].cpu().numpy()
+        sp = self._sensor_params
+        return [(int(k), Measurement(float(b), float(r), (sp.bearing_noise, sp.range_noise))) for k, (b, r) in zip(keys, br)]
+
+    def pprint(self):
+        self._sensor_params.pprint()
+        self._control_params.pprint()
+
+
+class SLAM2D(object):
+    """src/SS2D.cpp:189-208 over the engine's factor lists and k_slam."""
+
+    def __init__(self, map_params):
+        self._ses = _Session.current
+        if self._ses is None or self._ses.slam is not None:
+            raise RuntimeError("construct a Simulator2D first: SLAM2D joins the simulation it opened")
+        self._ses.slam = self
+        self._map_params = map_params
+        self._pending, self._pending_odometry = [], None
+        self.map = Environment(self._ses, False, map_params)
+
+    def add_prior(self, state):
+        """SLAM2D::addPrior(VehicleBeliefState) (SLAM2D.cpp:44-57); creates the engine (every parameter is known now)."""
+        if self._ses.engine is not None:
+            raise RuntimeError("add_prior: the prior is added once, at step 0")
+        self._ses.materialise(state)
+
+    def add_odometry(self, control_state):
+        """SLAM2D::addOdometry (SLAM2D.cpp:70-89): appended by the staged move that produced `control_state`."""
+        if control_state is not self._pending_odometry:
+            raise ValueError("add_odometry takes the ControlState of the Simulator2D.move that preceded it")
+        self._pending_odometry = None
+
+    def add_measurement(self, key, measurement, *unused):
+        self._pending.append((int(key), float(measurement.bearing), float(measurement.range)))
+
+    def optimize(self, update_covariance=True):
+        """SLAM2D::optimize (SLAM2D.cpp:374-430): pending measurements are appended, then one iSAM2-policy update with
+        all block marginals."""
+        import torch
+        e = self._ses.require_engine()
+        if self._pending_odometry is not None:
+            raise RuntimeError("optimize before add_odometry(control_state) of the last move")
+        lg = max(e.cfg.num_landmarks, 1)
+        if len(self._pending) > lg:
+            raise ValueError("more measurements than landmarks in one step")
+        keys = torch.zeros(1, lg, dtype=torch.int32)
+        br = torch.zeros(1, lg, 2, dtype=torch.float64)
+        for k, (key, b, r) in enumerate(self._pending):
+            keys[0, k], br[0, k, 0], br[0, k, 1] = key, b, r
+        cnt = torch.tensor([len(self._pending)], dtype=torch.int32)
+        if self._pending:
+            e.stage_add_measurements(keys.to(e.device), br.to(e.device), cnt.to(e.device))
+        self._pending = []
+        e.stage_optimize()
+        e.check_status()
+        if self._ses.vm is not None:
+            self._ses.vm._fresh = False
+
+    def key_size(self):
+        c = self._ses.require_engine().counts(0)
+        return c["poses"] + c["landmarks"]
+
+    def adjacency_degree_get(self):
+        self._A, self._X = self._ses.require_engine().adjacency(0)
+
+    def adjacency_out(self):
+        return self._A
+
+    def features_out(self):
+        return self._X.reshape(-1, 1)
+
+    def get_key_points(self, i):
+        e = self._ses.require_engine()
+        keys, lxy, _ = e.landmarks(0)
+        if i < len(keys):
+            return [lxy[i][0], lxy[i][1]]
+        xyt, _ = e.poses(0)
+        return [xyt[i - len(keys)][0], xyt[i - len(keys)][1]]
+
+    def print_graph(self):
+        p, k, b, r = self._ses.require_engine().factors(0)
+        for row in zip(p, k, b, r):
+            print("x%d - l%d: bearing %.6f range %.6f" % row)
+
+    def pprint(self):
+        self._map_params.pprint()
+
+
+class VirtualLandmark(object):
+    def __init__(self, point, probability, information, updated):
+        self.point, self.probability, self.information, self.updated = point, probability, information, updated
+
+    @property
+    def covariance(self):
+        return np.linalg.inv(self.information)
+
+
+class VirtualMap(object):
+    """src/SS2D.cpp:217-239 over the engine's virtual-map planes and k_map."""
+
+    def __init__(self, parameter, seed=0):
+        self._ses = _Session.current
+        if self._ses is None or self._ses.vm is not None:
+            raise RuntimeError("construct a Simulator2D first: VirtualMap joins the simulation it opened")
+        self._ses.vm = self
+        self._params, self._fresh = parameter, False
+
+    def _rebuild(self):
+        if not self._fresh:
+            self._ses.require_engine().stage_update_map(rebuild=True)
+            self._fresh = True
+
+    def update_probability(self, slam, sensor_model):
+        """VirtualMap::updateProbability(slam, sensor) (VirtualMap.cpp:61-84).  The device rebuilds occupancy and
+        information together (both are functions of the SLAM state only): the rebuild runs at the first of the two
+        update calls after an optimise, the second one finds its result in place."""
+        self._rebuild()
+
+    def update_information(self, map_, sensor_model):
+        """VirtualMap::updateInformation(map, sensor) (VirtualMap.cpp:256-271)."""
+        self._rebuild()
+
+    def get_parameter(self):
+        return self._params
+
+    @property
+    def rows(self):
+        return self._ses.require_engine().rows
+
+    @property
+    def cols(self):
+        return self._ses.require_engine().cols
+
+    def get_virtual_landmark_size(self):
+        return self.rows * self.cols
+
+    def explored(self):
+        return float(self._ses.require_engine().explored()[0])
+
+    def to_array(self):
+        return self._ses.require_engine().virtual_map(0)[0]
+
+    def to_cov_trace(self):
+        return self._ses.require_engine().virtual_map(0)[2]
+
+    def to_cov_array(self):
+        """VirtualMap::toCovArray (VirtualMap.cpp:140-151): (length, angle) grids."""
+        ln, an = self._ses.require_engine().cov_array()
+        return ln[0].cpu().numpy(), an[0].cpu().numpy()
+
+    def iter_virtual_landmarks(self):
+        e = self._ses.require_engine()
+        prob, info, _, upd = e.virtual_map(0)
+        c = e.cfg
+        for v in range(e.rows * e.cols):
+            r, col = divmod(v, e.cols)
+            pt = Point2((col + 0.5) * c.resolution + c.map_min_x, (r + 0.5) * c.resolution + c.map_min_y)
+            yield VirtualLandmark(pt, float(prob.reshape(-1)[v]), info[v], bool(upd[v]))
+
+
+BearingRangeSensorModelMeasurement = Measurement  # the pybind class name (src/SS2D.cpp:73)

@@ -101,6 +101,35 @@ int drlgx_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint3
  * (x, y, theta); active_dev: DEVICE uint8[n_envs] or NULL. */
 int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_dev);
 
+/* ---- staged form of the belief step -----------------------------------------------------------
+ * The reference's pybind classes are driven call by call (scripts/envs/pyss2d.py:102-138 SS2D.__init__, :171-206
+ * SS2D.simulate); the object-level shims (drl_graph_exploration_amd/ss2d.py) map every such call onto one of these.
+ * drlgx_step == stage_move; stage_measure (discarded); stage_measure + stage_add_measurements; stage_optimize;
+ * stage_update_map, fused.  All buffers are DEVICE memory; active_dev: uint8[n_envs] or NULL (= all). */
+/* SS2D.__init__ up to SLAM2D::addPrior (src/SS2D.cpp:173-176 Simulator2D(...), initialize_vehicle, random_landmarks;
+ * :191 SLAM2D::add_prior): like drlgx_reset_host but WITHOUT the first measure / optimise / map reductions. */
+int drlgx_stage_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint32_t *seeds, const double *start_xytheta);
+/* Simulator2D::move(odom, true) (src/SS2D.cpp:181) + SLAM2D::add_odometry (:193). odom_dev: double[n_envs*3]. */
+int drlgx_stage_move(drlgx_engine *e, const double *odom_dev, const uint8_t *active_dev);
+/* Simulator2D::measure() (src/SS2D.cpp:182): the noisy (bearing, range) of every ground-truth landmark that passes the
+ * sensor gates, in the reference's iteration order; advances the sensor RNG; adds nothing to the graph.
+ * keys_dev: int32[n_envs*num_landmarks], bearing_range_dev: double[n_envs*num_landmarks*2], count_dev: int32[n_envs]. */
+int drlgx_stage_measure(drlgx_engine *e, const uint8_t *active_dev, int32_t *keys_dev, double *bearing_range_dev, int32_t *count_dev);
+/* SLAM2D::add_measurement(key, m) (src/SS2D.cpp:194) for count[i] listed measurements of env i at its newest pose. */
+int drlgx_stage_add_measurements(drlgx_engine *e, const uint8_t *active_dev, const int32_t *keys_dev, const double *bearing_range_dev,
+                                 const int32_t *count_dev);
+/* SLAM2D::optimize(update_covariance = true) (src/SS2D.cpp:198). */
+int drlgx_stage_optimize(drlgx_engine *e, const uint8_t *active_dev);
+/* rebuild != 0: VirtualMap::update_probability(slam, sensor) + update_information(map, sensor) (src/SS2D.cpp:228-235);
+ * rebuild == 0: only the utility / explored sums of the stored planes (the state a freshly constructed VirtualMap is in). */
+int drlgx_stage_update_map(drlgx_engine *e, const uint8_t *active_dev, int rebuild);
+
+/* EMPlanner2D(parameter, ...) / EMPlanner2D::setParameter (src/Planner2D.cpp:73-77): the planner constants the kernels
+ * read (line-plan edge length, utility weights, occupancy threshold, distance angle weight, algorithm) can be replaced
+ * after drlgx_create - the reference constructs its planner after the simulator / SLAM objects. */
+int drlgx_set_planner_parameter(drlgx_engine *e, double angle_weight, double distance_weight0, double distance_weight1,
+                                double occupancy_threshold, double max_edge_length, int algorithm);
+
 /* EMPlanner2D::calculateUtility (static; src/em_exploration/Planner2D.cpp:354-366) for every
  * environment: U = sum_v tr(info_v^-1) + dist * (w0 - (w0 - w1) * known / V).
  * dist_dev: DEVICE double[n_envs] or NULL (= 0); out_dev: DEVICE double[n_envs]. */
