@@ -23,6 +23,13 @@ from .networks import GraphData, GraphSlice
 from .vecenv import VecExplorationEnv
 
 
+def _graph_to_host(d):
+    """A replay graph (GraphData or a GraphSlice view into a batched export) as compact host tensors: the on-disk form of
+    the reference's pickled PyG `Data` objects (scripts/train.py:33-35: the trainer, with its replay buffer, is pickled to
+    saved_training.pkl and re-loaded by every run_training.py epoch)."""
+    return GraphData(d.x.detach().cpu().clone(), d.edge_index.detach().cpu().clone(), d.edge_attr.detach().cpu().clone())
+
+
 def allreduce_gradients(model, group=None):
     """Average the gradients of `model` over all ranks with ONE flat all-reduce (3 MB..4 MB for the GCN: far below
     the xGMI per-link bandwidth-delay product, so a single bucket is optimal). No-op without a process group."""
@@ -82,6 +89,15 @@ class DeepQ(object):
         self.target_window = "reference"  # or "aligned": see td_targets
         # minibatch updates per vector step; None = one per environment step like the reference (n_envs per vector step)
         self.updates_per_vector_step = None
+
+    # ------------------------------------------------------------------ pickling (saved_training.pkl hand-off)
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["buffer"] = deque((_graph_to_host(t[0]), t[1], t[2], _graph_to_host(t[3]), t[4], t[5]) for t in self.buffer)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
 
     # ------------------------------------------------------------------ data
     @staticmethod
@@ -190,6 +206,9 @@ class DeepQ(object):
         device = env.device
         policy_net, target_net = model, modelTarget
         target_net.eval()
+        for t in self.buffer:  # a replay buffer re-loaded from saved_training.pkl holds host graphs: back to the device, once
+            t[0].to(device)
+            t[3].to(device)
         broadcast_parameters(policy_net)
         broadcast_parameters(target_net)
         optimizer = torch.optim.Adam(policy_net.parameters(), lr=1e-5)
@@ -313,6 +332,14 @@ class A2C(object):
 
     data_process = staticmethod(DeepQ.data_process)
     _host_offsets = staticmethod(DeepQ._host_offsets)
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["buffer"] = deque(([_graph_to_host(d) for d in b[0]],) + tuple(b[1:]) for b in self.buffer)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
 
     # ------------------------------------------------------------------ costs (policy.py:452-472)
     def policy_cost(self, prob, advantages, action, mask):

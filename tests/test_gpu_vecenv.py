@@ -299,3 +299,31 @@ def test_device_metrics_equal_the_host_getters():
     ln = ln.cpu().numpy()
     assert ln.shape == (n, 40, 40) and np.all(ln <= 1.0 + 1e-15) and (ln < 0.999).any() and np.isfinite(an.cpu().numpy()).all()
     env.close()
+
+
+def test_train_scripts_write_the_reference_artefacts(tmp_path):
+    """scripts/train.py + run_training.py over the HIP path: two short DQN epochs (one in-process, one as the reference's
+    per-epoch subprocess) leave saved_training.pkl (trainer + replay), Model_Policy.pt / Model_Target.pt, temp_*.csv and a
+    TensorBoard log with the reference's tags."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    from drl_graph_exploration_amd import tfevents, train
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = str(tmp_path / "data")
+    log = train.main(["DQN", "GCN", "--data-root", data, "--epochs", "1", "--epoch-steps", "16", "--observe", "8", "--batch", "8", "--n-envs", "4"])
+    obj = os.path.join(data, "training_object_data", "DQN_GCN")
+    for f in ("saved_training.pkl", "Model_Policy.pt", "Model_Target.pt", "temp_reward.csv", "temp_loss.csv"):
+        assert os.path.exists(os.path.join(obj, f)), f
+    with open(os.path.join(obj, "saved_training.pkl"), "rb") as f:
+        tr = pickle.load(f)
+    assert tr.step_t == 16 and len(tr.buffer) == 16 and tr.buffer[0][0].x.device.type == "cpu"
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    subprocess.check_call([sys.executable, "-m", "drl_graph_exploration_amd.run_training", "DQN", "GCN", "--data-root", data, "--n-envs", "4"],
+                          env=env, cwd=root, timeout=600)
+    with open(os.path.join(obj, "saved_training.pkl"), "rb") as f:
+        tr2 = pickle.load(f)
+    assert tr2.step_t == 32 and len(tr2.buffer) == 32
+    sc = tfevents.read_scalars(log)
+    assert sc and {t for _, _, t, _ in sc} <= {"Train/avg_reward", "Train/loss"} and any(t == "Train/loss" for _, _, t, _ in sc)
