@@ -229,15 +229,30 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
       lo_val.push_back(l);
       return (int)lo_val.size() - 1;
     };
+    // Only the transitions the update rules can take are followed (OccupancyMap.cpp:55-138): the landmark pre-updates
+    // apply `occupied` along the chain 0 -> occ(0) -> ...; a pose update leaves a cell at the minimum alone, adds
+    // `occupied` above the threshold and `free` otherwise.  (Following both successors of every state does not close:
+    // lo_occ and lo_free are not exact negatives of each other in floating point, so the values drift by ulps.)
     bool closed = true;
+    std::vector<int> is_chain{1};  // states reachable by landmark pre-updates alone
     for (size_t i = 0; i < lo_val.size(); ++i) {
       if (lo_val.size() > DRLGX_LO_TAB) {
         closed = false;
         break;
       }
       const double l = lo_val[i];
-      const int o = find_or_add(clampl(l + S.lo_occ)), f = find_or_add(clampl(l + S.lo_free));
-      const uint8_t flags = (uint8_t)((std::fabs(l - S.lo_min) < 1e-5 ? 1 : 0) | (l > S.occ_thresh + 1e-8 ? 2 : 0));
+      const bool frozen = std::fabs(l - S.lo_min) < 1e-5, above = l > S.occ_thresh + 1e-8;
+      int o = (int)i, f = (int)i;
+      if (above || is_chain[i]) {
+        o = find_or_add(clampl(l + S.lo_occ));
+        if ((size_t)o >= is_chain.size()) is_chain.push_back(0);
+        if (is_chain[i]) is_chain[o] = 1;
+      }
+      if (!above && !frozen) {
+        f = find_or_add(clampl(l + S.lo_free));
+        if ((size_t)f >= is_chain.size()) is_chain.push_back(0);
+      }
+      const uint8_t flags = (uint8_t)((frozen ? 1 : 0) | (above ? 2 : 0));
       lo_tr.push_back((uint8_t)o); lo_tr.push_back((uint8_t)f); lo_tr.push_back(flags); lo_tr.push_back(0);
     }
     if (closed && lo_val.size() <= DRLGX_LO_TAB) {

@@ -169,7 +169,7 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
   if (cnt[C_FLAG] && !sel.map_last_only) return;
   const drlgx_config &cfg = S.cfg;
   const int P = cnt[C_P], L = cnt[C_L];
-  const int V = S.V, cols = S.cols, rows = S.rows, W = S.win, W2 = W * W;
+  const int V = S.V, cols = S.cols, rows = S.rows, W = S.win;
   // LDS carve
   double *sp = smem;                       // [P_max][4]
   double *si = sp + (size_t)S.P_max * 4;   // [P_max][6]
@@ -264,6 +264,17 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
     //    read and written once per belief update.
     const double i0 = 1.0 / pow(cfg.sigma0, 2);
     const int extg = 20;
+    // the ladder's transition table packed into registers when it has <= 16 states (4 bits per next state, 2 per flag):
+    // a cell's walk over its sees-me bits is then pure ALU instead of one dependent LDS byte load per pose
+    const bool fsm_reg = S.lo_ntab > 0 && S.lo_ntab <= 16;
+    unsigned long long t_occ = 0ull, t_free = 0ull;
+    unsigned int t_flag = 0u;
+    if (fsm_reg)
+      for (int st2 = 0; st2 < S.lo_ntab; ++st2) {
+        t_occ |= (unsigned long long)(ltr[4 * st2] & 15) << (4 * st2);
+        t_free |= (unsigned long long)(ltr[4 * st2 + 1] & 15) << (4 * st2);
+        t_flag |= (unsigned int)(ltr[4 * st2 + 2] & 3) << (2 * st2);
+      }
     for (int c0 = 0; c0 < P; c0 += chunk) {
       const int nc = min(chunk, P - c0);
       const bool last = c0 + nc >= P;
@@ -275,14 +286,15 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
       __syncthreads();
       // (pose, window cell) pairs: a cheap pass keeps the ones in range and in the field of view (~45 % of the window)
       // in a compact list, so that the EKF push-through below runs on full waves
-      for (int e0 = 0; e0 < nc * W2; e0 += kThreads) {
+      // (candidate e = 64 pl + 8 wr + wc: an 8 x 8 slot grid per pose whatever the window width W <= 8 - no integer divisions)
+      for (int e0 = 0; e0 < nc * 64; e0 += kThreads) {
         const int e = e0 + tid;
         bool valid = false;
-        if (e < nc * W2) {
-          const int pl = e / W2, widx = e - pl * W2;
+        if (e < nc * 64) {
+          const int pl = e >> 6, widx = e & 63;
           const int p = c0 + pl;
-          if (!pskip[p]) {
-            const int wr = widx / W, wc = widx - wr * W;
+          const int wr = widx >> 3, wc = widx & 7;
+          if (!pskip[p] && wr < W && wc < W) {
             const int row = worg[2 * p] + wr, col = worg[2 * p + 1] + wc;
             if (row >= 0 && row < rows && col >= 0 && col < cols) {
               const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
@@ -303,9 +315,9 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
       const int npairs = *pcount;
       for (int k = tid; k < npairs; k += kThreads) {
         const int e = plist[k];
-        const int pl = e / W2, widx = e - pl * W2;
+        const int pl = e >> 6, widx = e & 63;
         const int p = c0 + pl;
-        const int wr = widx / W, wc = widx - wr * W;
+        const int wr = widx >> 3, wc = widx & 7;
         const int row = worg[2 * p] + wr, col = worg[2 * p + 1] + wc;
         const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
         const P2 pt{(col + 0.5) * cfg.resolution + cfg.map_min_x, (row + 0.5) * cfg.resolution + cfg.map_min_y};
@@ -333,7 +345,7 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
           const int pl = __ffsll((long long)m) - 1;
           m &= m - 1;
           const int p = c0 + pl;
-          const double *o = stage + ((size_t)pl * 64 + (row - worg[2 * p]) * W + (col - worg[2 * p + 1])) * 3;
+          const double *o = stage + ((size_t)pl * 64 + (row - worg[2 * p]) * 8 + (col - worg[2 * p + 1])) * 3;
           if (u) {
             ci_fuse(axx, axy, ayy, o[0], o[1], o[2]);
           } else {
@@ -358,7 +370,18 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
           st = (int)l;
         }
         m = omask[v];
-        if (fsm) {
+        if (fsm_reg) {
+          // a state that maps to itself is absorbing (the transition depends on the state only): the remaining bits
+          // cannot change it (cells at the clamped minimum / maximum, i.e. every cell seen more than a few times)
+          while (m) {
+            m &= m - 1;
+            const int f = (t_flag >> (2 * st)) & 3;
+            const int nst = (f & 1) ? st : (int)((((f & 2) ? t_occ : t_free) >> (4 * st)) & 15);
+            if (nst == st) break;
+            st = nst;
+          }
+          l = (double)st;
+        } else if (fsm) {
           while (m) {
             m &= m - 1;
             const int f = ltr[4 * st + 2];
