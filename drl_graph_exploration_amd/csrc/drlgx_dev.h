@@ -555,6 +555,13 @@ void drlgx_launch_fix_rollouts(const DrlgxState &S, hipStream_t st, int n_cand, 
 void drlgx_launch_rewards(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0,
                           double *rewards);
 void drlgx_launch_utility(const DrlgxState &S, hipStream_t st, const double *dist, double *out, int mode);
+// FastMarginals2 (k_fm2.hip): dense prior covariance per environment, then the per-candidate update
+void drlgx_launch_fm2_prior(const DrlgxState &S, hipStream_t st, const int32_t *env_ids, int n_env, double *sig, size_t sig_stride,
+                            int n_max);
+size_t drlgx_fm2_scratch_doubles(const DrlgxState &S, int nm_max);
+void drlgx_launch_fm2_update(const DrlgxState &S, hipStream_t st, int c0, int nc, const int32_t *cand_env, const int32_t *env_slot,
+                             const double *actions, const int32_t *n_actions, const double *sig, size_t sig_stride, double *scratch,
+                             size_t scratch_stride, int *iscratch, int nm_max, double *cov_out, int out_stride, int32_t *n_out);
 void drlgx_launch_metrics(const DrlgxState &S, hipStream_t st, double sigma0, double *out);
 void drlgx_launch_cov_array(const DrlgxState &S, hipStream_t st, double *length, double *angle);
 void drlgx_launch_line_plan(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, const double *goal,

@@ -59,6 +59,11 @@ struct drlgx_engine {
   double t_ms[DRLGX_N_TIMERS] = {0};
   int64_t t_n[DRLGX_N_TIMERS] = {0};
   std::string last_error;
+  // FastMarginals2 workspaces (allocated on first use): dense prior covariances, per-candidate scratch
+  double *fm2_sig = nullptr, *fm2_scratch = nullptr;
+  int *fm2_iscratch = nullptr;
+  int32_t *fm2_slot = nullptr;
+  size_t fm2_sig_stride = 0, fm2_scratch_stride = 0;
 };
 
 // every entry point makes the engine's device current (a process may drive several engines on several devices)
@@ -544,6 +549,38 @@ int drlgx_stage_update_map(drlgx_engine *e, const uint8_t *active_dev, int rebui
   DRLGX_ENTER(e);
   if (!e) return DRLGX_E_INVALID;
   drlgx_launch_map(e->S, e->stream, LaunchSel{0, e->S.n_envs, active_dev, nullptr, rebuild ? 0 : -2});
+  return check_launch(e);
+}
+
+// FastMarginals2::update for candidate action lists (k_fm2.hip)
+static const int kFm2Chunk = 128, kFm2MaxMeas = 256;
+int drlgx_fm2_update(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *actions_dev, const int32_t *n_actions_dev,
+                     double *cov_out_dev, int out_stride_poses, int32_t *n_out_dev) {
+  DRLGX_ENTER(e);
+  if (!e || n_cand < 0 || !cand_env_dev || !actions_dev || !n_actions_dev || !cov_out_dev || !n_out_dev ||
+      out_stride_poses < e->S.P_max + e->S.A_max)
+    return DRLGX_E_INVALID;
+  if (n_cand == 0) return DRLGX_OK;
+  const DrlgxState &S = e->S;
+  if (!e->fm2_sig) {
+    const size_t nmax = (size_t)3 * S.P_max + 2 * S.L_max;
+    e->fm2_sig_stride = nmax * nmax;
+    e->fm2_scratch_stride = drlgx_fm2_scratch_doubles(S, kFm2MaxMeas);
+    int r;
+    if ((r = dev_alloc(e, &e->fm2_sig, e->fm2_sig_stride * (size_t)S.n_envs))) return r;
+    if ((r = dev_alloc(e, &e->fm2_scratch, e->fm2_scratch_stride * (size_t)kFm2Chunk))) return r;
+    if ((r = dev_alloc(e, &e->fm2_iscratch, (size_t)2 * kFm2MaxMeas * kFm2Chunk))) return r;
+    if ((r = dev_alloc(e, &e->fm2_slot, (size_t)S.n_envs))) return r;
+    std::vector<int32_t> ident(S.n_envs);
+    for (int i = 0; i < S.n_envs; ++i) ident[i] = i;
+    HIPCHK(e, hipMemcpyAsync(e->fm2_slot, ident.data(), ident.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+  }
+  drlgx_launch_fm2_prior(S, e->stream, nullptr, S.n_envs, e->fm2_sig, e->fm2_sig_stride, 3 * S.P_max + 2 * S.L_max);
+  for (int c0 = 0; c0 < n_cand; c0 += kFm2Chunk)
+    drlgx_launch_fm2_update(S, e->stream, c0, std::min(kFm2Chunk, n_cand - c0), cand_env_dev, e->fm2_slot, actions_dev, n_actions_dev,
+                            e->fm2_sig, e->fm2_sig_stride, e->fm2_scratch, e->fm2_scratch_stride, e->fm2_iscratch, kFm2MaxMeas,
+                            cov_out_dev, out_stride_poses, n_out_dev);
   return check_launch(e);
 }
 

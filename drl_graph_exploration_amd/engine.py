@@ -130,6 +130,17 @@ class Engine(object):
                      ("occupancy_threshold", occupancy_threshold), ("max_edge_length", max_edge_length), ("algorithm", int(algorithm))):
             setattr(self.cfg, k, v)
 
+    def fm2_update(self, cand_env, actions, n_actions):
+        """FastMarginals2-style covariance look-ahead (drlgx_fm2_update): returns (cov [C, max_poses + max_actions, 3, 3]
+        float64, n_poses [C] int32); rows beyond n_poses[c] are undefined."""
+        self.use_torch_stream()
+        n = cand_env.numel()
+        stride = self.cfg.max_poses + self.cfg.max_actions
+        cov = torch.zeros(n, stride, 3, 3, dtype=torch.float64, device=self.device)
+        n_out = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self._chk(self.L.drlgx_fm2_update(self.h, n, _p(cand_env), _p(actions), _p(n_actions), _p(cov), stride, _p(n_out)))
+        return cov, n_out
+
     def utility(self, dist=None):
         self.use_torch_stream()
         out = torch.empty(self.n_envs, dtype=torch.float64, device=self.device)

@@ -124,6 +124,19 @@ int drlgx_stage_optimize(drlgx_engine *e, const uint8_t *active_dev);
  * rebuild == 0: only the utility / explored sums of the stored planes (the state a freshly constructed VirtualMap is in). */
 int drlgx_stage_update_map(drlgx_engine *e, const uint8_t *active_dev, int rebuild);
 
+/* FastMarginals2::update / propagate (src/em_exploration/FastMarginals.cpp:188-321) fed as the EM planner feeds it
+ * (src/em_exploration/Planner2D.cpp:652-737 updateNodeInformation_EM, :472-551 updateTrajectory_EM): for n_cand
+ * candidates (environment, action list) the 3x3 marginal covariance of EVERY pose after appending one predicted
+ * (noise-free) pose per action and the noise-free bearing-range factors from the new poses to the landmarks of the
+ * estimated map that pass the sensor gates - an EKF-style propagate / update, Sigma' = Sigma - Sigma A^T (I + A Sigma
+ * A^T)^-1 A Sigma, without re-solving and without touching the environments' state.
+ * cand_env_dev int32[n_cand]; actions_dev double[n_cand*max_actions*3]; n_actions_dev int32[n_cand];
+ * cov_out_dev double[n_cand*out_stride_poses*9] (row-major 3x3 per pose: the P old poses, then one per action),
+ * out_stride_poses >= max_poses + max_actions; n_out_dev int32[n_cand] = P + n_actions.  At most 256 predicted
+ * measurements per candidate (DRLGX_E_CAPACITY beyond). */
+int drlgx_fm2_update(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *actions_dev, const int32_t *n_actions_dev,
+                     double *cov_out_dev, int out_stride_poses, int32_t *n_out_dev);
+
 /* EMPlanner2D(parameter, ...) / EMPlanner2D::setParameter (src/Planner2D.cpp:73-77): the planner constants the kernels
  * read (line-plan edge length, utility weights, occupancy threshold, distance angle weight, algorithm) can be replaced
  * after drlgx_create - the reference constructs its planner after the simulator / SLAM objects. */

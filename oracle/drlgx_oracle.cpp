@@ -310,7 +310,8 @@ struct Isam {
   std::vector<MeasFactor> meas;
   double sig_b = 0, sig_r = 0;
   // outputs of the last solve
-  std::vector<double> cov;  // dense (2L+3P)^2, order [landmarks, poses]
+  std::vector<double> cov;   // dense (2L+3P)^2, order [landmarks, poses]; only the diagonal blocks are filled
+  std::vector<double> Linv;  // inverse of the Cholesky factor of the last solve: Sigma = Linv^T Linv
   int n = 0;
 
   int P() const { return (int)th_pose.size(); }
@@ -510,7 +511,8 @@ struct Isam {
     for (int i = 0; i < Pn; ++i)
       for (int r = 0; r < 3; ++r) d_pose[3 * i + r] = x[pidx(i) + r];
     // cov = A^-1 via Linv: Linv lower, cov = Linv^T Linv
-    std::vector<double> Li((size_t)n * n, 0.0);
+    std::vector<double> &Li = Linv;
+    Li.assign((size_t)n * n, 0.0);
     for (int c = 0; c < n; ++c) {
       Li[(size_t)c * n + c] = 1.0 / Lm[(size_t)c * n + c];
       for (int i = c + 1; i < n; ++i) {
@@ -1163,6 +1165,24 @@ void orc_get_factors(void *h, int *pose, int *key, double *bearing, double *rang
   }
 }
 // full state of the linearisation point (theta, delta) for parity checks of the SLAM kernel
+// the full covariance of the last solve (n x n, n = 2 L + 3 P, order [landmarks by slot, poses]): the joint marginals that
+// FastMarginals::recover provides to FastMarginals2 (FastMarginals.cpp:130-186)
+int orc_get_full_cov(void *h, double *out) {
+  const Isam &I = ((Env *)h)->slam.isam;
+  const int n = I.n;
+  if (out)
+    for (int a = 0; a < n; ++a)
+      for (int c = a; c < n; ++c) {
+        double s = 0;
+        for (int k = c; k < n; ++k) s += I.Linv[(size_t)k * n + a] * I.Linv[(size_t)k * n + c];
+        out[(size_t)a * n + c] = out[(size_t)c * n + a] = s;
+      }
+  return n;
+}
+void orc_get_slot_keys(void *h, int *out) {
+  const Slam &S = ((Env *)h)->slam;
+  for (size_t j = 0; j < S.slot_key.size(); ++j) out[j] = (int)S.slot_key[j];
+}
 void orc_dev_set_relin(double thr, int skip, int mode) {
   g_relin_thr = thr;
   g_relin_skip = skip;

@@ -73,6 +73,8 @@ def lib():
         L.orc_get_gt.argtypes = [C.c_void_p, dp, dp, ip]
         L.orc_get_adjacency.argtypes = [C.c_void_p, dp, dp]
         L.orc_get_factors.argtypes = [C.c_void_p, ip, ip, dp, dp]
+        L.orc_get_full_cov.argtypes = [C.c_void_p, dp]
+        L.orc_get_slot_keys.argtypes = [C.c_void_p, ip]
         L.orc_get_isam.argtypes = [C.c_void_p, dp, dp, dp, dp, ip]
         L.orc_kat_rng.argtypes = [C.c_uint32, C.c_int, C.c_int, dp]
         L.orc_kat_ci.argtypes = [dp, dp, dp]
@@ -257,6 +259,19 @@ class OracleSim(object):
         r = np.zeros(m)
         self.L.orc_get_factors(self.h, _ip(pose), _ip(key), _dp(b), _dp(r))
         return pose, key, b, r
+
+    def full_covariance(self):
+        """(n x n covariance of the last solve, L, P): order [landmarks by slot (2 each), poses (3 each)]."""
+        n = self.L.orc_get_full_cov(self.h, None)
+        out = np.zeros((n, n))
+        self.L.orc_get_full_cov(self.h, _dp(out))
+        return out, self.num_landmarks(), self.num_poses()
+
+    def slot_keys(self):
+        """Ground-truth key of every landmark slot (order of first sighting = the order of the iSAM state arrays)."""
+        out = np.zeros(max(self.num_landmarks(), 1), dtype=np.int32)
+        self.L.orc_get_slot_keys(self.h, _ip(out))
+        return out[:self.num_landmarks()]
 
     def isam_state(self):
         P, Ln = self.num_poses(), self.num_landmarks()

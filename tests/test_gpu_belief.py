@@ -544,3 +544,48 @@ def test_narrow_field_of_view_uses_exact_paths(fov_deg, max_range, num_lm):
                 compare_state(eng, i, sims[i], "fov %g step %d env %d" % (fov_deg, s, i))
     assert eng.status() == 0
     eng.close()
+
+
+def test_fm2_covariance_update_matches_the_restatement():
+    """drlgx_fm2_update (FastMarginals2::update / propagate fed as updateNodeInformation_EM / updateTrajectory_EM feed it)
+    against oracle/fm2_ref.py on the same beliefs and action lists: every pose's updated 3x3 covariance, rel 1e-6
+    (the prior joint covariance is a dense inverse on both sides)."""
+    from oracle import fm2_ref
+    n = 4
+    eng, cfg = make_engine(n, num_landmarks=60, max_poses=64)
+    ocfg = O.default_config(MAP, num_landmarks=60)
+    starts = generic_starts(n)
+    sims = [O.OracleSim(ocfg, lo, lo, start=tuple(starts[lo])) for lo in range(n)]
+    eng.reset(np.arange(n), np.arange(n), starts=starts)
+    for act in SCRIPT[:11]:
+        eng.step(torch.tensor([act] * n, dtype=torch.float64, device=eng.device))
+        for s in sims:
+            s.simulate(act)
+    assert eng.status() == 0
+    plans = [[(0.0, 0.0, -0.7), (2.0, 0.0, 0.0), (2.0, 0.0, 0.0), (0.8, 0.0, 0.0)], [(0.0, 0.0, 2.4), (2.0, 0.0, 0.0)],
+             [(0.0, 0.0, 0.3), (2.0, 0.0, 0.0), (2.0, 0.0, 0.0), (2.0, 0.0, 0.0), (2.0, 0.0, 0.0), (1.1, 0.0, 0.0)]]
+    cand_env, acts, nact = [], [], []
+    for e in range(n):
+        for p in plans:
+            cand_env.append(e)
+            a = np.zeros((cfg.max_actions, 3))
+            a[:len(p)] = p
+            acts.append(a)
+            nact.append(len(p))
+    ce = torch.tensor(cand_env, dtype=torch.int32, device=eng.device)
+    cov, n_out = eng.fm2_update(ce, torch.tensor(np.array(acts), device=eng.device), torch.tensor(nact, dtype=torch.int32, device=eng.device))
+    assert eng.status() == 0
+    cov, n_out = cov.cpu().numpy(), n_out.cpu().numpy()
+    seen_meas = 0
+    for c, (e, k) in enumerate(zip(cand_env, nact)):
+        want, n_meas = fm2_ref.fm2_update(sims[e], plans[c % len(plans)])
+        seen_meas += sum(n_meas)
+        assert n_out[c] == want.shape[0] == sims[e].num_poses() + k
+        np.testing.assert_allclose(cov[c, :n_out[c]], want, rtol=1e-6, atol=1e-10, err_msg="candidate %d" % c)
+        # the update only ever removes uncertainty from the old poses, and the belief itself is untouched
+        prior = np.linalg.inv(sims[e].poses()[1])
+        assert all(np.trace(cov[c, i]) <= np.trace(prior[i]) * (1 + 1e-9) for i in range(sims[e].num_poses()))
+    assert seen_meas > 20
+    for i in range(n):
+        compare_state(eng, i, sims[i], "after fm2 env %d" % i)
+    eng.close()

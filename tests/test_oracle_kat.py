@@ -137,3 +137,61 @@ def test_reward_is_utility_difference_and_invariants():
     u0 = env._sim.calculate_utility(0.0)
     env._sim.simulations_reward(acts[ks])
     assert env._sim.calculate_utility(0.0) == u0
+
+
+def test_fm2_restatement_equals_information_form():
+    """oracle/fm2_ref.py (FastMarginals2::update restated: Sigma' = Sigma - Sigma A^T (I + A Sigma A^T)^-1 A Sigma on
+    the updated keys' diagonal blocks, cross covariances of new poses by the F chains) against the same update done in
+    information form - append the new variables and add J^T J of the same linearised factors, then invert: the two are
+    algebraically identical (the reference's own USE_FAST_MARGINAL2 / isam2.update alternatives, Planner2D.cpp:502-511)."""
+    import math
+    from oracle import fm2_ref as F
+    sim = O.OracleSim(O.default_config(40, num_landmarks=60), 5, 5, start=(-3.2, 4.1, 0.4))
+    for a in [(1, 1, math.pi / 2)] * 4 + [(2, 0, 0), (2, 0, 0), (0, 0, 0.9), (2, 0, 0), (1.2, 0, 0)]:
+        sim.simulate(a)
+    actions = [(0.0, 0.0, -0.7), (2.0, 0.0, 0.0), (2.0, 0.0, 0.0), (0.8, 0.0, 0.0)]
+    got, n_meas = F.fm2_update(sim, actions)
+    assert sum(n_meas) >= 2  # predicted measurements exist, so the update is not the pure propagation
+    Sig, L, P = sim.full_covariance()
+    thp, _, thl, _, _ = sim.isam_state()
+    cfg = sim.cfg
+    K = len(actions)
+    n0, n = 2 * L + 3 * P, 2 * L + 3 * (P + K)
+    Lam = np.zeros((n, n))
+    Lam[:n0, :n0] = np.linalg.inv(Sig)
+    sig = np.array([cfg.translation_noise, cfg.translation_noise, cfg.rotation_noise])
+    sig_br = np.array([cfg.bearing_noise, cfg.range_noise])
+    pidx = lambda i: slice(2 * L + 3 * i, 2 * L + 3 * i + 3)  # noqa: E731
+    origin, val0 = F._pose(*sim.poses()[0][-1]), F._pose(*thp[-1])
+    keys, est_sorted, _ = sim.landmarks()
+    slot_of = {int(k): j for j, k in enumerate(sim.slot_keys())}
+    for k, a in enumerate(actions):
+        odom = F._pose(*a)
+        end = F._compose(origin, odom)
+        hx, H1b = F._between(val0, end)
+        h, _ = F._between(odom, hx)
+        Hl = np.array([[h[2], h[3], 0], [-h[3], h[2], 0], [0, 0, 1.0]])
+        J = np.zeros((3, n))
+        J[:, pidx(P + k - 1)] = (Hl @ H1b) / sig[:, None]
+        J[:, pidx(P + k)] = Hl / sig[:, None]
+        Lam += J.T @ J
+        for key, xy in zip(keys, est_sorted):
+            j = slot_of[int(key)]
+            dx, dy = xy[0] - end[0], xy[1] - end[1]
+            rng = math.hypot(dx, dy)
+            b = math.atan2(-end[3] * dx + end[2] * dy, end[2] * dx + end[3] * dy)
+            if rng < cfg.max_range and cfg.min_bearing < b < cfg.max_bearing and cfg.min_range < rng:
+                Jx, Jl = F._br_jacobians(end, thl[j])
+                J = np.zeros((2, n))
+                J[:, pidx(P + k)] = Jx / sig_br[:, None]
+                J[:, 2 * j:2 * j + 2] = Jl / sig_br[:, None]
+                Lam += J.T @ J
+        origin, val0 = end, end
+    full = np.linalg.inv(Lam)
+    for i in range(P + K):
+        np.testing.assert_allclose(got[i], full[pidx(i), pidx(i)], rtol=1e-7, atol=1e-12)
+    # with no landmark in view the update degenerates to the propagation cov1 = H1 (H0 cov0 H0^T + I) H1^T
+    far = O.OracleSim(O.default_config(40, num_landmarks=0), 1, 1, start=(0.0, 0.0, 0.0))
+    far.simulate((2, 0, 0))
+    g2, nm = F.fm2_update(far, [(2.0, 0.0, 0.0)])
+    assert nm == [0] and np.trace(g2[-1]) > np.trace(g2[-2])
