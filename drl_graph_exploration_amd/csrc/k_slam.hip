@@ -687,11 +687,16 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   if (!sel.on(bi)) return;
   const int inst = sel.base + bi;
   int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
-  if (cnt[C_FLAG]) return;
+  // `full`: the block marginals are wanted.  Look-ahead rollouts only need them at their last action (the virtual map is
+  // rebuilt there and nowhere else): the steps before it solve for the estimates only.  If that last action was rejected
+  // (nothing was appended) the marginals of the unchanged system are recomputed without counting as an update.
+  const bool full = sel.map_on(bi);
+  const bool refresh = cnt[C_FLAG] != 0;
+  if (refresh && !(sel.map_last_only && sel.n_act && full)) return;
   const drlgx_config &cfg = S.cfg;
   const int P = cnt[C_P], L = cnt[C_L], M = cnt[C_M];
   const int n_old_p = cnt[C_NEWP], n_old_l = cnt[C_NEWL];
-  const int count = cnt[C_ISAM] + 1;
+  const int count = cnt[C_ISAM] + (refresh ? 0 : 1);
   const int np = 3 * P, na = np + 1;
   // padded to 16x16 MFMA tiles; row np holds the rhs (its column and all pad rows / columns stay zero).  Only the lower
   // triangle is ever addressed and it is stored packed (row i at i (i + 1) / 2: half the LDS of the square, which keeps
@@ -743,7 +748,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
 
   // ---- 1. relinearisation policy (gtsam ISAM2: relinearizeSkip 10, relinearizeThreshold 0.1);
   //         theta (+ folded delta) is staged in LDS ----
-  const bool relin = (count % 10 == 0);
+  const bool relin = !refresh && (count % 10 == 0);
   for (int i = tid; i < P; i += kThreads) {
     Pose t{th_pose[4 * i], th_pose[4 * i + 1], th_pose[4 * i + 2], th_pose[4 * i + 3]};
     if (relin && i < n_old_p) {
@@ -901,7 +906,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   DRLGX_PROF(S, 5);
   for (int k = tid; k < np; k += kThreads) d_pose[k] = A[AT(np, k)];
   // ---- 6. landmark marginals: rec[6..9] <- G_m^T ( sum_{m' of the same landmark} Sigma[p_m][p_m'] G_m' ) ----
-  for (int m = tid; m < M; m += kThreads) {
+  for (int m = tid; full && m < M; m += kThreads) {
     const int j = ml[m], p = mp[m];
     double Wm[6] = {0, 0, 0, 0, 0, 0};
     FOR_EACH_OBSERVING_POSE(lmask + MW * j, MW, q) {
@@ -947,6 +952,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
     d_lm[2 * j + 1] = dy;
     est_lm[2 * j] = thl[2 * j] + dx;
     est_lm[2 * j + 1] = thl[2 * j + 1] + dy;
+    if (!full) continue;
     const double cs = 0.5 * (c01 + c10);
     lm_tr[j] = c00 + c11;
     const double id = 1.0 / (c00 * c11 - cs * cs);  // marginalCovariance(l).inverse() (SLAM2D.cpp:417)
@@ -963,6 +969,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
     const Pose t{thp[4 * i], thp[4 * i + 1], thp[4 * i + 2], thp[4 * i + 3]};
     const Pose e = compose(t, make_pose(A[AT(np, k0)], A[AT(np, k0 + 1)], A[AT(np, k0 + 2)]));
     est_pose[4 * i] = e.x; est_pose[4 * i + 1] = e.y; est_pose[4 * i + 2] = e.c; est_pose[4 * i + 3] = e.s;
+    if (!full) continue;
     const double c00 = -A[AT(k0, k0)], c10 = -A[AT((k0 + 1), k0)], c11 = -A[AT((k0 + 1), k0 + 1)];
     const double c20 = -A[AT((k0 + 2), k0)], c21 = -A[AT((k0 + 2), k0 + 1)], c22 = -A[AT((k0 + 2), k0 + 2)];
     pose_tr[i] = c00 + c11 + c22;
@@ -978,9 +985,11 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   }
   DRLGX_PROF(S, 7);
   if (tid == 0) {
-    cnt[C_ISAM] = count;
-    cnt[C_NEWP] = P;
-    cnt[C_NEWL] = L;
+    if (!refresh) {
+      cnt[C_ISAM] = count;
+      cnt[C_NEWP] = P;
+      cnt[C_NEWL] = L;
+    }
     if (bad[0]) atomicMin(S.status, DRLGX_E_NUMERIC);
   }
 }

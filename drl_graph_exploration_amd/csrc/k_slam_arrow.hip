@@ -89,11 +89,14 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   if (!sel.on(bi)) return;
   const int inst = sel.base + bi;
   int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
-  if (cnt[C_FLAG]) return;
+  // (`full` / `refresh`: see slam_body - intermediate look-ahead steps solve for the estimates only)
+  const bool full = sel.map_on(bi);
+  const bool refresh = cnt[C_FLAG] != 0;
+  if (refresh && !(sel.map_last_only && sel.n_act && full)) return;
   const drlgx_config &cfg = S.cfg;
   const int P = cnt[C_P], L = cnt[C_L], M = cnt[C_M];
   const int n_old_p = cnt[C_NEWP], n_old_l = cnt[C_NEWL];
-  const int count = cnt[C_ISAM] + 1;
+  const int count = cnt[C_ISAM] + (refresh ? 0 : 1);
   const int np = 2 * L, ncol = np + 1;              // landmark system: pivots [0, 2L), rhs row 2L
   const int Tn = (ncol + 15) / 16, N = 16 * Tn;
   const int ntiles = Tn * (Tn + 1) / 2;
@@ -170,7 +173,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   const double *meas_br = S.meas_br + (size_t)inst * S.M_max * 2;
 
   // ---- 1. relinearisation policy (gtsam ISAM2: relinearizeSkip 10, relinearizeThreshold 0.1); theta staged in LDS ----
-  const bool relin = (count % 10 == 0);
+  const bool relin = !refresh && (count % 10 == 0);
   for (int i = tid; i < P; i += kThreads) {
     Pose t{th_pose[4 * i], th_pose[4 * i + 1], th_pose[4 * i + 2], th_pose[4 * i + 3]};
     if (relin && i < n_old_p) {
@@ -516,7 +519,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     while (2 * s_top < P) s_top <<= 1;
     for (int s = (P > kSeg) ? s_top : 0; s >= kSeg; s >>= 1) {
       const int nel = (P - 1 - s) / (2 * s) + 1;  // eliminated poses of this level: s, 3s, ... < P
-      for (int k = tid; k < nel; k += kThreads) {
+      for (int k = tid; full && k < nel; k += kThreads) {
         const int i = (2 * k + 1) * s, l = i - s, r = i + s;
         const bool hr = r < P;
         double sll[9], srr[9], slr[9], sli[9], sri[9];
@@ -563,7 +566,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   DRLGX_PROF(S, 5);
   // ---- ... leaves: selected inverse (one thread per segment, last interior pose first) and solutions (one thread per
   //         (segment, column): x_i = E_i y_i - GL_i x_l - GR_i x_{i+1}); the separators' solutions go to X too ----
-  for (int g = tid; g < nsep; g += kThreads) {
+  for (int g = tid; full && g < nsep; g += kThreads) {
     const int l = g << kSegLog, nk = min(kSeg - 1, P - 1 - l), r = l + kSeg;
     if (nk > 0) {
       double sll[9], snn[9], sln[9], sli[9], sni[9], sii[6];
@@ -716,6 +719,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     d_lm[2 * j + 1] = dy;
     est_lm[2 * j] = thl[2 * j] + dx;
     est_lm[2 * j + 1] = thl[2 * j + 1] + dy;
+    if (!full) continue;
     const double c00 = -A[AT(2 * j, 2 * j)], cs = -A[AT(2 * j + 1, 2 * j)], c11 = -A[AT(2 * j + 1, 2 * j + 1)];
     lm_tr[j] = c00 + c11;
     const double id = 1.0 / (c00 * c11 - cs * cs);  // marginalCovariance(l).inverse() (SLAM2D.cpp:417)
@@ -733,7 +737,20 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   double *pose_tr = S.pose_tr + (size_t)inst * S.P_max;
   double *Sc = Sl;  // [3P][3]: rows of X_i (-C^-1) X_i^T   (the Takahashi cross blocks are dead by now)
   double *dz = Sr;  // [3P]:    X_B delta_l
-  {
+  if (!full) {
+    // estimates only: dz = X_B delta_l, one 16-lane row per row of X
+    const int sub = tid & 15, grp = tid >> 4, ngrp = kThreads / 16;
+    for (int row = grp; row < 3 * P; row += ngrp) {
+      const double *xr = X + (size_t)row * ldx;
+      double v = 0;
+      for (int c = sub; c < np; c += 16) v += xr[c] * A[AT(np, c)];
+      v += __shfl_xor(v, 8, 16);
+      v += __shfl_xor(v, 4, 16);
+      v += __shfl_xor(v, 2, 16);
+      v += __shfl_xor(v, 1, 16);
+      if (sub == 0) dz[row] = v;
+    }
+  } else {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lc = lane & 15, lr = lane >> 4;
     const int nrows = 3 * P, nrt = (nrows + 15) / 16, nK = (np + 15) / 16;
     for (int I = wave; I < nrt; I += kWaves) {
@@ -840,6 +857,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     const Pose t{thp[4 * i], thp[4 * i + 1], thp[4 * i + 2], thp[4 * i + 3]};
     const Pose e = compose(t, make_pose(dp0, dp1, dp2));
     est_pose[4 * i] = e.x; est_pose[4 * i + 1] = e.y; est_pose[4 * i + 2] = e.c; est_pose[4 * i + 3] = e.s;
+    if (!full) continue;
     const double *ti = Ti + 6 * i, *sc = Sc + 9 * i;  // sc[3 a + b] = (X_i (-C^-1) X_i^T)[a][b]: symmetric up to round-off
     const double c00 = ti[0] - sc[0], c10 = ti[1] - 0.5 * (sc[1] + sc[3]), c20 = ti[2] - 0.5 * (sc[2] + sc[6]);
     const double c11 = ti[3] - sc[4], c21 = ti[4] - 0.5 * (sc[5] + sc[7]), c22 = ti[5] - sc[8];
@@ -856,9 +874,11 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   }
   DRLGX_PROF(S, 9);
   if (tid == 0) {
-    cnt[C_ISAM] = count;
-    cnt[C_NEWP] = P;
-    cnt[C_NEWL] = L;
+    if (!refresh) {
+      cnt[C_ISAM] = count;
+      cnt[C_NEWP] = P;
+      cnt[C_NEWL] = L;
+    }
     if (bad[0]) atomicMin(S.status, DRLGX_E_NUMERIC);
   }
 }
