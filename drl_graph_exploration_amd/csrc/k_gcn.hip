@@ -29,11 +29,19 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------------
 // in/out degree counts for the two CSRs (the weighted degree is summed later in edge order: float atomics here would
 // make deg - and through the ReLU gates the whole forward/backward - depend on the arrival order)
-__global__ void k_degree(int E, const int64_t *ei, int *cnt_dst, int *cnt_src) {
+// An explicit self loop keeps its weight as the node's self term (PyG add_remaining_self_loops: only the REMAINING self
+// loops get the fill value 2): selfw[n] is preset to 2 and overwritten here.  Edges with an endpoint outside [0, N) are
+// ignored (the C ABI has no status word for the GCN calls).
+__global__ void k_degree(int N, int E, const int64_t *ei, const float *ew, int *cnt_dst, int *cnt_src, float *selfw) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  const int r = (int)ei[e], c = (int)ei[(size_t)E + e];
-  if (r == c) return;  // explicit self loops are folded into the self term (none in this application)
+  const int64_t r64 = ei[e], c64 = ei[(size_t)E + e];
+  if (r64 < 0 || r64 >= N || c64 < 0 || c64 >= N) return;
+  const int r = (int)r64, c = (int)c64;
+  if (r == c) {
+    selfw[r] = ew[e];
+    return;
+  }
   atomicAdd(&cnt_dst[c], 1);
   atomicAdd(&cnt_src[r], 1);
 }
@@ -91,12 +99,13 @@ __global__ __launch_bounds__(1024) void k_scan2(int n, const int *a, int *pa, co
     sb += b[i];
   }
 }
-__global__ void k_csr_fill(int E, const int64_t *ei, const int *ptr_dst, int *cur_dst, int *eid_dst, const int *ptr_src,
+__global__ void k_csr_fill(int N, int E, const int64_t *ei, const int *ptr_dst, int *cur_dst, int *eid_dst, const int *ptr_src,
                            int *cur_src, int *eid_src) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  const int r = (int)ei[e], c = (int)ei[(size_t)E + e];
-  if (r == c) return;
+  const int64_t r64 = ei[e], c64 = ei[(size_t)E + e];
+  if (r64 < 0 || r64 >= N || c64 < 0 || c64 >= N || r64 == c64) return;
+  const int r = (int)r64, c = (int)c64;
   eid_dst[ptr_dst[c] + atomicAdd(&cur_dst[c], 1)] = e;
   eid_src[ptr_src[r] + atomicAdd(&cur_src[r], 1)] = e;
 }
@@ -117,14 +126,14 @@ __global__ void k_csr_sort(int N, const int *ptr0, int *eid0, const int *ptr1, i
     eid[j + 1] = v;
   }
 }
-// deg[row] = sum of the row's edge weights in edge order, then the self loop weight 2 appended by
-// add_remaining_self_loops(fill_value = 2)  (PyG: scatter_add(edge_weight, row) with row = source)
-__global__ void k_degree_sum(int N, const float *ew, const int *ptr_src, const int *eid_src, float *deg) {
+// deg[row] = sum of the row's edge weights in edge order, then the self loop weight (2 from
+// add_remaining_self_loops(fill_value = 2), or the explicit self loop's own)  (PyG: scatter_add(edge_weight, row), row = source)
+__global__ void k_degree_sum(int N, const float *ew, const int *ptr_src, const int *eid_src, const float *selfw, float *deg) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float s = 0.f;
   for (int i = ptr_src[n]; i < ptr_src[n + 1]; ++i) s += ew[eid_src[i]];
-  deg[n] = s + 2.0f;
+  deg[n] = s + selfw[n];
 }
 // resolve (neighbour, normalised weight) per CSR slot, for the by-destination CSR (threads < N) and the by-source one.
 // dis = deg^-1/2 (inf -> 0).
@@ -150,7 +159,7 @@ __global__ void k_csr_finish(int N, int E, const int64_t *ei, const float *ew, c
 // ------------------------------------------------------------------------------------------------
 // layer 1: AX = Â X (5 features, padded to 8) and H1 = relu(AX W1 + b1); one workgroup per node
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_layer1(int N, int in_dim, int hidden, const float *x, const float *deg, const int *ptr,
+__global__ __launch_bounds__(256) void k_layer1(int N, int in_dim, int hidden, const float *x, const float *deg, const float *selfw, const int *ptr,
                                                 const int *nbr, const float *wn, const float *W1, const float *b1, float *AX,
                                                 float *H1) {
   const int n = blockIdx.x, t = threadIdx.x;
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(256) void k_layer1(int N, int in_dim, int hidden, c
   if (t < 8) {
     float s = 0.f;
     if (t < in_dim) {
-      s = (2.0f / deg[n]) * x[(size_t)n * in_dim + t];  // self loop: dis * 2 * dis
+      s = (selfw[n] / deg[n]) * x[(size_t)n * in_dim + t];  // self loop: dis * w_self * dis
       for (int i = ptr[n]; i < ptr[n + 1]; ++i) s += wn[i] * x[(size_t)nbr[i] * in_dim + t];
     }
     ax[t] = s;
@@ -173,14 +182,14 @@ __global__ __launch_bounds__(256) void k_layer1(int N, int in_dim, int hidden, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// aggregation out[n] = (2/deg[n]) H[n] + sum_i wn[i] H[nbr[i]]  (+ optional ReLU-gate by `gate` > 0)
+// aggregation out[n] = (selfw[n]/deg[n]) H[n] + sum_i wn[i] H[nbr[i]]  (+ optional ReLU-gate by `gate` > 0)
 // one workgroup per node, float4 per lane
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_aggregate(int N, int hidden, const float *H, const float *deg, const int *ptr, const int *nbr,
+__global__ __launch_bounds__(256) void k_aggregate(int N, int hidden, const float *H, const float *deg, const float *selfw, const int *ptr, const int *nbr,
                                                    const float *wn, const float *gate, float *out) {
   const int n = blockIdx.x;
   const int h4 = hidden >> 2;
-  const float self = 2.0f / deg[n];
+  const float self = selfw[n] / deg[n];
   const int a = ptr[n], b = ptr[n + 1];
   for (int c = threadIdx.x; c < h4; c += 256) {
     float4 v = reinterpret_cast<const float4 *>(H + (size_t)n * hidden)[c];
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(256) void k_colsum_part(int N, int C, const float *
 }
 
 struct GcnWs {
-  float *deg, *wn_dst, *wn_src, *AX, *H1, *AH1, *H2, *T0, *T1, *part;
+  float *deg, *selfw, *wn_dst, *wn_src, *AX, *H1, *AH1, *H2, *T0, *T1, *part;
   int *cnt_dst, *cnt_src, *ptr_dst, *ptr_src, *cur_dst, *cur_src, *eid_dst, *eid_src, *nbr_dst, *nbr_src;
   size_t part_floats, counters_bytes;
 };
@@ -560,6 +569,7 @@ size_t carve(GcnWs *w, char *base, int N, int E, int hidden, int out_dim) {
   const size_t NH = (size_t)N * hidden;
   const size_t part = std::max<size_t>((size_t)8 * hidden * hidden, (size_t)64 * hidden);
   takef(w ? &w->deg : &df, N);
+  takef(w ? &w->selfw : &df, N);
   takef(w ? &w->wn_dst : &df, E);
   takef(w ? &w->wn_src : &df, E);
   takef(w ? &w->AX : &df, (size_t)N * 8);
@@ -660,15 +670,16 @@ void colsum(hipStream_t st, const GcnWs &w, int N, int C, const float *X, float 
 
 void build_graph(hipStream_t st, const GcnWs &w, int N, int E, const int64_t *ei, const float *ew) {
   hipMemsetAsync(w.cnt_dst, 0, w.counters_bytes, st);  // cnt_dst, cnt_src, cur_dst, cur_src
-  if (E > 0) hipLaunchKernelGGL(k_degree, dim3((E + 255) / 256), dim3(256), 0, st, E, ei, w.cnt_dst, w.cnt_src);
+  hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.selfw), 0x40000000, (size_t)N, st);  // 2.0f: the improved-GCN fill value
+  if (E > 0) hipLaunchKernelGGL(k_degree, dim3((E + 255) / 256), dim3(256), 0, st, N, E, ei, ew, w.cnt_dst, w.cnt_src, w.selfw);
   hipLaunchKernelGGL(k_scan2, dim3(1), dim3(1024), 0, st, N, w.cnt_dst, w.ptr_dst, w.cnt_src, w.ptr_src);
   if (E > 0) {
-    hipLaunchKernelGGL(k_csr_fill, dim3((E + 255) / 256), dim3(256), 0, st, E, ei, w.ptr_dst, w.cur_dst, w.eid_dst, w.ptr_src,
+    hipLaunchKernelGGL(k_csr_fill, dim3((E + 255) / 256), dim3(256), 0, st, N, E, ei, w.ptr_dst, w.cur_dst, w.eid_dst, w.ptr_src,
                        w.cur_src, w.eid_src);
   }
   const dim3 gn((N + 127) / 128), g2((2 * N + 127) / 128), bn(128);
   hipLaunchKernelGGL(k_csr_sort, g2, bn, 0, st, N, w.ptr_dst, w.eid_dst, w.ptr_src, w.eid_src);
-  hipLaunchKernelGGL(k_degree_sum, gn, bn, 0, st, N, ew, w.ptr_src, w.eid_src, w.deg);
+  hipLaunchKernelGGL(k_degree_sum, gn, bn, 0, st, N, ew, w.ptr_src, w.eid_src, w.selfw, w.deg);
   hipLaunchKernelGGL(k_csr_finish, g2, bn, 0, st, N, E, ei, ew, w.deg, w.ptr_dst, w.eid_dst, w.nbr_dst, w.wn_dst, w.ptr_src,
                      w.eid_src, w.nbr_src, w.wn_src);
 }
@@ -692,9 +703,9 @@ int drlgx_gcn_forward(void *hip_stream, int n_nodes, int n_edges, int in_dim, in
   GcnWs w;
   carve(&w, reinterpret_cast<char *>(ws_dev), n_nodes, std::max(n_edges, 1), hidden, out_dim);
   build_graph(st, w, n_nodes, n_edges, edge_index, edge_attr);
-  hipLaunchKernelGGL(k_layer1, dim3(n_nodes), dim3(256), 0, st, n_nodes, in_dim, hidden, x, w.deg, w.ptr_dst, w.nbr_dst, w.wn_dst, W1,
+  hipLaunchKernelGGL(k_layer1, dim3(n_nodes), dim3(256), 0, st, n_nodes, in_dim, hidden, x, w.deg, w.selfw, w.ptr_dst, w.nbr_dst, w.wn_dst, W1,
                      b1, w.AX, w.H1);
-  hipLaunchKernelGGL(k_aggregate, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, w.H1, w.deg, w.ptr_dst, w.nbr_dst, w.wn_dst,
+  hipLaunchKernelGGL(k_aggregate, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, w.H1, w.deg, w.selfw, w.ptr_dst, w.nbr_dst, w.wn_dst,
                      (const float *)nullptr, w.AH1);
   // H2 = relu(AH1 W2 + b2) * mask   (fp32 MFMA, fused epilogue)
   gemm<false, false, 1>(st, n_nodes, hidden, hidden, w.AH1, hidden, W2, hidden, w.H2, hidden, b2, dropout_mask, 1);
@@ -726,7 +737,7 @@ int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, i
   colsum(st, w, n_nodes, hidden, w.T0, db2);
   gemm<false, true, 0>(st, n_nodes, hidden, hidden, w.T0, hidden, W2, hidden, w.T1, hidden, nullptr, nullptr, 1);  // T1 = dZ2 W2^T
   // dZ1 = (Â^T dAH1) * (H1 > 0)   -> T0
-  hipLaunchKernelGGL(k_aggregate, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, w.T1, w.deg, w.ptr_src, w.nbr_src, w.wn_src, w.H1,
+  hipLaunchKernelGGL(k_aggregate, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, w.T1, w.deg, w.selfw, w.ptr_src, w.nbr_src, w.wn_src, w.H1,
                      w.T0);
   // layer 1
   thin_tn(st, w, 8, hidden, n_nodes, w.AX, 8, w.T0, hidden, dW1, in_dim, db1);  // dW1 = AX^T dZ1 (AX rows are 8 wide), db1 = colsum(dZ1)

@@ -262,3 +262,26 @@ def test_dqn_minibatch_matches_float64_restatement(monkeypatch, tmp_path):
         # Adam's first step moves every parameter by lr * sign(grad) (up to eps): compare the step, not just the value
         step, rstep = v.double() - p0[k], pr[k].detach() - p0[k]
         assert float((step - rstep).abs().max()) < 2e-2 * 1e-3 + 1e-9, k
+
+
+def test_explicit_self_loops_keep_their_weight():
+    """PyG add_remaining_self_loops: a node with an explicit self loop keeps that weight instead of the fill value 2
+    (gcn_ref.gcn_norm does the same); edges pointing outside the graph are ignored instead of read out of bounds."""
+    from drl_graph_exploration_amd.networks import gcn_trunk
+    dev = torch.device("cuda", 0)
+    x, ei, ea, batch = random_batch(3, 77, dev)
+    N = x.shape[0]
+    loops = torch.tensor([0, 5, N - 1], device=dev)
+    ei2 = torch.cat([ei, torch.stack([loops, loops])], dim=1)
+    ea2 = torch.cat([ea, torch.tensor([0.7, 3.1, 1.9], device=dev)])
+    P = make_params(dev, 1)
+    out = gcn_trunk(x, ei2, ea2, P["conv1.weight"], P["conv1.bias"], P["conv2.weight"], P["conv2.bias"], P["fully_con1.weight"],
+                    P["fully_con1.bias"], None)
+    ref = gcn_ref.gcn_forward({k: v.detach() for k, v in P.items()}, x, ei2, ea2)
+    assert rel_err(out, ref) < 2e-4
+    plain = gcn_ref.gcn_forward({k: v.detach() for k, v in P.items()}, x, ei, ea)
+    assert rel_err(out, plain) > 1e-3  # the self-loop weights do matter
+    bad = torch.tensor([[0, N + 5], [N + 7, 1]], device=dev)
+    out2 = gcn_trunk(x, torch.cat([ei2, bad], dim=1), torch.cat([ea2, torch.ones(2, device=dev)]), P["conv1.weight"], P["conv1.bias"],
+                     P["conv2.weight"], P["conv2.bias"], P["fully_con1.weight"], P["fully_con1.bias"], None)
+    assert torch.equal(out2, out)
