@@ -197,6 +197,14 @@ class Engine(object):
                                                      _p(rewards)))
         return rewards
 
+    def graph_capacity(self):
+        """(max nodes, max edges, max frontiers per env) of one batched export."""
+        if not hasattr(self, "_gcap"):
+            a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+            self._chk(self.L.drlgx_graph_capacity(self.h, C.byref(a), C.byref(b), C.byref(c)))
+            self._gcap = (a.value, b.value, c.value)
+        return self._gcap
+
     def graph(self):
         """Batched ExplorationEnv.graph_matrix + DeepQ.data_process for all envs (one PyG-style batch).
         Returns a dict of CUDA tensors: x [N,5] f32, edge_index [2,E] i64, edge_attr [E] f32, node_off / edge_off

@@ -14,6 +14,7 @@ There is no CPU fallback: tensors must live on a HIP device.
 import ctypes as C
 import math
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -184,6 +185,8 @@ class GraphData(object):
     @staticmethod
     def collate(items):
         """torch_geometric DataLoader/Batch semantics: concatenate, offset edge_index by cumulative node counts."""
+        if items and all(isinstance(d, PoolRef) for d in items) and all(d.pool is items[0].pool for d in items):
+            return items[0].pool.collate(items)  # one gather per tensor instead of a few torch ops per graph
         xs, eis, eas, counts = [], [], [], []
         off = 0
         for d in items:
@@ -233,3 +236,95 @@ class GraphSlice(object):
     def to(self, device):
         x = self.x
         return self if x.device == torch.device(device) else GraphData(x, self.edge_index, self.edge_attr).to(device)
+
+
+class ReplayPool(object):
+    """Device-resident storage of the graphs a replay buffer refers to: every batched export (`Engine.graph`) is copied
+    once into one slot of three pooled tensors, a transition holds `PoolRef`s (slot, env) into it, and a mini-batch is
+    collated with ONE gather per tensor from host-built index arrays (the per-graph torch ops of a Python-side collate
+    cost more than the train step they feed).  Slots are recycled when no transition refers to them any more."""
+
+    def __init__(self, device, n_slots, cap_nodes, cap_edges, in_dim=5):
+        self.device, self.n_slots, self.cap_nodes, self.cap_edges = device, n_slots, cap_nodes, cap_edges
+        self.X = torch.empty(n_slots * cap_nodes, in_dim, dtype=torch.float32, device=device)
+        self.EI = torch.empty(2, n_slots * cap_edges, dtype=torch.int64, device=device)
+        self.EA = torch.empty(n_slots * cap_edges, dtype=torch.float32, device=device)
+        self.node_off = [None] * n_slots  # host int64 [n_graphs + 1] per slot
+        self.edge_off = [None] * n_slots
+        self.ref = [0] * n_slots
+        self._next = 0
+
+    def put(self, g):
+        """Copy one export (dict of `Engine.graph`, with host offsets `node_off_h` / `edge_off_h`) into a free slot."""
+        for k in range(self.n_slots):
+            slot = (self._next + k) % self.n_slots
+            if self.ref[slot] == 0:
+                break
+        else:
+            raise RuntimeError("replay pool exhausted: every slot is still referenced")
+        self._next = (slot + 1) % self.n_slots
+        N, E = int(g["node_off_h"][-1]), int(g["edge_off_h"][-1])
+        if N > self.cap_nodes or E > self.cap_edges:
+            raise RuntimeError("export larger than a replay-pool slot")
+        self.X[slot * self.cap_nodes:slot * self.cap_nodes + N] = g["x"]
+        self.EI[:, slot * self.cap_edges:slot * self.cap_edges + E] = g["edge_index"]
+        self.EA[slot * self.cap_edges:slot * self.cap_edges + E] = g["edge_attr"]
+        self.node_off[slot] = np.asarray(g["node_off_h"], dtype=np.int64)
+        self.edge_off[slot] = np.asarray(g["edge_off_h"], dtype=np.int64)
+        return slot
+
+    def collate(self, refs):
+        k = len(refs)
+        n0 = np.array([r.slot * self.cap_nodes + self.node_off[r.slot][r.env] for r in refs], dtype=np.int64)
+        nn = np.array([r.num_nodes for r in refs], dtype=np.int64)
+        e0 = np.array([r.slot * self.cap_edges + self.edge_off[r.slot][r.env] for r in refs], dtype=np.int64)
+        ne = np.array([self.edge_off[r.slot][r.env + 1] - self.edge_off[r.slot][r.env] for r in refs], dtype=np.int64)
+        loc = np.array([self.node_off[r.slot][r.env] for r in refs], dtype=np.int64)  # the graph's first node id inside its export
+        new_off = np.cumsum(nn) - nn
+        node_idx = np.repeat(n0 - new_off, nn) + np.arange(int(nn.sum()))
+        eoff = np.cumsum(ne) - ne
+        edge_idx = np.repeat(e0 - eoff, ne) + np.arange(int(ne.sum()))
+        shift = np.repeat(new_off - loc, ne)
+        batch = np.repeat(np.arange(k), nn)
+        dev = self.device
+        ni, ei_, sh, bt = (torch.from_numpy(a).to(dev) for a in (node_idx, edge_idx, shift, batch))
+        return GraphData(self.X[ni], self.EI[:, ei_] + sh, self.EA[ei_], bt)
+
+
+class PoolRef(object):
+    """One graph of a `ReplayPool` (what a replay transition holds); same duck type as GraphData."""
+
+    __slots__ = ("pool", "slot", "env", "batch")
+
+    def __init__(self, pool, slot, env):
+        self.pool, self.slot, self.env, self.batch = pool, int(slot), int(env), None
+
+    @property
+    def num_nodes(self):
+        o = self.pool.node_off[self.slot]
+        return int(o[self.env + 1] - o[self.env])
+
+    def _ranges(self):
+        p = self.pool
+        n0 = self.slot * p.cap_nodes + int(p.node_off[self.slot][self.env])
+        e0 = self.slot * p.cap_edges + int(p.edge_off[self.slot][self.env])
+        e1 = self.slot * p.cap_edges + int(p.edge_off[self.slot][self.env + 1])
+        return n0, n0 + self.num_nodes, e0, e1
+
+    @property
+    def x(self):
+        n0, n1, _, _ = self._ranges()
+        return self.pool.X[n0:n1]
+
+    @property
+    def edge_attr(self):
+        _, _, e0, e1 = self._ranges()
+        return self.pool.EA[e0:e1]
+
+    @property
+    def edge_index(self):
+        _, _, e0, e1 = self._ranges()
+        return self.pool.EI[:, e0:e1] - int(self.pool.node_off[self.slot][self.env])
+
+    def to(self, device):
+        return GraphData(self.x, self.edge_index, self.edge_attr).to(device)

@@ -11,6 +11,7 @@ target computation as the reference; the differences are the ones the batched ho
   flattened policy gradient over ranks (RCCL over xGMI, one collective per train step) before the clamp + Adam step.
 """
 import csv
+import math
 import os
 import random
 from collections import deque
@@ -19,7 +20,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .networks import GraphData, GraphSlice
+from .networks import GraphData, GraphSlice, PoolRef, ReplayPool
 from .vecenv import VecExplorationEnv
 
 
@@ -58,6 +59,14 @@ def broadcast_parameters(model, src=0, group=None):
         dist.broadcast(t.data, src=src, group=group)
 
 
+class ReplayList(list):
+    """The replay buffer: a list with the two deque methods the reference's trainer uses (O(1) random access for
+    `random.sample`; `popleft` moves 10^4 pointers, microseconds)."""
+
+    def popleft(self):
+        return self.pop(0)
+
+
 class DeepQ(object):
     def __init__(self, case_path, model_name, data_root="../data"):
         self.case_path = case_path
@@ -81,7 +90,7 @@ class DeepQ(object):
         self.INITIAL_EPSILON = 0.9
         self.max_grad_norm = 0.5
         self.map_size = 40
-        self.buffer = deque()
+        self.buffer = ReplayList()
         self.step_t = 0
         self.epsilon = self.INITIAL_EPSILON
         self.temp_loss = 0
@@ -90,10 +99,22 @@ class DeepQ(object):
         # minibatch updates per vector step; None = one per environment step like the reference (n_envs per vector step)
         self.updates_per_vector_step = None
 
+    @property
+    def temp_loss(self):
+        """Loss of the last `train` call (scripts/policy.py:249 `self.temp_loss = loss.item()`), synchronised on access."""
+        t = self.__dict__.get("_loss_t")
+        return float(t) if t is not None else self.__dict__.get("_loss_v", 0)
+
+    @temp_loss.setter
+    def temp_loss(self, v):
+        self.__dict__["_loss_v"], self.__dict__["_loss_t"] = v, None
+
     # ------------------------------------------------------------------ pickling (saved_training.pkl hand-off)
     def __getstate__(self):
         st = dict(self.__dict__)
-        st["buffer"] = deque((_graph_to_host(t[0]), t[1], t[2], _graph_to_host(t[3]), t[4], t[5]) for t in self.buffer)
+        st["_loss_v"], st["_loss_t"] = self.temp_loss, None
+        st["buffer"] = ReplayList((_graph_to_host(t[0]), t[1], t[2], _graph_to_host(t[3]), t[4], t[5]) for t in self.buffer)
+        st.pop("_pool", None)  # device storage: the pickled transitions carry their graphs themselves
         return st
 
     def __setstate__(self, st):
@@ -130,7 +151,7 @@ class DeepQ(object):
         y = torch.as_tensor(y, dtype=torch.float64, device=device)
         action = torch.as_tensor(action, dtype=torch.float64, device=device)
         loss = self.cost(out, y, action)
-        self.temp_loss = loss.item()
+        self._loss_t = loss.detach()  # read lazily (`temp_loss`): a `.item()` here would stall the host on every update
         loss.backward()
         allreduce_gradients(model)
         for param in model.parameters():
@@ -207,8 +228,20 @@ class DeepQ(object):
         policy_net, target_net = model, modelTarget
         target_net.eval()
         for t in self.buffer:  # a replay buffer re-loaded from saved_training.pkl holds host graphs: back to the device, once
-            t[0].to(device)
-            t[3].to(device)
+            if not isinstance(t[0], PoolRef):
+                t[0].to(device)
+                t[3].to(device)
+        # graphs of new transitions live in a device pool (one slot per batched export, recycled when unreferenced)
+        mn, me, _ = env.engine.graph_capacity()
+        n_slots = 2 * (int(math.ceil(self.REPLAY_MEMORY / n_envs)) + 2)
+        pool = getattr(self, "_pool", None)
+        if pool is None or pool.device != device or pool.cap_nodes < mn or pool.cap_edges < me or pool.n_slots < n_slots:
+            pool = self._pool = ReplayPool(device, n_slots, mn, me)
+
+        def release(t):
+            for d in (t[0], t[3]):
+                if isinstance(d, PoolRef):
+                    d.pool.ref[d.slot] -= 1
         broadcast_parameters(policy_net)
         broadcast_parameters(target_net)
         optimizer = torch.optim.Adam(policy_net.parameters(), lr=1e-5)
@@ -216,7 +249,8 @@ class DeepQ(object):
         recent = deque(self.total_reward[-1000:].tolist(), maxlen=1000)  # average reward window (policy.py:201-203)
 
         g = self._host_offsets(env.graph_matrix())
-        s_t = [self.data_process(g, i) for i in range(n_envs)]
+        slot_t = pool.put(g)
+        pool.ref[slot_t] += 1  # the current state's export is held until the next one replaces it
         while temp_i < self.epoch:
             if self.epsilon > self.FINAL_EPSILON and self.step_t > self.OBSERVE:
                 self.epsilon -= n_envs * (self.INITIAL_EPSILON - self.FINAL_EPSILON) / self.EXPLORE
@@ -253,16 +287,21 @@ class DeepQ(object):
             renew = done_h | env.truncated().cpu().numpy()
             g1 = self._host_offsets(env.graph_matrix())
             nfr1 = g1["n_frontier"].cpu().numpy()
-            s_t1 = [self.data_process(g1, i) for i in range(n_envs)]
+            slot_t1 = pool.put(g1)
             for i in range(n_envs):
-                self.buffer.append((s_t[i], int(a_loc[i]), float(r_h[i]), s_t1[i], bool(current_done[i]), int(nfr1[i])))
+                self.buffer.append((PoolRef(pool, slot_t, i), int(a_loc[i]), float(r_h[i]), PoolRef(pool, slot_t1, i),
+                                    bool(current_done[i]), int(nfr1[i])))
+                pool.ref[slot_t] += 1
+                pool.ref[slot_t1] += 1
                 if len(self.buffer) > self.REPLAY_MEMORY:
-                    self.buffer.popleft()
+                    release(self.buffer.popleft())
             if renew.any():
                 env.reset(np.nonzero(renew)[0])
                 g1 = self._host_offsets(env.graph_matrix())
-                s_t1 = [self.data_process(g1, i) for i in range(n_envs)]
-            g, s_t = g1, s_t1  # the next iteration's s_t
+                slot_t1 = pool.put(g1)
+            pool.ref[slot_t1] += 1
+            pool.ref[slot_t] -= 1
+            g, slot_t = g1, slot_t1  # the next iteration's s_t
             self.step_t += n_envs
             temp_i += n_envs
 
@@ -293,6 +332,7 @@ class DeepQ(object):
         torch.save(policy_net.state_dict(), os.path.join(self.object_path, "Model_Policy.pt"))
         torch.save(target_net.state_dict(), os.path.join(self.object_path, "Model_Target.pt"))
         torch.save(policy_net.state_dict(), os.path.join(self.weights_path, "MyModel.pt"))
+        pool.ref[slot_t] -= 1
         if own_env:
             env.close()
 
