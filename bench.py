@@ -507,6 +507,30 @@ def main():
                 roofline["traffic_source"] = "profiles/pmc_traffic.json is from other kernel sources (sha1 %s): not reported" % str(pmc.get("csrc_sha1"))[:12]
         except (OSError, KeyError, ValueError):
             pass
+        # second roofline entry, for the bound the SQ counters support: the belief step is neither an HBM nor an MFMA
+        # kernel - its waves spend most of their cycles parked on waitcnt / barriers of dependent fp64 chains - so the
+        # closest throughput ceiling is VALU instruction issue (one wave64 instruction per SIMD per 4 cycles).  Counters
+        # come from profiles/sq_counters.json (scripts/collect_profiles.sh), quoted only for THIS tree's kernel sources
+        roofline_issue = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "sq_counters.json")) as f:
+                sq = json.load(f)
+            if sq.get("csrc_sha1") == csrc_digest():
+                c = sq["kernels"][roofline["kernel"]]
+                peak = 256 * 4 * 2.4e9 / 4.0 / 1e9  # G wave64 VALU instructions/s: 1024 SIMDs, 4 cycles each
+                ach = c["SQ_INSTS_VALU"] / (roofline["avg_us_per_launch"] * 1e-6) / 1e9
+                wc = c["SQ_WAVE_CYCLES"]
+                roofline_issue = {
+                    "kernel": roofline["kernel"], "bound": "valu-issue", "achieved": ach, "peak": peak,
+                    "unit": "G wave64 VALU instructions/s", "frac": ach / peak,
+                    "wave_cycle_shares": {"issuing_any": c["SQ_ACTIVE_INST_ANY"] / wc, "issuing_valu": c["SQ_ACTIVE_INST_VALU"] / wc,
+                                          "parked_on_waitcnt_or_barrier": c["SQ_WAIT_ANY"] / wc,
+                                          "issue_stalled": c["SQ_WAIT_INST_ANY"] / wc},
+                    "mfma_f64_pipe_busy": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0),
+                    "valu_instructions_per_wave": c["SQ_INSTS_VALU"] / c["SQ_WAVES"],
+                    "source": "profiles/sq_counters.json (rocprofv3 --pmc SQ_*), kernel sources sha1 %s = this tree" % sq["csrc_sha1"][:12]}
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            pass
         total_steps = args.steps * N_ENVS * world
         out = {
             "metric": "env-steps/sec (256 parallel envs, ~64-node graphs)", "value": total_steps / elapsed,
@@ -517,7 +541,7 @@ def main():
                                    "~%.0f-node graphs (P=%.1f poses, L=%.1f landmarks, M=%.0f factors) from a device snapshot"
                                    % (P + 1 + L, P + 1, L, M),
                        "envs_per_gpu": N_ENVS, "map_size": MAP, "num_landmarks": NUM_LM, "parallelism": "env-sharded x%d" % world},
-            "roofline": roofline, "kernels": kernels, "event_pair_overhead_us": ev_over_us,
+            "roofline": roofline, "roofline_issue": roofline_issue, "kernels": kernels, "event_pair_overhead_us": ev_over_us,
             "ranks_in_process_group": (dist.get_world_size() if dist is not None else 1),
             "collective_backend": (dist.get_backend() if dist is not None else "none"),
         }

@@ -18,8 +18,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_write -- $BENCH > /dev/nu
 python scripts/rocpd_pmc.py "$(db /tmp/prof_fetch)" "$(db /tmp/prof_write)" > $out/pmc_traffic.json
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
   --kernel-trace -d /tmp/prof_sq -- $BENCH > /dev/null 2> $out/rocprof_sq.err
-python scripts/pmc_sq_summary.py "$(db /tmp/prof_sq)" > $out/sq_counters.txt
 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES \
   --kernel-trace -d /tmp/prof_sq2 -- $BENCH > /dev/null 2> $out/rocprof_sq2.err
-python scripts/pmc_sq_summary.py "$(db /tmp/prof_sq2)" > $out/sq_counters2.txt
+python scripts/pmc_sq_summary.py "$(db /tmp/prof_sq)" "$(db /tmp/prof_sq2)" --json $out/sq_counters.json > $out/sq_counters.txt
 ls -la $out
