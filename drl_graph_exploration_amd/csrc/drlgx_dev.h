@@ -46,6 +46,9 @@ struct DrlgxState {
   int lo_ntab;
   const double *lo_pv;
   const uint8_t *lo_tr;
+  unsigned long long lo_tocc, lo_tfree;  // lo_tr packed for <= 16 states: 4 bits per next state (occupied / free)
+  unsigned int lo_tflag;                 // 2 bits of flags per state
+  double vm_i0;                          // 1 / sigma0^2 (host pow, like the reference's initialisation)
   const int *lm_order;                                 // [LG] libstdc++ unordered_map iteration order of GT keys
   // --- simulator
   double *gt_pose;    // [n_inst][4] x,y,c,s
@@ -216,6 +219,16 @@ __device__ __forceinline__ double rcp_n(double x) {
   r = r * (2.0 - x * r);
   r = r * (2.0 - x * r);
   return r;
+}
+// one Newton step on v_rcp_f64 / v_rsq_f64 (raw relative error 5e-8 -> 2e-15 / 4e-15, scripts/micro/rcp_precision.hip):
+// for algebra whose results are only compared against a tolerance
+__device__ __forceinline__ double rcp_n1(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  return r * (2.0 - x * r);
+}
+__device__ __forceinline__ double rsqrt_n1(double x) {
+  const double r = __builtin_amdgcn_rsq(x);
+  return r * (1.5 - 0.5 * x * r * r);
 }
 __device__ __forceinline__ double rsqrt_n(double x) {
   double r = __builtin_amdgcn_rsq(x);

@@ -223,6 +223,9 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   S.lo_min = p2l(0.05);
   S.lo_max = l2p(0.95);  // sic: MAX_LOGODDS = LOGODDS2PROB(0.95)
   S.occ_thresh = p2l(0.5);
+  S.vm_i0 = 1.0 / std::pow(cfg->sigma0, 2);
+  S.lo_tocc = S.lo_tfree = 0ull;
+  S.lo_tflag = 0u;
   // occupancy ladder closure (see DrlgxState::lo_tr)
   std::vector<double> lo_val{0.0}, lo_pv;
   std::vector<uint8_t> lo_tr;
@@ -268,6 +271,12 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
         lo_pv.push_back(acc);
       }
       S.lo_ntab = (int)lo_val.size();
+      if (S.lo_ntab <= 16)
+        for (int i = 0; i < S.lo_ntab; ++i) {
+          S.lo_tocc |= (unsigned long long)(lo_tr[4 * i] & 15) << (4 * i);
+          S.lo_tfree |= (unsigned long long)(lo_tr[4 * i + 1] & 15) << (4 * i);
+          S.lo_tflag |= (unsigned int)(lo_tr[4 * i + 2] & 3) << (2 * i);
+        }
     } else {
       S.lo_ntab = 0;
       lo_pv.assign(1, 0.5);

@@ -60,10 +60,10 @@ __device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps
   // range < max_range && range > min_range, decided exactly on the squared distance (host-computed thresholds)
   if (!(g2 < S.r2_max_lt && g2 > S.r2_min_gt)) return false;
   if (kCheckFov && !in_fov(S, ps, pt)) return false;
-  const double rrange = rsqrt_n(g2);  // 1 / range
+  const double rrange = rsqrt_n1(g2);  // 1 / range
   double Hbx[3], Hbl[2], Hrx[3], Hrl[2];
   if (d2 > 1e-10) {  // |d| > 1e-5
-    const double rd2 = rcp_n(d2);
+    const double rd2 = rcp_n1(d2);
     const double a = -d.y * rd2, b = d.x * rd2;
     Hbx[0] = a * -1.0;
     Hbx[1] = b * -1.0;
@@ -84,36 +84,30 @@ __device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps
   }
   const double R0 = cfg.bearing_noise * cfg.bearing_noise, R3 = cfg.range_noise * cfg.range_noise;
   const double Hl0 = Hbl[0], Hl1 = Hbl[1], Hl2 = Hrl[0], Hl3 = Hrl[1];
-  // (Hl^T Hl)^-1 Hl^T  (Eigen fixed 2x2 inverse = adjugate / det)
-  const double h00 = Hl0 * Hl0 + Hl2 * Hl2, h01 = Hl0 * Hl1 + Hl2 * Hl3;
-  const double h10 = Hl1 * Hl0 + Hl3 * Hl2, h11 = Hl1 * Hl1 + Hl3 * Hl3;
-  const double id = rcp_n(h00 * h11 - h01 * h10);
-  const double i00 = h11 * id, i01 = -h01 * id, i10 = -h10 * id, i11 = h00 * id;
-  const double p00 = i00 * Hl0 + i01 * Hl1, p01 = i00 * Hl2 + i01 * Hl3;
-  const double p10 = i10 * Hl0 + i11 * Hl1, p11 = i10 * Hl2 + i11 * Hl3;
   // S = R + Hx * info.llt().solve(Hx^T); the LLT factor of the pose information (and the reciprocals of its
-  // diagonal) was computed once per pose: pi = l00 l10 l11 l20 l21 l22 r00 r11 r22
+  // diagonal) was computed once per pose: pi = . l10 . l20 l21 . r00 r11 r22
   double xb0, xb1, xb2, xr0, xr1, xr2;
   {
     const double l10 = pi[1], l20 = pi[3], l21 = pi[4], r00 = pi[6], r11 = pi[7], r22 = pi[8];
     double y0 = Hbx[0] * r00, y1 = (Hbx[1] - l10 * y0) * r11, y2 = (Hbx[2] - l20 * y0 - l21 * y1) * r22;
     xb2 = y2 * r22; xb1 = (y1 - l21 * xb2) * r11; xb0 = (y0 - l10 * xb1 - l20 * xb2) * r00;
-    y0 = Hrx[0] * r00; y1 = (Hrx[1] - l10 * y0) * r11; y2 = (Hrx[2] - l20 * y0 - l21 * y1) * r22;
+    y0 = Hrx[0] * r00; y1 = (Hrx[1] - l10 * y0) * r11;
+    y2 = (0.0 - l20 * y0 - l21 * y1) * r22;  // Hrx[2] = 0
     xr2 = y2 * r22; xr1 = (y1 - l21 * xr2) * r11; xr0 = (y0 - l10 * xr1 - l20 * xr2) * r00;
   }
-  double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-  s00 += Hbx[0] * xb0; s00 += Hbx[1] * xb1; s00 += Hbx[2] * xb2;
-  s01 += Hbx[0] * xr0; s01 += Hbx[1] * xr1; s01 += Hbx[2] * xr2;
-  s10 += Hrx[0] * xb0; s10 += Hrx[1] * xb1; s10 += Hrx[2] * xb2;
-  s11 += Hrx[0] * xr0; s11 += Hrx[1] * xr1; s11 += Hrx[2] * xr2;
-  s00 = R0 + s00; s01 = 0.0 + s01; s10 = 0.0 + s10; s11 = R3 + s11;
-  // cov = Hp S Hp^T
-  const double t00 = p00 * s00 + p01 * s10, t01 = p00 * s01 + p01 * s11;
-  const double t10 = p10 * s00 + p11 * s10, t11 = p10 * s01 + p11 * s11;
-  const double c00 = t00 * p00 + t01 * p01;
-  const double c10 = t10 * p00 + t11 * p01, c11 = t10 * p10 + t11 * p11;
-  // information = inverse(cov) by LLT (lower triangle of cov)
-  inv2_llt_fast(c00, c10, c11, oxx, oxy, oyy);
+  const double s00 = R0 + (Hbx[0] * xb0 + Hbx[1] * xb1 + Hbx[2] * xb2);
+  const double s01 = Hbx[0] * xr0 + Hbx[1] * xr1 + Hbx[2] * xr2;
+  const double s11 = R3 + (Hrx[0] * xr0 + Hrx[1] * xr1);
+  // The reference forms cov = Hp S Hp^T with Hp = (Hl^T Hl)^-1 Hl^T = Hl^-1 (Hl is square) and inverts it; the same
+  // matrix without the two inversions:  information = cov^-1 = Hl^T S^-1 Hl  (tolerance-only algebra: the values
+  // are compared at 1e-7, no decision depends on them)
+  const double rdet = rcp_n1(s00 * s11 - s01 * s01);
+  const double q00 = s11 * rdet, q01 = -s01 * rdet, q11 = s00 * rdet;
+  const double u0 = q00 * Hl0 + q01 * Hl2, u1 = q00 * Hl1 + q01 * Hl3;  // (S^-1 Hl) row 0
+  const double v0 = q01 * Hl0 + q11 * Hl2, v1 = q01 * Hl1 + q11 * Hl3;  // row 1
+  oxx = Hl0 * u0 + Hl2 * v0;
+  oxy = Hl0 * u1 + Hl2 * v1;
+  oyy = Hl1 * u1 + Hl3 * v1;
   return true;
 }
 
@@ -122,30 +116,39 @@ __device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps
 __device__ __forceinline__ void ci_fuse(double &axx, double &axy, double &ayy, double bxx, double bxy, double byy) {
   const double a = axx * ayy - axy * axy;
   const double b = bxx * byy - bxy * bxy;
-  // m1.llt().solve(m2).trace(), with reciprocal square roots instead of sqrt + divisions (this loop is issue-bound)
-  const double r00 = rsqrt_n(axx);
-  const double l10 = axy * r00;
-  const double r11 = rsqrt_n(ayy - l10 * l10);
-  double tr = 0;
-  {
-    double y0 = bxx * r00, y1 = (bxy - l10 * y0) * r11;
-    double x1 = y1 * r11, x0 = (y0 - l10 * x1) * r00;
-    tr += x0;
-    y0 = bxy * r00;
-    y1 = (byy - l10 * y0) * r11;
-    x1 = y1 * r11;
-    tr += x1;
-  }
-  const double c = a * tr;
+  // c = a * m1.llt().solve(m2).trace() = det(m1) trace(m1^-1 m2) = trace(adj(m1) m2): no factorisation needed
+  // (tolerance-only algebra; w is continuous across its clamps)
+  const double c = (ayy * bxx - axy * bxy) + (axx * byy - axy * bxy);
   const double d = a + b - c;
-  double w = 0.5 * (2 * b - c) * rcp_n(d);
-  if ((w < 0 && d < 0) || (w > 1 && d > 0))
-    w = 0.0;
-  else if ((w < 0 && d > 0) || (w > 1 && d < 0))
-    w = 1.0;
+  double w = 0.5 * (2 * b - c) * rcp_n1(d);
+  {  // the reference's two clamps, as selects (no branches on the chain)
+    const bool lo = w < 0, hi = w > 1, dn = d < 0, dp = d > 0;
+    const bool zero = (lo & dn) | (hi & dp), one = (lo & dp) | (hi & dn);
+    w = one ? 1.0 : w;
+    w = zero ? 0.0 : w;
+  }
   axx = w * axx + (1.0 - w) * bxx;
   axy = w * axy + (1.0 - w) * bxy;
   ayy = w * ayy + (1.0 - w) * byy;
+}
+
+// Sum over the 64 lanes of a wave, result in lane 63: DPP row shifts within the 16-lane rows, then the two gfx9
+// row broadcasts (15 -> next row, 31 -> upper half) - no LDS traffic, ~20 cycles per step.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_add(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, kCtrl, kRowMask, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), kCtrl, kRowMask, 0xf, true);
+  return v + __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum63(double v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row's sum
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+  return v;
 }
 
 __device__ __forceinline__ double block_sum(double v, double *scratch, int tid) {
@@ -200,19 +203,25 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
     for (int e = tid; e < P * 4; e += kThreads) sp[e] = ep[e];
     for (int e = tid; e < P * 6; e += kThreads) si[e] = pin[e];
     const double *el = S.est_lm + (size_t)inst * S.L_max * 2;
-    for (int v = tid; v < V; v += kThreads) lmc[v] = 0;
+    for (int v = tid; v < V; v += kThreads) {  // (the first chunk's masks too, while the loads above are in flight)
+      lmc[v] = 0;
+      mask[v] = 0ull;
+      omask[v] = 0ull;
+    }
+    if (tid == 0) *pcount = 0;
     for (int t = tid; t < S.lo_ntab; t += kThreads) {
       lpv[t] = S.lo_pv[t];
       reinterpret_cast<uint32_t *>(ltr)[t] = reinterpret_cast<const uint32_t *>(S.lo_tr)[t];
     }
     __syncthreads();
-    for (int j = tid; j < L; j += kThreads) {
+    DRLGX_PROF(S, 40);
+    // landmarks on the last threads, poses on the first ones: both in the same barrier interval
+    for (int j = kThreads - 1 - tid; j < L; j += kThreads) {
       // OccupancyMap::update(map): landmark cell (OccupancyMap.cpp:127-131); every landmark in a cell is one occupied update
       int r = (int)floor((el[2 * j + 1] - cfg.map_min_y) / cfg.resolution);
       int c = (int)floor((el[2 * j] - cfg.map_min_x) / cfg.resolution);
       if (!(r >= rows || r < 0 || c >= cols || c < 0)) atomicAdd(&lmc[r * cols + c], 1);
     }
-    __syncthreads();
     for (int p = tid; p < P; p += kThreads) {
       const double x = sp[4 * p], y = sp[4 * p + 1];
       int orow = (int)floor((y - cfg.map_min_y) / cfg.resolution);
@@ -226,13 +235,19 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
       worg[2 * p + 1] = (int)floor((x - cfg.max_range - cfg.map_min_x) / cfg.resolution - 0.5);
       const double *pi = si + 6 * p;
       pskip[p] = det3s(pi[0], pi[1], pi[2], pi[3], pi[4], pi[5]) < 1e-10 ? 1 : 0;  // VirtualMap.cpp:293-294
-      // state.information.llt(): factor once per pose, keep reciprocals of the diagonal
-      const LLT3 f(pi[0], pi[1], pi[2], pi[3], pi[4], pi[5]);
+      // state.information.llt(): factored once per pose; the push-through needs the off-diagonal entries and the
+      // reciprocals of the diagonal only (tolerance-only algebra: reciprocal square roots, no sqrt / division)
       double *o = sl + 9 * p;
-      o[0] = f.l00; o[1] = f.l10; o[2] = f.l11; o[3] = f.l20; o[4] = f.l21; o[5] = f.l22;
-      o[6] = 1.0 / f.l00; o[7] = 1.0 / f.l11; o[8] = 1.0 / f.l22;
+      const double r00 = rsqrt_n1(pi[0]);
+      const double l10 = pi[1] * r00, l20 = pi[2] * r00;
+      const double r11 = rsqrt_n1(pi[3] - l10 * l10);
+      const double l21 = (pi[4] - l20 * l10) * r11;
+      const double r22 = rsqrt_n1(pi[5] - l20 * l20 - l21 * l21);
+      o[1] = l10; o[3] = l20; o[4] = l21;
+      o[6] = r00; o[7] = r11; o[8] = r22;
     }
     __syncthreads();
+    DRLGX_PROF(S, 41);
     const bool use_bbox = !S.bbox_noop;
     if (use_bbox) {
       // bbox of the 3-degree sector sweep (OccupancyMap.cpp:79-96): (pose, sample) pairs in parallel
@@ -262,56 +277,93 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
     //    covariance-intersection fusion - instead of testing every (cell, pose) pair.  The last chunk's C pass also runs
     //    the occupancy ladder (branch-free over the poses), writes the cell and accumulates the reductions: every cell is
     //    read and written once per belief update.
-    const double i0 = 1.0 / pow(cfg.sigma0, 2);
+    const double i0 = S.vm_i0;
     const int extg = 20;
-    // the ladder's transition table packed into registers when it has <= 16 states (4 bits per next state, 2 per flag):
-    // a cell's walk over its sees-me bits is then pure ALU instead of one dependent LDS byte load per pose
+    // the ladder's transition table packed into registers when it has <= 16 states (4 bits per next state, 2 per flag,
+    // packed on the host): a cell's walk over its sees-me bits is then pure ALU instead of one dependent LDS byte load
+    // per pose
     const bool fsm_reg = S.lo_ntab > 0 && S.lo_ntab <= 16;
-    unsigned long long t_occ = 0ull, t_free = 0ull;
-    unsigned int t_flag = 0u;
-    if (fsm_reg)
-      for (int st2 = 0; st2 < S.lo_ntab; ++st2) {
-        t_occ |= (unsigned long long)(ltr[4 * st2] & 15) << (4 * st2);
-        t_free |= (unsigned long long)(ltr[4 * st2 + 1] & 15) << (4 * st2);
-        t_flag |= (unsigned int)(ltr[4 * st2 + 2] & 3) << (2 * st2);
-      }
+    const unsigned long long t_occ = S.lo_tocc, t_free = S.lo_tfree;
+    const unsigned int t_flag = S.lo_tflag;
     for (int c0 = 0; c0 < P; c0 += chunk) {
       const int nc = min(chunk, P - c0);
       const bool last = c0 + nc >= P;
-      for (int v = tid; v < V; v += kThreads) {
-        mask[v] = 0ull;
-        omask[v] = 0ull;
+      if (c0 > 0) {  // (the first chunk's masks were cleared while the pose tables were loading)
+        for (int v = tid; v < V; v += kThreads) {
+          mask[v] = 0ull;
+          omask[v] = 0ull;
+        }
+        if (tid == 0) *pcount = 0;
+        __syncthreads();
       }
-      if (tid == 0) *pcount = 0;
-      __syncthreads();
+      if (c0 == 0) DRLGX_PROF(S, 42);
       // (pose, window cell) pairs: a cheap pass keeps the ones in range and in the field of view (~45 % of the window)
       // in a compact list, so that the EKF push-through below runs on full waves
-      // (candidate e = 64 pl + 8 wr + wc: an 8 x 8 slot grid per pose whatever the window width W <= 8 - no integer divisions)
-      for (int e0 = 0; e0 < nc * 64; e0 += kThreads) {
-        const int e = e0 + tid;
-        bool valid = false;
-        if (e < nc * 64) {
-          const int pl = e >> 6, widx = e & 63;
-          const int p = c0 + pl;
-          const int wr = widx >> 3, wc = widx & 7;
-          if (!pskip[p] && wr < W && wc < W) {
-            const int row = worg[2 * p] + wr, col = worg[2 * p + 1] + wc;
-            if (row >= 0 && row < rows && col >= 0 && col < cols) {
-              const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
-              const P2 pt{(col + 0.5) * cfg.resolution + cfg.map_min_x, (row + 0.5) * cfg.resolution + cfg.map_min_y};
-              const double dx = ps.x - pt.x, dy = ps.y - pt.y;
-              // KDTreeR2::queryRadiusNeighbors / OccupancyMap range test: sqrt(d2) < max_range, exactly; then the field of view
-              valid = dx * dx + dy * dy < S.r2_max_lt && in_fov(S, ps, pt);
-            }
-          }
+      // (candidate e = 64 pl + 8 wr + wc: an 8 x 8 slot grid per pose whatever the window width W <= 8 - no integer
+      // divisions; a wave tests one pose's window per round).  Returns 1: accepted, 0: rejected, 2: in range but the
+      // field of view needs the exact bearing (thin wedge around the blind ray, or a narrow sensor).
+      auto pair_test = [&](int e) -> int {
+        const int pl = e >> 6, widx = e & 63;
+        const int p = c0 + pl;
+        const int wr = widx >> 3, wc = widx & 7;
+        const int row = worg[2 * p] + wr, col = worg[2 * p + 1] + wc;
+        const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
+        const P2 pt{(col + 0.5) * cfg.resolution + cfg.map_min_x, (row + 0.5) * cfg.resolution + cfg.map_min_y};
+        const double dx = ps.x - pt.x, dy = ps.y - pt.y;
+        // KDTreeR2::queryRadiusNeighbors / OccupancyMap range test: sqrt(d2) < max_range, exactly
+        const bool inr = !pskip[p] && wr < W && wc < W && row >= 0 && row < rows && col >= 0 && col < cols &&
+                         dx * dx + dy * dy < S.r2_max_lt;
+        const P2 d = transform_to(ps, pt);
+        const bool sure = S.fov_fast && (d.x >= 0.0 || fabs(d.y) > S.fov_tan * fabs(d.x));  // provably inside
+        return inr ? (sure ? 1 : 2) : 0;
+      };
+      auto pair_exact = [&](int e) -> bool {  // BearingRangeSensorModel::check on the bearing itself
+        const int pl = e >> 6, widx = e & 63;
+        const int p = c0 + pl;
+        const int row = worg[2 * p] + (widx >> 3), col = worg[2 * p + 1] + (widx & 7);
+        const Pose ps{sp[4 * p], sp[4 * p + 1], sp[4 * p + 2], sp[4 * p + 3]};
+        const P2 pt{(col + 0.5) * cfg.resolution + cfg.map_min_x, (row + 0.5) * cfg.resolution + cfg.map_min_y};
+        const double bearing = bearing_of<false>(ps, pt, nullptr, nullptr);
+        return bearing < cfg.max_bearing && bearing > cfg.min_bearing;
+      };
+      int e0 = 0;
+      // four rounds at a time as straight-line code (the LDS loads of the four candidates overlap), one LDS atomic per
+      // wave and group
+      for (; e0 + 4 * kThreads <= nc * 64; e0 += 4 * kThreads) {
+        int t[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = pair_test(e0 + r * kThreads + tid);
+        if (__ballot((t[0] | t[1] | t[2] | t[3]) & 2)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (t[r] == 2) t[r] = pair_exact(e0 + r * kThreads + tid) ? 1 : 0;
         }
-        const unsigned long long bal = __ballot(valid);
+        unsigned long long bal[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bal[r] = __ballot(t[r] == 1);
+        const int n0 = __popcll(bal[0]), n1 = __popcll(bal[1]), n2 = __popcll(bal[2]), n3 = __popcll(bal[3]);
+        int base = 0;
+        if (lane == 0 && (n0 + n1 + n2 + n3)) base = atomicAdd(pcount, n0 + n1 + n2 + n3);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int off[4] = {0, n0, n0 + n1, n0 + n1 + n2};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (t[r] == 1) plist[base + off[r] + __popcll(bal[r] & below)] = (unsigned short)(e0 + r * kThreads + tid);
+      }
+      for (; e0 < nc * 64; e0 += kThreads) {  // remaining rounds (waves beyond the last pose's window skip)
+        const int e = e0 + tid;
+        if ((e0 >> 6) + wave >= nc) continue;
+        int t = pair_test(e);
+        if (t == 2) t = pair_exact(e) ? 1 : 0;
+        const unsigned long long bal = __ballot(t == 1);
         int base = 0;
         if (lane == 0 && bal) base = atomicAdd(pcount, __popcll(bal));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (valid) plist[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)e;
+        if (t == 1) plist[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)e;
       }
       __syncthreads();
+      if (c0 == 0) DRLGX_PROF(S, 43);
       const int npairs = *pcount;
       for (int k = tid; k < npairs; k += kThreads) {
         const int e = plist[k];
@@ -325,106 +377,136 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
         if (in_bbox) atomicOr(&omask[row * cols + col], 1ull << pl);  // OccupancyMap::update visits this cell
         double a, b, d;
         if (predict_cell<false>(S, ps, sl + 9 * p, pt, a, b, d)) {
-          double *o = stage + ((size_t)pl * 64 + widx) * 3;
+          // stage slot of (pose, cell): the window spans at most 8 consecutive rows / columns, so (row mod 8, col mod 8)
+          // is unique within it - the cell pass finds the entry without the window origin
+          double *o = stage + ((size_t)pl * 64 + (row & 7) * 8 + (col & 7)) * 3;
           o[0] = a; o[1] = b; o[2] = d;
           atomicOr(&mask[row * cols + col], 1ull << pl);
         }
       }
       __syncthreads();
       if (c0 == 0) DRLGX_PROF(S, 21);
-      for (int v = tid; v < V; v += kThreads) {
-        const int row = v / cols, col = v - row * cols;
+      const bool wprof = S.prof && blockIdx.x == 0 && lane == 0 && c0 == 0;
+      long long ci_clk = 0;
+      // cell pass: one 8 x 8 tile of cells per wave and round (lane = 8 (row mod 8) + (col mod 8)).  Cells of a tile
+      // are seen by nearly the same poses, so the lanes' covariance-intersection chains have similar lengths and tiles
+      // away from the trajectory skip the loop altogether (row-major strips of 64 cells cross the whole map instead).
+      const int tiles_c = (cols + 7) >> 3, ntiles = ((rows + 7) >> 3) * tiles_c;
+      for (int t = wave; t < ntiles; t += kWaves) {
+        const int trow = t / tiles_c, tcol = t - trow * tiles_c;
+        const int row = 8 * trow + (lane >> 3), col = 8 * tcol + (lane & 7);
+        const bool ok = row < rows && col < cols;
+        const int v = ok ? row * cols + col : 0;
         double axx = i0, axy = 0.0, ayy = i0;
         int u = 0;
         if (c0 > 0) {
           axx = ixx[v]; axy = ixy[v]; ayy = iyy[v];
           u = upd[v];
         }
-        unsigned long long m = mask[v];
-        while (m) {
-          const int pl = __ffsll((long long)m) - 1;
+        unsigned long long m = ok ? mask[v] : 0ull;
+        const double *nx = stage + lane * 3;  // + 192 * (pose within the chunk): the slot is the lane
+        const long long tc0 = wprof ? wall_clock64() : 0;
+        if (m && !u) {  // the first update of an untouched cell replaces the prior (VirtualMap.cpp:300-304)
+          const double *o = nx + (__ffsll((long long)m) - 1) * 192;
+          axx = o[0]; axy = o[1]; ayy = o[2];
+          u = 1;
           m &= m - 1;
-          const int p = c0 + pl;
-          const double *o = stage + ((size_t)pl * 64 + (row - worg[2 * p]) * 8 + (col - worg[2 * p + 1])) * 3;
-          if (u) {
-            ci_fuse(axx, axy, ayy, o[0], o[1], o[2]);
+        }
+        if (m) {
+          // every further update is fused; the next entry is loaded before the current one is fused, so that the LDS
+          // latency stays off the dependent chain
+          const double *o = nx + (__ffsll((long long)m) - 1) * 192;
+          double nxx = o[0], nxy = o[1], nyy = o[2];
+          m &= m - 1;
+          while (true) {
+            const double bxx = nxx, bxy = nxy, byy = nyy;
+            const bool more = m != 0ull;
+            if (more) {
+              const double *o2 = nx + (__ffsll((long long)m) - 1) * 192;
+              nxx = o2[0]; nxy = o2[1]; nyy = o2[2];
+              m &= m - 1;
+            }
+            ci_fuse(axx, axy, ayy, bxx, bxy, byy);
+            if (!more) break;
+          }
+        }
+        if (wprof) ci_clk += wall_clock64() - tc0;
+        if (ok) {
+          ixx[v] = axx; ixy[v] = axy; iyy[v] = ayy;
+          upd[v] = (uint8_t)u;
+          // occupancy ladder (OccupancyMap.cpp:64-138): the landmarks of the cell, then the poses that see it in
+          // trajectory order (ascending mask bits); between chunks the log-odds value is parked in prob[]
+          double l = 0.0;  // LOGODDS_UNKNOWN
+          int st = 0;      // ... as a state of the precomputed ladder (DrlgxState::lo_tr) when it is closed
+          const bool fsm = S.lo_ntab > 0;
+          if (c0 == 0) {
+            for (int n = lmc[v]; n > 0; --n) {
+              l = fmin(S.lo_max, fmax(S.lo_min, l + S.lo_occ));
+              st = ltr[4 * st];
+            }
           } else {
-            axx = o[0]; axy = o[1]; ayy = o[2];
-            u = 1;
+            l = prob[v];
+            st = (int)l;
           }
-        }
-        ixx[v] = axx; ixy[v] = axy; iyy[v] = ayy;
-        upd[v] = (uint8_t)u;
-        // occupancy ladder (OccupancyMap.cpp:64-138): the landmarks of the cell, then the poses that see it in
-        // trajectory order (ascending mask bits); between chunks the log-odds value is parked in prob[]
-        double l = 0.0;  // LOGODDS_UNKNOWN
-        int st = 0;      // ... as a state of the precomputed ladder (DrlgxState::lo_tr) when it is closed
-        const bool fsm = S.lo_ntab > 0;
-        if (c0 == 0) {
-          for (int n = lmc[v]; n > 0; --n) {
-            l = fmin(S.lo_max, fmax(S.lo_min, l + S.lo_occ));
-            st = ltr[4 * st];
+          m = omask[v];
+          if (fsm_reg) {
+            // a state that maps to itself is absorbing (the transition depends on the state only): the remaining bits
+            // cannot change it (cells at the clamped minimum / maximum, i.e. every cell seen more than a few times)
+            while (m) {
+              m &= m - 1;
+              const int f = (t_flag >> (2 * st)) & 3;
+              const int nst = (f & 1) ? st : (int)((((f & 2) ? t_occ : t_free) >> (4 * st)) & 15);
+              if (nst == st) break;
+              st = nst;
+            }
+            l = (double)st;
+          } else if (fsm) {
+            while (m) {
+              m &= m - 1;
+              const int f = ltr[4 * st + 2];
+              st = (f & 1) ? st : ((f & 2) ? ltr[4 * st] : ltr[4 * st + 1]);
+            }
+            l = (double)st;
+          } else {
+            while (m) {
+              m &= m - 1;
+              if (fabs(l - S.lo_min) < 1e-5) continue;
+              const double add = (l > S.occ_thresh + 1e-8) ? S.lo_occ : S.lo_free;
+              l = fmin(S.lo_max, fmax(S.lo_min, l + add));
+            }
           }
-        } else {
-          l = prob[v];
-          st = (int)l;
-        }
-        m = omask[v];
-        if (fsm_reg) {
-          // a state that maps to itself is absorbing (the transition depends on the state only): the remaining bits
-          // cannot change it (cells at the clamped minimum / maximum, i.e. every cell seen more than a few times)
-          while (m) {
-            m &= m - 1;
-            const int f = (t_flag >> (2 * st)) & 3;
-            const int nst = (f & 1) ? st : (int)((((f & 2) ? t_occ : t_free) >> (4 * st)) & 15);
-            if (nst == st) break;
-            st = nst;
+          if (!last) {
+            prob[v] = l;
+            continue;
           }
-          l = (double)st;
-        } else if (fsm) {
-          while (m) {
-            m &= m - 1;
-            const int f = ltr[4 * st + 2];
-            st = (f & 1) ? st : ((f & 2) ? ltr[4 * st] : ltr[4 * st + 1]);
+          // VirtualMap::updateProbability: prob = sum over num_samples identical maps of p / n
+          double pv = 0.0;
+          if (fsm) {
+            pv = lpv[st];
+          } else {
+            const double pv1 = logodds2prob(l);
+            for (int s2 = 0; s2 < cfg.num_samples; ++s2) pv += pv1 / cfg.num_samples;
           }
-          l = (double)st;
-        } else {
-          while (m) {
-            m &= m - 1;
-            if (fabs(l - S.lo_min) < 1e-5) continue;
-            const double add = (l > S.occ_thresh + 1e-8) ? S.lo_occ : S.lo_free;
-            l = fmin(S.lo_max, fmax(S.lo_min, l + add));
-          }
+          prob[v] = pv;
+          // reductions (Planner2D.cpp:321-366, VirtualMap.cpp:47-59)
+          // trace and determinant of the covariance (= information^-1, 2 x 2): (a + d) / det, 1 / det
+          const double rdet = rcp_n1(axx * ayy - axy * axy);
+          const double tr = (axx + ayy) * rdet;
+          vtr[v] = tr;
+          utr += 1.0 * tr;
+          if (pv < cfg.occupancy_threshold) known += 1.0;
+          const double wgt = pv > 0.49 ? 1.0 : 0.0;
+          udet += wgt * rdet;
+          uwtr += wgt * tr;
+          const double x = (col + 0.5) * cfg.resolution + cfg.map_min_x, y = (row + 0.5) * cfg.resolution + cfg.map_min_y;
+          if ((pv < 0.49 || pv > 0.6) && cfg.map_min_x + extg <= x && x <= cfg.map_max_x - extg && cfg.map_min_y + extg <= y &&
+              y <= cfg.map_max_y - extg)
+            expl += 1.0;
         }
-        if (!last) {
-          prob[v] = l;
-          continue;
-        }
-        if (S.prof && tid == 0 && blockIdx.x == 0 && v == 0) S.prof[22] = wall_clock64() + (l == 1.2345e300 ? 1 : 0);
-        // VirtualMap::updateProbability: prob = sum over num_samples identical maps of p / n
-        double pv = 0.0;
-        if (fsm) {
-          pv = lpv[st];
-        } else {
-          const double pv1 = logodds2prob(l);
-          for (int s = 0; s < cfg.num_samples; ++s) pv += pv1 / cfg.num_samples;
-        }
-        prob[v] = pv;
-        if (S.prof && tid == 0 && blockIdx.x == 0 && v == 0) S.prof[23] = wall_clock64() + (pv == 1.2345e300 ? 1 : 0);
-        // reductions (Planner2D.cpp:321-366, VirtualMap.cpp:47-59)
-        double ca, cb, cd;
-        inv2_llt_fast(axx, axy, ayy, ca, cb, cd);
-        const double tr = ca + cd;
-        vtr[v] = tr;
-        utr += 1.0 * tr;
-        if (pv < cfg.occupancy_threshold) known += 1.0;
-        const double wgt = pv > 0.49 ? 1.0 : 0.0;
-        udet += wgt * rcp_n(axx * ayy - axy * axy);
-        uwtr += wgt * tr;
-        const double x = (col + 0.5) * cfg.resolution + cfg.map_min_x, y = (row + 0.5) * cfg.resolution + cfg.map_min_y;
-        if ((pv < 0.49 || pv > 0.6) && cfg.map_min_x + extg <= x && x <= cfg.map_max_x - extg && cfg.map_min_y + extg <= y &&
-            y <= cfg.map_max_y - extg)
-          expl += 1.0;
+      }
+      if (wprof) {
+        S.prof[48 + wave] = wall_clock64();
+        S.prof[56 + wave] = ci_clk;
       }
       __syncthreads();
     }
@@ -454,20 +536,19 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
   {
     double r5[5] = {utr, known, expl, udet, uwtr};
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
-      for (int o = 32; o > 0; o >>= 1) r5[k] += __shfl_down(r5[k], o);
+    for (int k = 0; k < 5; ++k) r5[k] = wave_sum63(r5[k]);
     __syncthreads();  // stage[] is free again
-    if ((tid & 63) == 0)
+    if ((tid & 63) == 63)
       for (int k = 0; k < 5; ++k) stage[k * kWaves + (tid >> 6)] = r5[k];
     __syncthreads();
-    if (tid < 5) {
-      double acc = 0;
-      for (int w = 0; w < kWaves; ++w) acc += stage[tid * kWaves + w];
-      stage[5 * kWaves + tid] = acc;
+    if (tid == 0) {  // wave-major order: the same summation order as before
+      double acc[5];
+      for (int k = 0; k < 5; ++k) {
+        acc[k] = 0;
+        for (int w = 0; w < kWaves; ++w) acc[k] += stage[k * kWaves + w];
+      }
+      utr = acc[0]; known = acc[1]; expl = acc[2]; udet = acc[3]; uwtr = acc[4];
     }
-    __syncthreads();
-    utr = stage[5 * kWaves + 0]; known = stage[5 * kWaves + 1]; expl = stage[5 * kWaves + 2];
-    udet = stage[5 * kWaves + 3]; uwtr = stage[5 * kWaves + 4];
   }
   DRLGX_PROF(S, 20);
   if (tid == 0) {
