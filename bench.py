@@ -186,16 +186,7 @@ def policy_bench(eng, dev, iters=10):
     n64 = int(g["node_off"][64])
     e64 = int(g["edge_off"][64])
     d64 = GraphData(g["x"][:n64], g["edge_index"][:, :e64], g["edge_attr"][:e64], g["batch"][:n64])
-    opt = torch.optim.Adam(model.parameters(), lr=1e-5)
-    w = torch.randn(n64, 1, device=dev)
-
-    def train_step():
-        opt.zero_grad()
-        q = model(d64, 0.5, batch=d64.batch)
-        ((q * w) ** 2).sum().div(64).backward()
-        for p in model.parameters():
-            p.grad.data.clamp_(-0.5, 0.5)
-        opt.step()
+    train_step = make_train_step(model, d64, dev)
     t_t = timed(train_step)
     flops_t = 3 * (2.0 * n64 * (5 * 1000 + 1000 * 1000 + 1000)) + 2.0 * 4 * (e64 + n64) * 1000
     out["train_step_ms"] = t_t * 1e3
@@ -288,6 +279,24 @@ def spawn_command(args_list, n):
             "--master-port", str(port), os.path.abspath(__file__)] + list(args_list)
 
 
+def make_train_step(model, d64, dev):
+    """The reference's DQN update on one collated mini-batch as the product issues it (`DeepQ.train` with the fused
+    optimiser: trunk forward with dropout, float64 cost + gradient, trunk backward, [gradient all-reduce over the ranks,]
+    clamp + Adam): synthetic targets, one action node per graph."""
+    import tempfile
+    from drl_graph_exploration_amd.optim import FusedAdam
+    from drl_graph_exploration_amd.policy import DeepQ
+    dq = DeepQ("bench_train/", "GCN", data_root=tempfile.mkdtemp(prefix="drlgx_bench_"))
+    opt = FusedAdam(model.parameters(), lr=1e-5, grad_clamp=dq.max_grad_norm)
+    n = d64.x.shape[0]
+    last = torch.cat([torch.nonzero(d64.batch[1:] != d64.batch[:-1]).view(-1), torch.tensor([n - 1], device=dev)])  # last node of every graph
+    action = torch.zeros(n, dtype=torch.float64, device=dev)
+    action[last] = 1.0
+    y = torch.zeros(n, dtype=torch.float64, device=dev)
+    y[last] = torch.randn(last.numel(), dtype=torch.float64, device=dev)
+    return lambda: dq.train(d64, action, y, dev, model, opt)
+
+
 def train_allreduce_bench(eng, dev, dist, world, iters=20, env_steps_per_iter=8):
     """BASELINE.json configs[3]: the exchange step of the path.  Every rank runs the reference's DQN update on a 64-graph
     batch of its own environments (GCN forward + backward through the HIP kernels, ONE flat all-reduce of the 1 008 001
@@ -299,24 +308,14 @@ def train_allreduce_bench(eng, dev, dist, world, iters=20, env_steps_per_iter=8)
     torch.manual_seed(0)
     model = GCN().to(dev)
     broadcast_parameters(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-5)
     eng.restore(0)
     g = eng.graph()
     n64, e64 = int(g["node_off"][64]), int(g["edge_off"][64])
     d64 = GraphData(g["x"][:n64].clone(), g["edge_index"][:, :e64].clone(), g["edge_attr"][:e64].clone(), g["batch"][:n64].clone())
-    w = torch.randn(n64, 1, device=dev)
     odom = torch.tensor([STEP_ACTION] * N_ENVS, dtype=torch.float64, device=dev)
     n_param = sum(p.numel() for p in model.parameters())
     flat = torch.zeros(n_param, dtype=torch.float32, device=dev)
-
-    def train_step():
-        opt.zero_grad()
-        q = model(d64, 0.5, batch=d64.batch)
-        ((q * w) ** 2).sum().div(64).backward()
-        allreduce_gradients(model)
-        for p_ in model.parameters():
-            p_.grad.data.clamp_(-0.5, 0.5)
-        opt.step()
+    train_step = make_train_step(model, d64, dev)
 
     def bracket(fn, n):
         for _ in range(3):

@@ -1,0 +1,210 @@
+// Trainer-side kernels of the DQN update (scripts/policy.py:137-178 and :234-253): mini-batch collation of replay graphs
+// out of the device pool, the TD targets, the squared-error cost with its gradient, and the clamp + Adam step.
+// Everything here replaces a handful of tiny framework ops each (and, in the reference, a device -> host -> device round
+// trip per update: `readout_j1_batch.cpu()`, numpy target loop, `torch.tensor(y)`), so the whole update is a fixed
+// sequence of kernel launches with no host synchronisation.  All of it is HBM-bound byte / elementwise work: one pass
+// over the data, coalesced.
+#include <cmath>
+#include <cstdint>
+
+#include "drlgx_dev.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// torch_geometric DataLoader / Batch.from_data_list over graphs stored in a pool (policy.py:146-153): graph g of the
+// mini-batch is rows [node_start, +node_cnt) of pool_x and columns [edge_start, +edge_cnt) of pool_ei / pool_ea, with
+// node ids relative to its export (first id = loc).  Output = PyG batch: x, edge_index shifted by the cumulative node
+// counts, edge_attr, batch vector.  One workgroup per graph; its output offsets are the sums over the earlier graphs.
+// desc: int64 [5][G] = node_start, node_cnt, edge_start, edge_cnt, loc.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_replay_collate(int G, const int64_t *desc, const float *pool_x, int in_dim, const int64_t *pool_ei,
+                                                        int64_t pool_edges, const float *pool_ea, float *x_out, int64_t *ei_out,
+                                                        int64_t E_total, float *ea_out, int64_t *batch_out) {
+  __shared__ long long red[2][4];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  long long sn = 0, se = 0;
+  for (int j = tid; j < g; j += 256) {
+    sn += desc[(size_t)G + j];
+    se += desc[3 * (size_t)G + j];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sn += __shfl_down(sn, o);
+    se += __shfl_down(se, o);
+  }
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = sn;
+    red[1][tid >> 6] = se;
+  }
+  __syncthreads();
+  const long long node_off = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  const long long edge_off = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const long long n0 = desc[g], nn = desc[(size_t)G + g], e0 = desc[2 * (size_t)G + g], ne = desc[3 * (size_t)G + g],
+                  loc = desc[4 * (size_t)G + g];
+  const float *xs = pool_x + n0 * in_dim;
+  float *xd = x_out + node_off * in_dim;
+  for (long long i = tid; i < nn * in_dim; i += 256) xd[i] = xs[i];
+  for (long long i = tid; i < nn; i += 256) batch_out[node_off + i] = g;
+  const long long shift = node_off - loc;
+  for (long long j = tid; j < ne; j += 256) {
+    ei_out[edge_off + j] = pool_ei[e0 + j] + shift;
+    ei_out[E_total + edge_off + j] = pool_ei[pool_edges + e0 + j] + shift;
+    ea_out[edge_off + j] = pool_ea[e0 + j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TD targets (policy.py:154-175).  Sample i reads the target network's read-out over the window [lo_i, hi_i) of q1 (the
+// host resolves the reference's slicing rule into these bounds), takes its maximum in float32 like np.max over the
+// float32 read-out, and writes  a_batch[pos_i] = 1,  y_batch[pos_i] = r_i (+ gamma max_q unless terminal)  in float64 into
+// the zero-initialised vectors over the current-state nodes.  meta: int64 [4][B] = lo, hi, pos, terminal.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_dqn_targets(int B, const float *q1, const int64_t *meta, const double *r, double gamma, double *a_batch, double *y_batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const long long lo = meta[i], hi = meta[(size_t)B + i], pos = meta[2 * (size_t)B + i];
+  const bool term = meta[3 * (size_t)B + i] != 0;
+  double t = r[i];
+  if (!term) {
+    float m = -INFINITY;
+    for (long long k = lo; k < hi; ++k) m = fmaxf(m, q1[k]);
+    t = r[i] + gamma * (double)m;
+  }
+  a_batch[pos] = 1.0;
+  y_batch[pos] = t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DeepQ.cost (policy.py:234-239) and its gradient with respect to the read-out:
+//   loss = sum_i (pred_i * a_i - y_i)^2 / batch   in float64 (y / action are float64 in the reference, the float32
+//   read-out is promoted);  d_pred_i = float32( 2 (pred_i a_i - y_i) a_i / batch ).
+// One workgroup (N is the node count of a mini-batch, a few thousand).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_dqn_loss_grad(int N, const float *pred, const double *action, const double *y, double batch,
+                                                        double *loss_out, float *d_pred) {
+  __shared__ double red[16];
+  const int tid = threadIdx.x;
+  double acc = 0.0;
+  for (int i = tid; i < N; i += 1024) {
+    const double a = action[i];
+    const double e = (double)pred[i] * a - y[i];
+    acc += e * e;
+    d_pred[i] = (float)((2.0 * e) * (1.0 / batch) * a);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    loss_out[0] = s / batch;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// `param.grad.data.clamp_(-c, c)` for every parameter followed by torch.optim.Adam.step() (policy.py:250-253; Adam with
+// its defaults, no weight decay, no amsgrad), all tensors of the model in one launch.  The arithmetic follows torch's
+// single-tensor Adam in float32:  m <- m + (1 - b1)(g - m);  v <- b2 v + (1 - b2) g g;
+// p <- p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)   (the scalars are formed on the host in double).
+// ------------------------------------------------------------------------------------------------
+constexpr int kAdamMaxTensors = 8;
+struct AdamTensors {
+  float *p[kAdamMaxTensors];
+  const float *g[kAdamMaxTensors];
+  float *m[kAdamMaxTensors];
+  float *v[kAdamMaxTensors];
+  long long first_block[kAdamMaxTensors + 1];  // blocks of 1024 elements, prefix over the tensors
+  long long n[kAdamMaxTensors];
+  int count;
+};
+__global__ __launch_bounds__(256) void k_adam(AdamTensors T, float clamp, float b1w, float b2, float b2w, float neg_step, float bc2_sqrt,
+                                              float eps) {
+  const long long blk = blockIdx.x;
+  int t = 0;
+  while (t + 1 < T.count && blk >= T.first_block[t + 1]) ++t;
+  const long long base = (blk - T.first_block[t]) * 1024;
+  float *p = T.p[t], *m = T.m[t], *v = T.v[t];
+  const float *g = T.g[t];
+  const long long n = T.n[t];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long i = base + u * 256 + threadIdx.x;
+    if (i < n) {
+      float gi = g[i];
+      if (clamp > 0.f) gi = fminf(fmaxf(gi, -clamp), clamp);
+      const float mi = m[i] + b1w * (gi - m[i]);
+      const float vi = v[i] * b2 + b2w * gi * gi;
+      m[i] = mi;
+      v[i] = vi;
+      p[i] = p[i] + neg_step * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int drlgx_replay_collate(void *hip_stream, int n_graphs, const int64_t *desc_dev, const float *pool_x, int in_dim, const int64_t *pool_ei,
+                         int64_t pool_edges, const float *pool_ea, float *x_out, int64_t *ei_out, int64_t n_edges_total, float *ea_out,
+                         int64_t *batch_out) {
+  if (n_graphs <= 0 || !desc_dev || !pool_x || in_dim <= 0 || !pool_ei || !pool_ea || !x_out || !ei_out || !ea_out || !batch_out ||
+      n_edges_total < 0 || pool_edges < 0)
+    return DRLGX_E_INVALID;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  hipLaunchKernelGGL(k_replay_collate, dim3(n_graphs), dim3(256), 0, st, n_graphs, desc_dev, pool_x, in_dim, pool_ei, pool_edges, pool_ea,
+                     x_out, ei_out, n_edges_total, ea_out, batch_out);
+  return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
+}
+
+int drlgx_dqn_targets(void *hip_stream, int n_samples, const float *q1, const int64_t *meta_dev, const double *r_dev, double gamma,
+                      int64_t n_nodes_total, double *a_batch, double *y_batch) {
+  if (n_samples <= 0 || !q1 || !meta_dev || !r_dev || n_nodes_total <= 0 || !a_batch || !y_batch) return DRLGX_E_INVALID;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  if (hipMemsetAsync(a_batch, 0, (size_t)n_nodes_total * sizeof(double), st) != hipSuccess) return DRLGX_E_HIP;
+  if (hipMemsetAsync(y_batch, 0, (size_t)n_nodes_total * sizeof(double), st) != hipSuccess) return DRLGX_E_HIP;
+  hipLaunchKernelGGL(k_dqn_targets, dim3((n_samples + 63) / 64), dim3(64), 0, st, n_samples, q1, meta_dev, r_dev, gamma, a_batch, y_batch);
+  return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
+}
+
+int drlgx_dqn_loss_grad(void *hip_stream, int n_nodes, const float *pred, const double *action, const double *y, double batch,
+                        double *loss_out, float *d_pred) {
+  if (n_nodes <= 0 || !pred || !action || !y || !(batch > 0) || !loss_out || !d_pred) return DRLGX_E_INVALID;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  hipLaunchKernelGGL(k_dqn_loss_grad, dim3(1), dim3(1024), 0, st, n_nodes, pred, action, y, batch, loss_out, d_pred);
+  return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
+}
+
+int drlgx_adam_step(void *hip_stream, int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                    float *const *exp_avg_sq, const int64_t *sizes, double lr, double beta1, double beta2, double eps, int64_t step,
+                    double grad_clamp) {
+  if (n_tensors <= 0 || n_tensors > kAdamMaxTensors || !params || !grads || !exp_avg || !exp_avg_sq || !sizes || step <= 0)
+    return DRLGX_E_INVALID;
+  AdamTensors T;
+  T.count = n_tensors;
+  long long blocks = 0;
+  for (int t = 0; t < n_tensors; ++t) {
+    if (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t] || sizes[t] <= 0) return DRLGX_E_INVALID;
+    T.p[t] = params[t];
+    T.g[t] = grads[t];
+    T.m[t] = exp_avg[t];
+    T.v[t] = exp_avg_sq[t];
+    T.n[t] = sizes[t];
+    T.first_block[t] = blocks;
+    blocks += (sizes[t] + 1023) / 1024;
+  }
+  T.first_block[n_tensors] = blocks;
+  for (int t = n_tensors; t < kAdamMaxTensors; ++t) {
+    T.p[t] = nullptr; T.g[t] = nullptr; T.m[t] = nullptr; T.v[t] = nullptr; T.n[t] = 0;
+    T.first_block[t + 1] = blocks;
+  }
+  // torch/optim/adam.py (_single_tensor_adam): python-float scalars, float32 tensor arithmetic
+  const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+  const double step_size = lr / bc1, bc2_sqrt = std::sqrt(bc2);
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, st, T, (float)grad_clamp, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), (float)(-step_size), (float)bc2_sqrt, (float)eps);
+  return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
+}
+
+}  // extern "C"

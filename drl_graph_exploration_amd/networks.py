@@ -73,6 +73,33 @@ class _GCNTrunk(torch.autograd.Function):
         return None, None, None, dW1, db1, dW2, db2, dWf, dbf, None
 
 
+def gcn_forward_raw(x, edge_index, edge_attr, params, mask=None):
+    """The trunk without an autograd graph: `params` = (W1, b1, W2, b2, Wf, bf) fp32 HIP tensors.  Returns (out, saved);
+    `saved` is what `gcn_backward_raw` needs (the workspace holds AX / H1 / AH1 / H2 and both CSRs)."""
+    if not x.is_cuda:
+        raise _lib.DrlgxError("drlgx GCN kernels need HIP tensors (no CPU fallback)")
+    L = _lib.lib()
+    W1, b1, W2, b2, Wf, bf = (t.detach() for t in params)
+    N, in_dim = x.shape
+    E = edge_index.shape[1]
+    hidden, out_dim = W1.shape[1], Wf.shape[0]
+    ws = torch.empty(L.drlgx_gcn_workspace_bytes(N, E, hidden, out_dim), dtype=torch.uint8, device=x.device)
+    out = torch.empty(N, out_dim, dtype=torch.float32, device=x.device)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _lib.check(L.drlgx_gcn_forward(C.c_void_p(stream), N, E, in_dim, hidden, out_dim, _p(x), _p(edge_index), _p(edge_attr), _p(W1), _p(b1),
+                                   _p(W2), _p(b2), _p(Wf), _p(bf), _p(mask), _p(out), _p(ws)))
+    return out, (x, edge_index, edge_attr, W1, W2, Wf, mask, ws, (N, E, in_dim, hidden, out_dim))
+
+
+def gcn_backward_raw(saved, d_out, grads):
+    """Gradients of the six parameter tensors written (not accumulated) into `grads` = (dW1, db1, dW2, db2, dWf, dbf)."""
+    L = _lib.lib()
+    x, edge_index, edge_attr, W1, W2, Wf, mask, ws, (N, E, in_dim, hidden, out_dim) = saved
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _lib.check(L.drlgx_gcn_backward(C.c_void_p(stream), N, E, in_dim, hidden, out_dim, _p(x), _p(edge_index), _p(edge_attr), _p(W1), _p(W2),
+                                    _p(Wf), _p(mask), _p(d_out), *(_p(g) for g in grads), _p(ws)))
+
+
 def gcn_trunk(x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf, mask=None):
     return _GCNTrunk.apply(x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf, mask)
 
@@ -96,8 +123,7 @@ def _dropout_mask(n, hidden, p, device):
         return None
     if p >= 1.0:
         return torch.zeros(n, hidden, device=device)
-    keep = (torch.rand(n, hidden, device=device) >= p).float()
-    return keep / (1.0 - p)
+    return torch.empty(n, hidden, device=device).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
 
 
 class GCN(torch.nn.Module):
@@ -108,6 +134,10 @@ class GCN(torch.nn.Module):
         self.conv1 = GCNConvParams(5, 1000, improved=True)
         self.conv2 = GCNConvParams(1000, 1000, improved=True)
         self.fully_con1 = torch.nn.Linear(1000, 1)
+
+    def trunk_parameters(self):
+        """(W1, b1, W2, b2, Wf, bf) in the order of drlgx_gcn_forward / _backward."""
+        return (self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.fully_con1.weight, self.fully_con1.bias)
 
     def forward(self, data, prob, batch=None):
         x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
@@ -273,58 +303,60 @@ class ReplayPool(object):
         self.edge_off[slot] = np.asarray(g["edge_off_h"], dtype=np.int64)
         return slot
 
-    def collate(self, refs):
-        k = len(refs)
-        n0 = np.array([r.slot * self.cap_nodes + self.node_off[r.slot][r.env] for r in refs], dtype=np.int64)
-        nn = np.array([r.num_nodes for r in refs], dtype=np.int64)
-        e0 = np.array([r.slot * self.cap_edges + self.edge_off[r.slot][r.env] for r in refs], dtype=np.int64)
-        ne = np.array([self.edge_off[r.slot][r.env + 1] - self.edge_off[r.slot][r.env] for r in refs], dtype=np.int64)
-        loc = np.array([self.node_off[r.slot][r.env] for r in refs], dtype=np.int64)  # the graph's first node id inside its export
-        new_off = np.cumsum(nn) - nn
-        node_idx = np.repeat(n0 - new_off, nn) + np.arange(int(nn.sum()))
-        eoff = np.cumsum(ne) - ne
-        edge_idx = np.repeat(e0 - eoff, ne) + np.arange(int(ne.sum()))
-        shift = np.repeat(new_off - loc, ne)
-        batch = np.repeat(np.arange(k), nn)
+    @staticmethod
+    def descriptors(refs):
+        """Host side of a collation: int64 [5, k] = node start in the pool, node count, edge start in the pool, edge count,
+        first node id inside the export (drlgx_replay_collate's `desc`), plus the node / edge totals."""
+        d = np.array([(r.n0, r.nn, r.e0, r.ne, r.loc) for r in refs], dtype=np.int64).T.copy()
+        return d, int(d[1].sum()), int(d[3].sum())
+
+    def collate_from(self, desc_dev, k, n_nodes, n_edges):
+        """The PyG batch of `k` pooled graphs from their device descriptors: one kernel, no host synchronisation."""
         dev = self.device
-        ni, ei_, sh, bt = (torch.from_numpy(a).to(dev) for a in (node_idx, edge_idx, shift, batch))
-        return GraphData(self.X[ni], self.EI[:, ei_] + sh, self.EA[ei_], bt)
+        x = torch.empty(n_nodes, self.X.shape[1], dtype=torch.float32, device=dev)
+        ei = torch.empty(2, n_edges, dtype=torch.int64, device=dev)
+        ea = torch.empty(n_edges, dtype=torch.float32, device=dev)
+        bt = torch.empty(n_nodes, dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib().drlgx_replay_collate(C.c_void_p(stream), k, _p(desc_dev), _p(self.X), self.X.shape[1], _p(self.EI),
+                                                   self.EI.shape[1], _p(self.EA), _p(x), _p(ei), n_edges, _p(ea), _p(bt)))
+        return GraphData(x, ei, ea, bt)
+
+    def collate(self, refs):
+        d, n_nodes, n_edges = self.descriptors(refs)
+        return self.collate_from(torch.from_numpy(d).to(self.device), len(refs), n_nodes, n_edges)
 
 
 class PoolRef(object):
-    """One graph of a `ReplayPool` (what a replay transition holds); same duck type as GraphData."""
+    """One graph of a `ReplayPool` (what a replay transition holds); same duck type as GraphData.  The graph's ranges in
+    the pooled tensors are resolved once, at construction."""
 
-    __slots__ = ("pool", "slot", "env", "batch")
+    __slots__ = ("pool", "slot", "env", "batch", "n0", "nn", "e0", "ne", "loc")
 
     def __init__(self, pool, slot, env):
         self.pool, self.slot, self.env, self.batch = pool, int(slot), int(env), None
+        no, eo = pool.node_off[self.slot], pool.edge_off[self.slot]
+        self.loc = int(no[self.env])
+        self.n0 = self.slot * pool.cap_nodes + self.loc
+        self.nn = int(no[self.env + 1]) - self.loc
+        self.e0 = self.slot * pool.cap_edges + int(eo[self.env])
+        self.ne = int(eo[self.env + 1] - eo[self.env])
 
     @property
     def num_nodes(self):
-        o = self.pool.node_off[self.slot]
-        return int(o[self.env + 1] - o[self.env])
-
-    def _ranges(self):
-        p = self.pool
-        n0 = self.slot * p.cap_nodes + int(p.node_off[self.slot][self.env])
-        e0 = self.slot * p.cap_edges + int(p.edge_off[self.slot][self.env])
-        e1 = self.slot * p.cap_edges + int(p.edge_off[self.slot][self.env + 1])
-        return n0, n0 + self.num_nodes, e0, e1
+        return self.nn
 
     @property
     def x(self):
-        n0, n1, _, _ = self._ranges()
-        return self.pool.X[n0:n1]
+        return self.pool.X[self.n0:self.n0 + self.nn]
 
     @property
     def edge_attr(self):
-        _, _, e0, e1 = self._ranges()
-        return self.pool.EA[e0:e1]
+        return self.pool.EA[self.e0:self.e0 + self.ne]
 
     @property
     def edge_index(self):
-        _, _, e0, e1 = self._ranges()
-        return self.pool.EI[:, e0:e1] - int(self.pool.node_off[self.slot][self.env])
+        return self.pool.EI[:, self.e0:self.e0 + self.ne] - self.loc
 
     def to(self, device):
         return GraphData(self.x, self.edge_index, self.edge_attr).to(device)

@@ -20,7 +20,12 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .networks import GraphData, GraphSlice, PoolRef, ReplayPool
+import ctypes as C
+
+from . import _lib
+from . import networks as NW
+from .networks import GCN, GraphData, GraphSlice, PoolRef, ReplayPool
+from .optim import FusedAdam
 from .vecenv import VecExplorationEnv
 
 
@@ -144,6 +149,30 @@ class DeepQ(object):
     def train(self, data, action, y, device, model, optimizer):
         model.train()
         data = data.to(device)
+        if type(model) is GCN and isinstance(optimizer, FusedAdam) and data.x.is_cuda:
+            # the same update as below as a fixed sequence of HIP launches, no autograd graph: trunk forward, cost and its
+            # gradient (drlgx_dqn_loss_grad), trunk backward straight into the gradient buffers, [all-reduce,] clamp + Adam
+            # in one kernel (drlgx_adam_step)
+            x = data.x
+            n = x.shape[0]
+            mask = NW._dropout_mask(n, 1000, 0.5, x.device)
+            out, saved = NW.gcn_forward_raw(x, data.edge_index, data.edge_attr, model.trunk_parameters(), mask)
+            y = torch.as_tensor(y, dtype=torch.float64, device=device)
+            action = torch.as_tensor(action, dtype=torch.float64, device=device)
+            loss = torch.empty(1, dtype=torch.float64, device=x.device)
+            d_out = torch.empty(n, 1, dtype=torch.float32, device=x.device)
+            vp = C.c_void_p
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(_lib.lib().drlgx_dqn_loss_grad(vp(stream), n, vp(out.data_ptr()), vp(action.data_ptr()), vp(y.data_ptr()),
+                                                      float(self.BATCH), vp(loss.data_ptr()), vp(d_out.data_ptr())))
+            self._loss_t = loss
+            NW.gcn_backward_raw(saved, d_out, optimizer.grads())
+            allreduce_gradients(model)
+            if optimizer.grad_clamp != self.max_grad_norm:
+                for param in model.parameters():
+                    param.grad.data.clamp_(-self.max_grad_norm, self.max_grad_norm)
+            optimizer.step()
+            return
         optimizer.zero_grad()
         out = model(data, 0.5, batch=data.batch)
         # the reference builds y / action as numpy float64 and `torch.tensor(y)` keeps that dtype: the product with
@@ -174,45 +203,95 @@ class DeepQ(object):
         CURRENT-state node counts n_i, although q1 is laid out by the next-state counts - so the window drifts away from
         sample i's own next-state frontier nodes whenever graphs grew during the step (quirks are
         restated, not fixed).  `"aligned"` reads the last fro1_i nodes of sample i's own next-state graph."""
-        n_j = torch.tensor([d[0].num_nodes for d in minibatch], device=device)
-        n_j1 = torch.tensor([d[3].num_nodes for d in minibatch], device=device)
-        fro1 = torch.tensor([d[5] for d in minibatch], device=device)
-        a_loc = torch.tensor([d[1] for d in minibatch], device=device)
-        r = torch.tensor([d[2] for d in minibatch], dtype=torch.float64, device=device)
-        term = torch.tensor([bool(d[4]) for d in minibatch], device=device)
-        off_j = torch.cumsum(n_j, 0) - n_j
-        n1_tot = int(q1.numel())
+        meta, r, n_tot = self._td_meta(minibatch, int(q1.numel()))
+        return self._td_apply(q1, torch.from_numpy(meta).to(device), torch.from_numpy(r).to(device), len(minibatch), n_tot,
+                              meta if not q1.is_cuda else None, r)
+
+    def _td_meta(self, minibatch, n1_tot):
+        """Host part of `td_targets`: int64 [4, B] = lo, hi (the read-out window of every sample in the collated next-state
+        read-out), pos (the sample's action node among the collated current-state nodes), terminal; float64 rewards [B];
+        the current-state node total.  Raises like numpy would on an empty window."""
+        n_j = np.array([d[0].num_nodes for d in minibatch], dtype=np.int64)
+        fro1 = np.array([d[5] for d in minibatch], dtype=np.int64)
+        a_loc = np.array([d[1] for d in minibatch], dtype=np.int64)
+        term = np.array([bool(d[4]) for d in minibatch])
+        off_j = np.cumsum(n_j) - n_j
         if self.target_window == "reference":
-            lo = off_j.clamp(max=n1_tot)                 # python slicing clips to the array
-            hi = (off_j + n_j).clamp(max=n1_tot)
+            lo = np.minimum(off_j, n1_tot)               # python slicing clips to the array
+            hi = np.minimum(off_j + n_j, n1_tot)
         else:
-            hi = torch.cumsum(n_j1, 0)
+            n_j1 = np.array([d[3].num_nodes for d in minibatch], dtype=np.int64)
+            hi = np.cumsum(n_j1)
             lo = hi - n_j1
-        lo = torch.maximum(lo, hi - fro1)                # [-fro1:] of the slice
+        lo = np.maximum(lo, hi - fro1)                   # [-fro1:] of the slice
         if bool(((hi <= lo) & ~term).any()):
             raise ValueError("zero-size array to reduction operation maximum which has no identity")  # as numpy would
-        pos = torch.arange(n1_tot, device=device)
-        # sample owning each position of q1 under the chosen windows (windows of different samples do not overlap)
-        seg = torch.searchsorted(hi, pos, right=True).clamp(max=len(minibatch) - 1)
-        inside = (pos >= lo[seg]) & (pos < hi[seg])
-        max_q = torch.full((len(minibatch),), -float("inf"), dtype=q1.dtype, device=device).scatter_reduce(
-            0, seg[inside], q1[inside], reduce="amax")
-        target = torch.where(term, r, r + self.GAMMA * max_q.to(torch.float64))
-        N = int(n_j.sum())
-        a_batch = torch.zeros(N, dtype=torch.float64, device=device)
-        y_batch = torch.zeros(N, dtype=torch.float64, device=device)
-        a_batch[off_j + a_loc] = 1.0
-        y_batch[off_j + a_loc] = target
+        meta = np.stack([lo, hi, off_j + a_loc, term.astype(np.int64)])
+        return meta, np.array([d[2] for d in minibatch], dtype=np.float64), int(n_j.sum())
+
+    def _td_apply(self, q1, meta_dev, r_dev, B, n_tot, meta_host=None, r_host=None):
+        """(a_batch, y_batch) from the read-out and the windows: drlgx_dqn_targets on the device; plain tensor ops for
+        host tensors (the host-logic tests)."""
+        if q1.is_cuda:
+            a_batch = torch.empty(n_tot, dtype=torch.float64, device=q1.device)
+            y_batch = torch.empty(n_tot, dtype=torch.float64, device=q1.device)
+            vp = C.c_void_p
+            stream = torch.cuda.current_stream(q1.device).cuda_stream
+            q1 = q1.contiguous()
+            _lib.check(_lib.lib().drlgx_dqn_targets(vp(stream), B, vp(q1.data_ptr()), vp(meta_dev.data_ptr()), vp(r_dev.data_ptr()),
+                                                    float(self.GAMMA), n_tot, vp(a_batch.data_ptr()), vp(y_batch.data_ptr())))
+            return a_batch, y_batch
+        a_batch = torch.zeros(n_tot, dtype=torch.float64)
+        y_batch = torch.zeros(n_tot, dtype=torch.float64)
+        for i in range(B):
+            lo, hi, pos, term = (int(v) for v in meta_host[:, i])
+            t = float(r_host[i])
+            if not term:
+                t = t + self.GAMMA * float(q1[lo:hi].max())  # float32 maximum, float64 arithmetic (policy.py:171-172)
+            a_batch[pos] = 1.0
+            y_batch[pos] = t
         return a_batch, y_batch
 
-    def _train_minibatch(self, device, policy_net, target_net, optimizer):
-        minibatch = random.sample(self.buffer, self.BATCH)
-        s_j = GraphData.collate([d[0] for d in minibatch])
-        s_j1 = GraphData.collate([d[3] for d in minibatch])
-        with torch.no_grad():
-            q1 = self.test(s_j1, 0.0, device, target_net).view(-1)
-        a_batch, y_batch = self.td_targets(minibatch, q1, device)
+    def _train_minibatch(self, device, policy_net, target_net, optimizer, prepared=None):
+        if prepared is None:
+            minibatch = random.sample(self.buffer, self.BATCH)
+            s_j = GraphData.collate([d[0] for d in minibatch])
+            s_j1 = GraphData.collate([d[3] for d in minibatch])
+            with torch.no_grad():
+                q1 = self.test(s_j1, 0.0, device, target_net).view(-1)
+            a_batch, y_batch = self.td_targets(minibatch, q1, device)
+        else:  # everything the host contributes was uploaded in one piece by _prepare_updates
+            pool, B = prepared["pool"], self.BATCH
+            s_j = pool.collate_from(prepared["desc_j"], B, prepared["N"], prepared["E"])
+            s_j1 = pool.collate_from(prepared["desc_j1"], B, prepared["N1"], prepared["E1"])
+            with torch.no_grad():
+                q1 = self.test(s_j1, 0.0, device, target_net).view(-1)
+            a_batch, y_batch = self._td_apply(q1, prepared["meta"], prepared["r"], B, prepared["N"])
         self.train(s_j, a_batch, y_batch, device, policy_net, optimizer)
+
+    def _prepare_updates(self, n_upd, device):
+        """Sample `n_upd` mini-batches (the buffer does not change between them, so sampling them up front draws the same
+        transitions as sampling before every update) and upload everything the host contributes to the updates - the
+        collation descriptors of s_j / s_j1, the TD-target windows, the rewards - as ONE int64 and ONE float64 tensor.
+        Returns a list of `prepared` dicts for `_train_minibatch`, or None when the buffer is not pool-backed."""
+        batches = [random.sample(self.buffer, self.BATCH) for _ in range(n_upd)]
+        first = batches[0][0][0]
+        if not isinstance(first, PoolRef):
+            return None, batches
+        pool, B = first.pool, self.BATCH
+        I = np.empty((n_upd, 14, B), dtype=np.int64)
+        R = np.empty((n_upd, B), dtype=np.float64)
+        tot = []
+        for u, mb in enumerate(batches):
+            if not all(isinstance(d[0], PoolRef) and isinstance(d[3], PoolRef) and d[0].pool is pool and d[3].pool is pool for d in mb):
+                return None, batches
+            I[u, 0:5], n, e = ReplayPool.descriptors([d[0] for d in mb])
+            I[u, 5:10], n1, e1 = ReplayPool.descriptors([d[3] for d in mb])
+            I[u, 10:14], R[u], _ = self._td_meta(mb, n1)
+            tot.append((n, e, n1, e1))
+        I_dev, R_dev = torch.from_numpy(I).to(device), torch.from_numpy(R).to(device)
+        return [dict(pool=pool, desc_j=I_dev[u, 0:5], desc_j1=I_dev[u, 5:10], meta=I_dev[u, 10:14], r=R_dev[u], N=tot[u][0],
+                     E=tot[u][1], N1=tot[u][2], E1=tot[u][3]) for u in range(n_upd)], batches
 
     # ------------------------------------------------------------------ main loop (policy.py:60-208)
     def running(self, model, modelTarget, test=False, n_envs=64, env=None, log_every=0):
@@ -244,7 +323,8 @@ class DeepQ(object):
                     d.pool.ref[d.slot] -= 1
         broadcast_parameters(policy_net)
         broadcast_parameters(target_net)
-        optimizer = torch.optim.Adam(policy_net.parameters(), lr=1e-5)
+        # torch.optim.Adam(policy_net.parameters(), lr=1e-5) of the reference with the gradient clamp fused in front
+        optimizer = FusedAdam(policy_net.parameters(), lr=1e-5, grad_clamp=self.max_grad_norm)
         temp_reward_data, temp_loss_data, rows = [], [], []
         recent = deque(self.total_reward[-1000:].tolist(), maxlen=1000)  # average reward window (policy.py:201-203)
 
@@ -312,8 +392,9 @@ class DeepQ(object):
                 n_upd = n_envs if self.updates_per_vector_step is None else int(self.updates_per_vector_step)
                 if self.step_t // self.TARGET_UPDATE > (self.step_t - n_envs) // self.TARGET_UPDATE:
                     target_net.load_state_dict(policy_net.state_dict())
-                for _ in range(n_upd):
-                    self._train_minibatch(device, policy_net, target_net, optimizer)
+                prepared, _ = self._prepare_updates(n_upd, device)
+                for u in range(n_upd):
+                    self._train_minibatch(device, policy_net, target_net, optimizer, None if prepared is None else prepared[u])
                 temp_loss_data.append([self.step_t, self.temp_loss])
 
             if log_every and (self.step_t // n_envs) % log_every == 0:

@@ -270,6 +270,33 @@ int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, i
                        const float *W2, const float *Wf, const float *dropout_mask, const float *d_out,
                        float *dW1, float *db1, float *dW2, float *db2, float *dWf, float *dbf, void *ws_dev);
 
+/* ---- DQN update (scripts/policy.py:137-178, :234-253): the pieces between the two GCN calls ---------------- */
+
+/* Mini-batch collation of replay graphs held in a device pool = torch_geometric DataLoader(s_j_batch, batch_size=BATCH)
+ * (scripts/policy.py:146-153): graph g is rows [node_start, +node_cnt) of pool_x ([rows][in_dim] f32) and columns
+ * [edge_start, +edge_cnt) of pool_ei ([2][pool_edges] i64) / pool_ea, its node ids start at loc.  desc_dev int64
+ * [5][n_graphs] = node_start, node_cnt, edge_start, edge_cnt, loc.  Outputs (DEVICE, sized by the caller from the counts):
+ * x_out [N][in_dim], ei_out [2][n_edges_total] (ids shifted by the cumulative node counts), ea_out, batch_out [N]. */
+int drlgx_replay_collate(void *hip_stream, int n_graphs, const int64_t *desc_dev, const float *pool_x, int in_dim,
+                         const int64_t *pool_ei, int64_t pool_edges, const float *pool_ea, float *x_out, int64_t *ei_out,
+                         int64_t n_edges_total, float *ea_out, int64_t *batch_out);
+/* TD targets, scripts/policy.py:154-175: sample i takes max(q1[lo_i:hi_i]) (float32, the target network's read-out over
+ * the collated next states; the caller resolves the reference's slicing into [lo, hi)), and
+ * a_batch[pos_i] = 1, y_batch[pos_i] = r_i + gamma max  (r_i alone when terminal_i) in float64; both vectors
+ * [n_nodes_total] are zeroed first.  meta_dev int64 [4][n_samples] = lo, hi, pos, terminal; r_dev double [n_samples]. */
+int drlgx_dqn_targets(void *hip_stream, int n_samples, const float *q1, const int64_t *meta_dev, const double *r_dev,
+                      double gamma, int64_t n_nodes_total, double *a_batch, double *y_batch);
+/* DeepQ.cost (scripts/policy.py:234-239) and d(cost)/d(pred): loss_out[0] = sum (pred a - y)^2 / batch (float64),
+ * d_pred float32 [n_nodes] - what loss.backward() hands to the network (scripts/policy.py:249). */
+int drlgx_dqn_loss_grad(void *hip_stream, int n_nodes, const float *pred, const double *action, const double *y,
+                        double batch, double *loss_out, float *d_pred);
+/* `param.grad.data.clamp_(-c, c)` + torch.optim.Adam.step() (scripts/policy.py:250-253; lr as given, no weight decay /
+ * amsgrad) for up to 8 fp32 tensors in one launch.  HOST arrays of DEVICE pointers; step = 1 for the first update;
+ * grad_clamp <= 0 disables the clamp. */
+int drlgx_adam_step(void *hip_stream, int n_tensors, float *const *params, const float *const *grads,
+                    float *const *exp_avg, float *const *exp_avg_sq, const int64_t *sizes, double lr, double beta1,
+                    double beta2, double eps, int64_t step, double grad_clamp);
+
 #ifdef __cplusplus
 }
 #endif

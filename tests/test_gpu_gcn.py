@@ -264,6 +264,98 @@ def test_dqn_minibatch_matches_float64_restatement(monkeypatch, tmp_path):
         assert float((step - rstep).abs().max()) < 2e-2 * 1e-3 + 1e-9, k
 
 
+def test_fused_dqn_update_equals_the_framework_path(monkeypatch, tmp_path):
+    """The DQN update as `DeepQ.running` issues it - mini-batches collated out of the device replay pool by
+    drlgx_replay_collate, TD targets by drlgx_dqn_targets, cost + gradient by drlgx_dqn_loss_grad, the trunk called without
+    an autograd graph, clamp + Adam in drlgx_adam_step - against the same three updates through the framework path (generic
+    collate, tensor-op targets on the host copy, autograd, element-wise clamp, torch.optim.Adam): targets and collated
+    batches bit-equal, losses and parameters after every step within float32 round-off of the update."""
+    import copy
+    import random
+    import drl_graph_exploration_amd.networks as NW
+    from drl_graph_exploration_amd.networks import GCN, GraphData, PoolRef, ReplayPool
+    from drl_graph_exploration_amd.optim import FusedAdam
+    from drl_graph_exploration_amd.policy import DeepQ
+    dev = torch.device("cuda", 0)
+    B, n_exports, n_env = 8, 3, 6
+    gen = torch.Generator().manual_seed(3)
+    pool = ReplayPool(dev, n_exports + 1, 512, 4096)
+    exports = []
+    for k in range(n_exports):  # batched exports like Engine.graph: n_env graphs each, host offsets beside
+        x, ei, ea, bt = random_batch(n_env, 300 + k, dev, nmin=10 if k == 0 else 18, nmax=18 if k == 0 else 28)  # graphs grow
+        cnt = torch.bincount(bt, minlength=n_env).cpu().numpy()
+        node_off = np.concatenate([[0], np.cumsum(cnt)])
+        ecnt = torch.bincount(bt[ei[0]], minlength=n_env).cpu().numpy()
+        edge_off = np.concatenate([[0], np.cumsum(ecnt)])
+        g = {"x": x, "edge_index": ei, "edge_attr": ea, "node_off_h": node_off, "edge_off_h": edge_off}
+        exports.append((pool.put(g), g))
+    plain, pooled = [], []
+    for i in range(2 * B):
+        (s0, g0), (s1, g1) = exports[0], exports[1 + i % 2]
+        e = i % n_env
+        r0, r1 = PoolRef(pool, s0, e), PoolRef(pool, s1, e)
+        fro1 = 1 + int(torch.randint(0, 3, (1,), generator=gen))
+        a = r0.num_nodes - 1 - int(torch.randint(0, 3, (1,), generator=gen))
+        rew, term = float(torch.randn(1, generator=gen)), i % 4 == 0
+        pooled.append((r0, a, rew, r1, term, fro1))
+        plain.append((GraphData(r0.x.clone(), r0.edge_index.clone(), r0.edge_attr.clone()), a, rew,
+                      GraphData(r1.x.clone(), r1.edge_index.clone(), r1.edge_attr.clone()), term, fro1))
+    # collation out of the pool = the generic concatenation
+    cp, cg = GraphData.collate([t[0] for t in pooled[:B]]), GraphData.collate([t[0] for t in plain[:B]])
+    for a_, b_ in ((cp.x, cg.x), (cp.edge_index, cg.edge_index), (cp.edge_attr, cg.edge_attr), (cp.batch, cg.batch)):
+        assert torch.equal(a_, b_)
+    torch.manual_seed(5)
+    pol_a = GCN().to(dev)
+    with torch.no_grad():
+        for b_ in (pol_a.conv1.bias, pol_a.conv2.bias, pol_a.fully_con1.bias):
+            b_.normal_(0, 0.05)
+    pol_b, tgt = copy.deepcopy(pol_a), copy.deepcopy(pol_a)
+    masks = {}
+
+    def fixed_mask(n, hidden, p, device):  # the same Bernoulli(0.5) mask for both paths (keyed by the batch size)
+        if p <= 0:
+            return None
+        if n not in masks:
+            masks[n] = (torch.rand(n, hidden, device=device, generator=torch.Generator(device=device).manual_seed(n)) >= 0.5).float() * 2.0
+        return masks[n]
+    monkeypatch.setattr(NW, "_dropout_mask", fixed_mask)
+    dq_a, dq_b = DeepQ("a/", "GCN", data_root=str(tmp_path)), DeepQ("b/", "GCN", data_root=str(tmp_path))
+    for dq, buf in ((dq_a, pooled), (dq_b, plain)):
+        dq.BATCH = B
+        dq.buffer.extend(buf)
+    order = [[(3 * u + 5 * j) % (2 * B) for j in range(B)] for u in range(3)]
+    opt_a = FusedAdam(pol_a.parameters(), lr=1e-3, grad_clamp=dq_a.max_grad_norm)
+    opt_b = torch.optim.Adam(pol_b.parameters(), lr=1e-3)
+    it = iter(order)
+    monkeypatch.setattr(random, "sample", lambda buf, k: [buf[i] for i in next(it)])
+    prepared, _ = dq_a._prepare_updates(3, dev)
+    assert prepared is not None
+    it = iter(order)
+    spy = {}
+    orig = dq_b.train
+
+    def spy_train(data, action, y, device, model, optimizer):
+        spy["y"] = y.clone()
+        return orig(data, action, y, device, model, optimizer)
+    dq_b.train = spy_train
+    orig_a = dq_a.train
+
+    def spy_train_a(data, action, y, device, model, optimizer):
+        spy["ya"], spy["aa"] = y.clone(), action.clone()
+        return orig_a(data, action, y, device, model, optimizer)
+    dq_a.train = spy_train_a
+    for u in range(3):
+        dq_a._train_minibatch(dev, pol_a, tgt, opt_a, prepared[u])
+        dq_b._train_minibatch(dev, pol_b, tgt, opt_b)
+        assert torch.equal(spy["ya"], spy["y"])  # same read-out, same windows: bit-equal float64 targets
+        assert float(spy["aa"].sum()) == B
+        assert dq_a.temp_loss == pytest.approx(dq_b.temp_loss, rel=1e-5)
+        for (k, va), vb in zip(pol_a.state_dict().items(), pol_b.state_dict().values()):
+            # one Adam step moves a parameter by at most ~lr: the two paths must agree to a small fraction of that
+            assert float((va - vb).abs().max()) < 2e-2 * 1e-3 * (u + 1), (u, k)
+    assert opt_a.step_count == 3
+
+
 def test_explicit_self_loops_keep_their_weight():
     """PyG add_remaining_self_loops: a node with an explicit self loop keeps that weight instead of the fill value 2
     (gcn_ref.gcn_norm does the same); edges pointing outside the graph are ignored instead of read out of bounds."""
