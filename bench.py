@@ -168,7 +168,7 @@ def policy_bench(eng, dev, iters=10):
     first = torch.cumsum(nfr, 0) - nfr
     fidx = torch.arange(cand_env.numel(), device=dev) - first[cand_env.long()]
     goals = g["frontier_xy"][cand_env.long(), fidx].contiguous()
-    data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"])
+    data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"], g["node_off"], g["edge_off"], g["max_graph_edges"])
     out["graph_nodes"], out["graph_edges"], out["candidates"] = N, E, int(cand_env.numel())
     out["graph_export_ms"] = timed(lambda: eng.graph()) * 1e3
     acts, nact = eng.line_plan(cand_env, goals)
@@ -185,7 +185,7 @@ def policy_bench(eng, dev, iters=10):
     # train step: 64-graph minibatch (the first 64 envs' graphs)
     n64 = int(g["node_off"][64])
     e64 = int(g["edge_off"][64])
-    d64 = GraphData(g["x"][:n64], g["edge_index"][:, :e64], g["edge_attr"][:e64], g["batch"][:n64])
+    d64 = GraphData(g["x"][:n64], g["edge_index"][:, :e64], g["edge_attr"][:e64], g["batch"][:n64], g["node_off"][:65], g["edge_off"][:65], g["max_graph_edges"])
     train_step = make_train_step(model, d64, dev)
     t_t = timed(train_step)
     flops_t = 3 * (2.0 * n64 * (5 * 1000 + 1000 * 1000 + 1000)) + 2.0 * 4 * (e64 + n64) * 1000
@@ -311,7 +311,8 @@ def train_allreduce_bench(eng, dev, dist, world, iters=20, env_steps_per_iter=8)
     eng.restore(0)
     g = eng.graph()
     n64, e64 = int(g["node_off"][64]), int(g["edge_off"][64])
-    d64 = GraphData(g["x"][:n64].clone(), g["edge_index"][:, :e64].clone(), g["edge_attr"][:e64].clone(), g["batch"][:n64].clone())
+    d64 = GraphData(g["x"][:n64].clone(), g["edge_index"][:, :e64].clone(), g["edge_attr"][:e64].clone(), g["batch"][:n64].clone(),
+                    g["node_off"][:65].clone(), g["edge_off"][:65].clone(), g["max_graph_edges"])
     odom = torch.tensor([STEP_ACTION] * N_ENVS, dtype=torch.float64, device=dev)
     n_param = sum(p.numel() for p in model.parameters())
     flat = torch.zeros(n_param, dtype=torch.float32, device=dev)

@@ -139,7 +139,7 @@ __global__ void k_degree_sum(int N, const float *ew, const int *ptr_src, const i
 // dis = deg^-1/2 (inf -> 0).
 __global__ void k_csr_finish(int N, int E, const int64_t *ei, const float *ew, const float *deg, const int *ptr_dst,
                              const int *eid_dst, int *nbr_dst, float *wn_dst, const int *ptr_src, const int *eid_src, int *nbr_src,
-                             float *wn_src) {
+                             float *wn_src, int *end_dst, int *end_src) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= 2 * N) return;
   const bool by_dst = n < N;
@@ -147,6 +147,7 @@ __global__ void k_csr_finish(int N, int E, const int64_t *ei, const float *ew, c
   int *nbr = by_dst ? nbr_dst : nbr_src;
   float *wn = by_dst ? wn_dst : wn_src;
   if (!by_dst) n -= N;
+  (by_dst ? end_dst : end_src)[n] = ptr[n + 1];
   for (int i = ptr[n]; i < ptr[n + 1]; ++i) {
     const int e = eid[i];
     const int r = (int)ei[e], c = (int)ei[(size_t)E + e];
@@ -157,10 +158,112 @@ __global__ void k_csr_finish(int N, int E, const int64_t *ei, const float *ew, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// Both CSRs, the degrees and the normalised weights of a BATCH of small graphs in one launch: one workgroup per graph
+// (a PyG batch / drlgx_graph export: graph g owns nodes [node_off[g], node_off[g+1]) and edges [edge_off[g],
+// edge_off[g+1]), every edge connects two of its nodes).  The graph's edges are sorted in LDS by (source node, edge id)
+// and by (destination node, edge id) - one 32-bit key each, two bitonic sorts run stage by stage together -, which IS
+// the CSR order of the generic build (rows by node, entries in edge order): the same rows, bit for bit, without its
+// eight launches (k_degree .. k_csr_finish are dominated by launch latency at these sizes).
+// Row r of graph g starts at edge_off[g] + (position of its first key): rows are contiguous inside a graph; self loops
+// and ignored edges sort to the end and leave unused slots there, hence explicit row ends.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCsrKeyShift = 14;               // key = local node << 14 | local edge id
+constexpr int kCsrMaxEdges = 1 << kCsrKeyShift;  // per graph (16 384; 2 x 64 KB of keys in LDS at that size)
+constexpr uint32_t kCsrNoKey = 0xffffffffu;
+
+__global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, const int64_t *ei, const float *ew, const int *node_off,
+                                                    const int *edge_off, float *deg, float *selfw_out, int *ptr_dst, int *end_dst,
+                                                    int *nbr_dst, float *wn_dst, int *ptr_src, int *end_src, int *nbr_src, float *wn_src) {
+  extern __shared__ uint32_t s_keys[];  // [2][P2]: by source, by destination
+  uint32_t *ks = s_keys, *kd = s_keys + P2;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int n0 = node_off[g], n1 = node_off[g + 1], e0 = edge_off[g];
+  const int ng = n1 - n0, eg = min(edge_off[g + 1] - e0, P2);  // (the caller promised eg <= P2)
+  for (int m = tid; m < ng; m += 256) selfw_out[n0 + m] = 2.0f;  // add_remaining_self_loops(fill_value = 2)
+  __syncthreads();
+  for (int j = tid; j < P2; j += 256) {
+    uint32_t a = kCsrNoKey, b = kCsrNoKey;
+    if (j < eg) {
+      const int64_t r = ei[e0 + j], c = ei[(size_t)E + e0 + j];
+      if (r >= n0 && r < n1 && c >= n0 && c < n1) {  // an edge with an endpoint outside the graph is ignored
+        if (r == c) {
+          selfw_out[r] = ew[e0 + j];  // an explicit self loop keeps its weight as the node's self term
+        } else {
+          a = ((uint32_t)(r - n0) << kCsrKeyShift) | (uint32_t)j;
+          b = ((uint32_t)(c - n0) << kCsrKeyShift) | (uint32_t)j;
+        }
+      }
+    }
+    ks[j] = a;
+    kd[j] = b;
+  }
+  __syncthreads();
+  // bitonic sort, ascending, both key arrays in the same stages
+  for (int k = 2; k <= P2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (P2 >> 1); t += 256) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), q = i | j;
+        const bool up = (i & k) == 0;
+        const uint32_t a0 = ks[i], a1 = ks[q], b0 = kd[i], b1 = kd[q];
+        if ((a0 > a1) == up) {
+          ks[i] = a1;
+          ks[q] = a0;
+        }
+        if ((b0 > b1) == up) {
+          kd[i] = b1;
+          kd[q] = b0;
+        }
+      }
+      __syncthreads();
+    }
+  // rows = key ranges; weighted degree = the by-source row summed in edge order, then the self term
+  auto lower = [&](const uint32_t *keys, uint32_t v) {
+    int lo = 0, hi = P2;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (keys[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  for (int m = tid; m < ng; m += 256) {
+    const uint32_t v0 = (uint32_t)m << kCsrKeyShift, v1 = (uint32_t)(m + 1) << kCsrKeyShift;
+    const int s0 = lower(ks, v0), s1 = lower(ks, v1), d0 = lower(kd, v0), d1 = lower(kd, v1);
+    const int n = n0 + m;
+    ptr_src[n] = e0 + s0;
+    end_src[n] = e0 + s1;
+    ptr_dst[n] = e0 + d0;
+    end_dst[n] = e0 + d1;
+    float dsum = 0.f;
+    for (int i = s0; i < s1; ++i) dsum += ew[e0 + (ks[i] & (kCsrMaxEdges - 1))];
+    deg[n] = dsum + selfw_out[n];
+  }
+  __threadfence_block();  // deg[] of the whole graph is read below
+  __syncthreads();
+  // entries: (neighbour, deg^-1/2[row] w deg^-1/2[col]), one thread per sorted position
+  for (int i = tid; i < eg; i += 256) {
+    const uint32_t a = ks[i], b = kd[i];
+    if (a != kCsrNoKey) {
+      const int j = (int)(a & (kCsrMaxEdges - 1));
+      const int r = n0 + (int)(a >> kCsrKeyShift), c = (int)ei[(size_t)E + e0 + j];
+      const float dr = deg[r] > 0 ? 1.0f / sqrtf(deg[r]) : 0.0f, dc = deg[c] > 0 ? 1.0f / sqrtf(deg[c]) : 0.0f;
+      nbr_src[e0 + i] = c;
+      wn_src[e0 + i] = dr * ew[e0 + j] * dc;
+    }
+    if (b != kCsrNoKey) {
+      const int j = (int)(b & (kCsrMaxEdges - 1));
+      const int c = n0 + (int)(b >> kCsrKeyShift), r = (int)ei[e0 + j];
+      const float dr = deg[r] > 0 ? 1.0f / sqrtf(deg[r]) : 0.0f, dc = deg[c] > 0 ? 1.0f / sqrtf(deg[c]) : 0.0f;
+      nbr_dst[e0 + i] = r;
+      wn_dst[e0 + i] = dr * ew[e0 + j] * dc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // layer 1: AX = Â X (5 features, padded to 8) and H1 = relu(AX W1 + b1); one workgroup per node
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_layer1(int N, int in_dim, int hidden, const float *x, const float *deg, const float *selfw, const int *ptr,
-                                                const int *nbr, const float *wn, const float *W1, const float *b1, float *AX,
+                                                const int *pend, const int *nbr, const float *wn, const float *W1, const float *b1, float *AX,
                                                 float *H1) {
   const int n = blockIdx.x, t = threadIdx.x;
   __shared__ float ax[8];
@@ -168,7 +271,7 @@ __global__ __launch_bounds__(256) void k_layer1(int N, int in_dim, int hidden, c
     float s = 0.f;
     if (t < in_dim) {
       s = (selfw[n] / deg[n]) * x[(size_t)n * in_dim + t];  // self loop: dis * w_self * dis
-      for (int i = ptr[n]; i < ptr[n + 1]; ++i) s += wn[i] * x[(size_t)nbr[i] * in_dim + t];
+      for (int i = ptr[n]; i < pend[n]; ++i) s += wn[i] * x[(size_t)nbr[i] * in_dim + t];
     }
     ax[t] = s;
     AX[(size_t)n * 8 + t] = s;
@@ -185,12 +288,12 @@ __global__ __launch_bounds__(256) void k_layer1(int N, int in_dim, int hidden, c
 // aggregation out[n] = (selfw[n]/deg[n]) H[n] + sum_i wn[i] H[nbr[i]]  (+ optional ReLU-gate by `gate` > 0)
 // one workgroup per node, float4 per lane
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_aggregate(int N, int hidden, const float *H, const float *deg, const float *selfw, const int *ptr, const int *nbr,
-                                                   const float *wn, const float *gate, float *out) {
+__global__ __launch_bounds__(256) void k_aggregate(int N, int hidden, const float *H, const float *deg, const float *selfw, const int *ptr,
+                                                   const int *pend, const int *nbr, const float *wn, const float *gate, float *out) {
   const int n = blockIdx.x;
   const int h4 = hidden >> 2;
   const float self = selfw[n] / deg[n];
-  const int a = ptr[n], b = ptr[n + 1];
+  const int a = ptr[n], b = pend[n];
   for (int c = threadIdx.x; c < h4; c += 256) {
     float4 v = reinterpret_cast<const float4 *>(H + (size_t)n * hidden)[c];
     float4 acc = make_float4(self * v.x, self * v.y, self * v.z, self * v.w);
@@ -548,7 +651,7 @@ __global__ __launch_bounds__(256) void k_colsum_part(int N, int C, const float *
 
 struct GcnWs {
   float *deg, *selfw, *wn_dst, *wn_src, *AX, *H1, *AH1, *H2, *T0, *T1, *part;
-  int *cnt_dst, *cnt_src, *ptr_dst, *ptr_src, *cur_dst, *cur_src, *eid_dst, *eid_src, *nbr_dst, *nbr_src;
+  int *cnt_dst, *cnt_src, *ptr_dst, *ptr_src, *cur_dst, *cur_src, *eid_dst, *eid_src, *nbr_dst, *nbr_src, *end_dst, *end_src;
   size_t part_floats, counters_bytes;
 };
 
@@ -591,6 +694,8 @@ size_t carve(GcnWs *w, char *base, int N, int E, int hidden, int out_dim) {
   takei(w ? &w->eid_src : &di, E);
   takei(w ? &w->nbr_dst : &di, E);
   takei(w ? &w->nbr_src : &di, E);
+  takei(w ? &w->end_dst : &di, N + 1);
+  takei(w ? &w->end_src : &di, N + 1);
   (void)out_dim;
   return off;
 }
@@ -681,7 +786,22 @@ void build_graph(hipStream_t st, const GcnWs &w, int N, int E, const int64_t *ei
   hipLaunchKernelGGL(k_csr_sort, g2, bn, 0, st, N, w.ptr_dst, w.eid_dst, w.ptr_src, w.eid_src);
   hipLaunchKernelGGL(k_degree_sum, gn, bn, 0, st, N, ew, w.ptr_src, w.eid_src, w.selfw, w.deg);
   hipLaunchKernelGGL(k_csr_finish, g2, bn, 0, st, N, E, ei, ew, w.deg, w.ptr_dst, w.eid_dst, w.nbr_dst, w.wn_dst, w.ptr_src,
-                     w.eid_src, w.nbr_src, w.wn_src);
+                     w.eid_src, w.nbr_src, w.wn_src, w.end_dst, w.end_src);
+}
+
+// false: a graph of the batch may have more edges than the per-graph kernel sorts in LDS (the caller falls back to build_graph)
+bool build_graph_batched(hipStream_t st, const GcnWs &w, int N, int E, const int64_t *ei, const float *ew, int G, const int *node_off,
+                         const int *edge_off, int max_edges_per_graph) {
+  if (max_edges_per_graph > kCsrMaxEdges) return false;
+  int P2 = 64;
+  while (P2 < max_edges_per_graph) P2 <<= 1;
+  const size_t lds = (size_t)2 * P2 * sizeof(uint32_t);
+  static bool attr_set[32] = {false};
+  const void *fns[] = {reinterpret_cast<const void *>(&k_csr_graphs)};
+  drlgx_ensure_lds_attr(attr_set, fns, 1, 160 * 1024);
+  hipLaunchKernelGGL(k_csr_graphs, dim3(G), dim3(256), lds, st, N, E, P2, ei, ew, node_off, edge_off, w.deg, w.selfw, w.ptr_dst, w.end_dst,
+                     w.nbr_dst, w.wn_dst, w.ptr_src, w.end_src, w.nbr_src, w.wn_src);
+  return true;
 }
 
 }  // namespace
@@ -693,24 +813,42 @@ size_t drlgx_gcn_workspace_bytes(int n_nodes, int n_edges, int hidden, int out_d
   return carve(nullptr, nullptr, n_nodes, std::max(n_edges, 1), hidden, out_dim) + 256;
 }
 
-int drlgx_gcn_forward(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim, const float *x,
-                      const int64_t *edge_index, const float *edge_attr, const float *W1, const float *b1, const float *W2,
-                      const float *b2, const float *Wf, const float *bf, const float *dropout_mask, float *out, void *ws_dev) {
+static int gcn_forward_impl(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim, const float *x,
+                            const int64_t *edge_index, const float *edge_attr, const float *W1, const float *b1, const float *W2,
+                            const float *b2, const float *Wf, const float *bf, const float *dropout_mask, float *out, void *ws_dev,
+                            int n_graphs, const int32_t *node_off, const int32_t *edge_off, int max_edges_per_graph) {
   if (n_nodes <= 0 || n_edges < 0 || in_dim <= 0 || in_dim > 8 || hidden <= 0 || (hidden & 3) || out_dim <= 0 || !x || !W1 || !b1 ||
       !W2 || !b2 || !Wf || !bf || !out || !ws_dev || (n_edges > 0 && (!edge_index || !edge_attr)))
     return DRLGX_E_INVALID;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   GcnWs w;
   carve(&w, reinterpret_cast<char *>(ws_dev), n_nodes, std::max(n_edges, 1), hidden, out_dim);
-  build_graph(st, w, n_nodes, n_edges, edge_index, edge_attr);
-  hipLaunchKernelGGL(k_layer1, dim3(n_nodes), dim3(256), 0, st, n_nodes, in_dim, hidden, x, w.deg, w.selfw, w.ptr_dst, w.nbr_dst, w.wn_dst, W1,
-                     b1, w.AX, w.H1);
-  hipLaunchKernelGGL(k_aggregate, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, w.H1, w.deg, w.selfw, w.ptr_dst, w.nbr_dst, w.wn_dst,
-                     (const float *)nullptr, w.AH1);
+  if (n_graphs <= 0 || !build_graph_batched(st, w, n_nodes, n_edges, edge_index, edge_attr, n_graphs, node_off, edge_off, max_edges_per_graph))
+    build_graph(st, w, n_nodes, n_edges, edge_index, edge_attr);
+  hipLaunchKernelGGL(k_layer1, dim3(n_nodes), dim3(256), 0, st, n_nodes, in_dim, hidden, x, w.deg, w.selfw, w.ptr_dst, w.end_dst, w.nbr_dst,
+                     w.wn_dst, W1, b1, w.AX, w.H1);
+  hipLaunchKernelGGL(k_aggregate, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, w.H1, w.deg, w.selfw, w.ptr_dst, w.end_dst, w.nbr_dst,
+                     w.wn_dst, (const float *)nullptr, w.AH1);
   // H2 = relu(AH1 W2 + b2) * mask   (fp32 MFMA, fused epilogue)
   gemm<false, false, 1>(st, n_nodes, hidden, hidden, w.AH1, hidden, W2, hidden, w.H2, hidden, b2, dropout_mask, 1);
   hipLaunchKernelGGL(k_linear_out, dim3((n_nodes + 3) / 4), dim3(256), 0, st, n_nodes, hidden, out_dim, w.H2, Wf, bf, out);
   return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
+}
+
+int drlgx_gcn_forward(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim, const float *x,
+                      const int64_t *edge_index, const float *edge_attr, const float *W1, const float *b1, const float *W2,
+                      const float *b2, const float *Wf, const float *bf, const float *dropout_mask, float *out, void *ws_dev) {
+  return gcn_forward_impl(hip_stream, n_nodes, n_edges, in_dim, hidden, out_dim, x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf,
+                          dropout_mask, out, ws_dev, 0, nullptr, nullptr, 0);
+}
+
+int drlgx_gcn_forward_batched(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim, const float *x,
+                              const int64_t *edge_index, const float *edge_attr, const float *W1, const float *b1, const float *W2,
+                              const float *b2, const float *Wf, const float *bf, const float *dropout_mask, float *out, void *ws_dev,
+                              int n_graphs, const int32_t *node_off, const int32_t *edge_off, int max_edges_per_graph) {
+  if (n_graphs <= 0 || !node_off || !edge_off || max_edges_per_graph < 0) return DRLGX_E_INVALID;
+  return gcn_forward_impl(hip_stream, n_nodes, n_edges, in_dim, hidden, out_dim, x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf,
+                          dropout_mask, out, ws_dev, n_graphs, node_off, edge_off, max_edges_per_graph);
 }
 
 int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim, const float *x,
@@ -737,8 +875,8 @@ int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, i
   colsum(st, w, n_nodes, hidden, w.T0, db2);
   gemm<false, true, 0>(st, n_nodes, hidden, hidden, w.T0, hidden, W2, hidden, w.T1, hidden, nullptr, nullptr, 1);  // T1 = dZ2 W2^T
   // dZ1 = (Â^T dAH1) * (H1 > 0)   -> T0
-  hipLaunchKernelGGL(k_aggregate, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, w.T1, w.deg, w.selfw, w.ptr_src, w.nbr_src, w.wn_src, w.H1,
-                     w.T0);
+  hipLaunchKernelGGL(k_aggregate, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, w.T1, w.deg, w.selfw, w.ptr_src, w.end_src, w.nbr_src,
+                     w.wn_src, w.H1, w.T0);
   // layer 1
   thin_tn(st, w, 8, hidden, n_nodes, w.AX, 8, w.T0, hidden, dW1, in_dim, db1);  // dW1 = AX^T dZ1 (AX rows are 8 wide), db1 = colsum(dZ1)
   return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;

@@ -20,7 +20,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_replay_collate(int G, const int64_t *desc, const float *pool_x, int in_dim, const int64_t *pool_ei,
                                                         int64_t pool_edges, const float *pool_ea, float *x_out, int64_t *ei_out,
-                                                        int64_t E_total, float *ea_out, int64_t *batch_out) {
+                                                        int64_t E_total, float *ea_out, int64_t *batch_out, int *node_off_out,
+                                                        int *edge_off_out) {
   __shared__ long long red[2][4];
   const int g = blockIdx.x, tid = threadIdx.x;
   long long sn = 0, se = 0;
@@ -41,6 +42,14 @@ __global__ __launch_bounds__(256) void k_replay_collate(int G, const int64_t *de
   const long long edge_off = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   const long long n0 = desc[g], nn = desc[(size_t)G + g], e0 = desc[2 * (size_t)G + g], ne = desc[3 * (size_t)G + g],
                   loc = desc[4 * (size_t)G + g];
+  if (tid == 0 && node_off_out && edge_off_out) {
+    node_off_out[g] = (int)node_off;
+    edge_off_out[g] = (int)edge_off;
+    if (g == G - 1) {
+      node_off_out[G] = (int)(node_off + nn);
+      edge_off_out[G] = (int)(edge_off + ne);
+    }
+  }
   const float *xs = pool_x + n0 * in_dim;
   float *xd = x_out + node_off * in_dim;
   for (long long i = tid; i < nn * in_dim; i += 256) xd[i] = xs[i];
@@ -147,13 +156,13 @@ extern "C" {
 
 int drlgx_replay_collate(void *hip_stream, int n_graphs, const int64_t *desc_dev, const float *pool_x, int in_dim, const int64_t *pool_ei,
                          int64_t pool_edges, const float *pool_ea, float *x_out, int64_t *ei_out, int64_t n_edges_total, float *ea_out,
-                         int64_t *batch_out) {
+                         int64_t *batch_out, int32_t *node_off_out, int32_t *edge_off_out) {
   if (n_graphs <= 0 || !desc_dev || !pool_x || in_dim <= 0 || !pool_ei || !pool_ea || !x_out || !ei_out || !ea_out || !batch_out ||
       n_edges_total < 0 || pool_edges < 0)
     return DRLGX_E_INVALID;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   hipLaunchKernelGGL(k_replay_collate, dim3(n_graphs), dim3(256), 0, st, n_graphs, desc_dev, pool_x, in_dim, pool_ei, pool_edges, pool_ea,
-                     x_out, ei_out, n_edges_total, ea_out, batch_out);
+                     x_out, ei_out, n_edges_total, ea_out, batch_out, node_off_out, edge_off_out);
   return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
 }
 

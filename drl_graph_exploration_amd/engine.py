@@ -209,7 +209,7 @@ class Engine(object):
         """Batched ExplorationEnv.graph_matrix + DeepQ.data_process for all envs (one PyG-style batch).
         Returns a dict of CUDA tensors: x [N,5] f32, edge_index [2,E] i64, edge_attr [E] f32, node_off / edge_off
         [n_envs+1] i32, batch [N] i64, n_frontier [n_envs] i32, frontier_xy [n_envs,Fmax,2] f64,
-        nearest_frontier_node [n_envs] i32 (local node id)."""
+        nearest_frontier_node [n_envs] i32 (local node id); max_graph_edges = the largest graph's edge count (host int)."""
         self.use_torch_stream()
         if not hasattr(self, "_gcap"):
             a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
@@ -226,12 +226,12 @@ class Engine(object):
         fxy = torch.zeros(self.n_envs, mf, 2, dtype=torch.float64, device=dev)
         near = torch.empty(self.n_envs, dtype=torch.int32, device=dev)
         self._chk(self.L.drlgx_graph(self.h, _p(node_off), _p(edge_off), _p(x), _p(ei), _p(ea), _p(nfr), _p(fxy), _p(near)))
-        tot = torch.stack([node_off[-1], edge_off[-1]]).cpu()
+        tot = torch.stack([node_off[-1], edge_off[-1], (edge_off[1:] - edge_off[:-1]).max()]).cpu()
         N, E = int(tot[0]), int(tot[1])
         counts = (node_off[1:] - node_off[:-1]).to(torch.int64)
-        batch = torch.repeat_interleave(torch.arange(self.n_envs, device=dev), counts)
+        batch = torch.repeat_interleave(torch.arange(self.n_envs, device=dev), counts, output_size=N)
         return dict(x=x[:N], edge_index=ei[:2 * E].view(2, E), edge_attr=ea[:E], node_off=node_off, edge_off=edge_off,
-                    batch=batch, n_frontier=nfr, frontier_xy=fxy, nearest_frontier_node=near)
+                    batch=batch, n_frontier=nfr, frontier_xy=fxy, nearest_frontier_node=near, max_graph_edges=int(tot[2]))
 
     def snapshot(self, slot=0):
         self.use_torch_stream()

@@ -26,7 +26,7 @@ def _p(t):
 
 class _GCNTrunk(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf, mask):
+    def forward(ctx, x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf, mask, segs=None):
         if not x.is_cuda:
             raise _lib.DrlgxError("drlgx GCN kernels need HIP tensors (no CPU fallback)")
         L = _lib.lib()
@@ -44,9 +44,8 @@ class _GCNTrunk(torch.autograd.Function):
         if mask is not None:
             mask = mask.contiguous().float()
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        rc = L.drlgx_gcn_forward(C.c_void_p(stream), N, E, in_dim, hidden, out_dim, _p(x), _p(edge_index), _p(edge_attr),
-                                 _p(W1c), _p(b1c), _p(W2c), _p(b2c), _p(Wfc), _p(bfc), _p(mask), _p(out), _p(ws))
-        _lib.check(rc)
+        _lib.check(_forward_call(L, stream, N, E, in_dim, hidden, out_dim, x, edge_index, edge_attr, (W1c, b1c, W2c, b2c, Wfc, bfc), mask, out,
+                                 ws, segs))
         ctx.save_for_backward(x, edge_index, edge_attr, W1c, W2c, Wfc, mask if mask is not None else torch.empty(0, device=x.device), ws)
         ctx.has_mask = mask is not None
         ctx.dims = (N, E, in_dim, hidden, out_dim)
@@ -70,10 +69,29 @@ class _GCNTrunk(torch.autograd.Function):
                                   _p(W2), _p(Wf), _p(mask) if ctx.has_mask else None, _p(d_out), _p(dW1), _p(db1), _p(dW2), _p(db2),
                                   _p(dWf), _p(dbf), _p(ws))
         _lib.check(rc)
-        return None, None, None, dW1, db1, dW2, db2, dWf, dbf, None
+        return None, None, None, dW1, db1, dW2, db2, dWf, dbf, None, None
 
 
-def gcn_forward_raw(x, edge_index, edge_attr, params, mask=None):
+def _forward_call(L, stream, N, E, in_dim, hidden, out_dim, x, edge_index, edge_attr, params, mask, out, ws, segs):
+    """drlgx_gcn_forward, or drlgx_gcn_forward_batched when the batch's graph boundaries are known
+    (`segs` = (n_graphs, node_off int32 [G+1], edge_off int32 [G+1] on the device, host bound on a graph's edge count))."""
+    args = [C.c_void_p(stream), N, E, in_dim, hidden, out_dim, _p(x), _p(edge_index), _p(edge_attr)] + [_p(t) for t in params] + \
+           [_p(mask), _p(out), _p(ws)]
+    if segs is not None:
+        return L.drlgx_gcn_forward_batched(*args, int(segs[0]), _p(segs[1]), _p(segs[2]), int(segs[3]))
+    return L.drlgx_gcn_forward(*args)
+
+
+def graph_segments(data):
+    """(n_graphs, node_off, edge_off, max edges of a graph) of a batch that carries its graph boundaries (Engine.graph
+    exports, pool collations), else None."""
+    no, eo, me = getattr(data, "node_off", None), getattr(data, "edge_off", None), getattr(data, "max_graph_edges", None)
+    if no is None or eo is None or me is None or not no.is_cuda or no.dtype != torch.int32 or eo.dtype != torch.int32:
+        return None
+    return (no.numel() - 1, no, eo, int(me))
+
+
+def gcn_forward_raw(x, edge_index, edge_attr, params, mask=None, segs=None):
     """The trunk without an autograd graph: `params` = (W1, b1, W2, b2, Wf, bf) fp32 HIP tensors.  Returns (out, saved);
     `saved` is what `gcn_backward_raw` needs (the workspace holds AX / H1 / AH1 / H2 and both CSRs)."""
     if not x.is_cuda:
@@ -86,8 +104,7 @@ def gcn_forward_raw(x, edge_index, edge_attr, params, mask=None):
     ws = torch.empty(L.drlgx_gcn_workspace_bytes(N, E, hidden, out_dim), dtype=torch.uint8, device=x.device)
     out = torch.empty(N, out_dim, dtype=torch.float32, device=x.device)
     stream = torch.cuda.current_stream(x.device).cuda_stream
-    _lib.check(L.drlgx_gcn_forward(C.c_void_p(stream), N, E, in_dim, hidden, out_dim, _p(x), _p(edge_index), _p(edge_attr), _p(W1), _p(b1),
-                                   _p(W2), _p(b2), _p(Wf), _p(bf), _p(mask), _p(out), _p(ws)))
+    _lib.check(_forward_call(L, stream, N, E, in_dim, hidden, out_dim, x, edge_index, edge_attr, (W1, b1, W2, b2, Wf, bf), mask, out, ws, segs))
     return out, (x, edge_index, edge_attr, W1, W2, Wf, mask, ws, (N, E, in_dim, hidden, out_dim))
 
 
@@ -100,8 +117,8 @@ def gcn_backward_raw(saved, d_out, grads):
                                     _p(Wf), _p(mask), _p(d_out), *(_p(g) for g in grads), _p(ws)))
 
 
-def gcn_trunk(x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf, mask=None):
-    return _GCNTrunk.apply(x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf, mask)
+def gcn_trunk(x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf, mask=None, segs=None):
+    return _GCNTrunk.apply(x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf, mask, segs)
 
 
 class GCNConvParams(torch.nn.Module):
@@ -143,7 +160,7 @@ class GCN(torch.nn.Module):
         x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
         mask = _dropout_mask(x.shape[0], 1000, float(prob), x.device)
         return gcn_trunk(x, edge_index, edge_weight, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
-                         self.fully_con1.weight, self.fully_con1.bias, mask)
+                         self.fully_con1.weight, self.fully_con1.bias, mask, graph_segments(data))
 
 
 def segment_softmax(src, index, num_segments):
@@ -168,7 +185,7 @@ class PolicyGCN(torch.nn.Module):
         x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
         dmask = _dropout_mask(x.shape[0], 1000, 0.5, x.device)  # F.dropout(x): p = 0.5 even at inference
         q = gcn_trunk(x, edge_index, edge_weight, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
-                      self.fully_con1.weight, self.fully_con1.bias, dmask)
+                      self.fully_con1.weight, self.fully_con1.bias, dmask, graph_segments(data))
         q = torch.masked_select(q.view(-1), mask)
         b = torch.masked_select(batch, mask)
         return segment_softmax(q, b, int(batch.max().item()) + 1 if batch.numel() else 0)
@@ -187,7 +204,7 @@ class ValueGCN(torch.nn.Module):
         x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
         dmask = _dropout_mask(x.shape[0], 1000, 0.5, x.device)
         h = gcn_trunk(x, edge_index, edge_weight, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
-                      self.fully_con1.weight, self.fully_con1.bias, dmask)
+                      self.fully_con1.weight, self.fully_con1.bias, dmask, graph_segments(data))
         g = int(batch.max().item()) + 1
         s = torch.zeros(g, h.shape[1], dtype=h.dtype, device=h.device).index_add_(0, batch, h)
         cnt = torch.zeros(g, dtype=h.dtype, device=h.device).index_add_(0, batch, torch.ones_like(batch, dtype=h.dtype))
@@ -197,8 +214,11 @@ class ValueGCN(torch.nn.Module):
 class GraphData(object):
     """Minimal stand-in for torch_geometric.data.Data / Batch (x, edge_index, edge_attr, batch, .to())."""
 
-    def __init__(self, x, edge_index, edge_attr, batch=None):
+    def __init__(self, x, edge_index, edge_attr, batch=None, node_off=None, edge_off=None, max_graph_edges=None):
         self.x, self.edge_index, self.edge_attr, self.batch = x, edge_index, edge_attr, batch
+        # optional graph boundaries of a batch (device int32 [n_graphs + 1]) and a host bound on the edges of one graph:
+        # the GCN builds its CSRs per graph from them
+        self.node_off, self.edge_off, self.max_graph_edges = node_off, edge_off, max_graph_edges
 
     @property
     def num_nodes(self):
@@ -210,6 +230,8 @@ class GraphData(object):
         self.edge_attr = self.edge_attr.to(device)
         if self.batch is not None:
             self.batch = self.batch.to(device)
+        if self.node_off is not None:
+            self.node_off, self.edge_off = self.node_off.to(device), self.edge_off.to(device)
         return self
 
     @staticmethod
@@ -310,21 +332,23 @@ class ReplayPool(object):
         d = np.array([(r.n0, r.nn, r.e0, r.ne, r.loc) for r in refs], dtype=np.int64).T.copy()
         return d, int(d[1].sum()), int(d[3].sum())
 
-    def collate_from(self, desc_dev, k, n_nodes, n_edges):
+    def collate_from(self, desc_dev, k, n_nodes, n_edges, max_graph_edges=None):
         """The PyG batch of `k` pooled graphs from their device descriptors: one kernel, no host synchronisation."""
         dev = self.device
         x = torch.empty(n_nodes, self.X.shape[1], dtype=torch.float32, device=dev)
         ei = torch.empty(2, n_edges, dtype=torch.int64, device=dev)
         ea = torch.empty(n_edges, dtype=torch.float32, device=dev)
         bt = torch.empty(n_nodes, dtype=torch.int64, device=dev)
+        offs = torch.empty(2, k + 1, dtype=torch.int32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(_lib.lib().drlgx_replay_collate(C.c_void_p(stream), k, _p(desc_dev), _p(self.X), self.X.shape[1], _p(self.EI),
-                                                   self.EI.shape[1], _p(self.EA), _p(x), _p(ei), n_edges, _p(ea), _p(bt)))
-        return GraphData(x, ei, ea, bt)
+                                                   self.EI.shape[1], _p(self.EA), _p(x), _p(ei), n_edges, _p(ea), _p(bt), _p(offs[0]),
+                                                   _p(offs[1])))
+        return GraphData(x, ei, ea, bt, offs[0], offs[1], max_graph_edges)
 
     def collate(self, refs):
         d, n_nodes, n_edges = self.descriptors(refs)
-        return self.collate_from(torch.from_numpy(d).to(self.device), len(refs), n_nodes, n_edges)
+        return self.collate_from(torch.from_numpy(d).to(self.device), len(refs), n_nodes, n_edges, int(d[3].max()))
 
 
 class PoolRef(object):

@@ -156,7 +156,7 @@ class DeepQ(object):
             x = data.x
             n = x.shape[0]
             mask = NW._dropout_mask(n, 1000, 0.5, x.device)
-            out, saved = NW.gcn_forward_raw(x, data.edge_index, data.edge_attr, model.trunk_parameters(), mask)
+            out, saved = NW.gcn_forward_raw(x, data.edge_index, data.edge_attr, model.trunk_parameters(), mask, NW.graph_segments(data))
             y = torch.as_tensor(y, dtype=torch.float64, device=device)
             action = torch.as_tensor(action, dtype=torch.float64, device=device)
             loss = torch.empty(1, dtype=torch.float64, device=x.device)
@@ -262,8 +262,8 @@ class DeepQ(object):
             a_batch, y_batch = self.td_targets(minibatch, q1, device)
         else:  # everything the host contributes was uploaded in one piece by _prepare_updates
             pool, B = prepared["pool"], self.BATCH
-            s_j = pool.collate_from(prepared["desc_j"], B, prepared["N"], prepared["E"])
-            s_j1 = pool.collate_from(prepared["desc_j1"], B, prepared["N1"], prepared["E1"])
+            s_j = pool.collate_from(prepared["desc_j"], B, prepared["N"], prepared["E"], prepared["ME"])
+            s_j1 = pool.collate_from(prepared["desc_j1"], B, prepared["N1"], prepared["E1"], prepared["ME1"])
             with torch.no_grad():
                 q1 = self.test(s_j1, 0.0, device, target_net).view(-1)
             a_batch, y_batch = self._td_apply(q1, prepared["meta"], prepared["r"], B, prepared["N"])
@@ -288,10 +288,10 @@ class DeepQ(object):
             I[u, 0:5], n, e = ReplayPool.descriptors([d[0] for d in mb])
             I[u, 5:10], n1, e1 = ReplayPool.descriptors([d[3] for d in mb])
             I[u, 10:14], R[u], _ = self._td_meta(mb, n1)
-            tot.append((n, e, n1, e1))
+            tot.append((n, e, n1, e1, int(I[u, 3].max()), int(I[u, 8].max())))
         I_dev, R_dev = torch.from_numpy(I).to(device), torch.from_numpy(R).to(device)
         return [dict(pool=pool, desc_j=I_dev[u, 0:5], desc_j1=I_dev[u, 5:10], meta=I_dev[u, 10:14], r=R_dev[u], N=tot[u][0],
-                     E=tot[u][1], N1=tot[u][2], E1=tot[u][3]) for u in range(n_upd)], batches
+                     E=tot[u][1], N1=tot[u][2], E1=tot[u][3], ME=tot[u][4], ME1=tot[u][5]) for u in range(n_upd)], batches
 
     # ------------------------------------------------------------------ main loop (policy.py:60-208)
     def running(self, model, modelTarget, test=False, n_envs=64, env=None, log_every=0):
@@ -338,7 +338,7 @@ class DeepQ(object):
             rewards = env.rewards_all_goals()
             cand_env, cand_node, cand_first = env.candidates
             nfr = g["n_frontier"].long()
-            batch_data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"])
+            batch_data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"], g["node_off"], g["edge_off"], g["max_graph_edges"])
             with torch.no_grad():
                 prob = self.epsilon if method == "bayesian" else 0.0
                 readout = self.test(batch_data, prob, device, policy_net).view(-1)
@@ -564,7 +564,7 @@ class A2C(object):
             rewards = env.rewards_all_goals()
             cand_env, cand_node, cand_first = env.candidates
             nfr = g["n_frontier"].long()
-            batch_data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"])
+            batch_data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"], g["node_off"], g["edge_off"], g["max_graph_edges"])
             mask = frontier_mask(g)
             with torch.no_grad():
                 readout = self.test(batch_data, g["batch"], mask, device, policy_net).view(-1)  # [C], env-major
@@ -594,7 +594,7 @@ class A2C(object):
 
             if len(self.buffer) == self.nstep:
                 with torch.no_grad():
-                    b1 = GraphData(g1["x"], g1["edge_index"], g1["edge_attr"], g1["batch"])
+                    b1 = GraphData(g1["x"], g1["edge_index"], g1["edge_attr"], g1["batch"], g1["node_off"], g1["edge_off"], g1["max_graph_edges"])
                     last_value = self.test(b1, g1["batch"], frontier_mask(g1), device, value_net).view(-1).cpu().numpy()
                 T = self.nstep
                 disc = self.discounted_returns(np.stack([b[2] for b in self.buffer]), np.stack([b[3] for b in self.buffer]),

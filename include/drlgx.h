@@ -264,6 +264,17 @@ int drlgx_gcn_forward(void *hip_stream, int n_nodes, int n_edges, int in_dim, in
                       const float *b1, const float *W2, const float *b2, const float *Wf, const float *bf,
                       const float *dropout_mask /* [n_nodes*hidden] or NULL */, float *out /* [n_nodes*out_dim] */,
                       void *ws_dev);
+/* The same forward for a BATCH of graphs whose boundaries the caller knows (a PyG `Batch` / what drlgx_graph and
+ * drlgx_replay_collate emit): graph g owns nodes [node_off[g], node_off[g+1]) and edges [edge_off[g], edge_off[g+1]),
+ * DEVICE int32 [n_graphs + 1]; every edge connects two nodes of its own graph (others are ignored); no graph has more
+ * than max_edges_per_graph edges (a host-side bound the caller knows: the export's capacity, the collation's counts).
+ * Same results bit for bit; the graph normalisation / CSR build is one launch (one workgroup per graph, its edges
+ * sorted in LDS) instead of eight; bounds beyond 16 384 edges per graph take the generic build. */
+int drlgx_gcn_forward_batched(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim,
+                              const float *x, const int64_t *edge_index, const float *edge_attr, const float *W1,
+                              const float *b1, const float *W2, const float *b2, const float *Wf, const float *bf,
+                              const float *dropout_mask, float *out, void *ws_dev, int n_graphs,
+                              const int32_t *node_off, const int32_t *edge_off, int max_edges_per_graph);
 /* Backward: given d(out) returns gradients of all six parameter tensors (accumulated = overwritten). */
 int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim,
                        const float *x, const int64_t *edge_index, const float *edge_attr, const float *W1,
@@ -276,10 +287,12 @@ int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, i
  * (scripts/policy.py:146-153): graph g is rows [node_start, +node_cnt) of pool_x ([rows][in_dim] f32) and columns
  * [edge_start, +edge_cnt) of pool_ei ([2][pool_edges] i64) / pool_ea, its node ids start at loc.  desc_dev int64
  * [5][n_graphs] = node_start, node_cnt, edge_start, edge_cnt, loc.  Outputs (DEVICE, sized by the caller from the counts):
- * x_out [N][in_dim], ei_out [2][n_edges_total] (ids shifted by the cumulative node counts), ea_out, batch_out [N]. */
+ * x_out [N][in_dim], ei_out [2][n_edges_total] (ids shifted by the cumulative node counts), ea_out, batch_out [N], and the
+ * graph boundaries in the form drlgx_gcn_forward_batched takes. */
 int drlgx_replay_collate(void *hip_stream, int n_graphs, const int64_t *desc_dev, const float *pool_x, int in_dim,
                          const int64_t *pool_ei, int64_t pool_edges, const float *pool_ea, float *x_out, int64_t *ei_out,
-                         int64_t n_edges_total, float *ea_out, int64_t *batch_out);
+                         int64_t n_edges_total, float *ea_out, int64_t *batch_out,
+                         int32_t *node_off_out /* [n_graphs + 1] or NULL */, int32_t *edge_off_out /* [n_graphs + 1] or NULL */);
 /* TD targets, scripts/policy.py:154-175: sample i takes max(q1[lo_i:hi_i]) (float32, the target network's read-out over
  * the collated next states; the caller resolves the reference's slicing into [lo, hi)), and
  * a_batch[pos_i] = 1, y_batch[pos_i] = r_i + gamma max  (r_i alone when terminal_i) in float64; both vectors

@@ -356,6 +356,54 @@ def test_fused_dqn_update_equals_the_framework_path(monkeypatch, tmp_path):
     assert opt_a.step_count == 3
 
 
+def test_batched_graph_build_equals_the_generic_one():
+    """drlgx_gcn_forward_batched (both CSRs, degrees and normalised weights of every graph by one workgroup, from the
+    batch's graph boundaries) gives the generic build's results bit for bit - forward and all parameter gradients - on
+    a batch with explicit self loops, an edge-free graph and one graph of ~10 000 edges (128 KB of sort keys in LDS);
+    a bound beyond the kernel's 16 384 edges per graph takes the generic build."""
+    from drl_graph_exploration_amd.networks import gcn_trunk
+    dev = torch.device("cuda", 0)
+    parts = [random_batch(5, 41, dev), random_batch(1, 42, dev, nmin=900, nmax=901), random_batch(3, 43, dev)]
+    g = torch.Generator().manual_seed(9)
+    n_big = parts[1][0].shape[0]
+    extra = torch.randint(0, n_big, (2, 4000), generator=g).to(dev)  # ~10 000 edges in the big graph
+    extra = extra[:, extra[0] != extra[1]]
+    parts[1] = (parts[1][0], torch.cat([parts[1][1], extra, extra.flip(0)], 1),
+                torch.cat([parts[1][2], torch.rand(2 * extra.shape[1], generator=g).to(dev) + 0.1]), parts[1][3])
+    xs, eis, eas, node_off, edge_off = [], [], [], [0], [0]
+    for x, ei, ea, bt in parts:
+        for k in range(int(bt.max()) + 1):
+            nodes = torch.nonzero(bt == k).view(-1)
+            lo, hi = int(nodes[0]), int(nodes[-1]) + 1
+            sel = (ei[0] >= lo) & (ei[0] < hi)
+            e, w = ei[:, sel] - lo + node_off[-1], ea[sel]
+            if len(xs) == 2:  # explicit self loops in the third graph
+                loops = torch.tensor([0, 3], device=dev) + node_off[-1]
+                e, w = torch.cat([e, torch.stack([loops, loops])], 1), torch.cat([w, torch.tensor([0.7, 3.1], device=dev)])
+            if len(xs) == 4:  # a graph without edges
+                e, w = e[:, :0], w[:0]
+            xs.append(x[lo:hi]); eis.append(e); eas.append(w)
+            node_off.append(node_off[-1] + hi - lo); edge_off.append(edge_off[-1] + e.shape[1])
+    x, ei, ea = torch.cat(xs), torch.cat(eis, 1).contiguous(), torch.cat(eas)
+    assert max(b - a for a, b in zip(edge_off[:-1], edge_off[1:])) > 8192
+    segs = (len(xs), torch.tensor(node_off, dtype=torch.int32, device=dev), torch.tensor(edge_off, dtype=torch.int32, device=dev),
+            max(b - a for a, b in zip(edge_off[:-1], edge_off[1:])))
+    mask = (torch.rand(x.shape[0], 1000, device=dev) >= 0.5).float() * 2.0
+    outs = []
+    for s_ in (None, segs, segs[:3] + (20000,)):
+        P = make_params(dev, 1)
+        out = gcn_trunk(x, ei, ea, P["conv1.weight"], P["conv1.bias"], P["conv2.weight"], P["conv2.bias"], P["fully_con1.weight"],
+                        P["fully_con1.bias"], mask, s_)
+        (out * torch.linspace(-1, 1, out.numel(), device=dev).view_as(out)).sum().backward()
+        outs.append((out.detach(), {k: v.grad.clone() for k, v in P.items()}))
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0])
+        for k in outs[0][1]:
+            assert torch.equal(outs[0][1][k], o[1][k]), k
+    ref = gcn_ref.gcn_forward({k: v.detach() for k, v in make_params(dev, 1).items()}, x, ei, ea, mask)
+    assert rel_err(outs[1][0], ref) < 2e-4
+
+
 def test_explicit_self_loops_keep_their_weight():
     """PyG add_remaining_self_loops: a node with an explicit self loop keeps that weight instead of the fill value 2
     (gcn_ref.gcn_norm does the same); edges pointing outside the graph are ignored instead of read out of bounds."""
