@@ -260,36 +260,103 @@ __global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// layer 1: AX = Â X (5 features, padded to 8) and H1 = relu(AX W1 + b1); one workgroup per node
+// layer 1 and the aggregation of layer 2, without materialising H1:
+//   AX = Â X (in_dim <= 8 features, rows padded to 8)                                     k_ax, one thread per (node, k)
+//   AH1[n] = sum_i w_i relu(AX[m_i] W1 + b1)  over n itself (self weight) and its neighbours   k_aggregate_l1
+// A row of H1 = relu(AX[m] W1 + b1) costs in_dim FMAs per element from 32 bytes of AX, against 4 KB of HBM / L2 traffic to
+// write it once and gather it ~8 times: it is recomputed where it is needed (also as the ReLU gate of the backward pass),
+// in the same operation order as a stored H1 would have had.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_layer1(int N, int in_dim, int hidden, const float *x, const float *deg, const float *selfw, const int *ptr,
-                                                const int *pend, const int *nbr, const float *wn, const float *W1, const float *b1, float *AX,
-                                                float *H1) {
-  const int n = blockIdx.x, t = threadIdx.x;
-  __shared__ float ax[8];
-  if (t < 8) {
-    float s = 0.f;
-    if (t < in_dim) {
-      s = (selfw[n] / deg[n]) * x[(size_t)n * in_dim + t];  // self loop: dis * w_self * dis
-      for (int i = ptr[n]; i < pend[n]; ++i) s += wn[i] * x[(size_t)nbr[i] * in_dim + t];
-    }
-    ax[t] = s;
-    AX[(size_t)n * 8 + t] = s;
+__global__ __launch_bounds__(256) void k_ax(int N, int in_dim, const float *x, const float *deg, const float *selfw, const int *ptr,
+                                            const int *pend, const int *nbr, const float *wn, float *AX) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int n = e >> 3, t = e & 7;
+  if (n >= N) return;
+  float s = 0.f;
+  if (t < in_dim) {
+    s = (selfw[n] / deg[n]) * x[(size_t)n * in_dim + t];  // self loop: dis * w_self * dis
+    for (int i = ptr[n]; i < pend[n]; ++i) s += wn[i] * x[(size_t)nbr[i] * in_dim + t];
   }
-  __syncthreads();
-  for (int c = t; c < hidden; c += 256) {
-    float s = b1[c];
-    for (int k = 0; k < in_dim; ++k) s += ax[k] * W1[(size_t)k * hidden + c];
-    H1[(size_t)n * hidden + c] = fmaxf(s, 0.f);
+  AX[(size_t)n * 8 + t] = s;
+}
+
+// H1[m][4c .. 4c+3] from AX[m] (8 floats), this thread's four W1 columns (w[k]) and biases
+__device__ __forceinline__ float4 h1_row(const float *AX, int m, int in_dim, const float4 (&w)[8], const float4 &bias) {
+  const float4 a0 = reinterpret_cast<const float4 *>(AX + (size_t)m * 8)[0], a1 = reinterpret_cast<const float4 *>(AX + (size_t)m * 8)[1];
+  const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  float4 s = bias;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k < in_dim) {
+      s.x += a[k] * w[k].x; s.y += a[k] * w[k].y; s.z += a[k] * w[k].z; s.w += a[k] * w[k].w;
+    }
+  return s;  // pre-activation
+}
+
+// H1 row from 8 staged AX values
+__device__ __forceinline__ float4 h1_row_lds(const float *ax, int in_dim, const float4 (&w)[8], const float4 &bias) {
+  const float4 a0 = reinterpret_cast<const float4 *>(ax)[0], a1 = reinterpret_cast<const float4 *>(ax)[1];
+  const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  float4 s = bias;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k < in_dim) {
+      s.x += a[k] * w[k].x; s.y += a[k] * w[k].y; s.z += a[k] * w[k].z; s.w += a[k] * w[k].w;
+    }
+  return s;
+}
+
+constexpr int kAggStage = 64;  // neighbour rows of AX (and their weights) staged in LDS; longer rows read the rest from memory
+constexpr int kAggNodes = 4;   // nodes per workgroup: the thread's W1 columns and biases are loaded once for all of them
+__global__ __launch_bounds__(256) void k_aggregate_l1(int N, int in_dim, int hidden, const float *AX, const float *W1, const float *b1,
+                                                      const float *deg, const float *selfw, const int *ptr, const int *pend, const int *nbr,
+                                                      const float *wn, float *out) {
+  __shared__ __attribute__((aligned(16))) float s_ax[kAggStage * 8];
+  __shared__ float s_wn[kAggStage];
+  const int tid = threadIdx.x;
+  const int h4 = hidden >> 2;
+  for (int c = tid; c < ((h4 + 255) & ~255); c += 256) {  // (one trip for hidden <= 1024; every thread takes part in the barriers)
+    const bool live = c < h4;
+    float4 w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = (live && k < in_dim) ? reinterpret_cast<const float4 *>(W1 + (size_t)k * hidden)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bias = live ? reinterpret_cast<const float4 *>(b1)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = blockIdx.x * kAggNodes; n < min(N, (blockIdx.x + 1) * kAggNodes); ++n) {
+      const int a = ptr[n], b = pend[n];
+      const int ns = min(b - a, kAggStage);
+      __syncthreads();
+      for (int e = tid; e < ns * 8; e += 256) {
+        s_ax[e] = AX[(size_t)nbr[a + (e >> 3)] * 8 + (e & 7)];
+        if ((e & 7) == 0) s_wn[e >> 3] = wn[a + (e >> 3)];
+      }
+      __syncthreads();
+      if (!live) continue;
+      const float self = selfw[n] / deg[n];
+      const float4 v = h1_row(AX, n, in_dim, w, bias);
+      float4 acc = make_float4(self * fmaxf(v.x, 0.f), self * fmaxf(v.y, 0.f), self * fmaxf(v.z, 0.f), self * fmaxf(v.w, 0.f));
+      for (int j = 0; j < ns; ++j) {
+        const float wi = s_wn[j];
+        const float4 u = h1_row_lds(s_ax + 8 * j, in_dim, w, bias);
+        acc.x += wi * fmaxf(u.x, 0.f); acc.y += wi * fmaxf(u.y, 0.f); acc.z += wi * fmaxf(u.z, 0.f); acc.w += wi * fmaxf(u.w, 0.f);
+      }
+      for (int i = a + ns; i < b; ++i) {
+        const float wi = wn[i];
+        const float4 u = h1_row(AX, nbr[i], in_dim, w, bias);
+        acc.x += wi * fmaxf(u.x, 0.f); acc.y += wi * fmaxf(u.y, 0.f); acc.z += wi * fmaxf(u.z, 0.f); acc.w += wi * fmaxf(u.w, 0.f);
+      }
+      reinterpret_cast<float4 *>(out + (size_t)n * hidden)[c] = acc;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// aggregation out[n] = (selfw[n]/deg[n]) H[n] + sum_i wn[i] H[nbr[i]]  (+ optional ReLU-gate by `gate` > 0)
-// one workgroup per node, float4 per lane
+// aggregation out[n] = (selfw[n]/deg[n]) H[n] + sum_i wn[i] H[nbr[i]], optionally gated by H1[n] > 0 with H1 recomputed
+// from AX / W1 / b1 (the ReLU of layer 1 in the backward pass);  one workgroup per node, float4 per lane
 // ------------------------------------------------------------------------------------------------
+template <bool kGate>
 __global__ __launch_bounds__(256) void k_aggregate(int N, int hidden, const float *H, const float *deg, const float *selfw, const int *ptr,
-                                                   const int *pend, const int *nbr, const float *wn, const float *gate, float *out) {
+                                                   const int *pend, const int *nbr, const float *wn, int in_dim, const float *AX,
+                                                   const float *W1, const float *b1, float *out) {
   const int n = blockIdx.x;
   const int h4 = hidden >> 2;
   const float self = selfw[n] / deg[n];
@@ -302,8 +369,11 @@ __global__ __launch_bounds__(256) void k_aggregate(int N, int hidden, const floa
       const float4 u = reinterpret_cast<const float4 *>(H + (size_t)nbr[i] * hidden)[c];
       acc.x += w * u.x; acc.y += w * u.y; acc.z += w * u.z; acc.w += w * u.w;
     }
-    if (gate) {
-      const float4 g = reinterpret_cast<const float4 *>(gate + (size_t)n * hidden)[c];
+    if (kGate) {
+      float4 wk[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) wk[k] = k < in_dim ? reinterpret_cast<const float4 *>(W1 + (size_t)k * hidden)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 g = h1_row(AX, n, in_dim, wk, reinterpret_cast<const float4 *>(b1)[c]);
       acc.x = g.x > 0.f ? acc.x : 0.f; acc.y = g.y > 0.f ? acc.y : 0.f;
       acc.z = g.z > 0.f ? acc.z : 0.f; acc.w = g.w > 0.f ? acc.w : 0.f;
     }
@@ -650,7 +720,7 @@ __global__ __launch_bounds__(256) void k_colsum_part(int N, int C, const float *
 }
 
 struct GcnWs {
-  float *deg, *selfw, *wn_dst, *wn_src, *AX, *H1, *AH1, *H2, *T0, *T1, *part;
+  float *deg, *selfw, *wn_dst, *wn_src, *AX, *b1s, *AH1, *H2, *T0, *T1, *part;
   int *cnt_dst, *cnt_src, *ptr_dst, *ptr_src, *cur_dst, *cur_src, *eid_dst, *eid_src, *nbr_dst, *nbr_src, *end_dst, *end_src;
   size_t part_floats, counters_bytes;
 };
@@ -676,7 +746,7 @@ size_t carve(GcnWs *w, char *base, int N, int E, int hidden, int out_dim) {
   takef(w ? &w->wn_dst : &df, E);
   takef(w ? &w->wn_src : &df, E);
   takef(w ? &w->AX : &df, (size_t)N * 8);
-  takef(w ? &w->H1 : &df, NH);
+  takef(w ? &w->b1s : &df, hidden);  // the forward's b1, for the backward's layer-1 ReLU gate (H1 is recomputed, not stored)
   takef(w ? &w->AH1 : &df, NH);
   takef(w ? &w->H2 : &df, NH);
   takef(w ? &w->T0 : &df, NH);
@@ -825,10 +895,11 @@ static int gcn_forward_impl(void *hip_stream, int n_nodes, int n_edges, int in_d
   carve(&w, reinterpret_cast<char *>(ws_dev), n_nodes, std::max(n_edges, 1), hidden, out_dim);
   if (n_graphs <= 0 || !build_graph_batched(st, w, n_nodes, n_edges, edge_index, edge_attr, n_graphs, node_off, edge_off, max_edges_per_graph))
     build_graph(st, w, n_nodes, n_edges, edge_index, edge_attr);
-  hipLaunchKernelGGL(k_layer1, dim3(n_nodes), dim3(256), 0, st, n_nodes, in_dim, hidden, x, w.deg, w.selfw, w.ptr_dst, w.end_dst, w.nbr_dst,
-                     w.wn_dst, W1, b1, w.AX, w.H1);
-  hipLaunchKernelGGL(k_aggregate, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, w.H1, w.deg, w.selfw, w.ptr_dst, w.end_dst, w.nbr_dst,
-                     w.wn_dst, (const float *)nullptr, w.AH1);
+  hipLaunchKernelGGL(k_ax, dim3((n_nodes * 8 + 255) / 256), dim3(256), 0, st, n_nodes, in_dim, x, w.deg, w.selfw, w.ptr_dst, w.end_dst, w.nbr_dst,
+                     w.wn_dst, w.AX);
+  hipLaunchKernelGGL(k_aggregate_l1, dim3((n_nodes + kAggNodes - 1) / kAggNodes), dim3(256), 0, st, n_nodes, in_dim, hidden, w.AX, W1, b1, w.deg, w.selfw, w.ptr_dst, w.end_dst,
+                     w.nbr_dst, w.wn_dst, w.AH1);
+  if (hipMemcpyAsync(w.b1s, b1, (size_t)hidden * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return DRLGX_E_HIP;
   // H2 = relu(AH1 W2 + b2) * mask   (fp32 MFMA, fused epilogue)
   gemm<false, false, 1>(st, n_nodes, hidden, hidden, w.AH1, hidden, W2, hidden, w.H2, hidden, b2, dropout_mask, 1);
   hipLaunchKernelGGL(k_linear_out, dim3((n_nodes + 3) / 4), dim3(256), 0, st, n_nodes, hidden, out_dim, w.H2, Wf, bf, out);
@@ -856,9 +927,9 @@ int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, i
                        const float *dropout_mask, const float *d_out, float *dW1, float *db1, float *dW2, float *db2, float *dWf,
                        float *dbf, void *ws_dev) {
   if (n_nodes <= 0 || in_dim <= 0 || in_dim > 8 || hidden <= 0 || (hidden & 3) || out_dim <= 0 || !d_out || !dW1 || !db1 || !dW2 ||
-      !db2 || !dWf || !dbf || !ws_dev || !W2 || !Wf)
+      !db2 || !dWf || !dbf || !ws_dev || !W1 || !W2 || !Wf)
     return DRLGX_E_INVALID;
-  (void)x; (void)edge_index; (void)edge_attr; (void)W1; (void)n_edges;  // the forward left AX/H1/AH1/H2 and both CSRs in ws
+  (void)x; (void)edge_index; (void)edge_attr; (void)n_edges;  // the forward left AX / b1 / AH1 / H2 and both CSRs in ws
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   GcnWs w;
   carve(&w, reinterpret_cast<char *>(ws_dev), n_nodes, std::max(n_edges, 1), hidden, out_dim);
@@ -875,8 +946,8 @@ int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, i
   colsum(st, w, n_nodes, hidden, w.T0, db2);
   gemm<false, true, 0>(st, n_nodes, hidden, hidden, w.T0, hidden, W2, hidden, w.T1, hidden, nullptr, nullptr, 1);  // T1 = dZ2 W2^T
   // dZ1 = (Â^T dAH1) * (H1 > 0)   -> T0
-  hipLaunchKernelGGL(k_aggregate, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, w.T1, w.deg, w.selfw, w.ptr_src, w.end_src, w.nbr_src,
-                     w.wn_src, w.H1, w.T0);
+  hipLaunchKernelGGL(k_aggregate<true>, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, w.T1, w.deg, w.selfw, w.ptr_src, w.end_src, w.nbr_src,
+                     w.wn_src, in_dim, w.AX, W1, w.b1s, w.T0);
   // layer 1
   thin_tn(st, w, 8, hidden, n_nodes, w.AX, 8, w.T0, hidden, dW1, in_dim, db1);  // dW1 = AX^T dZ1 (AX rows are 8 wide), db1 = colsum(dZ1)
   return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
