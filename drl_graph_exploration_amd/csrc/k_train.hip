@@ -150,9 +150,170 @@ __global__ __launch_bounds__(256) void k_adam(AdamTensors T, float clamp, float 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ExplorationEnv.rewards_all_goals, the normalisation (exploration_env.py:151-161): per environment the look-ahead rewards of
+// its frontiers [first_e, first_e + n_e) are mapped by np.interp from [min, max] onto [-1, 0] when the vehicle's nearest
+// frontier (the first one) is the (first) arg-max - loop_clo False -, else onto [-1, 1] - loop_clo True.  One wave per env.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_normalise_rewards(const double *raw, const int64_t *first, const int *n_frontier, double *out,
+                                                          uint8_t *loop_clo) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const long long f0 = first[e];
+  const int nf = n_frontier[e];
+  double lo = INFINITY, hi = -INFINITY;
+  for (int i = lane; i < nf; i += 64) {
+    const double v = raw[f0 + i];
+    lo = fmin(lo, v);
+    hi = fmax(hi, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, o));
+    hi = fmax(hi, __shfl_xor(hi, o));
+  }
+  if (nf <= 0) {
+    if (lane == 0) loop_clo[e] = 0;
+    return;
+  }
+  const bool loop = raw[f0] < hi;  // np.nanargmax returns the first maximum
+  const double top = loop ? 1.0 : 0.0, span = hi - lo;
+  const double slope = (top + 1.0) / (span > 0 ? span : 1.0);
+  for (int i = lane; i < nf; i += 64) {
+    const double v = raw[f0 + i];
+    out[f0 + i] = v >= hi ? top : slope * (v - lo) - 1.0;  // np.interp: slope * (x - xp[0]) + fp[0]; x >= xp[-1] -> fp[-1]
+  }
+  if (lane == 0) loop_clo[e] = loop ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PolicyGCN head (scripts/Networks.py:47-50): masked_select of the per-node read-out and of `batch`, then
+// torch_geometric.utils.softmax over every graph's selected nodes:  p = exp(q - max) / (sum exp(q - max) + 1e-16).
+// One wave per graph (graph boundaries node_off); the selected nodes of all graphs are written in node order, so a
+// graph's output offset is the number of selected nodes before its first node.
+// Backward:  dq_j = p_j (dp_j - sum_i p_i dp_i)  for the selected nodes, 0 elsewhere.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int masked_before(const uint8_t *mask, int n0, int lane) {
+  int c = 0;
+  for (int i = lane; i < n0; i += 64) c += mask[i] ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  return c;
+}
+__global__ __launch_bounds__(64) void k_segment_softmax(const float *q, const uint8_t *mask, const int *node_off, float *p_out) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const int n0 = node_off[g], n1 = node_off[g + 1];
+  int k = masked_before(mask, n0, lane);
+  float m = -INFINITY;
+  for (int i = n0 + lane; i < n1; i += 64)
+    if (mask[i]) m = fmaxf(m, q[i]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float s = 0.f;
+  for (int i = n0 + lane; i < n1; i += 64)
+    if (mask[i]) s += expf(q[i] - m);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float inv = 1.0f / (s + 1e-16f);
+  for (int b = n0; b < n1; b += 64) {
+    const int i = b + lane;
+    const bool on = i < n1 && mask[i];
+    const unsigned long long bal = __ballot(on);
+    if (on) p_out[k + __popcll(bal & ((1ull << lane) - 1ull))] = expf(q[i] - m) * inv;
+    k += __popcll(bal);
+  }
+}
+__global__ __launch_bounds__(64) void k_segment_softmax_bwd(const float *p, const float *dp, const uint8_t *mask, const int *node_off,
+                                                            float *dq) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const int n0 = node_off[g], n1 = node_off[g + 1];
+  const int k0 = masked_before(mask, n0, lane);
+  int cnt = 0;
+  for (int i = n0 + lane; i < n1; i += 64) cnt += mask[i] ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  float dot = 0.f;
+  for (int j = lane; j < cnt; j += 64) dot += p[k0 + j] * dp[k0 + j];
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+  int k = k0;
+  for (int b = n0; b < n1; b += 64) {
+    const int i = b + lane;
+    const bool on = i < n1 && mask[i];
+    const unsigned long long bal = __ballot(on);
+    if (i < n1) {
+      float v = 0.f;
+      if (on) {
+        const int j = k + __popcll(bal & ((1ull << lane) - 1ull));
+        v = p[j] * (dp[j] - dot);
+      }
+      dq[i] = v;
+    }
+    k += __popcll(bal);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ValueGCN head (scripts/Networks.py:66-70): global_mean_pool(x, batch).mean(dim=1) over the [N, C] read-out = per graph
+// the mean over its nodes of every column, then the mean over the columns.  One workgroup per graph.
+// Backward: dh[n][c] = dv[g] / (n_g C).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mean_pool(const float *h, int C, const int *node_off, float *v_out) {
+  __shared__ float red[4];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int n0 = node_off[g], n1 = node_off[g + 1];
+  float acc = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int n = n0; n < n1; ++n) s += h[(size_t)n * C + c];
+    acc += s / (float)max(n1 - n0, 1);  // the column's mean over the graph's nodes
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) v_out[g] = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+}
+__global__ __launch_bounds__(256) void k_mean_pool_bwd(const float *dv, int C, const int *node_off, float *dh) {
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int n0 = node_off[g], n1 = node_off[g + 1];
+  const float v = dv[g] / ((float)max(n1 - n0, 1) * (float)C);
+  for (long long e = tid; e < (long long)(n1 - n0) * C; e += 256) dh[(size_t)n0 * C + e] = v;
+}
+
 }  // namespace
 
 extern "C" {
+
+int drlgx_normalise_rewards(void *hip_stream, int n_envs, const double *raw, const int64_t *cand_first, const int32_t *n_frontier,
+                            double *out, uint8_t *loop_clo) {
+  if (n_envs <= 0 || !raw || !cand_first || !n_frontier || !out || !loop_clo) return DRLGX_E_INVALID;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  hipLaunchKernelGGL(k_normalise_rewards, dim3(n_envs), dim3(64), 0, st, raw, cand_first, n_frontier, out, loop_clo);
+  return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
+}
+
+int drlgx_segment_softmax(void *hip_stream, int n_graphs, const int32_t *node_off, const float *q, const uint8_t *mask, float *p_out) {
+  if (n_graphs <= 0 || !node_off || !q || !mask || !p_out) return DRLGX_E_INVALID;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  hipLaunchKernelGGL(k_segment_softmax, dim3(n_graphs), dim3(64), 0, st, q, mask, node_off, p_out);
+  return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
+}
+
+int drlgx_segment_softmax_backward(void *hip_stream, int n_graphs, const int32_t *node_off, const float *p, const float *d_p,
+                                   const uint8_t *mask, float *d_q) {
+  if (n_graphs <= 0 || !node_off || !p || !d_p || !mask || !d_q) return DRLGX_E_INVALID;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  hipLaunchKernelGGL(k_segment_softmax_bwd, dim3(n_graphs), dim3(64), 0, st, p, d_p, mask, node_off, d_q);
+  return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
+}
+
+int drlgx_mean_pool(void *hip_stream, int n_graphs, const int32_t *node_off, const float *h, int n_cols, float *v_out) {
+  if (n_graphs <= 0 || !node_off || !h || n_cols <= 0 || !v_out) return DRLGX_E_INVALID;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  hipLaunchKernelGGL(k_mean_pool, dim3(n_graphs), dim3(256), 0, st, h, n_cols, node_off, v_out);
+  return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
+}
+
+int drlgx_mean_pool_backward(void *hip_stream, int n_graphs, const int32_t *node_off, const float *d_v, int n_cols, float *d_h) {
+  if (n_graphs <= 0 || !node_off || !d_v || n_cols <= 0 || !d_h) return DRLGX_E_INVALID;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  hipLaunchKernelGGL(k_mean_pool_bwd, dim3(n_graphs), dim3(256), 0, st, d_v, n_cols, node_off, d_h);
+  return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
+}
+
 
 int drlgx_replay_collate(void *hip_stream, int n_graphs, const int64_t *desc_dev, const float *pool_x, int in_dim, const int64_t *pool_ei,
                          int64_t pool_edges, const float *pool_ea, float *x_out, int64_t *ei_out, int64_t n_edges_total, float *ea_out,

@@ -163,6 +163,58 @@ class GCN(torch.nn.Module):
                          self.fully_con1.weight, self.fully_con1.bias, mask, graph_segments(data))
 
 
+class _SegmentSoftmax(torch.autograd.Function):
+    """drlgx_segment_softmax / _backward: masked_select + per-graph softmax of the read-out (PolicyGCN head)."""
+
+    @staticmethod
+    def forward(ctx, q, mask, node_off, n_selected):
+        L = _lib.lib()
+        q = q.contiguous().float()
+        mask = mask.contiguous()
+        p = torch.empty(n_selected, dtype=torch.float32, device=q.device)
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        _lib.check(L.drlgx_segment_softmax(C.c_void_p(stream), node_off.numel() - 1, _p(node_off), _p(q), _p(mask), _p(p)))
+        ctx.save_for_backward(p, mask, node_off)
+        ctx.n = q.numel()
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        L = _lib.lib()
+        p, mask, node_off = ctx.saved_tensors
+        dq = torch.empty(ctx.n, dtype=torch.float32, device=p.device)
+        stream = torch.cuda.current_stream(p.device).cuda_stream
+        _lib.check(L.drlgx_segment_softmax_backward(C.c_void_p(stream), node_off.numel() - 1, _p(node_off), _p(p), _p(dp.contiguous().float()),
+                                                    _p(mask), _p(dq)))
+        return dq, None, None, None
+
+
+class _MeanPool(torch.autograd.Function):
+    """drlgx_mean_pool / _backward: global_mean_pool(h, batch).mean(dim=1) (ValueGCN head)."""
+
+    @staticmethod
+    def forward(ctx, h, node_off):
+        L = _lib.lib()
+        h = h.contiguous().float()
+        G = node_off.numel() - 1
+        v = torch.empty(G, dtype=torch.float32, device=h.device)
+        stream = torch.cuda.current_stream(h.device).cuda_stream
+        _lib.check(L.drlgx_mean_pool(C.c_void_p(stream), G, _p(node_off), _p(h), h.shape[1], _p(v)))
+        ctx.save_for_backward(node_off)
+        ctx.shape = tuple(h.shape)
+        return v
+
+    @staticmethod
+    def backward(ctx, dv):
+        L = _lib.lib()
+        (node_off,) = ctx.saved_tensors
+        dh = torch.empty(ctx.shape, dtype=torch.float32, device=dv.device)
+        stream = torch.cuda.current_stream(dv.device).cuda_stream
+        _lib.check(L.drlgx_mean_pool_backward(C.c_void_p(stream), node_off.numel() - 1, _p(node_off), _p(dv.contiguous().float()), ctx.shape[1],
+                                              _p(dh)))
+        return dh, None
+
+
 def segment_softmax(src, index, num_segments):
     """torch_geometric.utils.softmax (PyG 1.x): exp(src - segment max) / (segment sum + 1e-16)."""
     mx = torch.full((num_segments,), -float("inf"), dtype=src.dtype, device=src.device)
@@ -186,6 +238,9 @@ class PolicyGCN(torch.nn.Module):
         dmask = _dropout_mask(x.shape[0], 1000, 0.5, x.device)  # F.dropout(x): p = 0.5 even at inference
         q = gcn_trunk(x, edge_index, edge_weight, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
                       self.fully_con1.weight, self.fully_con1.bias, dmask, graph_segments(data))
+        segs = graph_segments(data)
+        if segs is not None and mask.dtype == torch.bool:  # wavefront segment reductions over the batch's graph boundaries
+            return _SegmentSoftmax.apply(q.view(-1), mask, segs[1], int(mask.sum()))
         q = torch.masked_select(q.view(-1), mask)
         b = torch.masked_select(batch, mask)
         return segment_softmax(q, b, int(batch.max().item()) + 1 if batch.numel() else 0)
@@ -205,6 +260,9 @@ class ValueGCN(torch.nn.Module):
         dmask = _dropout_mask(x.shape[0], 1000, 0.5, x.device)
         h = gcn_trunk(x, edge_index, edge_weight, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
                       self.fully_con1.weight, self.fully_con1.bias, dmask, graph_segments(data))
+        segs = graph_segments(data)
+        if segs is not None:
+            return _MeanPool.apply(h, segs[1])
         g = int(batch.max().item()) + 1
         s = torch.zeros(g, h.shape[1], dtype=h.dtype, device=h.device).index_add_(0, batch, h)
         cnt = torch.zeros(g, dtype=h.dtype, device=h.device).index_add_(0, batch, torch.ones_like(batch, dtype=h.dtype))
@@ -239,7 +297,7 @@ class GraphData(object):
         """torch_geometric DataLoader/Batch semantics: concatenate, offset edge_index by cumulative node counts."""
         if items and all(isinstance(d, PoolRef) for d in items) and all(d.pool is items[0].pool for d in items):
             return items[0].pool.collate(items)  # one gather per tensor instead of a few torch ops per graph
-        xs, eis, eas, counts = [], [], [], []
+        xs, eis, eas, counts, ecounts = [], [], [], [], []
         off = 0
         for d in items:
             x = d.x
@@ -249,10 +307,12 @@ class GraphData(object):
             eis.append(d.edge_index_global + (off - d.node0) if isinstance(d, GraphSlice) else d.edge_index + off)
             eas.append(d.edge_attr)
             counts.append(n)
+            ecounts.append(int(eas[-1].shape[0]))
             off += n
         dev = xs[0].device
-        batch = torch.repeat_interleave(torch.arange(len(items), device=dev), torch.tensor(counts, device=dev))
-        return GraphData(torch.cat(xs), torch.cat(eis, dim=1), torch.cat(eas), batch)
+        batch = torch.repeat_interleave(torch.arange(len(items), device=dev), torch.tensor(counts, device=dev), output_size=off)
+        offs = torch.from_numpy(np.stack([np.concatenate([[0], np.cumsum(counts)]), np.concatenate([[0], np.cumsum(ecounts)])]).astype(np.int32)).to(dev)
+        return GraphData(torch.cat(xs), torch.cat(eis, dim=1), torch.cat(eas), batch, offs[0], offs[1], max(ecounts))
 
 
 class GraphSlice(object):

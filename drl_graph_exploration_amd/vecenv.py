@@ -23,11 +23,26 @@ from .config import default_config, start_pose
 from .engine import Engine
 
 
-def normalise_rewards(raw, cand_env, cand_first, n_envs):
+def normalise_rewards(raw, cand_env, cand_first, n_envs, n_frontier=None):
     """exploration_env.py:151-161 for every env at once. raw [C] f64 look-ahead rewards of the (env, frontier)
     candidates in env-major order, cand_env [C] i64, cand_first [n_envs] i64 (index of each env's frontier 0 = the
     vehicle's nearest frontier). Returns (normalised [C], loop_clo [n_envs] bool): the nearest frontier is the
-    (first) arg-max -> np.interp to [-1, 0], loop_clo False; otherwise [-1, 1], loop_clo True."""
+    (first) arg-max -> np.interp to [-1, 0], loop_clo False; otherwise [-1, 1], loop_clo True.
+    Device tensors go through drlgx_normalise_rewards (one wave per env); the tensor-op form below is the host mirror the
+    CPU tests check against np.interp."""
+    if raw.is_cuda:
+        import ctypes as C
+        from . import _lib
+        if n_frontier is None:
+            n_frontier = torch.diff(torch.cat([cand_first, torch.tensor([raw.numel()], device=raw.device)])).to(torch.int32)
+        raw = raw.contiguous()
+        out = torch.empty_like(raw)
+        loop = torch.empty(n_envs, dtype=torch.uint8, device=raw.device)
+        vp = C.c_void_p
+        _lib.check(_lib.lib().drlgx_normalise_rewards(vp(torch.cuda.current_stream(raw.device).cuda_stream), n_envs, vp(raw.data_ptr()),
+                                                      vp(cand_first.contiguous().data_ptr()), vp(n_frontier.contiguous().data_ptr()),
+                                                      vp(out.data_ptr()), vp(loop.data_ptr())))
+        return out, loop.bool()
     e = cand_env
     lo = torch.full((n_envs,), float("inf"), dtype=raw.dtype, device=raw.device).scatter_reduce(0, e, raw, reduce="amin")
     hi = torch.full((n_envs,), -float("inf"), dtype=raw.dtype, device=raw.device).scatter_reduce(0, e, raw, reduce="amax")
@@ -146,7 +161,7 @@ class VecExplorationEnv(object):
         actions, n_act = all_actions if all_actions is not None else (self._actions, self._n_act)
         kmax = max(int(n_act.max().item()), 1) if n_act.numel() else 1  # host bound: unreached action indices are not launched
         raw = self.engine.lookahead(self._cand_env, actions, n_act, max_n_actions=kmax)
-        r, self.loop_clo = normalise_rewards(raw, self._cand_env.long(), self._cand_first, self.n_envs)
+        r, self.loop_clo = normalise_rewards(raw, self._cand_env.long(), self._cand_first, self.n_envs, self._graph["n_frontier"])
         return (r, raw) if return_raw else r
 
     # ------------------------------------------------------------------ step (exploration_env.py:98-105)

@@ -310,6 +310,26 @@ int drlgx_adam_step(void *hip_stream, int n_tensors, float *const *params, const
                     float *const *exp_avg, float *const *exp_avg_sq, const int64_t *sizes, double lr, double beta1,
                     double beta2, double eps, int64_t step, double grad_clamp);
 
+/* ---- env wrapper / actor-critic heads ------------------------------------------------------------------------- */
+
+/* The normalisation of ExplorationEnv.rewards_all_goals (scripts/envs/exploration_env.py:151-161) for every env: raw
+ * look-ahead rewards of env e's frontiers at [cand_first[e], +n_frontier[e]) -> np.interp onto [-1, 0] (nearest frontier
+ * is the first arg-max, loop_clo 0) or [-1, 1] (loop_clo 1).  All pointers DEVICE. */
+int drlgx_normalise_rewards(void *hip_stream, int n_envs, const double *raw, const int64_t *cand_first,
+                            const int32_t *n_frontier, double *out, uint8_t *loop_clo);
+/* PolicyGCN head (scripts/Networks.py:47-50): masked_select + torch_geometric.utils.softmax over every graph's selected
+ * nodes.  q / mask over all N nodes, graph boundaries node_off int32 [n_graphs + 1]; p_out holds the selected nodes of
+ * all graphs in node order (sum(mask) values).  Backward: d_q over all N nodes (0 outside the mask). */
+int drlgx_segment_softmax(void *hip_stream, int n_graphs, const int32_t *node_off, const float *q, const uint8_t *mask,
+                          float *p_out);
+int drlgx_segment_softmax_backward(void *hip_stream, int n_graphs, const int32_t *node_off, const float *p,
+                                   const float *d_p, const uint8_t *mask, float *d_q);
+/* ValueGCN head (scripts/Networks.py:66-70): global_mean_pool(h, batch).mean(dim=1) of the [N][n_cols] read-out, one
+ * value per graph; backward d_h [N][n_cols]. */
+int drlgx_mean_pool(void *hip_stream, int n_graphs, const int32_t *node_off, const float *h, int n_cols, float *v_out);
+int drlgx_mean_pool_backward(void *hip_stream, int n_graphs, const int32_t *node_off, const float *d_v, int n_cols,
+                             float *d_h);
+
 #ifdef __cplusplus
 }
 #endif

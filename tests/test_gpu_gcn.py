@@ -404,6 +404,62 @@ def test_batched_graph_build_equals_the_generic_one():
     assert rel_err(outs[1][0], ref) < 2e-4
 
 
+def test_hip_heads_and_reward_normalisation_equal_the_tensor_op_forms(monkeypatch):
+    """The actor-critic heads as wavefront segment reductions (drlgx_segment_softmax, drlgx_mean_pool, with their
+    backward kernels) against the tensor-op forms of the same modules (taken when a batch carries no graph boundaries):
+    outputs and all parameter gradients; drlgx_normalise_rewards against the np.interp mirror."""
+    import drl_graph_exploration_amd.networks as NW
+    from drl_graph_exploration_amd.networks import GraphData, PolicyGCN, ValueGCN
+    from drl_graph_exploration_amd.vecenv import normalise_rewards
+    dev = torch.device("cuda", 0)
+    G = 7
+    x, ei, ea, batch = random_batch(G, 55, dev)
+    cnt = torch.bincount(batch, minlength=G)
+    node_off = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(cnt, 0)]).to(torch.int32)
+    ecnt = torch.bincount(batch[ei[0]], minlength=G)
+    edge_off = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(ecnt, 0)]).to(torch.int32)
+    gen = torch.Generator().manual_seed(2)
+    mask = torch.zeros(x.shape[0], dtype=torch.bool)
+    for g in range(G):  # the last 1..5 nodes of every graph are its frontier nodes
+        mask[int(node_off[g + 1]) - 1 - int(torch.randint(0, 5, (1,), generator=gen)):int(node_off[g + 1])] = True
+    mask = mask.to(dev)
+    fixed = (torch.rand(x.shape[0], 1000, device=dev) >= 0.5).float() * 2.0
+    monkeypatch.setattr(NW, "_dropout_mask", lambda n, hidden, p, device: fixed if p > 0 else None)
+    plain = GraphData(x, ei, ea, batch)
+    segd = GraphData(x, ei, ea, batch, node_off, edge_off, int(ecnt.max()))
+    for cls in (PolicyGCN, ValueGCN):
+        torch.manual_seed(1)
+        net = cls().to(dev)
+        outs = []
+        for d in (plain, segd):
+            net.zero_grad()
+            out = net(d, mask, batch=batch)
+            wgt = torch.linspace(0.5, 1.5, out.numel(), device=dev)
+            (out * wgt).sum().backward()
+            outs.append((out.detach().clone(), [p.grad.clone() for p in net.parameters()]))
+        assert outs[0][0].shape == outs[1][0].shape
+        assert rel_err(outs[1][0], outs[0][0]) < 1e-5, cls.__name__
+        for ga, gb in zip(outs[1][1], outs[0][1]):
+            # (the softmax is shift-invariant: the gradient of the read-out bias is round-off around zero in both forms)
+            assert float((ga - gb).abs().max()) < 1e-4 * float(gb.abs().max()) + 1e-6, cls.__name__
+        if cls is PolicyGCN:  # a distribution per graph
+            sums = torch.zeros(G, device=dev).index_add_(0, batch[mask], outs[1][0])
+            assert float((sums - 1).abs().max()) < 1e-5
+    # reward normalisation
+    nfr = torch.tensor([3, 1, 5, 2, 8, 1, 4], dtype=torch.int32)
+    first = torch.cumsum(nfr, 0) - nfr
+    raw = torch.randn(int(nfr.sum()), dtype=torch.float64, generator=gen)
+    raw[first[2]] = raw[first[2]:first[2] + 5].max() + 1.0  # env 2: the nearest frontier is the maximum
+    raw[first[4]:first[4] + 8] = 0.25                        # env 4: all equal
+    cand_env = torch.repeat_interleave(torch.arange(len(nfr)), nfr.long())
+    r_host, l_host = normalise_rewards(raw, cand_env, first.long(), len(nfr))
+    r_dev, l_dev = normalise_rewards(raw.to(dev), cand_env.to(dev), first.long().to(dev), len(nfr), nfr.to(dev))
+    assert torch.equal(l_dev.cpu(), l_host)
+    np.testing.assert_allclose(r_dev.cpu().numpy(), r_host.numpy(), rtol=0, atol=4e-16)
+    r_dev2, _ = normalise_rewards(raw.to(dev), cand_env.to(dev), first.long().to(dev), len(nfr))  # counts derived from the offsets
+    assert torch.equal(r_dev2, r_dev)
+
+
 def test_explicit_self_loops_keep_their_weight():
     """PyG add_remaining_self_loops: a node with an explicit self loop keeps that weight instead of the fill value 2
     (gcn_ref.gcn_norm does the same); edges pointing outside the graph are ignored instead of read out of bounds."""
