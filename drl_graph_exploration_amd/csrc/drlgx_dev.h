@@ -277,6 +277,19 @@ struct LLT3 {
     x0 = (y0 - l10 * x1 - l20 * x2) / l00;
   }
 };
+// inverse of a symmetric positive definite 3x3 (c00 c10 c20 c11 c21 c22) by cofactors and ONE reciprocal, in the storage
+// order of the pose information (i00 i10 i20 i11 i21 i22).  Used where the reference inverts a marginal covariance by LLT
+// (SLAM2D.cpp:395-408): the values are compared at 1e-7, no decision depends on them.
+__device__ __forceinline__ void inv3_sym_fast(double c00, double c10, double c20, double c11, double c21, double c22, double *o) {
+  const double k00 = c11 * c22 - c21 * c21, k10 = c20 * c21 - c10 * c22, k20 = c10 * c21 - c20 * c11;
+  const double id = rcp_n(c00 * k00 + c10 * k10 + c20 * k20);
+  o[0] = k00 * id;
+  o[1] = k10 * id;
+  o[2] = k20 * id;
+  o[3] = (c00 * c22 - c20 * c20) * id;
+  o[4] = (c10 * c20 - c00 * c21) * id;
+  o[5] = (c00 * c11 - c10 * c10) * id;
+}
 __device__ __forceinline__ double det3s(double a00, double a01, double a02, double a11, double a12, double a22) {
   return a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02);
 }

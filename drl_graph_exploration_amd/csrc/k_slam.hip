@@ -973,15 +973,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
     const double c00 = -A[AT(k0, k0)], c10 = -A[AT((k0 + 1), k0)], c11 = -A[AT((k0 + 1), k0 + 1)];
     const double c20 = -A[AT((k0 + 2), k0)], c21 = -A[AT((k0 + 2), k0 + 1)], c22 = -A[AT((k0 + 2), k0 + 2)];
     pose_tr[i] = c00 + c11 + c22;
-    LLT3 llt(c00, c10, c20, c11, c21, c22);
-    double x0, x1, x2;
-    double *pi = pose_info + 6 * i;
-    llt.solve(1, 0, 0, x0, x1, x2);
-    pi[0] = x0; pi[1] = x1; pi[2] = x2;
-    llt.solve(0, 1, 0, x0, x1, x2);
-    pi[3] = x1; pi[4] = x2;
-    llt.solve(0, 0, 1, x0, x1, x2);
-    pi[5] = x2;
+    inv3_sym_fast(c00, c10, c20, c11, c21, c22, pose_info + 6 * i);
   }
   DRLGX_PROF(S, 7);
   if (tid == 0) {

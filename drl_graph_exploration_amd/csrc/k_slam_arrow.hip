@@ -226,36 +226,68 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   DRLGX_PROF(S, 1);
   // ---- 3. blocks: Lambda_jj, eta_j per landmark; D_i, eta_p,i, T_{i+1,i} per pose ----
   const double wb = 1.0 / (cfg.bearing_noise * cfg.bearing_noise), wr = 1.0 / (cfg.range_noise * cfg.range_noise);
-  const int pose_t0 = ((L + 63) & ~63) % kThreads;
-  for (int j = tid; j < L; j += kThreads) {
-    double a = 0, b = 0, d = 0, g0 = 0, g1 = 0;
-    MaskIter it(lmask + MW * j, MW);
-    for (;;) {
-      int ip[4];
-      const int n = it.next4(ip);
-      if (n == 0) break;
-      double2 rv[4][3];  // Jl (4) and e (2) of up to four observations, loaded together
+  {
+    // landmark blocks: the observations of a landmark are split over S3 lanes (see the landmark system below for why),
+    // partial sums combined by a butterfly
+    int S3 = 1;
+    while (S3 < 64 && L * (S3 * 2) <= kThreads) S3 <<= 1;
+    const int per_pass = kThreads / S3;
+    for (int j0 = 0; j0 < L; j0 += per_pass) {
+      const int j = j0 + tid / S3, s3 = tid & (S3 - 1);
+      const bool work = j < L;
+      double acc[5] = {0, 0, 0, 0, 0};  // Lambda_jj (a b d), J^T W e (g0 g1)
+      auto visit = [&](const int (&ip)[4], int n) {
+        double2 rv[4][3];  // Jl (4) and e (2) of up to four observations, loaded together
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const double2 *r2 = reinterpret_cast<const double2 *>(rec + (size_t)REC * (obs[j * P + ip[u]] - 1) + 6);
-        rv[u][0] = r2[0]; rv[u][1] = r2[1]; rv[u][2] = r2[2];
-      }
+        for (int u = 0; u < 4; ++u) {
+          const double2 *r2 = reinterpret_cast<const double2 *>(rec + (size_t)REC * (obs[j * P + ip[u < n ? u : 0]] - 1) + 6);
+          rv[u][0] = r2[0]; rv[u][1] = r2[1]; rv[u][2] = r2[2];
+        }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (u >= n) break;
-        const double r6 = rv[u][0].x, r7 = rv[u][0].y, r8 = rv[u][1].x, r9 = rv[u][1].y, r10 = rv[u][2].x, r11 = rv[u][2].y;
-        a += r6 * wb * r6 + r8 * wr * r8;
-        b += r6 * wb * r7 + r8 * wr * r9;
-        d += r7 * wb * r7 + r9 * wr * r9;
-        g0 += r6 * wb * r10 + r8 * wr * r11;
-        g1 += r7 * wb * r10 + r9 * wr * r11;
+        for (int u = 0; u < 4; ++u) {
+          if (u >= n) break;
+          const double r6 = rv[u][0].x, r7 = rv[u][0].y, r8 = rv[u][1].x, r9 = rv[u][1].y, r10 = rv[u][2].x, r11 = rv[u][2].y;
+          acc[0] += r6 * wb * r6 + r8 * wr * r8;
+          acc[1] += r6 * wb * r7 + r8 * wr * r9;
+          acc[2] += r7 * wb * r7 + r9 * wr * r9;
+          acc[3] += r6 * wb * r10 + r8 * wr * r11;
+          acc[4] += r7 * wb * r10 + r9 * wr * r11;
+        }
+      };
+      if (work) {
+        const unsigned long long *mk = lmask + MW * j;
+        int ip[4] = {0, 0, 0, 0}, n = 0;
+        if (S3 == 1) {
+          MaskIter it(mk, MW);
+          for (;;) {
+            n = it.next4(ip);
+            if (n == 0) break;
+            visit(ip, n);
+            if (n < 4) break;
+          }
+        } else {
+          for (int i = s3; i < P; i += S3)
+            if ((mk[i >> 6] >> (i & 63)) & 1ull) {
+              ip[n++] = i;
+              if (n == 4) {
+                visit(ip, 4);
+                n = 0;
+              }
+            }
+          if (n) visit(ip, n);
+        }
       }
-      if (n < 4) break;
+      for (int o = S3 >> 1; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[k] += __shfl_xor(acc[k], o);
+      if (work && s3 == 0) {
+        double *lb = lamb + 8 * j;
+        lb[0] = acc[0]; lb[1] = acc[1]; lb[2] = acc[2];
+        lb[6] = -acc[3]; lb[7] = -acc[4];  // eta_j
+      }
     }
-    double *lb = lamb + 8 * j;
-    lb[0] = a; lb[1] = b; lb[2] = d;
-    lb[6] = -g0; lb[7] = -g1;  // eta_j
   }
+  const int pose_t0 = 0;
   for (int i = (tid - pose_t0 + kThreads) % kThreads; i < P; i += kThreads) {
     double B[9], g[3], O[9];
     pose_block(S, inst, thp, rec, mstart, i, P, wb, wr, B, g, O);
@@ -630,32 +662,22 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   DRLGX_PROF(S, 10);
   // ---- 7. landmark system [C r]: rows 2j, 2j+1 at column c (lower triangle + the rhs column) ----
   {
-    // one thread per (landmark, 4 columns): the observing poses are visited in ascending order, four at a time with
-    // all their loads (32-byte rows of X, the factor's B block) issued before the first use - X lives in L2 / HBM
+    // one work item per (landmark, 4 columns).  Its observing poses are split over S_ lanes (as many as the workgroup
+    // has to spare: a sparse world has a handful of landmarks, each seen from dozens of poses - one thread per item would
+    // walk them in dependent rounds of L2 latency); every lane visits its poses four at a time with all their loads (32-byte
+    // rows of X, the factor's B block) issued before the first use, and the lanes' partial sums are combined by a
+    // butterfly (a fixed tree: deterministic)
     const int nq = ldx >> 2, q_rhs = np >> 2;
-    for (int e = tid; e < L * nq; e += kThreads) {
-      const int j = e / nq, q = e - j * nq, c0 = 4 * q;
-      if (c0 > 2 * j + 1 && q != q_rhs) continue;
+    const int items = L * nq;
+    int S_ = 1;
+    while (S_ < 64 && items * (S_ * 2) <= kThreads) S_ <<= 1;
+    const int per_pass = kThreads / S_;
+    for (int e0 = 0; e0 < items; e0 += per_pass) {
+      const int e = e0 + tid / S_, s = tid & (S_ - 1);
+      const int j = e < items ? e / nq : 0, q = e < items ? e - j * nq : 0, c0 = 4 * q;
+      const bool work = e < items && !(c0 > 2 * j + 1 && q != q_rhs);
       double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
-      int w = 0;
-      unsigned long long m = lmask[MW * j];
-      bool more = true;
-      while (more) {
-        int ip[4];
-        int n = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          while (!m && w + 1 < MW) m = lmask[MW * j + (++w)];
-          if (m) {
-            ip[u] = 64 * w + __ffsll((long long)m) - 1;
-            m &= m - 1;
-            n = u + 1;
-          } else {
-            ip[u] = ip[0];
-          }
-        }
-        if (n == 0) break;
-        more = n == 4;
+      auto visit = [&](const int (&ip)[4], int n) {
         double2 xv[4][3][2];
         double bm[4][6];
 #pragma unroll
@@ -683,7 +705,38 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
             a1[cc] += bm[u][1] * x0[cc] + bm[u][3] * x1[cc] + bm[u][5] * x2[cc];
           }
         }
+      };
+      if (work) {
+        const unsigned long long *mk = lmask + MW * j;
+        int ip[4] = {0, 0, 0, 0}, n = 0;
+        if (S_ == 1) {  // every observing pose, ascending
+          MaskIter it(mk, MW);
+          for (;;) {
+            n = it.next4(ip);
+            if (n == 0) break;
+            visit(ip, n);
+            if (n < 4) break;
+          }
+        } else {        // this lane's share: the poses i = s (mod S_)
+          for (int i = s; i < P; i += S_)
+            if ((mk[i >> 6] >> (i & 63)) & 1ull) {
+              ip[n++] = i;
+              if (n == 4) {
+                visit(ip, 4);
+                n = 0;
+              }
+            }
+          if (n) visit(ip, n);
+        }
       }
+      for (int o = S_ >> 1; o > 0; o >>= 1) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          a0[cc] += __shfl_xor(a0[cc], o);
+          a1[cc] += __shfl_xor(a1[cc], o);
+        }
+      }
+      if (!work || s != 0) continue;
       const double *lb = lamb + 8 * j;
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
@@ -862,15 +915,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     const double c00 = ti[0] - sc[0], c10 = ti[1] - 0.5 * (sc[1] + sc[3]), c20 = ti[2] - 0.5 * (sc[2] + sc[6]);
     const double c11 = ti[3] - sc[4], c21 = ti[4] - 0.5 * (sc[5] + sc[7]), c22 = ti[5] - sc[8];
     pose_tr[i] = c00 + c11 + c22;
-    LLT3 llt(c00, c10, c20, c11, c21, c22);  // information = inverse(covariance) by LLT (SLAM2D.cpp:395-408)
-    double q0, q1, q2;
-    double *pi = pose_info + 6 * i;
-    llt.solve(1, 0, 0, q0, q1, q2);
-    pi[0] = q0; pi[1] = q1; pi[2] = q2;
-    llt.solve(0, 1, 0, q0, q1, q2);
-    pi[3] = q1; pi[4] = q2;
-    llt.solve(0, 0, 1, q0, q1, q2);
-    pi[5] = q2;
+    inv3_sym_fast(c00, c10, c20, c11, c21, c22, pose_info + 6 * i);  // information = inverse(covariance) (SLAM2D.cpp:395-408)
   }
   DRLGX_PROF(S, 9);
   if (tid == 0) {
