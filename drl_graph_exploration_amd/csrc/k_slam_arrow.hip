@@ -803,6 +803,41 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
       v += __shfl_xor(v, 1, 16);
       if (sub == 0) dz[row] = v;
     }
+  } else if (c_lds && np <= 12) {
+    // a handful of landmarks: one thread per pose does its three rows of Z = X_B [-C^-1 | delta_l] and the 3 x 3 product
+    // with X_i^T on the vector units (at most 3 * 13 * 12 + 108 multiply-adds) - four rounds of matrix-core tiles with
+    // their operand loads would cost more than that
+    for (int i = tid; i < P; i += kThreads) {
+      double xr[3][12];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) xr[r][k] = k < np ? X[(size_t)(3 * i + r) * ldx + k] : 0.0;
+      double sc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, dzr[3] = {0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        if (c < np) {
+          double z[3] = {0, 0, 0};
+#pragma unroll
+          for (int k = 0; k < 12; ++k)
+            if (k < np) {
+              const double m = A[AT(max(k, c), min(k, c))];
+              z[0] += xr[0][k] * m; z[1] += xr[1][k] * m; z[2] += xr[2][k] * m;
+            }
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            sc[r][0] += z[r] * xr[0][c]; sc[r][1] += z[r] * xr[1][c]; sc[r][2] += z[r] * xr[2][c];
+          }
+          const double dl = A[AT(np, c)];
+          dzr[0] += xr[0][c] * dl; dzr[1] += xr[1][c] * dl; dzr[2] += xr[2][c] * dl;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        dz[3 * i + r] = dzr[r];
+        Sc[9 * i + 3 * r] = sc[r][0]; Sc[9 * i + 3 * r + 1] = sc[r][1]; Sc[9 * i + 3 * r + 2] = sc[r][2];
+      }
+    }
   } else {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lc = lane & 15, lr = lane >> 4;
     const int nrows = 3 * P, nrt = (nrows + 15) / 16, nK = (np + 15) / 16;
