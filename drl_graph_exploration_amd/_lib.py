@@ -99,7 +99,7 @@ def lib():
     L.drlgx_gcn_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.drlgx_gcn_forward.argtypes = [vp] + [C.c_int] * 5 + [vp] * 12
     L.drlgx_gcn_backward.argtypes = [vp] + [C.c_int] * 5 + [vp] * 15
-    L.drlgx_replay_collate.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
+    L.drlgx_replay_collate.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     L.drlgx_gcn_forward_batched.argtypes = [vp] + [C.c_int] * 5 + [vp] * 12 + [C.c_int, vp, vp, C.c_int]
     L.drlgx_dqn_targets.argtypes = [vp, C.c_int, vp, vp, vp, C.c_double, C.c_int64, vp, vp]
     L.drlgx_dqn_loss_grad.argtypes = [vp, C.c_int, vp, vp, vp, C.c_double, vp, vp]

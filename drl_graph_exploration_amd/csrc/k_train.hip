@@ -21,7 +21,7 @@ namespace {
 __global__ __launch_bounds__(256) void k_replay_collate(int G, const int64_t *desc, const float *pool_x, int in_dim, const int64_t *pool_ei,
                                                         int64_t pool_edges, const float *pool_ea, float *x_out, int64_t *ei_out,
                                                         int64_t E_total, float *ea_out, int64_t *batch_out, int *node_off_out,
-                                                        int *edge_off_out) {
+                                                        int *edge_off_out, const float *pool_q, float *q_out) {
   __shared__ long long red[2][4];
   const int g = blockIdx.x, tid = threadIdx.x;
   long long sn = 0, se = 0;
@@ -50,12 +50,16 @@ __global__ __launch_bounds__(256) void k_replay_collate(int G, const int64_t *de
       edge_off_out[G] = (int)(edge_off + ne);
     }
   }
-  const float *xs = pool_x + n0 * in_dim;
-  float *xd = x_out + node_off * in_dim;
-  for (long long i = tid; i < nn * in_dim; i += 256) xd[i] = xs[i];
-  for (long long i = tid; i < nn; i += 256) batch_out[node_off + i] = g;
+  if (x_out) {  // (NULL: only the per-node cache is gathered)
+    const float *xs = pool_x + n0 * in_dim;
+    float *xd = x_out + node_off * in_dim;
+    for (long long i = tid; i < nn * in_dim; i += 256) xd[i] = xs[i];
+    for (long long i = tid; i < nn; i += 256) batch_out[node_off + i] = g;
+  }
+  if (pool_q && q_out)  // a per-node value stored beside the pooled graphs (the target network's cached read-out)
+    for (long long i = tid; i < nn; i += 256) q_out[node_off + i] = pool_q[n0 + i];
   const long long shift = node_off - loc;
-  for (long long j = tid; j < ne; j += 256) {
+  for (long long j = tid; x_out && j < ne; j += 256) {
     ei_out[edge_off + j] = pool_ei[e0 + j] + shift;
     ei_out[E_total + edge_off + j] = pool_ei[pool_edges + e0 + j] + shift;
     ea_out[edge_off + j] = pool_ea[e0 + j];
@@ -317,13 +321,14 @@ int drlgx_mean_pool_backward(void *hip_stream, int n_graphs, const int32_t *node
 
 int drlgx_replay_collate(void *hip_stream, int n_graphs, const int64_t *desc_dev, const float *pool_x, int in_dim, const int64_t *pool_ei,
                          int64_t pool_edges, const float *pool_ea, float *x_out, int64_t *ei_out, int64_t n_edges_total, float *ea_out,
-                         int64_t *batch_out, int32_t *node_off_out, int32_t *edge_off_out) {
-  if (n_graphs <= 0 || !desc_dev || !pool_x || in_dim <= 0 || !pool_ei || !pool_ea || !x_out || !ei_out || !ea_out || !batch_out ||
-      n_edges_total < 0 || pool_edges < 0)
+                         int64_t *batch_out, int32_t *node_off_out, int32_t *edge_off_out, const float *pool_q, float *q_out) {
+  const bool graphs = x_out != nullptr;
+  if (n_graphs <= 0 || !desc_dev || !pool_x || in_dim <= 0 || !pool_ei || !pool_ea || n_edges_total < 0 || pool_edges < 0 ||
+      (graphs ? (!ei_out || !ea_out || !batch_out) : (!pool_q || !q_out)))
     return DRLGX_E_INVALID;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   hipLaunchKernelGGL(k_replay_collate, dim3(n_graphs), dim3(256), 0, st, n_graphs, desc_dev, pool_x, in_dim, pool_ei, pool_edges, pool_ea,
-                     x_out, ei_out, n_edges_total, ea_out, batch_out, node_off_out, edge_off_out);
+                     x_out, ei_out, n_edges_total, ea_out, batch_out, node_off_out, edge_off_out, pool_q, q_out);
   return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
 }
 

@@ -365,6 +365,10 @@ class ReplayPool(object):
         self.edge_off = [None] * n_slots
         self.ref = [0] * n_slots
         self._next = 0
+        # one cached float per pooled node (the DQN trainer keeps the target network's read-out here), with the version of
+        # the weights it was computed with per slot
+        self.Q = torch.empty(n_slots * cap_nodes, dtype=torch.float32, device=device)
+        self.q_version = [None] * n_slots
 
     def put(self, g):
         """Copy one export (dict of `Engine.graph`, with host offsets `node_off_h` / `edge_off_h`) into a free slot."""
@@ -383,7 +387,17 @@ class ReplayPool(object):
         self.EA[slot * self.cap_edges:slot * self.cap_edges + E] = g["edge_attr"]
         self.node_off[slot] = np.asarray(g["node_off_h"], dtype=np.int64)
         self.edge_off[slot] = np.asarray(g["edge_off_h"], dtype=np.int64)
+        self.q_version[slot] = None
         return slot
+
+    def export(self, slot):
+        """The batched export stored in `slot` as one GraphData (views into the pool, with its graph boundaries)."""
+        no, eo = self.node_off[slot], self.edge_off[slot]
+        N, E = int(no[-1]), int(eo[-1])
+        n0, e0 = slot * self.cap_nodes, slot * self.cap_edges
+        offs = torch.from_numpy(np.stack([no, eo]).astype(np.int32)).to(self.device)
+        return GraphData(self.X[n0:n0 + N], self.EI[:, e0:e0 + E].contiguous(), self.EA[e0:e0 + E], None, offs[0], offs[1],
+                         int(np.diff(eo).max()) if len(eo) > 1 else 0)
 
     @staticmethod
     def descriptors(refs):
@@ -392,19 +406,31 @@ class ReplayPool(object):
         d = np.array([(r.n0, r.nn, r.e0, r.ne, r.loc) for r in refs], dtype=np.int64).T.copy()
         return d, int(d[1].sum()), int(d[3].sum())
 
-    def collate_from(self, desc_dev, k, n_nodes, n_edges, max_graph_edges=None):
-        """The PyG batch of `k` pooled graphs from their device descriptors: one kernel, no host synchronisation."""
+    def collate_from(self, desc_dev, k, n_nodes, n_edges, max_graph_edges=None, with_q=False):
+        """The PyG batch of `k` pooled graphs from their device descriptors: one kernel, no host synchronisation.
+        with_q: also gather the pool's per-node cache (`.q` of the result)."""
         dev = self.device
         x = torch.empty(n_nodes, self.X.shape[1], dtype=torch.float32, device=dev)
         ei = torch.empty(2, n_edges, dtype=torch.int64, device=dev)
         ea = torch.empty(n_edges, dtype=torch.float32, device=dev)
         bt = torch.empty(n_nodes, dtype=torch.int64, device=dev)
         offs = torch.empty(2, k + 1, dtype=torch.int32, device=dev)
+        q = torch.empty(n_nodes, dtype=torch.float32, device=dev) if with_q else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(_lib.lib().drlgx_replay_collate(C.c_void_p(stream), k, _p(desc_dev), _p(self.X), self.X.shape[1], _p(self.EI),
                                                    self.EI.shape[1], _p(self.EA), _p(x), _p(ei), n_edges, _p(ea), _p(bt), _p(offs[0]),
-                                                   _p(offs[1])))
-        return GraphData(x, ei, ea, bt, offs[0], offs[1], max_graph_edges)
+                                                   _p(offs[1]), _p(self.Q) if with_q else None, _p(q)))
+        d = GraphData(x, ei, ea, bt, offs[0], offs[1], max_graph_edges)
+        d.q = q
+        return d
+
+    def gather_q(self, desc_dev, k, n_nodes):
+        """The per-node cache of `k` pooled graphs, concatenated in collation order."""
+        q = torch.empty(n_nodes, dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().drlgx_replay_collate(C.c_void_p(stream), k, _p(desc_dev), _p(self.X), self.X.shape[1], _p(self.EI),
+                                                   self.EI.shape[1], _p(self.EA), None, None, 0, None, None, None, None, _p(self.Q), _p(q)))
+        return q
 
     def collate(self, refs):
         d, n_nodes, n_edges = self.descriptors(refs)

@@ -263,13 +263,27 @@ class DeepQ(object):
         else:  # everything the host contributes was uploaded in one piece by _prepare_updates
             pool, B = prepared["pool"], self.BATCH
             s_j = pool.collate_from(prepared["desc_j"], B, prepared["N"], prepared["E"], prepared["ME"])
-            s_j1 = pool.collate_from(prepared["desc_j1"], B, prepared["N1"], prepared["E1"], prepared["ME1"])
-            with torch.no_grad():
-                q1 = self.test(s_j1, 0.0, device, target_net).view(-1)
+            # the target network's read-out over the next states (`self.test(s_j1_batch, 0.0, device, target_net)`): a
+            # function of the graph and the frozen target weights only, evaluated once per stored export and target refresh
+            # (_refresh_target_readout) and gathered here
+            q1 = pool.gather_q(prepared["desc_j1"], B, prepared["N1"])
             a_batch, y_batch = self._td_apply(q1, prepared["meta"], prepared["r"], B, prepared["N"])
         self.train(s_j, a_batch, y_batch, device, policy_net, optimizer)
 
-    def _prepare_updates(self, n_upd, device):
+    def _refresh_target_readout(self, pool, slots, device, target_net):
+        """Target-network read-out (dropout off) of every export in `slots` whose cached values are older than the current
+        target weights: one forward over the export's whole batch, stored beside the pooled graphs."""
+        ver = self.__dict__.setdefault("_target_version", 0)
+        for slot in slots:
+            if pool.q_version[slot] == ver:
+                continue
+            g = pool.export(slot)
+            with torch.no_grad():
+                q = self.test(g, 0.0, device, target_net).view(-1)
+            pool.Q[slot * pool.cap_nodes:slot * pool.cap_nodes + q.numel()] = q
+            pool.q_version[slot] = ver
+
+    def _prepare_updates(self, n_upd, device, target_net):
         """Sample `n_upd` mini-batches (the buffer does not change between them, so sampling them up front draws the same
         transitions as sampling before every update) and upload everything the host contributes to the updates - the
         collation descriptors of s_j / s_j1, the TD-target windows, the rewards - as ONE int64 and ONE float64 tensor.
@@ -289,6 +303,7 @@ class DeepQ(object):
             I[u, 5:10], n1, e1 = ReplayPool.descriptors([d[3] for d in mb])
             I[u, 10:14], R[u], _ = self._td_meta(mb, n1)
             tot.append((n, e, n1, e1, int(I[u, 3].max()), int(I[u, 8].max())))
+        self._refresh_target_readout(pool, sorted({d[3].slot for mb in batches for d in mb}), device, target_net)
         I_dev, R_dev = torch.from_numpy(I).to(device), torch.from_numpy(R).to(device)
         return [dict(pool=pool, desc_j=I_dev[u, 0:5], desc_j1=I_dev[u, 5:10], meta=I_dev[u, 10:14], r=R_dev[u], N=tot[u][0],
                      E=tot[u][1], N1=tot[u][2], E1=tot[u][3], ME=tot[u][4], ME1=tot[u][5]) for u in range(n_upd)], batches
@@ -323,6 +338,7 @@ class DeepQ(object):
                     d.pool.ref[d.slot] -= 1
         broadcast_parameters(policy_net)
         broadcast_parameters(target_net)
+        self._target_version = self.__dict__.get("_target_version", 0) + 1  # (the caller may hand in another target network)
         # torch.optim.Adam(policy_net.parameters(), lr=1e-5) of the reference with the gradient clamp fused in front
         optimizer = FusedAdam(policy_net.parameters(), lr=1e-5, grad_clamp=self.max_grad_norm)
         temp_reward_data, temp_loss_data, rows = [], [], []
@@ -392,7 +408,8 @@ class DeepQ(object):
                 n_upd = n_envs if self.updates_per_vector_step is None else int(self.updates_per_vector_step)
                 if self.step_t // self.TARGET_UPDATE > (self.step_t - n_envs) // self.TARGET_UPDATE:
                     target_net.load_state_dict(policy_net.state_dict())
-                prepared, _ = self._prepare_updates(n_upd, device)
+                    self._target_version = self.__dict__.get("_target_version", 0) + 1  # cached target read-outs are stale
+                prepared, _ = self._prepare_updates(n_upd, device, target_net)
                 for u in range(n_upd):
                     self._train_minibatch(device, policy_net, target_net, optimizer, None if prepared is None else prepared[u])
                 temp_loss_data.append([self.step_t, self.temp_loss])

@@ -288,11 +288,15 @@ int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, i
  * [edge_start, +edge_cnt) of pool_ei ([2][pool_edges] i64) / pool_ea, its node ids start at loc.  desc_dev int64
  * [5][n_graphs] = node_start, node_cnt, edge_start, edge_cnt, loc.  Outputs (DEVICE, sized by the caller from the counts):
  * x_out [N][in_dim], ei_out [2][n_edges_total] (ids shifted by the cumulative node counts), ea_out, batch_out [N], and the
- * graph boundaries in the form drlgx_gcn_forward_batched takes. */
+ * graph boundaries in the form drlgx_gcn_forward_batched takes.  pool_q / q_out (optional): one float per pooled node
+ * gathered the same way - the target network's read-out, which depends on the graph and the (frozen) target weights only and
+ * is therefore evaluated once per stored graph and target refresh instead of once per mini-batch (scripts/policy.py:154-156);
+ * with x_out NULL only this value is gathered. */
 int drlgx_replay_collate(void *hip_stream, int n_graphs, const int64_t *desc_dev, const float *pool_x, int in_dim,
                          const int64_t *pool_ei, int64_t pool_edges, const float *pool_ea, float *x_out, int64_t *ei_out,
                          int64_t n_edges_total, float *ea_out, int64_t *batch_out,
-                         int32_t *node_off_out /* [n_graphs + 1] or NULL */, int32_t *edge_off_out /* [n_graphs + 1] or NULL */);
+                         int32_t *node_off_out /* [n_graphs + 1] or NULL */, int32_t *edge_off_out /* [n_graphs + 1] or NULL */,
+                         const float *pool_q /* [rows] or NULL */, float *q_out /* [N] or NULL */);
 /* TD targets, scripts/policy.py:154-175: sample i takes max(q1[lo_i:hi_i]) (float32, the target network's read-out over
  * the collated next states; the caller resolves the reference's slicing into [lo, hi)), and
  * a_batch[pos_i] = 1, y_batch[pos_i] = r_i + gamma max  (r_i alone when terminal_i) in float64; both vectors

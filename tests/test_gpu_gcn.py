@@ -266,7 +266,8 @@ def test_dqn_minibatch_matches_float64_restatement(monkeypatch, tmp_path):
 
 def test_fused_dqn_update_equals_the_framework_path(monkeypatch, tmp_path):
     """The DQN update as `DeepQ.running` issues it - mini-batches collated out of the device replay pool by
-    drlgx_replay_collate, TD targets by drlgx_dqn_targets, cost + gradient by drlgx_dqn_loss_grad, the trunk called without
+    drlgx_replay_collate, the target network's read-out evaluated once per stored export and gathered per mini-batch, TD
+    targets by drlgx_dqn_targets, cost + gradient by drlgx_dqn_loss_grad, the trunk called without
     an autograd graph, clamp + Adam in drlgx_adam_step - against the same three updates through the framework path (generic
     collate, tensor-op targets on the host copy, autograd, element-wise clamp, torch.optim.Adam): targets and collated
     batches bit-equal, losses and parameters after every step within float32 round-off of the update."""
@@ -328,7 +329,7 @@ def test_fused_dqn_update_equals_the_framework_path(monkeypatch, tmp_path):
     opt_b = torch.optim.Adam(pol_b.parameters(), lr=1e-3)
     it = iter(order)
     monkeypatch.setattr(random, "sample", lambda buf, k: [buf[i] for i in next(it)])
-    prepared, _ = dq_a._prepare_updates(3, dev)
+    prepared, _ = dq_a._prepare_updates(3, dev, tgt)  # (this also evaluates the target network once per pooled export)
     assert prepared is not None
     it = iter(order)
     spy = {}
