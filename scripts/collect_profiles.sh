@@ -22,3 +22,11 @@ rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU 
   --kernel-trace -d /tmp/prof_sq2 -- $BENCH > /dev/null 2> $out/rocprof_sq2.err
 python scripts/pmc_sq_summary.py "$(db /tmp/prof_sq)" "$(db /tmp/prof_sq2)" --json $out/sq_counters.json > $out/sq_counters.txt
 ls -la $out
+# the bench line itself, the 2-rank control flow on one device (gloo), and the step-vs-trajectory-length tables
+python bench.py > $out/bench.json 2> $out/bench.err
+DRLGX_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 50 --warmup 5 > $out/bench_2ranks_gloo.json 2> $out/bench_2ranks_gloo.err
+python scripts/bench_vs_poses.py 206 100 phases > $out/vs_poses_100lm.txt 2>&1
+python scripts/bench_vs_poses.py 206 8 phases > $out/vs_poses_8lm.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_gcn -- python $OLDPWD/scripts/profile_gcn.py > /dev/null 2>&1)
+python scripts/rocpd_summary.py "$(db /tmp/prof_gcn)" --by-grid k_ > $out/gcn_kernels_by_grid.csv 2>/dev/null
+ls -la $out
