@@ -257,15 +257,18 @@ def config5_bench(device_index, n_envs=256, warm=108, timed=8):
             "env_steps_per_sec": n_envs / dt}
 
 
+BELIEF_STEP_SOURCES = ("drlgx_dev.h", "drlgx_fields.h", "k_sim.hip", "k_slam.hip", "k_slam_arrow.hip", "k_map.hip", "k_step.hip",
+                       "drlgx_engine.cpp")
+
+
 def csrc_digest():
-    """sha1 over the kernel sources: ties a PMC traffic file to the tree it was measured on (no .git on the GPU box)."""
-    import glob
+    """sha1 over the sources of the belief-step kernels (the fused step's translation unit and the engine): ties a PMC
+    counter file to the tree it was measured on (no .git on the GPU box)."""
     import hashlib
     h = hashlib.sha1()
-    for f in sorted(glob.glob(os.path.join(ROOT, "drl_graph_exploration_amd", "csrc", "*.h*")) +
-                    glob.glob(os.path.join(ROOT, "drl_graph_exploration_amd", "csrc", "*.cpp"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for name in BELIEF_STEP_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(ROOT, "drl_graph_exploration_amd", "csrc", name), "rb").read())
     return h.hexdigest()
 
 

@@ -257,7 +257,7 @@ int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]);
 /* Forward of GCN / PolicyGCN trunk: H1 = relu(Â X W1 + b1), H2 = relu(Â H1 W2 + b2) [* dropout mask],
  * out = H2 Wf^T + bf, with Â = D^-1/2 (A_w + 2I) D^-1/2 built from (edge_index, edge_attr).
  * All pointers DEVICE, fp32 (edge_index int64 as PyG).  hidden = W1 cols, out_dim = Wf rows.
- * ws_dev: workspace of drlgx_gcn_workspace_bytes(). H1/H2 are kept in the workspace for backward. */
+ * ws_dev: workspace of drlgx_gcn_workspace_bytes(); it keeps what the backward call needs (AX, b1, AH1, H2, both CSRs). */
 size_t drlgx_gcn_workspace_bytes(int n_nodes, int n_edges, int hidden, int out_dim);
 int drlgx_gcn_forward(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim,
                       const float *x, const int64_t *edge_index, const float *edge_attr, const float *W1,

@@ -8,7 +8,7 @@ from drl_graph_exploration_amd.engine import Engine
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 108
-cfg = default_config(50, num_landmarks=500, max_poses=127, max_landmarks=128, max_factors=3800)
+cfg = default_config(50, num_landmarks=500, max_poses=127, max_landmarks=127, max_factors=3800)
 eng = Engine(cfg, n, 0)
 rng = np.random.RandomState(0)
 starts = np.stack([rng.uniform(-12, 12, n), rng.uniform(-12, 12, n), rng.uniform(-3, 3, n)], 1)
@@ -29,3 +29,15 @@ eng.synchronize()
 dt = (time.time() - t0) / K
 print("n_envs %d: %.3f ms per step, %.0f env-steps/s" % (n, dt * 1e3, n / dt))
 print({k: (round(v[0] / max(v[1], 1) * 1e3, 1), v[1]) for k, v in eng.timing_read().items() if v[1]})
+# in-kernel phase stamps of block 0 of the SLAM kernel (k_slam_arrow)
+import ctypes as C
+out = (C.c_int64 * 64)()
+eng.L.drlgx_debug_phase_clocks_host(eng.h, 1, None)
+eng.step(torch.tensor([loop[(warm + K) % len(loop)]] * n, dtype=torch.float64, device=eng.device))
+eng.L.drlgx_debug_phase_clocks_host(eng.h, 0, out)
+order = [0, 1, 2, 3, 4, 5, 10, 6, 7, 8, 9]
+names = ["tables+linearise", "blocks", "leaf factor", "leaf rhs down", "separator CR", "leaf up + selinv", "landmark system", "sweep", "lm out", "pose out"]
+a = np.array(out[:11], dtype=np.float64)[order]
+c = eng.counts(0)
+print("block 0 (%d poses, %d landmarks, %d factors), us: " % (c["poses"], c["landmarks"], c["factors"]) +
+      ", ".join("%s %.1f" % (names[k], (a[k + 1] - a[k]) / 100.0) for k in range(10)))
