@@ -228,6 +228,38 @@ def dqn_loop_bench(device_index, n_envs=256, iters=8):
             "reference_published": "~3.8 RL iterations/s (A2C+GCN, authors' PC; BASELINE.md) - other hardware, reported beside"}
 
 
+def a2c_loop_bench(device_index, n_envs=256, iters=40):
+    """The configuration BASELINE.md's only published rate is quoted on (A2C + GCN, ~3.8 RL iterations/s on the authors' PC),
+    as a secondary figure: wall-clock rate of `A2C.running` (graph export, look-ahead rewards, actor and critic forward,
+    sampled actions, env step, and one actor-critic update over all n_envs x nstep transitions every nstep = 40 vector
+    steps like the reference), in RL iterations (decisions) per second."""
+    import tempfile
+    from drl_graph_exploration_amd.networks import PolicyGCN, ValueGCN
+    from drl_graph_exploration_amd.policy import A2C
+    from drl_graph_exploration_amd.vecenv import VecExplorationEnv
+    dev = torch.device("cuda", device_index)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        a2c = A2C("bench_a2c/", data_root=tmp)
+        actor, critic = PolicyGCN().to(dev), ValueGCN().to(dev)
+        env = VecExplorationEnv(MAP, n_envs, env_index=0, test=True, device=device_index)
+        a2c.epoch = n_envs * 2  # warm-up (no update inside: the buffer is kept for the timed call)
+        a2c.running(actor, critic, test=True, env=env)
+        a2c.epoch = n_envs * iters  # 40 vector steps: the buffer reaches nstep once -> exactly one update in the timed region
+        a2c.buffer.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        a2c.running(actor, critic, test=True, env=env)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        env.close()
+    return {"workload": "A2C.running, %d envs in lock-step, 40 m map, %d vector steps with one update over %d transitions" % (
+                n_envs, iters, n_envs * iters),
+            "ms_per_vector_step": dt / iters * 1e3, "rl_iterations_per_sec": n_envs * iters / dt,
+            "reference_published": "~3.8 RL iterations/s (A2C+GCN, authors' PC; BASELINE.md) - other hardware, reported beside"}
+
+
 def config5_bench(device_index, n_envs=256, warm=108, timed=8):
     """BASELINE config 5 scale as a secondary figure: 50 m map, 500 landmarks, graphs grown by a fixed motion loop to
     ~110 poses / ~95 landmarks (k_slam_arrow with a ~200 x 200 landmark system, k_map in pose chunks); per-stage kernels."""
@@ -555,6 +587,7 @@ def main():
             out["policy_path"] = policy_bench(eng, dev)
             out["config5_scale"] = config5_bench(local_rank)
             out["dqn_loop"] = dqn_loop_bench(local_rank)
+            out["a2c_loop"] = a2c_loop_bench(local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu_thread"] = (out["value"] / world) / out["cpu_baseline"]["value"]

@@ -435,6 +435,24 @@ class DeepQ(object):
             env.close()
 
 
+def sample_frontiers(p, n_frontier, rng=np.random):
+    """`np.random.choice(fro, 1, p=p_env / p_env.sum())[0]` for every env (scripts/policy.py:392-394) at once.  `p` holds the
+    envs' frontier probabilities back to back, `n_frontier` their counts.  Legacy RandomState.choice draws ONE uniform per
+    call and searches the normalised cumulative sum, so n_envs uniforms from the same stream in env order pick exactly the
+    actions the reference's per-env calls would."""
+    n_frontier = np.asarray(n_frontier, dtype=np.int64)
+    n = len(n_frontier)
+    u = rng.random_sample(n)
+    width = int(n_frontier.max())
+    live = np.arange(width)[None, :] < n_frontier[:, None]
+    P2 = np.zeros((n, width))
+    P2[live] = np.asarray(p, dtype=np.float64)
+    P2 /= P2.sum(axis=1, keepdims=True)                      # p / p.sum()
+    cdf = np.cumsum(P2, axis=1)
+    cdf /= cdf[np.arange(n), n_frontier - 1][:, None]        # choice(): cdf /= cdf[-1]
+    return ((cdf <= u[:, None]) & live).sum(axis=1).astype(np.int64)  # cdf.searchsorted(u, side="right")
+
+
 class A2C(object):
     """The reference's advantage actor-critic trainer (scripts/policy.py:262-503) over a `VecExplorationEnv`.
 
@@ -474,6 +492,7 @@ class A2C(object):
     def __getstate__(self):
         st = dict(self.__dict__)
         st["buffer"] = deque(([_graph_to_host(d) for d in b[0]],) + tuple(b[1:]) for b in self.buffer)
+        st.pop("_pool", None)  # device storage: the pickled window carries its graphs itself
         return st
 
     def __setstate__(self, st):
@@ -574,9 +593,23 @@ class A2C(object):
             end = g["node_off"][1:].long()[g["batch"]]
             return torch.arange(n, device=device) >= end - g["n_frontier"].long()[g["batch"]]
 
+        # the graphs of the n-step window live in a device pool (one slot per batched export): the update collates its
+        # chunks out of it with one kernel each instead of a few tensor ops per graph
+        mn, me, _ = env.engine.graph_capacity()
+        pool = getattr(self, "_pool", None)
+        if pool is None or pool.device != device or pool.cap_nodes < mn or pool.cap_edges < me or pool.n_slots < self.nstep + 2:
+            pool = self._pool = ReplayPool(device, self.nstep + 2, mn, me)
+        for k in range(pool.n_slots):
+            pool.ref[k] = 0
+        for b in self.buffer:  # (a window carried over from an earlier call keeps its own graphs)
+            for d in b[0]:
+                if isinstance(d, PoolRef) and d.pool is pool:
+                    pool.ref[d.slot] = 1
         g = self._host_offsets(env.graph_matrix())
+        slot = pool.put(g)
+        pool.ref[slot] = 1
         while temp_i < self.epoch:
-            s_t = [self.data_process(g, i) for i in range(n_envs)]
+            s_t = [PoolRef(pool, slot, i) for i in range(n_envs)]
             env.actions_all_goals()
             rewards = env.rewards_all_goals()
             cand_env, cand_node, cand_first = env.candidates
@@ -587,10 +620,7 @@ class A2C(object):
                 readout = self.test(batch_data, g["batch"], mask, device, policy_net).view(-1)  # [C], env-major
                 val = self.test(batch_data, g["batch"], mask, device, value_net).view(-1)       # [n_envs]
             p_h, first_h, nfr_h = readout.cpu().numpy().astype(np.float64), cand_first.cpu().numpy(), nfr.cpu().numpy()
-            choice = np.zeros(n_envs, dtype=np.int64)
-            for i in range(n_envs):
-                p = p_h[first_h[i]:first_h[i] + nfr_h[i]]
-                choice[i] = rng.choice(int(nfr_h[i]), 1, p=p / p.sum())[0]
+            choice = sample_frontiers(p_h, nfr_h, rng)
             choice_t = torch.as_tensor(choice, device=device)
             r_t = rewards[cand_first + choice_t]
             key_size = (g["node_off"][1:] - g["node_off"][:-1]).long() - nfr
@@ -605,6 +635,8 @@ class A2C(object):
             if renew.any():
                 env.reset(np.nonzero(renew)[0])
             g1 = self._host_offsets(env.graph_matrix())
+            slot1 = pool.put(g1)
+            pool.ref[slot1] = 1
             self.buffer.append((s_t, a_loc, r_h, current_done | done_h, nfr_h.copy(), val_h))
             self.step_t += n_envs
             temp_i += n_envs
@@ -616,23 +648,28 @@ class A2C(object):
                 T = self.nstep
                 disc = self.discounted_returns(np.stack([b[2] for b in self.buffer]), np.stack([b[3] for b in self.buffer]),
                                                last_value, self.GAMMA)
-                items, a_b, m_b, adv_b, dr_b = [], [], [], [], []
-                for i in range(n_envs):  # trajectory-major, as the reference's DataLoader over one env's buffer
-                    for t in range(T):
-                        st, al, _, _, fro, v = self.buffer[t]
-                        n_nodes = st[i].num_nodes
-                        a = np.zeros(n_nodes, dtype=np.float32)
-                        a[al[i]] = 1.0
-                        m = np.zeros(n_nodes, dtype=bool)
-                        m[n_nodes - int(fro[i]):] = True
-                        y = np.zeros(n_nodes, dtype=np.float32)
-                        y[al[i]] = disc[t, i] - v[i]
-                        items.append(st[i]); a_b.append(a); m_b.append(m); adv_b.append(y); dr_b.append(disc[t, i])
-                self.train(items, np.concatenate(a_b), np.concatenate(m_b), np.array(dr_b), np.concatenate(adv_b), device,
-                           policy_net, value_net, optimizer, n_traj=n_envs)
+                # trajectory-major (env by env, then time), as the reference's DataLoader over one env's buffer; the per-node
+                # vectors (one-hot action, frontier mask, advantage at the action node) are built for all graphs at once
+                items = [self.buffer[t][0][i] for i in range(n_envs) for t in range(T)]
+                nn_ = np.array([d.num_nodes for d in items], dtype=np.int64)
+                al_ = np.stack([b[1] for b in self.buffer]).T.reshape(-1)       # [env, t] -> flat
+                fro_ = np.stack([b[4] for b in self.buffer]).T.reshape(-1)
+                v_ = np.stack([b[5] for b in self.buffer]).T.reshape(-1)
+                dr_ = disc.T.reshape(-1)
+                off_ = np.cumsum(nn_) - nn_
+                tot_ = int(nn_.sum())
+                a_all = np.zeros(tot_, dtype=np.float32)
+                a_all[off_ + al_] = 1.0
+                y_all = np.zeros(tot_, dtype=np.float32)
+                y_all[off_ + al_] = (dr_ - v_).astype(np.float32)
+                local = np.arange(tot_) - np.repeat(off_, nn_)
+                m_all = local >= np.repeat(nn_ - fro_, nn_)
+                self.train(items, a_all, m_all, dr_, y_all, device, policy_net, value_net, optimizer, n_traj=n_envs)
                 temp_loss_data.append([self.step_t, self.temp_loss])
                 self.buffer.clear()
-            g = g1
+                for k in range(pool.n_slots):
+                    pool.ref[k] = 1 if k == slot1 else 0
+            g, slot = g1, slot1
 
             if log_every and (self.step_t // n_envs) % log_every == 0:
                 print("TIMESTEP", self.step_t, "/ Loss", self.temp_loss, "/ Entropy", self.entro,

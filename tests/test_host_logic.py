@@ -254,6 +254,23 @@ def test_gradient_allreduce_gloo_world_size_2():
         assert torch.allclose(a, (x + y) / 2, rtol=1e-6, atol=1e-7)
 
 
+def test_vectorised_action_sampling_equals_per_env_choice():
+    """A2C samples one frontier per env with np.random.choice(fro, 1, p=p / p.sum()) (scripts/policy.py:392-394);
+    `sample_frontiers` does it for all envs at once from the same stream: same actions, same stream position afterwards."""
+    from drl_graph_exploration_amd.policy import sample_frontiers
+    gen = np.random.RandomState(5)
+    nfr = gen.randint(1, 9, size=200)
+    p = gen.rand(int(nfr.sum())).astype(np.float32).astype(np.float64) + 1e-35
+    first = np.cumsum(nfr) - nfr
+    np.random.seed(11)
+    ref = np.array([np.random.choice(int(k), 1, p=p[f:f + k] / p[f:f + k].sum())[0] for f, k in zip(first, nfr)])
+    after_ref = np.random.random_sample()
+    np.random.seed(11)
+    got = sample_frontiers(p, nfr, np.random)
+    assert np.array_equal(got, ref)
+    assert np.random.random_sample() == after_ref
+
+
 def test_a2c_costs_and_returns(tmp_path):
     """A2C cost functions and n-step returns against hand evaluation (scripts/policy.py:364-369, 452-472)."""
     import torch
