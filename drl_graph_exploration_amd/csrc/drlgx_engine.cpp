@@ -509,6 +509,38 @@ int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_de
   return check_launch(e);
 }
 
+// One action index of the chosen plans of all envs (ExplorationEnv.step: `for a in actions: self._sim.simulate(a)`,
+// scripts/envs/exploration_env.py:98-105): env i executes actions[i][action_index] while action_index < n_actions[i].
+// map_last_only: the virtual map (a pure function of the SLAM state, rebuilt from the untouched map every time) is rebuilt
+// at each env's LAST action only, and the marginals only where the map needs them - the state after the plan is the same.
+int drlgx_step_plan(drlgx_engine *e, const double *actions_dev, const int32_t *n_actions_dev, int action_index, int map_last_only) {
+  DRLGX_ENTER(e);
+  if (!e || !actions_dev || !n_actions_dev || action_index < 0 || action_index >= e->S.A_max) return DRLGX_E_INVALID;
+  LaunchSel sel{0, e->S.n_envs, nullptr, n_actions_dev, action_index};
+  sel.map_last_only = map_last_only ? 1 : 0;
+  const int pb = std::min(max_bound(e) + 1, e->S.P_max);
+  for (int &v : e->pbound) v = std::min(v + 1, e->S.P_max);
+  const int stride = e->S.A_max * 3;
+  if (drlgx_step_fusable(e->S, pb) && !e->per_stage) {
+    ScopedTimer t(e, 5);
+    drlgx_launch_step(e->S, e->stream, sel, actions_dev, stride, 2);
+  } else {
+    {
+      ScopedTimer t(e, 0);
+      drlgx_launch_sim(e->S, e->stream, sel, actions_dev, stride, 2);
+    }
+    {
+      ScopedTimer t(e, 1);
+      drlgx_launch_slam(e->S, e->stream, sel, pb);
+    }
+    {
+      ScopedTimer t(e, 2);
+      drlgx_launch_map(e->S, e->stream, sel);
+    }
+  }
+  return check_launch(e);
+}
+
 // ---- staged form of the belief step: one call per call of SS2D.__init__ / SS2D.simulate (scripts/envs/pyss2d.py) -------
 int drlgx_stage_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint32_t *seeds, const double *start) {
   DRLGX_ENTER(e);

@@ -89,6 +89,12 @@ class Engine(object):
         self._chk(self.L.drlgx_step(self.h, _p(odom), _p(active)))
 
     # ---- staged belief step (one call per call of the reference's SS2D.__init__ / SS2D.simulate)
+
+    def step_plan(self, actions, n_actions, action_index, map_last_only=True):
+        """One action index of every env's plan (drlgx_step_plan): actions [n_envs, max_actions, 3] f64, n_actions [n_envs]
+        i32 on the device; with `map_last_only` the virtual map is rebuilt at each env's last action only."""
+        self.use_torch_stream()
+        self._chk(self.L.drlgx_step_plan(self.h, _p(actions), _p(n_actions), int(action_index), 1 if map_last_only else 0))
     def stage_reset(self, env_ids, seeds, starts):
         env_ids = np.ascontiguousarray(env_ids, dtype=np.int32)
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32)

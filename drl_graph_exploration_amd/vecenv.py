@@ -174,13 +174,18 @@ class VecExplorationEnv(object):
         nact = self._n_act[c]
         return self.step_actions(acts, nact)
 
-    def step_actions(self, acts, nact):
+    def step_actions(self, acts, nact, map_every_action=False):
+        """Execute `nact[i]` actions of `acts[i]` in every env.  The virtual map is a pure function of the SLAM state, so it
+        is rebuilt at each env's last action only unless `map_every_action` (per-step metrics of the map) asks otherwise."""
         kmax = int(nact.max().item())
+        if acts.shape[1] < self.cfg.max_actions:  # drlgx_step_plan strides the plans by the engine's max_actions
+            acts = torch.cat([acts, acts.new_zeros(acts.shape[0], self.cfg.max_actions - acts.shape[1], 3)], dim=1)
+        acts = acts.contiguous()
+        nact = nact.to(torch.int32).contiguous()
         for k in range(kmax):
-            active = (nact > k).to(torch.uint8)
-            odom = acts[:, k].contiguous()
-            self.engine.step(odom, active)
-            self.dist += torch.where(active.bool(), torch.sqrt(odom[:, 0] ** 2 + odom[:, 1] ** 2), torch.zeros_like(self.dist))
+            self.engine.step_plan(acts, nact, k, map_last_only=not map_every_action)
+        live = torch.arange(acts.shape[1], device=self.device)[None, :] < nact[:, None]
+        self.dist += (torch.sqrt(acts[:, :, 0] ** 2 + acts[:, :, 1] ** 2) * live).sum(dim=1)
         self.engine.check_status()
         self._graph = None
         return self._get_obs(), self.done(), {}

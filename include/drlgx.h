@@ -101,6 +101,14 @@ int drlgx_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint3
  * (x, y, theta); active_dev: DEVICE uint8[n_envs] or NULL. */
 int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_dev);
 
+/* ExplorationEnv.step (scripts/envs/exploration_env.py:98-105: `for a in actions: self._sim.simulate(a)`) one action
+ * index at a time for all envs: env i executes actions[i][action_index] (DEVICE double [n_envs][max_actions][3], the plans
+ * drlgx_line_plan emits) while action_index < n_actions[i].  map_last_only != 0: the virtual map - a pure function of the
+ * SLAM state - is rebuilt at each env's last action only (and the marginal covariances only where the map needs them);
+ * the state after the plan is the same, intermediate getters of the map see the previous rebuild. */
+int drlgx_step_plan(drlgx_engine *e, const double *actions_dev, const int32_t *n_actions_dev, int action_index,
+                    int map_last_only);
+
 /* ---- staged form of the belief step -----------------------------------------------------------
  * The reference's pybind classes are driven call by call (scripts/envs/pyss2d.py:102-138 SS2D.__init__, :171-206
  * SS2D.simulate); the object-level shims (drl_graph_exploration_amd/ss2d.py) map every such call onto one of these.

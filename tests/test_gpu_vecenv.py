@@ -124,6 +124,38 @@ def test_emexplorer_facade_single_env():
     assert sim.step == ref.step
 
 
+def test_plan_execution_with_one_map_rebuild_equals_rebuilding_every_action():
+    """`step` executes a plan action by action (exploration_env.py:98-105).  The virtual map is a pure function of the SLAM
+    state, so drlgx_step_plan rebuilds it (and the marginals it needs) at each env's last action only: the state after the
+    plan - estimates, information, virtual map, metrics - is bit-equal to rebuilding after every action, over two decisions."""
+    from drl_graph_exploration_amd.vecenv import VecExplorationEnv
+    n = 6
+    envs = [VecExplorationEnv(40, n, env_index=3, test=True, device=0) for _ in range(2)]
+    for d in range(2):
+        choice = None
+        for e, every in zip(envs, (True, False)):
+            e.graph_matrix()
+            acts, nact = e.actions_all_goals()
+            if choice is None:
+                nfr = e._graph["n_frontier"].long()
+                choice = (torch.arange(n, device=e.device) * 3 + d) % nfr  # some frontier of every env
+                assert int(nact[e._cand_first + choice].max()) >= 3     # multi-action plans
+            c = e._cand_first + choice
+            e.step_actions(acts[c], nact[c], map_every_action=every)
+        a, b = envs
+        assert torch.equal(a.metrics(), b.metrics())
+        assert torch.equal(a.status(), b.status())
+        for i in range(n):
+            for x, y in zip(a.engine.poses(i), b.engine.poses(i)):
+                np.testing.assert_array_equal(x, y)
+            for x, y in zip(a.engine.landmarks(i), b.engine.landmarks(i)):
+                np.testing.assert_array_equal(x, y)
+            for x, y in zip(a.engine.virtual_map(i), b.engine.virtual_map(i)):
+                np.testing.assert_array_equal(x, y)
+    for e in envs:
+        e.close()
+
+
 def test_deepq_running_smoke(tmp_path):
     from drl_graph_exploration_amd.networks import GCN
     from drl_graph_exploration_amd.policy import DeepQ
