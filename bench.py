@@ -244,9 +244,9 @@ def a2c_loop_bench(device_index, n_envs=256, iters=40):
         a2c = A2C("bench_a2c/", data_root=tmp)
         actor, critic = PolicyGCN().to(dev), ValueGCN().to(dev)
         env = VecExplorationEnv(MAP, n_envs, env_index=0, test=True, device=device_index)
-        a2c.epoch = n_envs * 2  # warm-up (no update inside: the buffer is kept for the timed call)
+        a2c.epoch, a2c.nstep = n_envs * 2, 2  # warm-up: two vector steps and one small update (first-use allocations)
         a2c.running(actor, critic, test=True, env=env)
-        a2c.epoch = n_envs * iters  # 40 vector steps: the buffer reaches nstep once -> exactly one update in the timed region
+        a2c.epoch, a2c.nstep = n_envs * iters, 40  # 40 vector steps: exactly one update over all of them in the timed region
         a2c.buffer.clear()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

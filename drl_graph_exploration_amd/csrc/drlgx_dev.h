@@ -572,6 +572,8 @@ void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p
 size_t drlgx_map_lds_bytes(const DrlgxState &S, int *chunk_out);
 // fused simulate + SLAM + map kernel (k_step.hip); usable when the SLAM system and the map stage fit the LDS
 bool drlgx_step_fusable(const DrlgxState &S, int p_bound);
+bool drlgx_step_arrow_fusable(const DrlgxState &S);
+void drlgx_launch_step_arrow(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure);
 void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure);  // requires drlgx_step_fusable
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel);  // sel.act_idx == -2: reductions only
 void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,

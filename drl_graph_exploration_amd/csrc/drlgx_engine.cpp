@@ -489,6 +489,9 @@ int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_de
     // one fused kernel per step (timer 5); timing mode 2 launches the stage kernels separately (timers 0-2)
     ScopedTimer t(e, 5);
     drlgx_launch_step(e->S, e->stream, sel, odom_dev, 3, 2);
+  } else if (drlgx_step_arrow_fusable(e->S) && !e->per_stage) {
+    ScopedTimer t(e, 5);  // longer trajectories: the same fusion around the pose-chain solver
+    drlgx_launch_step_arrow(e->S, e->stream, sel, odom_dev, 3, 2);
   } else {
     {
       ScopedTimer t(e, 0);
@@ -524,6 +527,9 @@ int drlgx_step_plan(drlgx_engine *e, const double *actions_dev, const int32_t *n
   if (drlgx_step_fusable(e->S, pb) && !e->per_stage) {
     ScopedTimer t(e, 5);
     drlgx_launch_step(e->S, e->stream, sel, actions_dev, stride, 2);
+  } else if (drlgx_step_arrow_fusable(e->S) && !e->per_stage) {
+    ScopedTimer t(e, 5);
+    drlgx_launch_step_arrow(e->S, e->stream, sel, actions_dev, stride, 2);
   } else {
     {
       ScopedTimer t(e, 0);
@@ -726,6 +732,11 @@ int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env
       if (drlgx_step_fusable(S, pb) && !e->per_stage) {
         ScopedTimer t(e, 5);
         drlgx_launch_step(S, e->stream, sel, act, S.A_max * 3, 1);
+        continue;
+      }
+      if (drlgx_step_arrow_fusable(e->S) && !e->per_stage) {
+        ScopedTimer t(e, 5);
+        drlgx_launch_step_arrow(S, e->stream, sel, act, S.A_max * 3, 1);
         continue;
       }
       {

@@ -22,8 +22,9 @@ with tempfile.TemporaryDirectory() as tmp:
     a2c = A2C("b/", data_root=tmp)
     actor, critic = PolicyGCN().to(dev), ValueGCN().to(dev)
     env = VecExplorationEnv(bench.MAP, n_envs, env_index=0, test=True, device=0)
-    a2c.epoch = n_envs * 2
+    a2c.epoch, a2c.nstep = n_envs * 2, 2  # warm-up incl. one small update (first-use allocations)
     a2c.running(actor, critic, test=True, env=env)
+    a2c.nstep = 40
     a2c.buffer.clear()
     for name, label in (("graph_matrix", "graph export"), ("actions_all_goals", "line plans"), ("rewards_all_goals", "look-ahead rewards"),
                         ("step", "env.step"), ("reset", "env.reset")):

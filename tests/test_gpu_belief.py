@@ -454,7 +454,11 @@ def test_variant_follows_the_trajectory_length():
                 assert eng.counts(i)["poses"] == s + 2
                 compare_state(eng, i, sims[i], "env %d step %d" % (i, s), mask_knife_edge=True)
     # poses after step s = s + 2: the fused LDS kernel serves up to 42 poses
-    assert fused_steps[39] and fused_steps[40] and not fused_steps[41] and not fused_steps[86]
+    assert fused_steps[39] and fused_steps[40]
+    # beyond that the pose-chain solver takes over: also as ONE kernel with the simulator and the map (k_step_arrow), so the
+    # spans alone do not tell the two apart - the stage-kernel form of the same steps is exercised by timing mode 2 and by
+    # test_larger_capacities_use_the_pose_chain_solver
+    assert fused_steps[41] and fused_steps[86]
     eng.close()
 
 

@@ -156,6 +156,39 @@ def test_plan_execution_with_one_map_rebuild_equals_rebuilding_every_action():
         e.close()
 
 
+def test_long_plans_with_one_map_rebuild_stay_within_tolerance():
+    """The same property beyond the LDS-resident solver (43+ poses: pose-chain solver, whose solve-only steps sum the pose
+    deltas in another order than the full ones): scripted 8-action plans up to ~80 poses, the state after every plan within
+    the engine-vs-oracle tolerances of the state rebuilt after every action."""
+    import math
+    from drl_graph_exploration_amd.vecenv import VecExplorationEnv
+    n = 4
+    starts = np.array([[-7.3183, -6.2718, 0.1234], [3.1, 4.7, 2.2], [-2.4, 8.8, -1.0], [9.1, -3.3, 0.5]])
+    envs = [VecExplorationEnv(40, n, env_index=0, test=True, device=0, starts=starts, num_landmarks=30) for _ in range(2)]
+    loop = [(2, 0, 0)] * 3 + [(0, 0, math.pi / 2)] + [(2, 0, 0)] * 2 + [(0.7, 0, 0.4), (1.0, 0, -0.3)]
+    dev = envs[0].device
+    acts = torch.zeros(n, envs[0].cfg.max_actions, 3, dtype=torch.float64, device=dev)
+    acts[:, :len(loop)] = torch.tensor(loop, dtype=torch.float64, device=dev)
+    nact = torch.tensor([8, 7, 8, 5], dtype=torch.int32, device=dev)
+    for plan in range(10):
+        for e, every in zip(envs, (True, False)):
+            e.step_actions(acts, nact, map_every_action=every)
+        a, b = envs
+        np.testing.assert_allclose(b.metrics().cpu().numpy(), a.metrics().cpu().numpy(), rtol=1e-7)
+        for i in range(n):
+            (pa, ia), (pb, ib) = a.engine.poses(i), b.engine.poses(i)
+            assert pa.shape == pb.shape
+            np.testing.assert_allclose(pb, pa, rtol=0, atol=1e-9)
+            np.testing.assert_allclose(ib, ia, rtol=1e-7, atol=1e-9 * np.abs(ia).max())
+            va, vb = a.engine.virtual_map(i), b.engine.virtual_map(i)
+            np.testing.assert_array_equal(vb[0], va[0])  # occupancy probabilities: ladder states
+            for x, y in zip(va[1:], vb[1:]):
+                np.testing.assert_allclose(y, x, rtol=1e-7, atol=1e-12)
+    assert int(envs[0].engine.counts(0)["poses"]) > 80
+    for e in envs:
+        e.close()
+
+
 def test_deepq_running_smoke(tmp_path):
     from drl_graph_exploration_amd.networks import GCN
     from drl_graph_exploration_amd.policy import DeepQ
