@@ -839,6 +839,15 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
       }
     }
   } else {
+    if (!c_lds) {
+      // the swept system lives in the workspace as a square matrix of which the lower triangle is valid: mirror it, so that
+      // the B operand below is read along rows (16 lanes = 128 contiguous bytes) whichever side of the diagonal a tile is on
+      for (int e = tid; e < np * np; e += kThreads) {
+        const int i = e / np, j = e - i * np;
+        if (j > i) A[(size_t)i * N + j] = A[(size_t)j * N + i];
+      }
+      __syncthreads();
+    }
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lc = lane & 15, lr = lane >> 4;
     const int nrows = 3 * P, nrt = (nrows + 15) / 16, nK = (np + 15) / 16;
     for (int I = wave; I < nrt; I += kWaves) {
@@ -863,9 +872,10 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
       double sp[4][3];
 #pragma unroll
       for (int r = 0; r < 4; ++r) sp[r][0] = sp[r][1] = sp[r][2] = 0.0;
-      for (int J = 0; J < Tn; ++J) {
+      // epilogue of one 16 x 16 tile of Z (accumulator `acc`, column tile J): products with the three X rows of each
+      // accumulator row's pose, and the delta_l column
+      auto epilogue = [&](const v4d &acc, int J) {
         const int c = 16 * J + lc;
-        // the three X rows of each accumulator row's pose at this lane's column (epilogue), issued before the products
         double xe[4][3];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -876,8 +886,19 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
           xe[r][1] = ok ? xb[ldx] : 0.0;
           xe[r][2] = ok ? xb[2 * ldx] : 0.0;
         }
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-        if (panel) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + lr + 4 * r;
+          sp[r][0] += acc[r] * xe[r][0];  // (zeros outside the matrix)
+          sp[r][1] += acc[r] * xe[r][1];
+          sp[r][2] += acc[r] * xe[r][2];
+          if (row < nrows && c == np) dz[row] = acc[r];
+        }
+      };
+      if (panel) {
+        for (int J = 0; J < Tn; ++J) {
+          const int c = 16 * J + lc;
+          v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
           for (int K = 0; K < kPanel; ++K) {
             if (K < nK) {
@@ -890,27 +911,48 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
               acc = mfma4(pan[K], bv, acc);
             }
           }
-        } else {
+          epilogue(acc, J);
+        }
+      } else {
+        // wide systems (workspace variant, mirrored above): four column tiles at a time share the A operand, and the
+        // operands of step K + 1 are loaded before the sixteen matrix instructions of step K
+        auto load_step = [&](int K, int J0, double (&av)[4], double (&bv)[4][4]) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int k = 16 * K + 4 * lr + t;
+            const bool kin = k < np;
+            const int kc = kin ? k : 0;
+            av[t] = (kin && arow_ok) ? xa[kc] : 0.0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int c = 16 * (J0 + g) + lc;
+              const bool cin = c <= np && J0 + g < Tn;
+              const double v = A[c == np ? (size_t)np * N + kc : (size_t)kc * N + (cin ? c : 0)];  // delta_l row / mirrored -C^-1
+              bv[g][t] = (kin && cin) ? v : 0.0;
+            }
+          }
+        };
+        for (int J0 = 0; J0 < Tn; J0 += 4) {
+          v4d acc[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = v4d{0.0, 0.0, 0.0, 0.0};
+          double avn[4], bvn[4][4];
+          load_step(0, J0, avn, bvn);
           for (int K = 0; K < nK; ++K) {
-            const int k0 = 16 * K + 4 * lr;
-            double av[4], bv[4];
+            double av[4], bv[4][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-              const int k = k0 + t;
-              const bool kin = k < np;
-              av[t] = (kin && arow_ok) ? xa[k] : 0.0;
-              bv[t] = (kin && c <= np) ? A[AT(max(k, c), min(k, c))] : 0.0;
-            }
-            acc = mfma4(av, bv, acc);
-          }
-        }
+              av[t] = avn[t];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * I + lr + 4 * r;
-          sp[r][0] += acc[r] * xe[r][0];  // (zeros outside the matrix)
-          sp[r][1] += acc[r] * xe[r][1];
-          sp[r][2] += acc[r] * xe[r][2];
-          if (row < nrows && c == np) dz[row] = acc[r];
+              for (int g = 0; g < 4; ++g) bv[g][t] = bvn[g][t];
+            }
+            if (K + 1 < nK) load_step(K + 1, J0, avn, bvn);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = mfma4(av, bv[g], acc[g]);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            if (J0 + g < Tn) epilogue(acc[g], J0 + g);
         }
       }
 #pragma unroll
