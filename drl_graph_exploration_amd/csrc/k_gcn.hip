@@ -283,67 +283,74 @@ __global__ __launch_bounds__(256) void k_ax(int N, int in_dim, const float *x, c
 }
 
 // H1[m][4c .. 4c+3] from AX[m] (8 floats), this thread's four W1 columns (w[k]) and biases
+template <int IN = 0>  // IN > 0: the number of input features at compile time (the reference's 5): straight-line code
 __device__ __forceinline__ float4 h1_row(const float *AX, int m, int in_dim, const float4 (&w)[8], const float4 &bias) {
   const float4 a0 = reinterpret_cast<const float4 *>(AX + (size_t)m * 8)[0], a1 = reinterpret_cast<const float4 *>(AX + (size_t)m * 8)[1];
   const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
   float4 s = bias;
 #pragma unroll
   for (int k = 0; k < 8; ++k)
-    if (k < in_dim) {
+    if (IN > 0 ? k < IN : k < in_dim) {
       s.x += a[k] * w[k].x; s.y += a[k] * w[k].y; s.z += a[k] * w[k].z; s.w += a[k] * w[k].w;
     }
   return s;  // pre-activation
 }
 
 // H1 row from 8 staged AX values
+template <int IN = 0>
 __device__ __forceinline__ float4 h1_row_lds(const float *ax, int in_dim, const float4 (&w)[8], const float4 &bias) {
   const float4 a0 = reinterpret_cast<const float4 *>(ax)[0], a1 = reinterpret_cast<const float4 *>(ax)[1];
   const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
   float4 s = bias;
 #pragma unroll
   for (int k = 0; k < 8; ++k)
-    if (k < in_dim) {
+    if (IN > 0 ? k < IN : k < in_dim) {
       s.x += a[k] * w[k].x; s.y += a[k] * w[k].y; s.z += a[k] * w[k].z; s.w += a[k] * w[k].w;
     }
   return s;
 }
 
 constexpr int kAggStage = 64;  // neighbour rows of AX (and their weights) staged in LDS; longer rows read the rest from memory
-constexpr int kAggNodes = 4;   // nodes per workgroup: the thread's W1 columns and biases are loaded once for all of them
+constexpr int kAggNodes = 4;   // nodes per workgroup: the thread's W1 columns and biases are loaded once for all of them, and
+                               // the neighbour lists of all of them are staged together (one round of memory latency)
+template <int IN>
 __global__ __launch_bounds__(256) void k_aggregate_l1(int N, int in_dim, int hidden, const float *AX, const float *W1, const float *b1,
                                                       const float *deg, const float *selfw, const int *ptr, const int *pend, const int *nbr,
                                                       const float *wn, float *out) {
-  __shared__ __attribute__((aligned(16))) float s_ax[kAggStage * 8];
-  __shared__ float s_wn[kAggStage];
+  __shared__ __attribute__((aligned(16))) float s_ax[kAggNodes][kAggStage * 8];
+  __shared__ float s_wn[kAggNodes][kAggStage];
   const int tid = threadIdx.x;
   const int h4 = hidden >> 2;
-  for (int c = tid; c < ((h4 + 255) & ~255); c += 256) {  // (one trip for hidden <= 1024; every thread takes part in the barriers)
-    const bool live = c < h4;
+  const int nb0 = blockIdx.x * kAggNodes, nn = min(kAggNodes, N - nb0);
+  for (int e = tid; e < nn * kAggStage * 8; e += 256) {
+    const int q = e / (kAggStage * 8), r = e - q * (kAggStage * 8);
+    const int n = nb0 + q, a = ptr[n], j = r >> 3;
+    if (a + j < pend[n]) {
+      s_ax[q][r] = AX[(size_t)nbr[a + j] * 8 + (r & 7)];
+      if ((r & 7) == 0) s_wn[q][j] = wn[a + j];
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < h4; c += 256) {
     float4 w[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = (live && k < in_dim) ? reinterpret_cast<const float4 *>(W1 + (size_t)k * hidden)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 bias = live ? reinterpret_cast<const float4 *>(b1)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int n = blockIdx.x * kAggNodes; n < min(N, (blockIdx.x + 1) * kAggNodes); ++n) {
+    for (int k = 0; k < 8; ++k) w[k] = k < in_dim ? reinterpret_cast<const float4 *>(W1 + (size_t)k * hidden)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bias = reinterpret_cast<const float4 *>(b1)[c];
+    for (int q = 0; q < nn; ++q) {
+      const int n = nb0 + q;
       const int a = ptr[n], b = pend[n];
       const int ns = min(b - a, kAggStage);
-      __syncthreads();
-      for (int e = tid; e < ns * 8; e += 256) {
-        s_ax[e] = AX[(size_t)nbr[a + (e >> 3)] * 8 + (e & 7)];
-        if ((e & 7) == 0) s_wn[e >> 3] = wn[a + (e >> 3)];
-      }
-      __syncthreads();
-      if (!live) continue;
       const float self = selfw[n] / deg[n];
-      const float4 v = h1_row(AX, n, in_dim, w, bias);
+      const float4 v = h1_row<IN>(AX, n, in_dim, w, bias);
       float4 acc = make_float4(self * fmaxf(v.x, 0.f), self * fmaxf(v.y, 0.f), self * fmaxf(v.z, 0.f), self * fmaxf(v.w, 0.f));
       for (int j = 0; j < ns; ++j) {
-        const float wi = s_wn[j];
-        const float4 u = h1_row_lds(s_ax + 8 * j, in_dim, w, bias);
+        const float wi = s_wn[q][j];
+        const float4 u = h1_row_lds<IN>(s_ax[q] + 8 * j, in_dim, w, bias);
         acc.x += wi * fmaxf(u.x, 0.f); acc.y += wi * fmaxf(u.y, 0.f); acc.z += wi * fmaxf(u.z, 0.f); acc.w += wi * fmaxf(u.w, 0.f);
       }
       for (int i = a + ns; i < b; ++i) {
         const float wi = wn[i];
-        const float4 u = h1_row(AX, nbr[i], in_dim, w, bias);
+        const float4 u = h1_row<IN>(AX, nbr[i], in_dim, w, bias);
         acc.x += wi * fmaxf(u.x, 0.f); acc.y += wi * fmaxf(u.y, 0.f); acc.z += wi * fmaxf(u.z, 0.f); acc.w += wi * fmaxf(u.w, 0.f);
       }
       reinterpret_cast<float4 *>(out + (size_t)n * hidden)[c] = acc;
@@ -1043,8 +1050,15 @@ static int gcn_forward_impl(void *hip_stream, int n_nodes, int n_edges, int in_d
     build_graph(st, w, n_nodes, n_edges, edge_index, edge_attr);
   hipLaunchKernelGGL(k_ax, dim3((n_nodes * 8 + 255) / 256), dim3(256), 0, st, n_nodes, in_dim, x, w.deg, w.selfw, w.ptr_dst, w.end_dst, w.nbr_dst,
                      w.wn_dst, w.AX);
-  hipLaunchKernelGGL(k_aggregate_l1, dim3((n_nodes + kAggNodes - 1) / kAggNodes), dim3(256), 0, st, n_nodes, in_dim, hidden, w.AX, W1, b1, w.deg, w.selfw, w.ptr_dst, w.end_dst,
-                     w.nbr_dst, w.wn_dst, w.AH1);
+  {
+    const dim3 ga((n_nodes + kAggNodes - 1) / kAggNodes), ba(256);
+    if (in_dim == 5)  // the reference's feature count: compiled straight-line
+      hipLaunchKernelGGL(k_aggregate_l1<5>, ga, ba, 0, st, n_nodes, in_dim, hidden, w.AX, W1, b1, w.deg, w.selfw, w.ptr_dst, w.end_dst, w.nbr_dst,
+                         w.wn_dst, w.AH1);
+    else
+      hipLaunchKernelGGL(k_aggregate_l1<0>, ga, ba, 0, st, n_nodes, in_dim, hidden, w.AX, W1, b1, w.deg, w.selfw, w.ptr_dst, w.end_dst, w.nbr_dst,
+                         w.wn_dst, w.AH1);
+  }
   if (hipMemcpyAsync(w.b1s, b1, (size_t)hidden * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return DRLGX_E_HIP;
   // H2 = relu(AH1 W2 + b2) * mask   (fp32 MFMA, fused epilogue)
   gemm<false, false, 1>(st, n_nodes, hidden, hidden, w.AH1, hidden, W2, hidden, w.H2, hidden, b2, dropout_mask, 1);
