@@ -173,23 +173,29 @@ constexpr int kCsrKeyShift = 14;               // key = local node << 14 | local
 constexpr int kCsrMaxEdges = 1 << kCsrKeyShift;  // per graph (16 384; 2 x 64 KB of keys in LDS at that size)
 constexpr uint32_t kCsrNoKey = 0xffffffffu;
 
-__global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, const int64_t *ei, const float *ew, const int *node_off,
+__global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, int extra, const int64_t *ei, const float *ew, const int *node_off,
                                                     const int *edge_off, float *deg, float *selfw_out, int *ptr_dst, int *end_dst,
                                                     int *nbr_dst, float *wn_dst, int *ptr_src, int *end_src, int *nbr_src, float *wn_src) {
-  extern __shared__ uint32_t s_keys[];  // [2][P2]: by source, by destination
+  extern __shared__ uint32_t s_keys[];  // [2][P2]: by source, by destination; then (extra) the weights and packed endpoints
   uint32_t *ks = s_keys, *kd = s_keys + P2;
+  float *s_w = reinterpret_cast<float *>(s_keys + 2 * (size_t)P2);
+  uint32_t *s_pk = s_keys + 3 * (size_t)P2;
   const int g = blockIdx.x, tid = threadIdx.x;
   const int n0 = node_off[g], n1 = node_off[g + 1], e0 = edge_off[g];
   const int ng = n1 - n0, eg = min(edge_off[g + 1] - e0, P2);  // (the caller promised eg <= P2)
+  const bool ext = extra && ng <= 65535;  // the edges' weights and local endpoints stay in LDS: the later passes read no edge from memory
   for (int m = tid; m < ng; m += 256) selfw_out[n0 + m] = 2.0f;  // add_remaining_self_loops(fill_value = 2)
   __syncthreads();
   for (int j = tid; j < P2; j += 256) {
     uint32_t a = kCsrNoKey, b = kCsrNoKey;
     if (j < eg) {
       const int64_t r = ei[e0 + j], c = ei[(size_t)E + e0 + j];
+      const float wj = ew[e0 + j];
+      if (ext) s_w[j] = wj;
       if (r >= n0 && r < n1 && c >= n0 && c < n1) {  // an edge with an endpoint outside the graph is ignored
+        if (ext) s_pk[j] = (uint32_t)(r - n0) | ((uint32_t)(c - n0) << 16);
         if (r == c) {
-          selfw_out[r] = ew[e0 + j];  // an explicit self loop keeps its weight as the node's self term
+          selfw_out[r] = wj;  // an explicit self loop keeps its weight as the node's self term
         } else {
           a = ((uint32_t)(r - n0) << kCsrKeyShift) | (uint32_t)j;
           b = ((uint32_t)(c - n0) << kCsrKeyShift) | (uint32_t)j;
@@ -200,24 +206,36 @@ __global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, const 
     kd[j] = b;
   }
   __syncthreads();
-  // bitonic sort, ascending, both key arrays in the same stages
-  for (int k = 2; k <= P2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (P2 >> 1); t += 256) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), q = i | j;
-        const bool up = (i & k) == 0;
-        const uint32_t a0 = ks[i], a1 = ks[q], b0 = kd[i], b1 = kd[q];
-        if ((a0 > a1) == up) {
-          ks[i] = a1;
-          ks[q] = a0;
-        }
-        if ((b0 > b1) == up) {
-          kd[i] = b1;
-          kd[q] = b0;
+  // bitonic sort, ascending, both key arrays in the same stages.  Wave w owns the contiguous segment of P2 / 4 keys
+  // [w P2/4, (w+1) P2/4): a compare-exchange at distance j < P2/4 stays inside the segment, and a wave's LDS operations
+  // execute in order, so only the stages that cross segments (three of the 55 at P2 = 1024) take workgroup barriers
+  {
+    const int seg = P2 >> 2, wave = tid >> 6, lane = tid & 63;
+    auto exchange = [&](int t, int k, int j) {
+      const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), q = i | j;
+      const bool up = (i & k) == 0;
+      const uint32_t a0 = ks[i], a1 = ks[q], b0 = kd[i], b1 = kd[q];
+      const uint32_t alo = min(a0, a1), ahi = max(a0, a1), blo = min(b0, b1), bhi = max(b0, b1);
+      ks[i] = up ? alo : ahi;  // (unconditional stores: no divergent branches in the 55 stages)
+      ks[q] = up ? ahi : alo;
+      kd[i] = up ? blo : bhi;
+      kd[q] = up ? bhi : blo;
+    };
+    for (int k = 2; k <= P2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        if (seg >= 64 && j < seg) {  // inside the segments: this wave's seg / 2 pairs, wave-level ordering only
+          for (int u = lane; u < (seg >> 1); u += 64) exchange(wave * (seg >> 1) + u, k, j);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {                      // across segments (or a tiny sort): other waves' results in, other waves' operands out
+          __syncthreads();
+          for (int t = tid; t < (P2 >> 1); t += 256) exchange(t, k, j);
+          __syncthreads();
         }
       }
-      __syncthreads();
-    }
+    __syncthreads();
+  }
   // rows = key ranges; weighted degree = the by-source row summed in edge order, then the self term
   auto lower = [&](const uint32_t *keys, uint32_t v) {
     int lo = 0, hi = P2;
@@ -236,7 +254,10 @@ __global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, const 
     ptr_dst[n] = e0 + d0;
     end_dst[n] = e0 + d1;
     float dsum = 0.f;
-    for (int i = s0; i < s1; ++i) dsum += ew[e0 + (ks[i] & (kCsrMaxEdges - 1))];
+    for (int i = s0; i < s1; ++i) {
+      const int j = (int)(ks[i] & (kCsrMaxEdges - 1));
+      dsum += ext ? s_w[j] : ew[e0 + j];
+    }
     deg[n] = dsum + selfw_out[n];
   }
   __threadfence_block();  // deg[] of the whole graph is read below
@@ -246,17 +267,17 @@ __global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, const 
     const uint32_t a = ks[i], b = kd[i];
     if (a != kCsrNoKey) {
       const int j = (int)(a & (kCsrMaxEdges - 1));
-      const int r = n0 + (int)(a >> kCsrKeyShift), c = (int)ei[(size_t)E + e0 + j];
+      const int r = n0 + (int)(a >> kCsrKeyShift), c = ext ? n0 + (int)(s_pk[j] >> 16) : (int)ei[(size_t)E + e0 + j];
       const float dr = deg[r] > 0 ? 1.0f / sqrtf(deg[r]) : 0.0f, dc = deg[c] > 0 ? 1.0f / sqrtf(deg[c]) : 0.0f;
       nbr_src[e0 + i] = c;
-      wn_src[e0 + i] = dr * ew[e0 + j] * dc;
+      wn_src[e0 + i] = dr * (ext ? s_w[j] : ew[e0 + j]) * dc;
     }
     if (b != kCsrNoKey) {
       const int j = (int)(b & (kCsrMaxEdges - 1));
-      const int c = n0 + (int)(b >> kCsrKeyShift), r = (int)ei[e0 + j];
+      const int c = n0 + (int)(b >> kCsrKeyShift), r = ext ? n0 + (int)(s_pk[j] & 0xffffu) : (int)ei[e0 + j];
       const float dr = deg[r] > 0 ? 1.0f / sqrtf(deg[r]) : 0.0f, dc = deg[c] > 0 ? 1.0f / sqrtf(deg[c]) : 0.0f;
       nbr_dst[e0 + i] = r;
-      wn_dst[e0 + i] = dr * ew[e0 + j] * dc;
+      wn_dst[e0 + i] = dr * (ext ? s_w[j] : ew[e0 + j]) * dc;
     }
   }
 }
@@ -1018,11 +1039,12 @@ bool build_graph_batched(hipStream_t st, const GcnWs &w, int N, int E, const int
   if (max_edges_per_graph > kCsrMaxEdges) return false;
   int P2 = 64;
   while (P2 < max_edges_per_graph) P2 <<= 1;
-  const size_t lds = (size_t)2 * P2 * sizeof(uint32_t);
+  const int extra = P2 <= 4096 ? 1 : 0;  // weights + packed endpoints beside the keys: 16 bytes per edge slot, <= 64 KB
+  const size_t lds = (size_t)(extra ? 4 : 2) * P2 * sizeof(uint32_t);
   static bool attr_set[32] = {false};
   const void *fns[] = {reinterpret_cast<const void *>(&k_csr_graphs)};
   drlgx_ensure_lds_attr(attr_set, fns, 1, 160 * 1024);
-  hipLaunchKernelGGL(k_csr_graphs, dim3(G), dim3(256), lds, st, N, E, P2, ei, ew, node_off, edge_off, w.deg, w.selfw, w.ptr_dst, w.end_dst,
+  hipLaunchKernelGGL(k_csr_graphs, dim3(G), dim3(256), lds, st, N, E, P2, extra, ei, ew, node_off, edge_off, w.deg, w.selfw, w.ptr_dst, w.end_dst,
                      w.nbr_dst, w.wn_dst, w.ptr_src, w.end_src, w.nbr_src, w.wn_src);
   return true;
 }
