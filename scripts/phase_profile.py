@@ -22,13 +22,6 @@ names = {0:"start",1:"relin+clear+tables",2:"landmark+pose blocks",3:"G",4:"Schu
 print("k_slam phases (us, block 0):")
 for k in range(1, 8): print("  %-24s %8.2f" % (names[k], (a[k]-a[k-1]) / 100.0))
 print("  total %.2f" % ((a[7]-a[0]) / 100.0))
-print("  sweep sub-phases (us): panel+barrier %.2f, pivot inverse %.2f, tiles %.2f" % (a[8]/100.0, a[9]/100.0, a[10]/100.0))
-print("  shader clock during sweeps: %.0f MHz" % (a[11] / max(a[12], 1) * 100.0))
-last = np.array(out[:], dtype=np.int64)
-t0 = min(last[24 + 5 * w] for w in range(8))
-for w in range(8):
-    b5 = last[24 + 5 * w: 29 + 5 * w] - t0
-    print("  wave %d (step K=3): start %5d  P done %5d  W done %5d  barrier2 passed %5d  end %5d" % (w, b5[0], b5[1], b5[2], b5[3], b5[4]))
 print("k_sim phases (us, block 0): load %.2f, move %.2f, measure-1 %.2f, measure-2 %.2f, store %.2f, total %.2f" % (tuple((a[i+1]-a[i])/100.0 for i in (8,9,10,11,12)) + ((a[13]-a[8])/100.0,)))
 print("k_map phases: see scripts/phase_profile_map.py")
 eng.timing_enable(True); eng.timing_read()
