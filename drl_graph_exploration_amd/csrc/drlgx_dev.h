@@ -89,7 +89,7 @@ struct DrlgxState {
   int *slam_iws;  // [n_inst][slam_iws_stride] observation table + per-pose factor ranges
   size_t slam_iws_stride;
   int *status;  // [1]
-  long long *prof;  // [64] development aid: wall_clock64() stamps of the phases of block 0 (or null)
+  long long *prof;  // [128] development aid: wall_clock64() stamps of the phases of block 0 (or null)
 };
 
 // phase stamp (100 MHz constant clock) — only block 0 / thread 0, only when profiling is armed

@@ -1045,10 +1045,11 @@ int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]) {
   DRLGX_ENTER(e);
   if (!e) return DRLGX_E_INVALID;
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  if (out && e->S.prof) HIPCHK(e, hipMemcpy(out, e->S.prof, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  // (arm & 2: the second bank of 64 stamps - per-wave stamps of one sweep block step)
+  if (out && e->S.prof) HIPCHK(e, hipMemcpy(out, e->S.prof + ((arm & 2) ? 64 : 0), 64 * sizeof(long long), hipMemcpyDeviceToHost));
   if (arm && !e->S.prof) {
     long long *p = nullptr;
-    int r = dev_alloc(e, &p, 64);
+    int r = dev_alloc(e, &p, 128);
     if (r) return r;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     e->S.prof = p;

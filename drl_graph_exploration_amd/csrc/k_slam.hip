@@ -47,11 +47,19 @@ __device__ __forceinline__ size_t up8(size_t b) { return (b + 7) & ~(size_t)7; }
 __device__ __forceinline__ double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
   r = r * (2.0 - x * r);
+#ifndef DRLGX_EXP_N1
   r = r * (2.0 - x * r);
+#endif
   return r;
 }
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+// doubles of the LDS region of a packed N x N system swept by sweep_packed_fast: the packed lower triangle, or the sweep's
+// panels (two pivot-column panels, two W panels, two E tiles, two diagonal-tile dumps) that alias it
+__host__ __device__ inline size_t sweep_region_doubles(size_t N) {
+  const size_t a = N * (N + 1) / 2, b = 64 * N + 1024;
+  return a > b ? a : b;
+}
 constexpr int kWaves = kThreads / 64;
 
 struct SweepCtx {
@@ -79,13 +87,6 @@ struct SweepCtx {
 // "KS": a 16-vector v is stored as v[(c & 3) * 4 + (c >> 2)] so that the 4 K-steps of an MFMA operand lane are one
 // 32-byte read.
 // ------------------------------------------------------------------------------------------------------------------
-struct Sw16 {
-  double *pan[2];   // [N][16] KS
-  double *wt;       // [N][16] KS
-  double *einv[2];  // [16][16] KS (E is symmetric)
-  double *dscr[2];  // [64][4]: accumulator dump (lane, reg) of the next diagonal tile
-  double *es;       // inversion scratch of the E-wave: vs[4][16], e4[16], d4[16], ws[64]
-};
 __device__ __forceinline__ int ks16(int c) { return (c & 3) * 4 + (c >> 2); }
 
 __device__ __forceinline__ v4d mfma4(const double (&a)[4], const double (&b)[4], v4d c) {
@@ -196,128 +197,319 @@ __device__ __forceinline__ void inv16(const SweepCtx &x, int K, v4d &d) {
   }
 }
 
-template <int KI, int FT>
-__device__ __forceinline__ void sweep16_block(const SweepCtx &x, const Sw16 &L, v4d (&acc)[FT]) {
-  const int N = x.N, lc = x.lc, lr = x.lr, I = x.I;
-  const int b = KI & 1;
-  double *pan = L.pan[b];
-  const int kb = 16 * KI;
-  const bool has_mask = x.np < kb + 16;  // the last block holds the rhs row / pads: they are not pivots
-  const bool trg = x.tr && KI == 3;
-  if (trg) x.tr[0] = clock64();
-  // ---- P: publish the pivot tile column (masked columns / rows as zeros) ----
-  if (x.live && I >= KI) {
-    const bool colact = kb + lc < x.np;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pan[(16 * I + lr + 4 * r) * 16 + ks16(lc)] = colact ? acc[KI][r] : 0.0;
+// ---- in-wave 16 x 16 SPD inversion by 4 x 4 BLOCK pivots on the fp64 matrix cores ----
+// Same contract as inv16 (d: full symmetric tile in accumulator layout <- -D^-1 on the first `nact` pivots), four block
+// steps instead of sixteen scalar ones.  Block step Kb (rows / columns 4 Kb .. 4 Kb + 3 = accumulator register Kb):
+//   E4 = -(pivot block)^-1                  closed form (2 x 2 blocks, two reciprocals), from ten v_readlane values
+//   W^T = E4 D[Kb rows, :]                  ONE MFMA: A operand = E4 (lanes lc < 4), B operand = register Kb as it is;
+//                                           output register 0 at lane (lr, lc) = W[lc][lr] = the A operand of the update
+//   D <- D + W (D[Kb rows, :] with the pivot columns replaced by -I)   ONE MFMA; with the pivot columns of the
+//                                           accumulator input zeroed this leaves -W there, exactly
+//   pivot rows <- -W^T, pivot block <- E4   selects
+// The dependent chain per block is ~25 fp64 operations + two MFMAs instead of four scalar pivots of ~10 operations plus
+// their permlane / DPP broadcasts (scripts/emul/inv16_blk_emul.py checks the index algebra against numpy).
+struct Inv16Lane {  // lane constants of the block inversion
+  bool lr1, c1, top, left, ua, ub, lc_lt4;
+  double sel;  // -1 where (lc & 3) == lr, else 0: the "-I" of the pivot columns in the B operand
+  __device__ __forceinline__ Inv16Lane(int lr, int lc) {
+    lr1 = lr & 1; c1 = lc & 1; top = lr < 2; left = (lc & 3) < 2;
+    ua = top ? c1 : lr1; ub = top ? lr1 : c1;
+    lc_lt4 = lc < 4;
+    sel = ((lc & 3) == lr) ? -1.0 : 0.0;
   }
-  if (I == KI) {
+};
+template <int Kb>
+__device__ __forceinline__ void inv16_blk_step(const SweepCtx &x, const Inv16Lane &q, v4d &d) {
+  constexpr int c0 = 4 * Kb;
+  const double a00 = readlane_f64(d[Kb], c0);
+  const double a10 = readlane_f64(d[Kb], 16 + c0), a11 = readlane_f64(d[Kb], 16 + c0 + 1);
+  const double a20 = readlane_f64(d[Kb], 32 + c0), a21 = readlane_f64(d[Kb], 32 + c0 + 1), a22 = readlane_f64(d[Kb], 32 + c0 + 2);
+  const double a30 = readlane_f64(d[Kb], 48 + c0), a31 = readlane_f64(d[Kb], 48 + c0 + 1), a32 = readlane_f64(d[Kb], 48 + c0 + 2),
+               a33 = readlane_f64(d[Kb], 48 + c0 + 3);
+  // P = [a00 a10; a10 a11], Q = [a20 a21; a30 a31], R = [a22 a32; a32 a33]: block inverse through S = R - Q P^-1 Q^T.
+  // (A variant that carries det P as a scale, so that the two reciprocals are not in sequence - dependent depth ~16
+  // instead of ~29 operations - measured SLOWER, 3172 against 2988 cycles per tile: the step is bound by instruction
+  // issue of the one wave that runs it, not by latency; scripts/micro/inv16_bench.hip.)
+  const double detp = a00 * a11 - a10 * a10;
+  const double ip = fast_rcp(detp);
+  const double p00 = a11 * ip, p10 = -a10 * ip, p11 = a00 * ip;           // P^-1
+  const double t00 = a20 * p00 + a21 * p10, t01 = a20 * p10 + a21 * p11;  // T = Q P^-1
+  const double t10 = a30 * p00 + a31 * p10, t11 = a30 * p10 + a31 * p11;
+  const double s00 = a22 - (t00 * a20 + t01 * a21);                       // S = R - T Q^T
+  const double s10 = a32 - (t10 * a20 + t11 * a21);
+  const double s11 = a33 - (t10 * a30 + t11 * a31);
+  const double dets = s00 * s11 - s10 * s10;
+  const double is = fast_rcp(dets);
+  const double r00 = s11 * is, r10 = -s10 * is, r11 = s00 * is;           // S^-1
+  const double u00 = r00 * t00 + r10 * t10, u01 = r00 * t01 + r10 * t11;  // U = S^-1 T
+  const double u10 = r10 * t00 + r11 * t10, u11 = r10 * t01 + r11 * t11;
+  if (x.lane == 0 && (!(a00 > 0) || !(detp > 0) || !(s00 > 0) || !(dets > 0))) x.bad[0] = 1;
+  // this lane's entry E4[lr][lc & 3] of  E4 = -D^-1 = -[P^-1 + T^T U, -U^T; -U, S^-1]
+  const double t0x = q.lr1 ? t01 : t00, t1x = q.lr1 ? t11 : t10;  // T[.][lr & 1]
+  const double u0c = q.c1 ? u01 : u00, u1c = q.c1 ? u11 : u10;    // U[.][lc & 1]
+  const double pI = (q.lr1 == q.c1) ? (q.lr1 ? p11 : p00) : p10;
+  const double rI = (q.lr1 == q.c1) ? (q.lr1 ? r11 : r00) : r10;
+  const double e_tl = -(pI + t0x * u0c + t1x * u1c);
+  const double uo = q.ua ? (q.ub ? u11 : u10) : (q.ub ? u01 : u00);  // U[lr - 2][c] below the diagonal, U[c - 2][lr] above
+  const double e_lane = (q.top == q.left) ? (q.top ? e_tl : -rI) : uo;
+  const double eA = q.lc_lt4 ? e_lane : 0.0;
+  const v4d z = {0.0, 0.0, 0.0, 0.0};
+  const v4d wt4 = __builtin_amdgcn_mfma_f64_16x16x4f64(eA, d[Kb], z, 0, 0, 0);
+  const double wt = wt4[0];  // lane (lr, lc): W[lc][lr],  W = D[:, Kb columns] E4
+  const bool inK = (x.lc >> 2) == Kb;
+  const double bop = inK ? q.sel : d[Kb];
+  v4d cin;
 #pragma unroll
-    for (int u = 0; u < KI; ++u) {
-      double *o = pan + (16 * u + lc) * 16 + lr * 4;  // A[16 K + lr + 4 r][16 u + lc] -> PAN[16 u + lc][KS(lr + 4 r)]
+  for (int r = 0; r < 4; ++r) cin[r] = inK ? 0.0 : d[r];
+  d = __builtin_amdgcn_mfma_f64_16x16x4f64(wt, bop, cin, 0, 0, 0);
+  d[Kb] = inK ? e_lane : -wt;
+}
+// nact: number of pivots of this tile (1 .. 16); the rows / columns beyond are not pivots and their content afterwards is
+// finite but meaningless (every user of E multiplies them by the zeroed panel columns or never reads them)
+__device__ __forceinline__ void inv16_blk(const SweepCtx &x, int nact, v4d &d) {
+  if (nact < 16) {  // decouple the inactive rows / columns: identity there
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (kb + lr + 4 * r < x.np) ? acc[u][r] : 0.0;
+    for (int r = 0; r < 4; ++r) {
+      const int row = x.lr + 4 * r;
+      if (row >= nact || x.lc >= nact) d[r] = (row == x.lc) ? 1.0 : 0.0;
     }
   }
-  constexpr int KN = (KI + 1 < FT) ? KI + 1 : KI;
-  const bool have_next = kb + 16 < x.np;
-  if (have_next && I == KI + 1) {  // current values of the next diagonal tile, for the look-ahead
-    double *o = L.dscr[(KI + 1) & 1] + 4 * x.lane;
+  const Inv16Lane q(x.lr, x.lc);
+  inv16_blk_step<0>(x, q, d);
+  inv16_blk_step<1>(x, q, d);
+  inv16_blk_step<2>(x, q, d);
+  inv16_blk_step<3>(x, q, d);
+}
+
+// ---- the fast sweep as ONE runtime loop over the block steps ----
+// (Round 2 instantiated a block step per tile column: 145 KB of straight-line code for seven steps - more than twice the
+// 64 KB instruction cache, so the wave that inverts the diagonal tiles, alone on the critical path, ran its 16 pivots out
+// of cold instruction fetches: 5.3 k cycles in the kernel against 3.8 k warm.)  One copy of the step now serves every
+// tile column K; the accumulator tile "K" is selected by uniform branches over the statically indexed registers.
+//
+// LDS panels are stored as OPERAND IMAGES: a 16 x 16 block X is kept as the four MFMA operand registers of every lane,
+//   img[(s >> 1) * 128 + 2 * lane + (s & 1)] = X[lc][4 s + lr],
+// two lane-linear 16-byte halves (conflict-free ds_read_b128 / ds_write_b128; the row-major [16] KS layout of round 2 put
+// every lane of a 16-lane group on two banks).  The same registers serve as the A operand of X . and as the B operand of
+// . X^T.  With that, products are formed TRANSPOSED so that an MFMA result is directly the next MFMA's operand:
+//   W_I^T = E_K PAN_I^T   (A = image of E_K (symmetric), B = image of PAN_I)   -> registers = image of W_I
+//   A_Iu += W_I PAN_u^T   (A = those registers, B = image of PAN_u)
+// and the E-wave's look-ahead  D_{K+1} += W_{K+1} PAN_{K+1}^T needs no LDS round trip any more.  A wave needs the W of
+// other waves only for the pivot rows (A_Ku <- -W_u^T); that replacement is deferred until after the next step's barrier
+// (W images double buffered), which leaves ONE workgroup barrier per block step instead of two.
+struct SwL {  // every buffer twice (index = block step & 1); address arithmetic, no pointer tables (they would go to scratch)
+  double *base;  // pan[2][16 N] operand images of the pivot tile column, wt[2][16 N] images of W_I = PAN_I E_K,
+  int n16;       // einv[2][256] image of E_K = -D_K^-1 (= the accumulator registers of the inverting wave),
+                 // dscr[2][256] accumulator registers of the next diagonal tile (lane-linear)
+  __device__ __forceinline__ double *pan(int b) const { return base + b * n16; }
+  __device__ __forceinline__ double *wt(int b) const { return base + (2 + b) * n16; }
+  __device__ __forceinline__ double *einv(int b) const { return base + 4 * n16 + b * 256; }
+  __device__ __forceinline__ double *dscr(int b) const { return base + 4 * n16 + 512 + b * 256; }
+};
+__device__ __forceinline__ void ld_op(const double *img, int lane, double (&o)[4]) {
+  const double2 a = *reinterpret_cast<const double2 *>(img + 2 * lane), b = *reinterpret_cast<const double2 *>(img + 128 + 2 * lane);
+  o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+}
+__device__ __forceinline__ void st_op(double *img, int lane, double v0, double v1, double v2, double v3) {
+  *reinterpret_cast<double2 *>(img + 2 * lane) = make_double2(v0, v1);
+  *reinterpret_cast<double2 *>(img + 128 + 2 * lane) = make_double2(v2, v3);
+}
+// offset inside an operand image of the element (row lr + 4 r, column lc) that a lane holds in accumulator layout
+__device__ __forceinline__ int acc_off(int lr, int lc, int r) {
+  return (lc >> 3) * 128 + 2 * (16 * (lc & 3) + lr + 4 * r) + ((lc >> 2) & 1);
+}
+
+// The sweep of ONE ROLE: the wave that owns tile row I (I = -1: no tile row) and, with kE, inverts the diagonal tiles.
+// The role is a compile-time constant - every register index except "tile column K" is static and the tile loops have no
+// branches - and the block steps are a runtime loop, so each wave runs ~2-5 KB of code that stays in the instruction cache.
+// A: the packed lower triangle (LDS); the panels alias it once the tiles are in registers.  Every role executes the same
+// sequence of workgroup barriers.
+template <int I, bool kE>
+__device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &x, double *A, int N) {
+  constexpr int NT = I >= 0 ? I + 1 : 1;
+  auto AT = [&](int i, int j) -> int { return i * (i + 1) / 2 + j; };
+  const int lane = x.lane, lc = x.lc, lr = x.lr, np = x.np;
+  const int nK = (np + 15) >> 4;
+  v4d acc[NT];
+  if constexpr (I >= 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = acc[KN][r];
+    for (int u = 0; u <= I; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + lr + 4 * r, j = 16 * u + lc;
+        acc[u][r] = (i < N && j < N) ? A[AT(max(i, j), min(i, j))] : 0.0;
+      }
   }
-  if (trg) x.tr[1] = clock64();
+  __syncthreads();  // every tile is in registers: the LDS region of A now holds the sweep panels
+  const SwL L{A, 16 * N};
+  if constexpr (I == 0) st_op(L.dscr(0), lane, acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
   __syncthreads();
-  // ---- W = PAN_I E_K ----
-  v4d w = {0.0, 0.0, 0.0, 0.0};
-  if (x.live) {
-    double aP[4], eB[4];
-    ld4(pan + (16 * I + lc) * 16 + lr * 4, aP);
-    ld4(L.einv[b] + lc * 16 + lr * 4, eB);
-    w = mfma4(aP, eB, w);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) L.wt[(16 * I + lr + 4 * r) * 16 + ks16(lc)] = w[r];
+  if constexpr (kE) {  // E_0
+    double t[4];
+    ld_op(L.dscr(0), lane, t);
+    v4d d = {t[0], t[1], t[2], t[3]};
+    inv16_blk(x, min(16, np), d);
+    st_op(L.einv(0), lane, d[0], d[1], d[2], d[3]);
   }
-  // ---- look-ahead: E_{K+1}.  The E-wave forms W_{K+1} = PAN_{K+1} E_K itself (it must not wait for the wave that owns
-  //      that row to publish it), updates the diagonal tile D_{K+1} += W_{K+1} PAN_{K+1}^T before the second barrier and
-  //      inverts it right after ----
-  v4d dn = {0.0, 0.0, 0.0, 0.0};
-  if (x.ewave && have_next) {
-    double aP[4], eB[4], aW[4], bP[4], t[4];
-    ld4(pan + (16 * (KI + 1) + lc) * 16 + lr * 4, aP);  // also the B operand of the update (PAN_{K+1}^T)
-    ld4(L.einv[b] + lc * 16 + lr * 4, eB);
-    v4d w1 = {0.0, 0.0, 0.0, 0.0};
-    w1 = mfma4(aP, eB, w1);
-    // accumulator layout -> A-operand layout through the wave-private scratch
+  const int aoff[4] = {acc_off(lr, lc, 0), acc_off(lr, lc, 1), acc_off(lr, lc, 2), acc_off(lr, lc, 3)};
+#pragma clang loop unroll(disable)
+  for (int K = 0; K < nK; ++K) {
+    const int kb = 16 * K, b = K & 1;
+    const bool has_mask = np < kb + 16;  // the last block holds the rhs row / pads: they are not pivots
+    const bool have_next = kb + 16 < np;
+    const bool trg = x.tr && K == 3;
+    if (trg) x.tr[0] = clock64();
+    // ---- P: publish the pivot tile column (masked columns / rows as zeros) ----
+    if constexpr (I >= 0) {
+      double *pan = L.pan(b);
+      if (K <= I) {
+        const bool colact = kb + lc < np;
+        double *pI = pan + 256 * I;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) L.es[(lr + 4 * r) * 16 + ks16(lc)] = w1[r];
-    wave_lds_sync();
-    ld4(L.es + lc * 16 + lr * 4, aW);
-    ld4(L.dscr[(KI + 1) & 1] + 4 * x.lane, t);
-    dn = v4d{t[0], t[1], t[2], t[3]};
+        for (int u = 0; u <= I; ++u)  // (a ladder of scalar branches selects the statically indexed tile K)
+          if (u == K) {
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) bP[s2] = aP[s2];
-    dn = mfma4(aW, bP, dn);
-  }
-  if (trg) x.tr[2] = clock64();
-  __syncthreads();
-  if (trg) x.tr[3] = clock64();
-  if (x.ewave && have_next) {
-    inv16(x, KI + 1, dn);
-    double *eo = L.einv[(KI + 1) & 1];
+            for (int r = 0; r < 4; ++r) pI[aoff[r]] = colact ? acc[u][r] : 0.0;
+          }
+        if (K == I) {  // the transposed tiles (I, u < I): accumulator registers = operand image of PAN_u
 #pragma unroll
-    for (int r = 0; r < 4; ++r) eo[(lr + 4 * r) * 16 + ks16(lc)] = dn[r];
-  }
-  // ---- U ----
-  if (x.live) {
-    if (I != KI || has_mask) {
-      double aW[4];
-      ld4(L.wt + (16 * I + lc) * 16 + lr * 4, aW);
+          for (int u = 0; u < I; ++u)
+            st_op(pan + 256 * u, lane, (kb + lr < np) ? acc[u][0] : 0.0, (kb + lr + 4 < np) ? acc[u][1] : 0.0,
+                  (kb + lr + 8 < np) ? acc[u][2] : 0.0, (kb + lr + 12 < np) ? acc[u][3] : 0.0);
+        }
+      }
+      if (have_next && K + 1 == I)  // current values of the next diagonal tile, for the look-ahead
+        st_op(L.dscr((K + 1) & 1), lane, acc[NT - 1][0], acc[NT - 1][1], acc[NT - 1][2], acc[NT - 1][3]);
+    }
+    if (trg) x.tr[1] = clock64();
+    __syncthreads();  // panels of step K, E_K, the W images of step K - 1
+    const double *pan = L.pan(b);
+    // ---- deferred from step K - 1: its pivot rows A_{K-1,u} <- -(W_u)^T (all rows active: only the last block is masked) ----
+    if constexpr (I >= 1) {
+      if (K == I + 1) {
+        const double *wp = L.wt((K - 1) & 1);
 #pragma unroll
-      for (int u = FT - 1; u >= 0; --u) {
-        if (u <= I && (u != KI || I == KI)) {  // tile column K is replaced below, except in wave K (masked rows keep the update)
-          double bP[4];
-          ld4(pan + (16 * u + lc) * 16 + lr * 4, bP);
-          acc[u] = mfma4(aW, bP, acc[u]);
+        for (int u = 0; u < I; ++u) {
+          double t[4];
+          ld_op(wp + 256 * u, lane, t);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[u][r] = -t[r];
         }
       }
     }
-    if (I > KI) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[KI][r] = -w[r];  // A_IK <- A_IK D^-1 (masked columns: W = 0)
-    }
-    if (I == KI) {
-      // pivot rows: A_Ku <- -(W_u)^T, pivot block <- E_K; rows >= np (rhs, pads) keep the regular update, their pivot
-      // columns take -W like any other row
-#pragma unroll
-      for (int u = 0; u < KI; ++u) {
-        double t[4];
-        ld4(L.wt + (16 * u + lc) * 16 + lr * 4, t);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[u][r] = (kb + lr + 4 * r < x.np) ? -t[r] : acc[u][r];
+    // ---- look-ahead (critical path): E_{K+1} = -(D_{K+1} + W_{K+1} PAN_{K+1}^T)^-1 ----
+    if constexpr (kE) {
+      if (have_next) {
+        // (this chain is the critical path of the whole sweep: it outranks the SIMD partner's update work)
+        __builtin_amdgcn_s_setprio(3);
+        double aP[4], eB[4], t[4];
+        ld_op(pan + 256 * (K + 1), lane, aP);
+        ld_op(L.einv(b), lane, eB);
+        ld_op(L.dscr((K + 1) & 1), lane, t);
+        v4d w1 = {0.0, 0.0, 0.0, 0.0};
+        w1 = mfma4(eB, aP, w1);  // image of W_{K+1}
+        const double aW[4] = {w1[0], w1[1], w1[2], w1[3]};
+        v4d dn = {t[0], t[1], t[2], t[3]};
+        dn = mfma4(aW, aP, dn);
+        if (trg) x.tr[2] = clock64();
+#ifndef DRLGX_EXP_NOINV
+        inv16_blk(x, min(16, np - kb - 16), dn);
+#endif
+        st_op(L.einv((K + 1) & 1), lane, dn[0], dn[1], dn[2], dn[3]);
+        __builtin_amdgcn_s_setprio(0);
+        if (trg) x.tr[3] = clock64();
       }
-      double e[4], t[4];
-      ld4(L.einv[b] + lc * 16 + lr * 4, e);       // E[lr + 4 r][lc]
-      ld4(L.wt + (16 * KI + lc) * 16 + lr * 4, t);  // W[16 K + lc][lr + 4 r]
-      const bool colact = kb + lc < x.np;
+    }
+    // ---- W, U ----
+    if constexpr (I >= 0) {
+      double aP[4], eB[4];
+      ld_op(pan + 256 * I, lane, aP);
+      ld_op(L.einv(b), lane, eB);
+      v4d wv = {0.0, 0.0, 0.0, 0.0};
+      wv = mfma4(eB, aP, wv);  // image of W_I
+      double *wI = L.wt(b) + 256 * I;
+      st_op(wI, lane, wv[0], wv[1], wv[2], wv[3]);
+      const double aW[4] = {wv[0], wv[1], wv[2], wv[3]};
+      if (K != I || has_mask) {
+        // A_Iu += W_I PAN_u^T (tile column K is replaced below, except in wave K whose masked rows keep the update); the
+        // next tile's operand is loaded while this tile's MFMAs run
+        // two tiles at a time: their MFMA chains are independent, so the matrix pipe is issued back to back (a chain on
+        // ONE accumulator waits ~20 cycles per link for the previous result)
+        double bP[2][2][4];
+        ld_op(pan, lane, bP[0][0]);
+        if (I >= 1) ld_op(pan + 256, lane, bP[0][1]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool rowact = kb + lr + 4 * r < x.np;
-        acc[KI][r] = rowact ? (colact ? e[r] : -t[r]) : (colact ? -w[r] : acc[KI][r]);
+        for (int u = 0; u <= I; u += 2) {
+          constexpr int I1 = I >= 0 ? I : 0;
+          const int h = (u >> 1) & 1, u1 = u + 1 <= I1 ? u + 1 : u;
+          if (u + 2 <= I) ld_op(pan + 256 * (u + 2), lane, bP[h ^ 1][0]);
+          if (u + 3 <= I) ld_op(pan + 256 * (u + 3), lane, bP[h ^ 1][1]);
+#ifndef DRLGX_EXP_NOU
+          const bool d0 = u != K || K == I, d1 = u + 1 <= I && (u + 1 != K || K == I);
+          if (d0 && d1) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+              acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[s2], bP[h][0][s2], acc[u], 0, 0, 0);
+              acc[u1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[s2], bP[h][1][s2], acc[u1], 0, 0, 0);
+            }
+          } else if (d0) {
+            acc[u] = mfma4(aW, bP[h][0], acc[u]);
+          } else if (d1) {
+            acc[u1] = mfma4(aW, bP[h][1], acc[u1]);
+          }
+#endif
+        }
+      }
+      if (K <= I) {
+        wave_lds_sync();  // own image -> accumulator layout
+        double w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = wI[aoff[r]];
+        if (K < I) {
+#pragma unroll
+          for (int u = 0; u < I; ++u)
+            if (u == K) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[u][r] = -w[r];  // A_IK <- A_IK D^-1 (masked columns: W = 0)
+            }
+        } else {
+          // pivot block <- E_K; rows >= np (rhs, pads) keep the regular update, their pivot columns take -W like any other
+          // row; the pivot rows of the tiles (K, u < K) follow after the next barrier
+          const bool colact = kb + lc < np;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool rowact = kb + lr + 4 * r < np;
+            acc[NT - 1][r] = rowact ? (colact ? eB[r] : -aW[r]) : (colact ? -w[r] : acc[NT - 1][r]);
+          }
+        }
+      }
+    }
+    if (trg) x.tr[4] = clock64();
+  }
+  __syncthreads();
+  // the pivot rows of the last block (masked: rows >= np keep their regular update)
+  if constexpr (I >= 1) {
+    if (I == nK - 1) {
+      const int kb = 16 * I;
+      const double *wp = L.wt(I & 1);
+#pragma unroll
+      for (int u = 0; u < I; ++u) {
+        double t[4];
+        ld_op(wp + 256 * u, lane, t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[u][r] = (kb + lr + 4 * r < np) ? -t[r] : acc[u][r];
       }
     }
   }
-  if (trg) x.tr[4] = clock64();
-}
-
-#define SW16_END_STAMP
-template <int FT, int KI = 0>
-__device__ __forceinline__ void sweep16_all(const SweepCtx &x, const Sw16 &L, v4d (&acc)[FT]) {
-  if constexpr (KI < FT) {
-    if (16 * KI < x.np) {
-      sweep16_block<KI, FT>(x, L, acc);
-      sweep16_all<FT, KI + 1>(x, L, acc);
-    }
+  __syncthreads();
+  if constexpr (I >= 0) {
+#pragma unroll
+    for (int u = 0; u <= I; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + lr + 4 * r, j = 16 * u + lc;
+        if (j <= i && i < N) A[AT(i, j)] = acc[u][r];
+      }
   }
 }
 
@@ -481,72 +673,42 @@ __device__ __forceinline__ void pose_block(const DrlgxState &S, int inst, const 
 }
 
 // Symmetric Gauss-Jordan sweep of the packed lower triangle `A` (LDS, row i at i (i + 1) / 2, N = 16 Tn <= 16 FT rows; the
-// region must hold max(N (N + 1) / 2, 48 N + 1280) doubles: the sweep panels alias it while the tiles are in registers) on
+// region must hold sweep_region_doubles(N) doubles: the sweep panels alias it while the tiles are in registers) on
 // the pivots [0, np); rows >= np (the rhs row np, pads) are carried along.  Afterwards A holds -A_pp^-1 and row np the
 // solution.  All kThreads threads of the workgroup call it (block barriers inside).
 template <int FT>
 __device__ __forceinline__ void sweep_packed_fast(const DrlgxState &S, double *A, int np, int N, int Tn, int *bad, int tid) {
-  auto AT = [&](int i, int j) -> int { return i * (i + 1) / 2 + j; };
-  {
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // tile rows r and FT-1-r share a SIMD (waves w and w+4): lower-triangle MFMA work is balanced across the SIMDs
-    int trow = wv < FT / 2 ? wv : (FT - 1) - (wv - FT / 2);
-    if (Tn == FT) {
-      // no idle tile row: the wave of row 0 (one tile of update work) also inverts the diagonal tiles, and its SIMD
-      // partner takes the next lightest row, so that the inversion chain competes with the fewest MFMAs:
-      // SIMD pairs (0, 1), (2, FT-1), (3, FT-2), ...
-      trow = wv == 0 ? 0 : wv == FT / 2 ? 1 : wv < FT / 2 ? wv + 1 : FT + FT / 2 - wv;
-    }
-    SweepCtx x{trow, lane, lane & 15, lane >> 4, np, N, trow < Tn, trow == (Tn < FT ? FT - 1 : 0), bad, (S.prof && blockIdx.x == 0 && lane == 0) ? S.prof + 24 + 5 * wv : nullptr};
-    v4d acc[FT];
-#pragma unroll
-    for (int u = 0; u < FT; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * x.I + x.lr + 4 * r, j = 16 * u + x.lc;
-        acc[u][r] = (i < N && j < N) ? A[AT(max(i, j), min(i, j))] : 0.0;
-      }
-    __syncthreads();  // every tile is in registers: the LDS region of A now holds the sweep panels
-    Sw16 Lp;
-    {
-      double *q = A;
-      Lp.pan[0] = q; q += 16 * N;
-      Lp.pan[1] = q; q += 16 * N;
-      Lp.wt = q; q += 16 * N;
-      Lp.einv[0] = q; q += 256;
-      Lp.einv[1] = q; q += 256;
-      Lp.dscr[0] = q; q += 256;
-      Lp.dscr[1] = q; q += 256;
-      Lp.es = q;  // 256 doubles
-    }
-    if (x.I == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Lp.dscr[0][4 * lane + r] = acc[0][r];
-    }
-    __syncthreads();
-    if (x.ewave) {  // E_0
-      v4d d;
-      {
-        double t[4];
-        ld4(Lp.dscr[0] + 4 * lane, t);
-        d = v4d{t[0], t[1], t[2], t[3]};
-      }
-      inv16(x, 0, d);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Lp.einv[0][(x.lr + 4 * r) * 16 + ks16(x.lc)] = d[r];
-    }
-    sweep16_all<FT>(x, Lp, acc);
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < FT; ++u) {
-      if (u > x.I) continue;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * x.I + x.lr + 4 * r, j = 16 * u + x.lc;
-        if (j <= i && i < N) A[AT(i, j)] = acc[u][r];
-      }
-    }
+  static_assert(FT == 8, "one role per wave of the 512-thread workgroup");
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // tile rows r and FT-1-r share a SIMD (waves w and w+4): lower-triangle MFMA work is balanced across the SIMDs
+  int trow = wv < FT / 2 ? wv : (FT - 1) - (wv - FT / 2);
+  if (Tn == FT) {
+    // no idle tile row: the wave of row 0 (one tile of update work) also inverts the diagonal tiles, and its SIMD
+    // partner takes the next lightest row, so that the inversion chain competes with the fewest MFMAs:
+    // SIMD pairs (0, 1), (2, FT-1), (3, FT-2), ...
+    trow = wv == 0 ? 0 : wv == FT / 2 ? 1 : wv < FT / 2 ? wv + 1 : FT + FT / 2 - wv;
+  }
+  const bool live = trow < Tn, ewave = trow == (Tn < FT ? FT - 1 : 0);
+  const SweepCtx x{trow, lane, lane & 15, lane >> 4, np, N, live, ewave, bad,
+                   (S.prof && blockIdx.x == 0 && lane == 0) ? S.prof + 64 + 5 * wv : nullptr};
+  if (!live) {
+    if (ewave) sweep_role<-1, true>(S, x, A, N);
+    else sweep_role<-1, false>(S, x, A, N);
+    return;
+  }
+  switch (trow) {
+    case 0:
+      if (ewave) sweep_role<0, true>(S, x, A, N);
+      else sweep_role<0, false>(S, x, A, N);
+      break;
+    case 1: sweep_role<1, false>(S, x, A, N); break;
+    case 2: sweep_role<2, false>(S, x, A, N); break;
+    case 3: sweep_role<3, false>(S, x, A, N); break;
+    case 4: sweep_role<4, false>(S, x, A, N); break;
+    case 5: sweep_role<5, false>(S, x, A, N); break;
+    case 6: sweep_role<6, false>(S, x, A, N); break;
+    default: sweep_role<7, false>(S, x, A, N); break;
   }
 }
 
@@ -704,7 +866,7 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   const int Tn = (na + 15) / 16, N = 16 * Tn;
   auto AT = [&](int i, int j) -> int { return i * (i + 1) / 2 + j; };
   // (the matrix region is reused for the sweep panels while the tiles are in registers)
-  const size_t a_doubles = max((size_t)N * (N + 1) / 2, (size_t)48 * N + 1280);
+  const size_t a_doubles = sweep_region_doubles(N);
   if (Tn > FT) {
     // more poses than this kernel was launched for (the host's bound was wrong): flag it, touch nothing
     if (tid == 0) atomicMin(S.status, DRLGX_E_CAPACITY);
@@ -1008,7 +1170,7 @@ size_t slam_small_bytes(int P_max, int L_max, int M_max) {
 // workspace variant (factor records and the observation table overflow to the workspace)
 size_t arrow_lds_bytes(int P_max, int L_max, int M_max) {
   const size_t N = 16 * (((size_t)2 * L_max + 1 + 15) / 16);
-  const size_t sys = N <= 16 * kFastTilesArrow ? std::max(N * (N + 1) / 2, 48 * N + 1280) : 32 * N + 1280;
+  const size_t sys = N <= 16 * kFastTilesArrow ? sweep_region_doubles(N) : 32 * N + 1280;
   return arrow_small_bytes(P_max, L_max, M_max) + sys * 8 + 64;
 }
 
@@ -1018,7 +1180,7 @@ size_t arrow_lds_bytes(int P_max, int L_max, int M_max) {
 bool drlgx_slam_in_lds(int P_max, int L_max, int M_max) {
   const size_t nf = 16 * kslam::kFastTiles;
   return kslam::slam_dim(P_max) <= nf &&
-         kslam::slam_small_bytes(P_max, L_max, M_max) + std::max(nf * (nf + 1) / 2, 48 * nf + 1280) * 8 <= (size_t)kslam::kLdsBudget;
+         kslam::slam_small_bytes(P_max, L_max, M_max) + kslam::sweep_region_doubles(nf) * 8 <= (size_t)kslam::kLdsBudget;
 }
 // capacities the SLAM kernels can serve at all (checked by drlgx_create)
 bool drlgx_slam_capacity_ok(int P_max, int L_max, int M_max) {

@@ -137,7 +137,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   unsigned short *obs;
   double *rec_ws = wsd; wsd += (size_t)S.M_max * REC;
   double *Aws = wsd; wsd += (size_t)(2 * S.L_max + 17) * (2 * S.L_max + 17);
-  const size_t sys_bytes = (c_lds ? max((size_t)N * (N + 1) / 2, (size_t)48 * N + 1280) : (size_t)32 * N + 1280) * 8;
+  const size_t sys_bytes = (c_lds ? sweep_region_doubles(N) : (size_t)32 * N + 1280) * 8;
   if (off + sys_bytes + up8((size_t)L * P * 2) + 32 <= (size_t)lds_bytes) {
     obs = reinterpret_cast<unsigned short *>(smem_raw + off); off += (up8((size_t)L * P * 2) + 31) & ~(size_t)31;
   } else {

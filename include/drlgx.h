@@ -257,7 +257,8 @@ int drlgx_timing_enable(drlgx_engine *e, int on);
 int drlgx_timing_read_host(drlgx_engine *e, double ms[DRLGX_N_TIMERS], int64_t launches[DRLGX_N_TIMERS]);
 
 /* Development aid: arm (1) / disarm (0) in-kernel phase stamps (wall_clock64, 100 MHz) written by block 0
- * of k_slam (slots 0-10) and k_map (slots 16-22); out (may be NULL) receives the last stamps. */
+ * of k_slam (slots 0-10) and k_map (slots 16-22); out (may be NULL) receives the last stamps (arm & 2: the second
+ * bank of 64 - per-wave cycle stamps of one block step of the sweep). */
 int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]);
 
 /* ---- GCN policy (scripts/Networks.py:12-70 over PyG GCNConv(improved=True)) ------------------- */
