@@ -603,9 +603,9 @@ __device__ __forceinline__ void pivot_inverse_from(int np, int q0i, const double
       }
 }
 
-// Pose i's diagonal block B (3x3, full) and gradient g of the prior / odometry / own bearing-range factors linearised at
-// thp, and - for i + 1 < P - the block O = (i + 1, i) of the odometry factor i (SLAM2D.cpp:44-89; records: linearize_br)
-__device__ __forceinline__ void pose_block(const DrlgxState &S, int inst, const double *thp, const double *rec, const int *mstart,
+// Pose i's diagonal block B (3x3, full) and gradient g of the prior / odometry (odo[i] = measured odometry between the
+// poses i and i + 1: x, y, cos, sin) / own bearing-range factors linearised at thp, and - for i + 1 < P - the block O = (i + 1, i) of the odometry factor i (SLAM2D.cpp:44-89; records: linearize_br)
+__device__ __forceinline__ void pose_block(const DrlgxState &S, int inst, const double *thp, const double *odo, const double *rec, const int *mstart,
                                            int i, int P, double wb, double wr, double *B, double *g, double *O) {
   const drlgx_config &cfg = S.cfg;
   for (int k = 0; k < 9; ++k) B[k] = 0.0;
@@ -631,7 +631,7 @@ __device__ __forceinline__ void pose_block(const DrlgxState &S, int inst, const 
                         1.0 / (cfg.translation_noise * cfg.translation_noise),
                         1.0 / (cfg.rotation_noise * cfg.rotation_noise)};
   if (i > 0) {  // odometry factor i-1 seen from its second key: J2 = Hlocal (SLAM2D.cpp:59-89)
-    const double *oo = S.odo + ((size_t)inst * S.P_max + (i - 1)) * 4;
+    const double *oo = odo + 4 * (i - 1);
     const Pose tm{thp[4 * (i - 1)], thp[4 * (i - 1) + 1], thp[4 * (i - 1) + 2], thp[4 * (i - 1) + 3]};
     const Pose hx = between(tm, ti, nullptr);
     const Pose h = between(Pose{oo[0], oo[1], oo[2], oo[3]}, hx, nullptr);
@@ -644,7 +644,7 @@ __device__ __forceinline__ void pose_block(const DrlgxState &S, int inst, const 
     }
   }
   if (i + 1 < P) {  // odometry factor i from its first key: J1 = Hlocal * H1; also block (i+1, i) = J2^T W J1
-    const double *oo = S.odo + ((size_t)inst * S.P_max + i) * 4;
+    const double *oo = odo + 4 * i;
     const Pose tn{thp[4 * (i + 1)], thp[4 * (i + 1) + 1], thp[4 * (i + 1) + 2], thp[4 * (i + 1) + 3]};
     double H1[9];
     const Pose hx = between(ti, tn, H1);
@@ -840,9 +840,476 @@ __device__ __forceinline__ void sweep_regtiles(double *A, double *pbase, int np,
   }
 }
 
+// ---- software barrier among the waves that run the SLAM front end beside the simulator wave (k_step) ----
+// A monotonic LDS counter: every participating wave adds one and waits (lane 0, s_sleep) until all have arrived.  The
+// hardware barrier cannot be used there: the simulator wave does not take part.
+struct SubBarrier {
+  int *cnt;
+  int nwaves, phase;
+  __device__ __forceinline__ void sync(int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    ++phase;
+    if (lane == 0) {
+      __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < nwaves * phase) __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+};
+
 // The fast path: <= 42 poses (N <= 16 FT = 128), the whole problem in LDS.  Longer trajectories: arrow_body (k_slam_arrow.hip).
+//
+// The update is split in two so that the fused step kernel can run the first part BESIDE the simulator wave:
+//   front  everything that does not depend on this step's measurements: relinearisation policy and theta staging,
+//          linearisation of the factors that existed before the step, the pose blocks (the new pose's initial guess and
+//          its odometry factor only depend on the commanded odometry and the previous estimate), the landmark sums over
+//          the old factors.  In k_step it runs on 7 waves with software barriers (front<true>), in k_slam on all 8.
+//   back   the new factors (linearisation, their terms appended to the sums in factor order - the same order of additions
+//          as a single pass over all factors, so both kernels produce identical bits), landmark elimination, sweep, outputs.
+struct SlamCtx {
+  int inst, P, L, M;     // poses of the system; landmarks / factors known so far (front) or final (back)
+  int Lb, Mb;            // carve bounds of the per-landmark / per-factor arrays
+  int np, N, Tn, MW;
+  int n_old_p, n_old_l, count;
+  bool relin;
+  // LDS
+  double *thp, *odl, *thl, *lamb, *A, *rec;
+  int *mstart, *bad, *lstart;
+  unsigned short *mp, *ml, *lfac, *obs;
+  unsigned long long *lmask;
+
+  __device__ __forceinline__ int AT(int i, int j) const { return i * (i + 1) / 2 + j; }
+
+  // LDS carve from byte offset `off` of the dynamic shared memory: small arrays first, then the dense system; the factor
+  // records and the observation table go to the HBM workspace when they do not fit
+  __device__ __forceinline__ void setup(const DrlgxState &S, unsigned char *smem_raw, size_t off, int lds_bytes, int inst_, int P_, int Lb_, int Mb_) {
+    inst = inst_; P = P_; Lb = Lb_; Mb = Mb_;
+    np = 3 * P;
+    // padded to 16x16 MFMA tiles; row np holds the rhs (its column and all pad rows / columns stay zero).  Only the lower
+    // triangle is ever addressed and it is stored packed (row i at i (i + 1) / 2)
+    Tn = (np + 1 + 15) / 16; N = 16 * Tn;
+    MW = (P + 63) >> 6;
+    auto take = [&](size_t bytes) { unsigned char *q = smem_raw + off; off += up8(bytes); return q; };
+    thp = reinterpret_cast<double *>(take((size_t)P * 4 * 8));
+    odl = reinterpret_cast<double *>(take((size_t)P * 4 * 8));
+    thl = reinterpret_cast<double *>(take((size_t)Lb * 2 * 8));
+    lamb = reinterpret_cast<double *>(take((size_t)Lb * 8 * 8));
+    mstart = reinterpret_cast<int *>(take((size_t)(P + 2) * 4));
+    lstart = reinterpret_cast<int *>(take((size_t)(Lb + 2) * 4));
+    mp = reinterpret_cast<unsigned short *>(take((size_t)Mb * 2));
+    ml = reinterpret_cast<unsigned short *>(take((size_t)Mb * 2));
+    lfac = reinterpret_cast<unsigned short *>(take((size_t)Mb * 2));
+    bad = reinterpret_cast<int *>(take(8));
+    // poses observing each landmark as bit masks (MW 64-bit words): the per-landmark loops visit only those poses
+    lmask = reinterpret_cast<unsigned long long *>(take((size_t)Lb * MW * 8));
+    off = (off + 31) & ~(size_t)31;
+    A = reinterpret_cast<double *>(smem_raw + off); off += sweep_region_doubles(N) * 8;  // (reused for the sweep panels)
+    double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
+    const size_t big = (size_t)Mb * REC * 8 + up8((size_t)Lb * P * 2);
+    if (off + big <= (size_t)lds_bytes) {
+      rec = reinterpret_cast<double *>(smem_raw + off); off += (size_t)Mb * REC * 8;
+      obs = reinterpret_cast<unsigned short *>(smem_raw + off);
+    } else {
+      rec = wsd; wsd += (size_t)S.M_max * REC;
+      obs = reinterpret_cast<unsigned short *>(wsd);
+    }
+  }
+
+  // tables + the (expensive) linearisation of the factors [m0, m1), one thread each
+  __device__ __forceinline__ void factor_tables(const DrlgxState &S, int m0, int m1, int t, int nt) const {
+    const int *meas_pose = S.meas_pose + (size_t)inst * S.M_max;
+    const int *meas_lm = S.meas_lm + (size_t)inst * S.M_max;
+    const double *meas_br = S.meas_br + (size_t)inst * S.M_max * 2;
+    for (int m = m0 + t; m < m1; m += nt) {
+      const int p = meas_pose[m], j = meas_lm[m];
+      mp[m] = (unsigned short)p;
+      ml[m] = (unsigned short)j;
+      if (m == 0 || meas_pose[m - 1] != p) mstart[p] = m;
+      obs[j * P + p] = (unsigned short)(m + 1);
+      atomicOr(&lmask[MW * j + (p >> 6)], 1ull << (p & 63));
+      linearize_br(thp + 4 * p, thl + 2 * j, meas_br[2 * m], meas_br[2 * m + 1], rec + (size_t)REC * m);
+    }
+  }
+
+  // kSub: called by the threads 64 .. kThreads-1 (ft = tid - 64) while wave 0 simulates; Pf / L / M are the counts before
+  // the step, the new pose (index Pf) comes from `odomP`.  Otherwise by all threads with the final counts (Pf = P).
+  template <bool kSub>
+  __device__ __forceinline__ void front(const DrlgxState &S, int tid, int Pf, int Lf, int Mf, int n_old_p_, int n_old_l_, int count_,
+                                        bool refresh, const double *odom3, SubBarrier sb) {
+    const drlgx_config &cfg = S.cfg;
+    const int ft = kSub ? tid - 64 : tid, fn = kSub ? kThreads - 64 : kThreads, lane = tid & 63;
+    auto bar = [&]() {
+      if constexpr (kSub) sb.sync(lane);
+      else __syncthreads();
+    };
+    L = Lf; M = Mf; n_old_p = n_old_p_; n_old_l = n_old_l_; count = count_;
+    double *th_pose = S.th_pose + (size_t)inst * S.P_max * 4;
+    double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
+    double *th_lm = S.th_lm + (size_t)inst * S.L_max * 2;
+    double *d_lm = S.d_lm + (size_t)inst * S.L_max * 2;
+    // ---- 1. relinearisation policy (gtsam ISAM2: relinearizeSkip 10, relinearizeThreshold 0.1);
+    //         theta (+ folded delta) is staged in LDS ----
+    relin = !refresh && (count % 10 == 0);
+    for (int i = ft; i < Pf; i += fn) {
+      Pose t{th_pose[4 * i], th_pose[4 * i + 1], th_pose[4 * i + 2], th_pose[4 * i + 3]};
+      if (relin && i < n_old_p) {
+        const double a = fabs(d_pose[3 * i]), b = fabs(d_pose[3 * i + 1]), c = fabs(d_pose[3 * i + 2]);
+        if (fmax(a, fmax(b, c)) >= 0.1) {
+          t = compose(t, make_pose(d_pose[3 * i], d_pose[3 * i + 1], d_pose[3 * i + 2]));
+          th_pose[4 * i] = t.x; th_pose[4 * i + 1] = t.y; th_pose[4 * i + 2] = t.c; th_pose[4 * i + 3] = t.s;
+        }
+      }
+      thp[4 * i] = t.x; thp[4 * i + 1] = t.y; thp[4 * i + 2] = t.c; thp[4 * i + 3] = t.s;
+      if (i + 1 < Pf) {  // measured odometry between pose i and i + 1
+        const double *oo = S.odo + ((size_t)inst * S.P_max + i) * 4;
+        odl[4 * i] = oo[0]; odl[4 * i + 1] = oo[1]; odl[4 * i + 2] = oo[2]; odl[4 * i + 3] = oo[3];
+      }
+    }
+    if constexpr (kSub) {
+      // the pose this step appends: SLAM2D::addOdometry's initial guess = last estimate * odom (SLAM2D.cpp:70-89), the same
+      // expressions as the simulator wave evaluates (k_sim.hip sim_step_body), which stores them to HBM
+      if (ft == fn - 1) {
+        const Pose odomP = make_pose(odom3[0], odom3[1], odom3[2]);
+        const double *ep = S.est_pose + ((size_t)inst * S.P_max + (Pf - 1)) * 4;
+        const Pose p2 = compose(Pose{ep[0], ep[1], ep[2], ep[3]}, odomP);
+        thp[4 * Pf] = p2.x; thp[4 * Pf + 1] = p2.y; thp[4 * Pf + 2] = p2.c; thp[4 * Pf + 3] = p2.s;
+        odl[4 * (Pf - 1)] = odomP.x; odl[4 * (Pf - 1) + 1] = odomP.y; odl[4 * (Pf - 1) + 2] = odomP.c; odl[4 * (Pf - 1) + 3] = odomP.s;
+      }
+    }
+    for (int j = ft; j < Lf; j += fn) {
+      double x = th_lm[2 * j], y = th_lm[2 * j + 1];
+      if (relin && j < n_old_l && fmax(fabs(d_lm[2 * j]), fabs(d_lm[2 * j + 1])) >= 0.1) {
+        x += d_lm[2 * j];
+        y += d_lm[2 * j + 1];
+        th_lm[2 * j] = x;
+        th_lm[2 * j + 1] = y;
+      }
+      thl[2 * j] = x;
+      thl[2 * j + 1] = y;
+    }
+    // ---- 2. clear the system; factor tables (factors are appended in pose order: contiguous ranges) ----
+    {
+      double2 *A2 = reinterpret_cast<double2 *>(A);
+      const int n2 = (int)((size_t)N * (N + 1) / 2 / 2);  // (N is a multiple of 16: even)
+      for (int e = ft; e < n2; e += fn) A2[e] = make_double2(0.0, 0.0);
+    }
+    for (int e = ft; e < Lb * P; e += fn) obs[e] = 0;
+    for (int e = ft; e < MW * Lb; e += fn) lmask[e] = 0ull;
+    for (int e = ft; e <= P; e += fn) mstart[e] = 0x7fffffff;
+    if (ft == 0) bad[0] = 0;
+    bar();
+    factor_tables(S, 0, Mf, ft, fn);
+    bar();
+    // poses without factors get the empty range [next pose's start, same): the first assigned start at or after p, i.e.
+    // the suffix minimum of the raw starts (they increase with the pose); one wave, top chunk first
+    if (ft < 64) {
+      int carry = 0x7fffffff;
+      for (int base = (P >> 6) << 6; base >= 0; base -= 64) {
+        const int q = base + ft;
+        int v = q < P ? mstart[q] : (q == P ? Mf : 0x7fffffff);  // (the end of the list = the start of this step's factors)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int w = __shfl_down(v, o);
+          if (ft + o < 64) v = min(v, w);
+        }
+        v = min(v, carry);
+        if (q <= P) mstart[q] = v;
+        carry = __shfl(v, 0);
+      }
+    }
+    bar();
+    // ---- 3. block assembly.  first waves: one thread per landmark; following waves: one thread per pose ----
+    const double wb = 1.0 / (cfg.bearing_noise * cfg.bearing_noise), wr = 1.0 / (cfg.range_noise * cfg.range_noise);
+    const int pose_t0 = ((Lf + 63) & ~63) % fn;  // poses start on a fresh wave so both roles overlap
+    for (int j = ft; j < Lf; j += fn) {
+      double a = 0, b = 0, d = 0, g0 = 0, g1 = 0;
+      FOR_EACH_OBSERVING_POSE(lmask + MW * j, MW, p) {
+        const double *r = rec + (size_t)REC * (obs[j * P + p] - 1);
+        a += r[6] * wb * r[6] + r[8] * wr * r[8];
+        b += r[6] * wb * r[7] + r[8] * wr * r[9];
+        d += r[7] * wb * r[7] + r[9] * wr * r[9];
+        g0 += r[6] * wb * r[10] + r[8] * wr * r[11];
+        g1 += r[7] * wb * r[10] + r[9] * wr * r[11];
+      }
+      double *lb = lamb + 8 * j;
+      lb[0] = a; lb[1] = b; lb[2] = d; lb[3] = g0; lb[4] = g1;  // (sums so far; back() appends this step's terms)
+    }
+    for (int i = (ft - pose_t0 + fn) % fn; i < P; i += fn) {
+      double B[9], g[3], O[9];
+      pose_block(S, inst, thp, odl, rec, mstart, i, P, wb, wr, B, g, O);
+      if (i + 1 < P)
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) A[AT((3 * (i + 1) + r), 3 * i + c)] = O[r * 3 + c];
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c <= r; ++c) A[AT((3 * i + r), 3 * i + c)] = B[r * 3 + c];
+        A[AT(np, 3 * i + r)] = -g[r];  // rhs lives in the augmented row
+      }
+    }
+  }
+
+  // everything after the simulator: all kThreads threads, hardware barriers.  Lfin / Mfin: the final counts (>= the front's).
+  template <int FT>
+  __device__ __forceinline__ void back(const DrlgxState &S, int tid, int Lfin, int Mfin, bool full, bool refresh) {
+    const drlgx_config &cfg = S.cfg;
+    const double wb = 1.0 / (cfg.bearing_noise * cfg.bearing_noise), wr = 1.0 / (cfg.range_noise * cfg.range_noise);
+    int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
+    double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
+    double *th_lm = S.th_lm + (size_t)inst * S.L_max * 2;
+    double *d_lm = S.d_lm + (size_t)inst * S.L_max * 2;
+    const int L0 = L, M0 = M;
+    L = Lfin; M = Mfin;
+    // ---- this step's landmarks and factors (all of them observed from the newest pose) ----
+    for (int j = L0 + tid; j < L; j += kThreads) {
+      thl[2 * j] = th_lm[2 * j];
+      thl[2 * j + 1] = th_lm[2 * j + 1];
+      double *lb = lamb + 8 * j;
+      lb[0] = lb[1] = lb[2] = lb[3] = lb[4] = 0.0;
+    }
+    if (tid == 0) mstart[P] = M;
+    __syncthreads();
+    factor_tables(S, M0, M, tid, kThreads);
+    __syncthreads();
+    DRLGX_PROF(S, 1);
+    // ---- landmark blocks: this step's term (at most one per landmark) closes the sum, then Lambda_jj^-1 and eta_j;
+    //      CSR offsets of the per-landmark factor lists (one wave); the newest pose's own factors close its block ----
+    for (int j = tid; j < L; j += kThreads) {
+      double *lb = lamb + 8 * j;
+      double a = lb[0], b = lb[1], d = lb[2], g0 = lb[3], g1 = lb[4];
+      const int m1 = M > M0 ? obs[j * P + (P - 1)] : 0;
+      if (m1 > M0) {
+        const double *r = rec + (size_t)REC * (m1 - 1);
+        a += r[6] * wb * r[6] + r[8] * wr * r[8];
+        b += r[6] * wb * r[7] + r[8] * wr * r[9];
+        d += r[7] * wb * r[7] + r[9] * wr * r[9];
+        g0 += r[6] * wb * r[10] + r[8] * wr * r[11];
+        g1 += r[7] * wb * r[10] + r[9] * wr * r[11];
+      }
+      const double id = 1.0 / (a * d - b * b);
+      lb[0] = a; lb[1] = b; lb[2] = d;
+      lb[3] = d * id; lb[4] = -b * id; lb[5] = a * id;  // Lambda_jj^-1
+      lb[6] = -g0; lb[7] = -g1;                           // eta_j
+    }
+    if (tid >= kThreads - 64) {  // exclusive scan of the observation counts -> lstart[0 .. L]
+      const int ln = tid - (kThreads - 64);
+      int carry = 0;
+      for (int base = 0; base < L; base += 64) {
+        const int j = base + ln;
+        int k = 0;
+        if (j < L)
+          for (int w = 0; w < MW; ++w) k += __popcll(lmask[MW * j + w]);
+        int v = k;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int u = __shfl_up(v, o);
+          if (ln >= o) v += u;
+        }
+        if (j < L) lstart[j] = carry + v - k;
+        carry += __shfl(v, 63);
+      }
+      if (ln == 0) lstart[L] = carry;
+    }
+    if (M > M0 && tid == kThreads / 2) {
+      // pose_block's own-factor loop for the factors appended after the front ran (same expressions, same order)
+      const int i = P - 1;
+      double B[6], g[3];
+      for (int r = 0, q = 0; r < 3; ++r)
+        for (int c = 0; c <= r; ++c, ++q) B[q] = A[AT(3 * i + r, 3 * i + c)];
+      for (int r = 0; r < 3; ++r) g[r] = -A[AT(np, 3 * i + r)];
+      for (int m = M0; m < M; ++m) {
+        const double *l = rec + (size_t)REC * m;
+        for (int r = 0, q = 0; r < 3; ++r) {
+          for (int c = 0; c <= r; ++c, ++q) B[q] += l[r] * wb * l[c] + l[3 + r] * wr * l[3 + c];
+          g[r] += l[r] * wb * l[10] + l[3 + r] * wr * l[11];
+        }
+      }
+      for (int r = 0, q = 0; r < 3; ++r) {
+        for (int c = 0; c <= r; ++c, ++q) A[AT(3 * i + r, 3 * i + c)] = B[q];
+        A[AT(np, 3 * i + r)] = -g[r];
+      }
+    }
+    __syncthreads();
+    DRLGX_PROF(S, 2);
+    // ---- 4. landmark elimination: rec[0..5] <- G_m = Lambda_pl Lambda_ll^-1 (3x2), rec[6..11] <- H_m = G_m Lambda_jj
+    //         (= Lambda_pl; the Jacobian of the landmark and the residual are not needed any more);
+    //         per-landmark factor lists lfac[lstart[j] ..] in pose order ----
+    for (int m = tid; m < M; m += kThreads) {
+      double *l = rec + (size_t)REC * m;
+      const double *lb = lamb + 8 * ml[m];
+      double g[6], h[6];
+      for (int r = 0; r < 3; ++r) {
+        const double b0 = l[r] * wb * l[6] + l[3 + r] * wr * l[8];
+        const double b1 = l[r] * wb * l[7] + l[3 + r] * wr * l[9];
+        g[r * 2 + 0] = b0 * lb[3] + b1 * lb[4];
+        g[r * 2 + 1] = b0 * lb[4] + b1 * lb[5];
+      }
+      for (int r = 0; r < 3; ++r) {
+        h[r * 2 + 0] = g[r * 2] * lb[0] + g[r * 2 + 1] * lb[1];
+        h[r * 2 + 1] = g[r * 2] * lb[1] + g[r * 2 + 1] * lb[2];
+      }
+      for (int k = 0; k < 6; ++k) l[k] = g[k];
+      for (int k = 0; k < 6; ++k) l[6 + k] = h[k];
+    }
+    for (int j = (tid + kThreads / 2) % kThreads; j < L; j += kThreads) {
+      int t = lstart[j];
+      FOR_EACH_OBSERVING_POSE(lmask + MW * j, MW, p) lfac[t++] = (unsigned short)(obs[j * P + p] - 1);
+    }
+    __syncthreads();
+    DRLGX_PROF(S, 3);
+    //      Schur complement: S_pq -= sum_j G_m Lambda_jj G_mq^T   (Lambda_pl = G Lambda_jj = H)
+    {
+      const int npairs = P * (P + 1) / 2;
+      for (int e = tid; e < npairs; e += kThreads) {
+        int p = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+        while ((p + 1) * (p + 2) / 2 <= e) ++p;
+        while (p * (p + 1) / 2 > e) --p;
+        const int q = e - p * (p + 1) / 2;
+        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        bool any = false;
+        for (int m = mstart[p]; m < mstart[p + 1]; ++m) {
+          const int mq1 = obs[ml[m] * P + q];
+          if (!mq1) continue;
+          any = true;
+          const double *h = rec + (size_t)REC * m + 6, *gq = rec + (size_t)REC * (mq1 - 1);
+          for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) acc[r * 3 + c] += h[r * 2] * gq[c * 2] + h[r * 2 + 1] * gq[c * 2 + 1];
+        }
+        if (any)
+          for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+              if (p == q && c > r) continue;
+              A[AT((3 * p + r), 3 * q + c)] -= acc[r * 3 + c];
+            }
+      }
+      for (int p = (tid + kThreads / 2) % kThreads; p < P; p += kThreads) {  // rhs_p -= sum_m G_m eta_j (idle waves)
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int m = mstart[p]; m < mstart[p + 1]; ++m) {
+          const double *g = rec + (size_t)REC * m, *lb = lamb + 8 * ml[m];
+          s0 += g[0] * lb[6] + g[1] * lb[7];
+          s1 += g[2] * lb[6] + g[3] * lb[7];
+          s2 += g[4] * lb[6] + g[5] * lb[7];
+        }
+        A[AT(np, 3 * p + 0)] -= s0;
+        A[AT(np, 3 * p + 1)] -= s1;
+        A[AT(np, 3 * p + 2)] -= s2;
+      }
+    }
+    __syncthreads();
+    DRLGX_PROF(S, 4);
+    // ---- 5. sweep: one tile row per wave (sweep_packed_fast) ----
+    sweep_packed_fast<FT>(S, A, np, N, Tn, bad, tid);
+    __syncthreads();
+    DRLGX_PROF(S, 5);
+    for (int k = tid; k < np; k += kThreads) d_pose[k] = A[AT(np, k)];
+    // ---- 6. landmark marginals: rec[6..9] <- G_m^T ( sum_{m' of the same landmark} Sigma[p_m][p_m'] G_m' ).  The factors
+    //         m' of the landmark come from its list; a factor's sum is split over S6 adjacent lanes (the longest list is
+    //         the latency of this phase) and combined by a butterfly (a fixed tree: deterministic) ----
+    if (full) {
+      const int sh6 = 4 * M <= kThreads ? 2 : 2 * M <= kThreads ? 1 : 0, S6 = 1 << sh6;
+      const int per_pass = kThreads >> sh6;
+      for (int m0 = 0; m0 < M; m0 += per_pass) {
+        const int m = m0 + (tid >> sh6), s6 = tid & (S6 - 1);
+        const bool work = m < M;
+        double Wm[6] = {0, 0, 0, 0, 0, 0};
+        if (work) {
+          const int j = ml[m], p = mp[m];
+          const int t0 = lstart[j], t1 = lstart[j + 1];
+          for (int t = t0 + s6; t < t1; t += S6) {
+            const int mq = lfac[t], q = mp[mq];
+            const double *gq = rec + (size_t)REC * mq;
+            // Sigma[p][q] = -(swept block): the packed triangle holds the block as rows of the later pose
+            const int hi = max(p, q), lo = min(p, q);
+            double tb[9];
+            for (int a = 0; a < 3; ++a)
+              for (int b = 0; b < 3; ++b) {
+                const int ra = (hi == lo) ? max(a, b) : a, cb = (hi == lo) ? min(a, b) : b;
+                tb[a * 3 + b] = A[AT(3 * hi + ra, 3 * lo + cb)];
+              }
+            for (int r = 0; r < 3; ++r) {
+              double s0 = 0, s1 = 0;
+              for (int c = 0; c < 3; ++c) {
+                const double sg = -((p >= q) ? tb[r * 3 + c] : tb[c * 3 + r]);
+                s0 += sg * gq[c * 2];
+                s1 += sg * gq[c * 2 + 1];
+              }
+              Wm[r * 2] += s0;
+              Wm[r * 2 + 1] += s1;
+            }
+          }
+        }
+        for (int o = S6 >> 1; o > 0; o >>= 1)
+#pragma unroll
+          for (int k = 0; k < 6; ++k) Wm[k] += __shfl_xor(Wm[k], o);
+        if (work && s6 == 0) {
+          double *g = rec + (size_t)REC * m;
+          g[6] = g[0] * Wm[0] + g[2] * Wm[2] + g[4] * Wm[4];
+          g[7] = g[0] * Wm[1] + g[2] * Wm[3] + g[4] * Wm[5];
+          g[8] = g[1] * Wm[0] + g[3] * Wm[2] + g[5] * Wm[4];
+          g[9] = g[1] * Wm[1] + g[3] * Wm[3] + g[5] * Wm[5];
+        }
+      }
+    }
+    __syncthreads();
+    DRLGX_PROF(S, 6);
+    double *est_lm = S.est_lm + (size_t)inst * S.L_max * 2;
+    double *lm_info = S.lm_info + (size_t)inst * S.L_max * 3;
+    double *lm_tr = S.lm_tr + (size_t)inst * S.L_max;
+    for (int j = tid; j < L; j += kThreads) {
+      const double *lb = lamb + 8 * j;
+      double c00 = lb[3], c01 = lb[4], c10 = lb[4], c11 = lb[5];
+      // delta_j = Lambda^-1 eta_j - sum_m G_m^T delta_p
+      double dx = lb[3] * lb[6] + lb[4] * lb[7], dy = lb[4] * lb[6] + lb[5] * lb[7];
+      for (int t = lstart[j]; t < lstart[j + 1]; ++t) {
+        const int mq = lfac[t], p = mp[mq];
+        const double *g = rec + (size_t)REC * mq;
+        c00 += g[6]; c01 += g[7]; c10 += g[8]; c11 += g[9];
+        const double dp0 = A[AT(np, 3 * p)], dp1 = A[AT(np, 3 * p + 1)], dp2 = A[AT(np, 3 * p + 2)];
+        dx -= g[0] * dp0 + g[2] * dp1 + g[4] * dp2;
+        dy -= g[1] * dp0 + g[3] * dp1 + g[5] * dp2;
+      }
+      d_lm[2 * j] = dx;
+      d_lm[2 * j + 1] = dy;
+      est_lm[2 * j] = thl[2 * j] + dx;
+      est_lm[2 * j + 1] = thl[2 * j + 1] + dy;
+      if (!full) continue;
+      const double cs = 0.5 * (c01 + c10);
+      lm_tr[j] = c00 + c11;
+      const double id = 1.0 / (c00 * c11 - cs * cs);  // marginalCovariance(l).inverse() (SLAM2D.cpp:417)
+      lm_info[3 * j] = c11 * id;
+      lm_info[3 * j + 1] = -cs * id;
+      lm_info[3 * j + 2] = c00 * id;
+    }
+    // ---- 7. pose estimates, information = inverse(covariance) by LLT (SLAM2D.cpp:395-408) ----
+    double *est_pose = S.est_pose + (size_t)inst * S.P_max * 4;
+    double *pose_info = S.pose_info + (size_t)inst * S.P_max * 6;
+    double *pose_tr = S.pose_tr + (size_t)inst * S.P_max;
+    for (int i = (tid + kThreads / 2) % kThreads; i < P; i += kThreads) {
+      const int k0 = 3 * i;
+      const Pose t{thp[4 * i], thp[4 * i + 1], thp[4 * i + 2], thp[4 * i + 3]};
+      const Pose e = compose(t, make_pose(A[AT(np, k0)], A[AT(np, k0 + 1)], A[AT(np, k0 + 2)]));
+      est_pose[4 * i] = e.x; est_pose[4 * i + 1] = e.y; est_pose[4 * i + 2] = e.c; est_pose[4 * i + 3] = e.s;
+      if (!full) continue;
+      const double c00 = -A[AT(k0, k0)], c10 = -A[AT((k0 + 1), k0)], c11 = -A[AT((k0 + 1), k0 + 1)];
+      const double c20 = -A[AT((k0 + 2), k0)], c21 = -A[AT((k0 + 2), k0 + 1)], c22 = -A[AT((k0 + 2), k0 + 2)];
+      pose_tr[i] = c00 + c11 + c22;
+      inv3_sym_fast(c00, c10, c20, c11, c21, c22, pose_info + 6 * i);
+    }
+    DRLGX_PROF(S, 7);
+    if (tid == 0) {
+      if (!refresh) {
+        cnt[C_ISAM] = count;
+        cnt[C_NEWP] = P;
+        cnt[C_NEWL] = L;
+      }
+      if (bad[0]) atomicMin(S.status, DRLGX_E_NUMERIC);
+    }
+  }
+};
+
+// The SLAM stage after the simulator.  `pre` (have_pre): the context whose front() already ran beside the simulator (k_step)
+// for the counts before the step.  smem_off: first byte of the dynamic LDS the stage may use.
 template <int FT>
-__device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &sel, int lds_bytes) {
+__device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel &sel, int lds_bytes, size_t smem_off, const SlamCtx &pre, bool have_pre) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int bi = blockIdx.x;
@@ -855,297 +1322,29 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
   const bool full = sel.map_on(bi);
   const bool refresh = cnt[C_FLAG] != 0;
   if (refresh && !(sel.map_last_only && sel.n_act && full)) return;
-  const drlgx_config &cfg = S.cfg;
   const int P = cnt[C_P], L = cnt[C_L], M = cnt[C_M];
-  const int n_old_p = cnt[C_NEWP], n_old_l = cnt[C_NEWL];
-  const int count = cnt[C_ISAM] + (refresh ? 0 : 1);
-  const int np = 3 * P, na = np + 1;
-  // padded to 16x16 MFMA tiles; row np holds the rhs (its column and all pad rows / columns stay zero).  Only the lower
-  // triangle is ever addressed and it is stored packed (row i at i (i + 1) / 2: half the LDS of the square, which keeps
-  // the factor records on chip for ~700 factors instead of ~230)
-  const int Tn = (na + 15) / 16, N = 16 * Tn;
-  auto AT = [&](int i, int j) -> int { return i * (i + 1) / 2 + j; };
-  // (the matrix region is reused for the sweep panels while the tiles are in registers)
-  const size_t a_doubles = sweep_region_doubles(N);
-  if (Tn > FT) {
+  if ((3 * P + 1 + 15) / 16 > FT) {
     // more poses than this kernel was launched for (the host's bound was wrong): flag it, touch nothing
     if (tid == 0) atomicMin(S.status, DRLGX_E_CAPACITY);
     return;
   }
   DRLGX_PROF(S, 0);
-
-  // ---- LDS carve: small arrays first, then the dense system; overflow goes to the HBM workspace ----
-  size_t off = 0;
-  double *thp = reinterpret_cast<double *>(smem_raw + off); off += up8((size_t)P * 4 * 8);
-  double *thl = reinterpret_cast<double *>(smem_raw + off); off += up8((size_t)L * 2 * 8);
-  double *lamb = reinterpret_cast<double *>(smem_raw + off); off += up8((size_t)L * 8 * 8);
-  int *mstart = reinterpret_cast<int *>(smem_raw + off); off += up8((size_t)(P + 2) * 4);
-  unsigned short *mp = reinterpret_cast<unsigned short *>(smem_raw + off); off += up8((size_t)M * 2);
-  unsigned short *ml = reinterpret_cast<unsigned short *>(smem_raw + off); off += up8((size_t)M * 2);
-  int *bad = reinterpret_cast<int *>(smem_raw + off); off += 8;
-  // poses observing each landmark as bit masks (MW 64-bit words): the per-landmark loops visit only those poses
-  const int MW = (P + 63) >> 6;
-  unsigned long long *lmask = reinterpret_cast<unsigned long long *>(smem_raw + off); off += (size_t)L * MW * 8;
-  off = (off + 31) & ~(size_t)31;
-  double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
-  double *A = reinterpret_cast<double *>(smem_raw + off); off += a_doubles * 8;
-  // per-factor records and the landmark x pose observation table: LDS if they fit
-  const size_t big = (size_t)M * REC * 8 + up8((size_t)L * P * 2);
-  double *rec;
-  unsigned short *obs;
-  if (off + big <= (size_t)lds_bytes) {
-    rec = reinterpret_cast<double *>(smem_raw + off); off += (size_t)M * REC * 8;
-    obs = reinterpret_cast<unsigned short *>(smem_raw + off);
+  SlamCtx c;
+  if (have_pre && !refresh && pre.P == P && L <= pre.Lb && M <= pre.Mb) {
+    c = pre;
   } else {
-    rec = wsd; wsd += (size_t)S.M_max * REC;
-    obs = reinterpret_cast<unsigned short *>(wsd);
-  }
-  double *th_pose = S.th_pose + (size_t)inst * S.P_max * 4;
-  double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
-  double *th_lm = S.th_lm + (size_t)inst * S.L_max * 2;
-  double *d_lm = S.d_lm + (size_t)inst * S.L_max * 2;
-  const int *meas_pose = S.meas_pose + (size_t)inst * S.M_max;
-  const int *meas_lm = S.meas_lm + (size_t)inst * S.M_max;
-  const double *meas_br = S.meas_br + (size_t)inst * S.M_max * 2;
-
-  // ---- 1. relinearisation policy (gtsam ISAM2: relinearizeSkip 10, relinearizeThreshold 0.1);
-  //         theta (+ folded delta) is staged in LDS ----
-  const bool relin = !refresh && (count % 10 == 0);
-  for (int i = tid; i < P; i += kThreads) {
-    Pose t{th_pose[4 * i], th_pose[4 * i + 1], th_pose[4 * i + 2], th_pose[4 * i + 3]};
-    if (relin && i < n_old_p) {
-      const double a = fabs(d_pose[3 * i]), b = fabs(d_pose[3 * i + 1]), c = fabs(d_pose[3 * i + 2]);
-      if (fmax(a, fmax(b, c)) >= 0.1) {
-        t = compose(t, make_pose(d_pose[3 * i], d_pose[3 * i + 1], d_pose[3 * i + 2]));
-        th_pose[4 * i] = t.x; th_pose[4 * i + 1] = t.y; th_pose[4 * i + 2] = t.c; th_pose[4 * i + 3] = t.s;
-      }
-    }
-    thp[4 * i] = t.x; thp[4 * i + 1] = t.y; thp[4 * i + 2] = t.c; thp[4 * i + 3] = t.s;
-  }
-  for (int j = tid; j < L; j += kThreads) {
-    double x = th_lm[2 * j], y = th_lm[2 * j + 1];
-    if (relin && j < n_old_l && fmax(fabs(d_lm[2 * j]), fabs(d_lm[2 * j + 1])) >= 0.1) {
-      x += d_lm[2 * j];
-      y += d_lm[2 * j + 1];
-      th_lm[2 * j] = x;
-      th_lm[2 * j + 1] = y;
-    }
-    thl[2 * j] = x;
-    thl[2 * j + 1] = y;
-  }
-  // ---- 2. clear the system; factor tables (factors are appended in pose order: contiguous ranges) ----
-  {
-    double2 *A2 = reinterpret_cast<double2 *>(A);
-    const int n2 = (int)((size_t)N * (N + 1) / 2 / 2);  // (N is a multiple of 16: even)
-    for (int e = tid; e < n2; e += kThreads) A2[e] = make_double2(0.0, 0.0);
-  }
-  for (int e = tid; e < L * P; e += kThreads) obs[e] = 0;
-  for (int e = tid; e < MW * L; e += kThreads) lmask[e] = 0ull;
-  for (int e = tid; e <= P; e += kThreads) mstart[e] = M;
-  if (tid == 0) bad[0] = 0;
-  __syncthreads();
-  // one thread per factor: tables + the (expensive) linearisation, once
-  for (int m = tid; m < M; m += kThreads) {
-    const int p = meas_pose[m], j = meas_lm[m];
-    mp[m] = (unsigned short)p;
-    ml[m] = (unsigned short)j;
-    if (m == 0 || meas_pose[m - 1] != p) mstart[p] = m;
-    obs[j * P + p] = (unsigned short)(m + 1);
-    atomicOr(&lmask[MW * j + (p >> 6)], 1ull << (p & 63));
-    linearize_br(thp + 4 * p, thl + 2 * j, meas_br[2 * m], meas_br[2 * m + 1], rec + (size_t)REC * m);
-  }
-  __syncthreads();
-  {
-    // poses without factors get the empty range [next pose's start, same): first assigned start at or after p
-    int v = M;
-    if (tid < P) {
-      int q = tid;
-      v = mstart[q];
-      while (v == M && q < P) v = mstart[++q];  // mstart[P] = M
-    }
+    // stand-alone kernel, a rejected move, or more new landmarks / factors than the front reserved room for: everything now
+    c.setup(S, smem_raw, smem_off, lds_bytes, inst, P, L, M);
+    c.front<false>(S, tid, P, L, M, cnt[C_NEWP], cnt[C_NEWL], cnt[C_ISAM] + (refresh ? 0 : 1), refresh, nullptr, SubBarrier{nullptr, 0, 0});
     __syncthreads();
-    if (tid < P) mstart[tid] = v;
   }
-  __syncthreads();
-  DRLGX_PROF(S, 1);
-  // ---- 3. block assembly.  first waves: one thread per landmark; following waves: one thread per pose ----
-  const double wb = 1.0 / (cfg.bearing_noise * cfg.bearing_noise), wr = 1.0 / (cfg.range_noise * cfg.range_noise);
-  const int pose_t0 = ((L + 63) & ~63) % kThreads;  // poses start on a fresh wave so both roles overlap
-  for (int j = tid; j < L; j += kThreads) {
-    double a = 0, b = 0, d = 0, g0 = 0, g1 = 0;
-    FOR_EACH_OBSERVING_POSE(lmask + MW * j, MW, p) {
-      const int m1 = obs[j * P + p];
-      const double *r = rec + (size_t)REC * (m1 - 1);
-      a += r[6] * wb * r[6] + r[8] * wr * r[8];
-      b += r[6] * wb * r[7] + r[8] * wr * r[9];
-      d += r[7] * wb * r[7] + r[9] * wr * r[9];
-      g0 += r[6] * wb * r[10] + r[8] * wr * r[11];
-      g1 += r[7] * wb * r[10] + r[9] * wr * r[11];
-    }
-    const double id = 1.0 / (a * d - b * b);
-    double *lb = lamb + 8 * j;
-    lb[0] = a; lb[1] = b; lb[2] = d;
-    lb[3] = d * id; lb[4] = -b * id; lb[5] = a * id;  // Lambda_jj^-1
-    lb[6] = -g0; lb[7] = -g1;                           // eta_j
-  }
-  for (int i = (tid - pose_t0 + kThreads) % kThreads; i < P; i += kThreads) {
-    double B[9], g[3], O[9];
-    pose_block(S, inst, thp, rec, mstart, i, P, wb, wr, B, g, O);
-    if (i + 1 < P)
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) A[AT((3 * (i + 1) + r), 3 * i + c)] = O[r * 3 + c];
-    for (int r = 0; r < 3; ++r) {
-      for (int c = 0; c <= r; ++c) A[AT((3 * i + r), 3 * i + c)] = B[r * 3 + c];
-      A[AT(np, 3 * i + r)] = -g[r];  // rhs lives in the augmented row
-    }
-  }
-  __syncthreads();
-  DRLGX_PROF(S, 2);
-  // ---- 4. landmark elimination: rec[0..5] <- G_m = Lambda_pl Lambda_ll^-1 (3x2) ----
-  for (int m = tid; m < M; m += kThreads) {
-    double *l = rec + (size_t)REC * m;
-    const double *lb = lamb + 8 * ml[m];
-    double g[6];
-    for (int r = 0; r < 3; ++r) {
-      const double b0 = l[r] * wb * l[6] + l[3 + r] * wr * l[8];
-      const double b1 = l[r] * wb * l[7] + l[3 + r] * wr * l[9];
-      g[r * 2 + 0] = b0 * lb[3] + b1 * lb[4];
-      g[r * 2 + 1] = b0 * lb[4] + b1 * lb[5];
-    }
-    for (int k = 0; k < 6; ++k) l[k] = g[k];
-  }
-  __syncthreads();
-  DRLGX_PROF(S, 3);
-  //      Schur complement: S_pq -= sum_j G_m Lambda_jj G_mq^T   (Lambda_pl = G Lambda_jj)
-  {
-    const int npairs = P * (P + 1) / 2;
-    for (int e = tid; e < npairs; e += kThreads) {
-      int p = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
-      while ((p + 1) * (p + 2) / 2 <= e) ++p;
-      while (p * (p + 1) / 2 > e) --p;
-      const int q = e - p * (p + 1) / 2;
-      double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      bool any = false;
-      for (int m = mstart[p]; m < mstart[p + 1]; ++m) {
-        const int j = ml[m];
-        const int mq1 = obs[j * P + q];
-        if (!mq1) continue;
-        any = true;
-        const double *g = rec + (size_t)REC * m, *gq = rec + (size_t)REC * (mq1 - 1), *lb = lamb + 8 * j;
-        double h[6];  // G_m Lambda_jj  (3x2)
-        for (int r = 0; r < 3; ++r) {
-          h[r * 2 + 0] = g[r * 2] * lb[0] + g[r * 2 + 1] * lb[1];
-          h[r * 2 + 1] = g[r * 2] * lb[1] + g[r * 2 + 1] * lb[2];
-        }
-        for (int r = 0; r < 3; ++r)
-          for (int c = 0; c < 3; ++c) acc[r * 3 + c] += h[r * 2] * gq[c * 2] + h[r * 2 + 1] * gq[c * 2 + 1];
-      }
-      if (any)
-        for (int r = 0; r < 3; ++r)
-          for (int c = 0; c < 3; ++c) {
-            if (p == q && c > r) continue;
-            A[AT((3 * p + r), 3 * q + c)] -= acc[r * 3 + c];
-          }
-    }
-    for (int p = (tid + kThreads / 2) % kThreads; p < P; p += kThreads) {  // rhs_p -= sum_m G_m eta_j (idle waves)
-      double s0 = 0, s1 = 0, s2 = 0;
-      for (int m = mstart[p]; m < mstart[p + 1]; ++m) {
-        const double *g = rec + (size_t)REC * m, *lb = lamb + 8 * ml[m];
-        s0 += g[0] * lb[6] + g[1] * lb[7];
-        s1 += g[2] * lb[6] + g[3] * lb[7];
-        s2 += g[4] * lb[6] + g[5] * lb[7];
-      }
-      A[AT(np, 3 * p + 0)] -= s0;
-      A[AT(np, 3 * p + 1)] -= s1;
-      A[AT(np, 3 * p + 2)] -= s2;
-    }
-  }
-  __syncthreads();
-  DRLGX_PROF(S, 4);
-  // ---- 5. sweep: one tile row per wave (sweep_packed_fast) ----
-  sweep_packed_fast<FT>(S, A, np, N, Tn, bad, tid);
-  __syncthreads();
-  DRLGX_PROF(S, 5);
-  for (int k = tid; k < np; k += kThreads) d_pose[k] = A[AT(np, k)];
-  // ---- 6. landmark marginals: rec[6..9] <- G_m^T ( sum_{m' of the same landmark} Sigma[p_m][p_m'] G_m' ) ----
-  for (int m = tid; full && m < M; m += kThreads) {
-    const int j = ml[m], p = mp[m];
-    double Wm[6] = {0, 0, 0, 0, 0, 0};
-    FOR_EACH_OBSERVING_POSE(lmask + MW * j, MW, q) {
-      const int mq1 = obs[j * P + q];
-      const double *gq = rec + (size_t)REC * (mq1 - 1);
-      for (int r = 0; r < 3; ++r) {
-        double s0 = 0, s1 = 0;
-        for (int c = 0; c < 3; ++c) {
-          const int ra = 3 * p + r, cb = 3 * q + c;
-          const double sg = -((ra >= cb) ? A[AT(ra, cb)] : A[AT(cb, ra)]);
-          s0 += sg * gq[c * 2];
-          s1 += sg * gq[c * 2 + 1];
-        }
-        Wm[r * 2] += s0;
-        Wm[r * 2 + 1] += s1;
-      }
-    }
-    double *g = rec + (size_t)REC * m;
-    g[6] = g[0] * Wm[0] + g[2] * Wm[2] + g[4] * Wm[4];
-    g[7] = g[0] * Wm[1] + g[2] * Wm[3] + g[4] * Wm[5];
-    g[8] = g[1] * Wm[0] + g[3] * Wm[2] + g[5] * Wm[4];
-    g[9] = g[1] * Wm[1] + g[3] * Wm[3] + g[5] * Wm[5];
-  }
-  __syncthreads();
-  DRLGX_PROF(S, 6);
-  double *est_lm = S.est_lm + (size_t)inst * S.L_max * 2;
-  double *lm_info = S.lm_info + (size_t)inst * S.L_max * 3;
-  double *lm_tr = S.lm_tr + (size_t)inst * S.L_max;
-  for (int j = tid; j < L; j += kThreads) {
-    const double *lb = lamb + 8 * j;
-    double c00 = lb[3], c01 = lb[4], c10 = lb[4], c11 = lb[5];
-    // delta_j = Lambda^-1 eta_j - sum_m G_m^T delta_p
-    double dx = lb[3] * lb[6] + lb[4] * lb[7], dy = lb[4] * lb[6] + lb[5] * lb[7];
-    FOR_EACH_OBSERVING_POSE(lmask + MW * j, MW, p) {
-      const int m1 = obs[j * P + p];
-      const double *g = rec + (size_t)REC * (m1 - 1);
-      c00 += g[6]; c01 += g[7]; c10 += g[8]; c11 += g[9];
-      const double dp0 = A[AT(np, 3 * p)], dp1 = A[AT(np, 3 * p + 1)], dp2 = A[AT(np, 3 * p + 2)];
-      dx -= g[0] * dp0 + g[2] * dp1 + g[4] * dp2;
-      dy -= g[1] * dp0 + g[3] * dp1 + g[5] * dp2;
-    }
-    d_lm[2 * j] = dx;
-    d_lm[2 * j + 1] = dy;
-    est_lm[2 * j] = thl[2 * j] + dx;
-    est_lm[2 * j + 1] = thl[2 * j + 1] + dy;
-    if (!full) continue;
-    const double cs = 0.5 * (c01 + c10);
-    lm_tr[j] = c00 + c11;
-    const double id = 1.0 / (c00 * c11 - cs * cs);  // marginalCovariance(l).inverse() (SLAM2D.cpp:417)
-    lm_info[3 * j] = c11 * id;
-    lm_info[3 * j + 1] = -cs * id;
-    lm_info[3 * j + 2] = c00 * id;
-  }
-  // ---- 7. pose estimates, information = inverse(covariance) by LLT (SLAM2D.cpp:395-408) ----
-  double *est_pose = S.est_pose + (size_t)inst * S.P_max * 4;
-  double *pose_info = S.pose_info + (size_t)inst * S.P_max * 6;
-  double *pose_tr = S.pose_tr + (size_t)inst * S.P_max;
-  for (int i = (tid + kThreads / 2) % kThreads; i < P; i += kThreads) {
-    const int k0 = 3 * i;
-    const Pose t{thp[4 * i], thp[4 * i + 1], thp[4 * i + 2], thp[4 * i + 3]};
-    const Pose e = compose(t, make_pose(A[AT(np, k0)], A[AT(np, k0 + 1)], A[AT(np, k0 + 2)]));
-    est_pose[4 * i] = e.x; est_pose[4 * i + 1] = e.y; est_pose[4 * i + 2] = e.c; est_pose[4 * i + 3] = e.s;
-    if (!full) continue;
-    const double c00 = -A[AT(k0, k0)], c10 = -A[AT((k0 + 1), k0)], c11 = -A[AT((k0 + 1), k0 + 1)];
-    const double c20 = -A[AT((k0 + 2), k0)], c21 = -A[AT((k0 + 2), k0 + 1)], c22 = -A[AT((k0 + 2), k0 + 2)];
-    pose_tr[i] = c00 + c11 + c22;
-    inv3_sym_fast(c00, c10, c20, c11, c21, c22, pose_info + 6 * i);
-  }
-  DRLGX_PROF(S, 7);
-  if (tid == 0) {
-    if (!refresh) {
-      cnt[C_ISAM] = count;
-      cnt[C_NEWP] = P;
-      cnt[C_NEWL] = L;
-    }
-    if (bad[0]) atomicMin(S.status, DRLGX_E_NUMERIC);
-  }
+  c.back<FT>(S, tid, L, M, full, refresh);
+}
+
+template <int FT>
+__device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &sel, int lds_bytes) {
+  SlamCtx none;
+  slam_finish<FT>(S, sel, lds_bytes, 0, none, false);
 }
 
 template <int FT>
@@ -1162,9 +1361,9 @@ constexpr int kArrowRegTiles = 20;  // ... beyond: up to 20 register tiles per w
 
 // LDS needed by the always-resident small arrays of the fast path
 size_t slam_dim(int P_max) { return 16 * (((size_t)3 * P_max + 1 + 15) / 16); }
-size_t slam_small_bytes(int P_max, int L_max, int M_max) {
-  return (size_t)P_max * 32 + (size_t)L_max * 16 + (size_t)L_max * 64 + (size_t)L_max * 8 * ((P_max + 63) / 64) + (size_t)(P_max + 2) * 4 +
-         (size_t)M_max * 4 + 128;
+size_t slam_small_bytes(int P_max, int L_max, int M_max) {  // (SlamCtx::setup)
+  return (size_t)P_max * 64 + (size_t)L_max * 16 + (size_t)L_max * 64 + (size_t)L_max * 8 * ((P_max + 63) / 64) + (size_t)(P_max + 2) * 4 +
+         (size_t)(L_max + 2) * 4 + (size_t)M_max * 6 + 160;
 }
 // LDS the arrow path cannot do without at full capacity: tables + the packed landmark system or the panels of the
 // workspace variant (factor records and the observation table overflow to the workspace)

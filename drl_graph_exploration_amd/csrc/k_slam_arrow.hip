@@ -290,7 +290,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   const int pose_t0 = 0;
   for (int i = (tid - pose_t0 + kThreads) % kThreads; i < P; i += kThreads) {
     double B[9], g[3], O[9];
-    pose_block(S, inst, thp, rec, mstart, i, P, wb, wr, B, g, O);
+    pose_block(S, inst, thp, S.odo + (size_t)inst * S.P_max * 4, rec, mstart, i, P, wb, wr, B, g, O);
     double *dd = Dd + 6 * i;
     dd[0] = B[0]; dd[1] = B[3]; dd[2] = B[6]; dd[3] = B[4]; dd[4] = B[7]; dd[5] = B[8];
     for (int r = 0; r < 3; ++r) X[(size_t)(3 * i + r) * ldx + np] = -g[r];  // eta_p: the rhs column of X

@@ -16,20 +16,52 @@
 
 namespace kstep {
 
+// LDS of the simulator wave (two mt19937 streams, the normal variates and the in-range list of a measure() call); the SLAM
+// stage of k_step carves behind it because its front end runs WHILE the simulator wave works
+__host__ __device__ inline size_t sim_lds_bytes(int LG) {
+  return ((size_t)2 * DRLGX_MT_STRIDE * 4 + (size_t)(2 * LG + 2) * 8 + (size_t)LG * 4 + 16 + 31) & ~(size_t)31;
+}
+
 template <int FT>
 __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
                                                           int n_measure, int lds_bytes, int map_chunk) {
   static_assert(kslam::kThreads == kmap::kThreads, "the fused kernel runs both stages with one workgroup size");
   extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
   const int tid = threadIdx.x;
+  const int bi = blockIdx.x;
+  // ---- what the SLAM front end needs is read before the simulator wave starts to change it ----
+  const size_t sim_bytes = sim_lds_bytes(S.LG);
+  int *sub_cnt = reinterpret_cast<int *>(step_smem + sim_bytes - 16);
+  kslam::SlamCtx ctx;
+  bool pre = false;
+  double od3[3] = {0, 0, 0};
+  int P0 = 0, L0 = 0, M0 = 0, isam = 0;
+  if (sel.on(bi)) {
+    const int inst = sel.base + bi;
+    const int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
+    P0 = cnt[C_P]; L0 = cnt[C_L]; M0 = cnt[C_M]; isam = cnt[C_ISAM];
+    const double *od = odom + (size_t)bi * odom_stride + (size_t)sel.act_idx * 3;
+    od3[0] = od[0]; od3[1] = od[1]; od3[2] = od[2];
+    const drlgx_config &cfg = S.cfg;
+    // the simulator's own acceptance test (sim_step_body): a rejected move appends nothing - no front end then
+    const bool accepted = (cfg.map_min_x < od3[0] && od3[0] < cfg.map_max_x) && (cfg.map_min_y < od3[1] && od3[1] < cfg.map_max_y) && P0 < S.P_max;
+    pre = accepted && (3 * (P0 + 1) + 1 + 15) / 16 <= FT;
+    if (pre)  // room for the landmarks / factors a step may add (more: slam_finish starts over)
+      ctx.setup(S, step_smem, sim_bytes, lds_bytes, inst, P0 + 1, min(S.L_max, L0 + 48), min(S.M_max, M0 + 48));
+  }
+  if (tid == 0) *sub_cnt = 0;
+  __syncthreads();
   if (tid < 64) {
+    // wave 0: the (single-wave) simulator; the other seven waves: the part of the SLAM update that does not depend on it
     uint32_t *l0 = reinterpret_cast<uint32_t *>(step_smem);
     uint32_t *l1 = l0 + DRLGX_MT_STRIDE;
     double *dyn = reinterpret_cast<double *>(step_smem + 2 * DRLGX_MT_STRIDE * sizeof(uint32_t));  // 5008 B: 16-aligned
     ksim::sim_step_body(S, sel, odom, odom_stride, n_measure, l0, l1, dyn, tid);
+  } else if (pre) {
+    ctx.front<true>(S, tid, P0, L0, M0, P0, L0, isam + 1, false, od3, kslam::SubBarrier{sub_cnt, kslam::kThreads / 64 - 1, 0});
   }
   __syncthreads();
-  kslam::slam_body<FT>(S, sel, lds_bytes);
+  kslam::slam_finish<FT>(S, sel, lds_bytes, sim_bytes, ctx, pre);
   __syncthreads();
   kmap::map_body(S, sel, 1, map_chunk);
 }
@@ -56,8 +88,12 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step_arrow(DrlgxState S, La
 
 bool drlgx_step_fusable(const DrlgxState &S, int p_bound) {
   int chunk = 0;
-  return drlgx_slam_in_lds(p_bound < S.P_max ? p_bound : S.P_max, S.L_max, S.M_max) && drlgx_map_lds_bytes(S, &chunk) <= (size_t)kslam::kLdsBudget &&
-         (size_t)(2 * DRLGX_MT_STRIDE * 4 + (2 * S.LG + 2) * 8 + S.LG * 4) <= (size_t)kslam::kLdsBudget;
+  const int Pb = p_bound < S.P_max ? p_bound : S.P_max;
+  const size_t nf = 16 * kslam::kFastTiles;
+  // (the SLAM stage sits behind the simulator's LDS: its front end runs beside the simulator wave)
+  return drlgx_slam_in_lds(Pb, S.L_max, S.M_max) &&
+         kstep::sim_lds_bytes(S.LG) + kslam::slam_small_bytes(Pb, S.L_max, S.M_max) + kslam::sweep_region_doubles(nf) * 8 <= (size_t)kslam::kLdsBudget &&
+         drlgx_map_lds_bytes(S, &chunk) <= (size_t)kslam::kLdsBudget;
 }
 
 // the fused step around the pose-chain solver: its LDS-swept landmark system (<= 63 landmarks) and the same map / simulator
