@@ -89,7 +89,7 @@ struct DrlgxState {
   int *slam_iws;  // [n_inst][slam_iws_stride] observation table + per-pose factor ranges
   size_t slam_iws_stride;
   int *status;  // [1]
-  long long *prof;  // [128] development aid: wall_clock64() stamps of the phases of block 0 (or null)
+  long long *prof;  // [1024] development aid: wall_clock64() stamps of the phases of block 0 (or null)
 };
 
 // phase stamp (100 MHz constant clock) — only block 0 / thread 0, only when profiling is armed
@@ -324,15 +324,17 @@ __device__ inline MtStream mt_load(uint32_t *lds, const uint32_t *g, int lane) {
   s.cons = lds[DRLGX_MT_N + 1];
   return s;
 }
-// both streams of an instance (contiguous in HBM, 2 x 626 words) in one go: every load is issued before the first wait
-__device__ inline void mt_load2(uint32_t *lds0, uint32_t *lds1, const uint32_t *g, int lane, MtStream &a, MtStream &b) {
+// both streams of an instance (contiguous in HBM, 2 x 626 words) in one go: every load is issued before the first wait.
+// Two halves, so that the caller can put work that does not need the streams between the issue and the first use.
+__device__ inline void mt_load2_issue(const uint32_t *g, int lane, uint4 (&v)[5]) {
   const uint4 *g4 = reinterpret_cast<const uint4 *>(g);  // 2 * 626 words = 313 uint4, 16-byte aligned per instance
-  uint4 v[5];
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const int i = lane + 64 * k;
     v[k] = (i < 313) ? g4[i] : make_uint4(0, 0, 0, 0);
   }
+}
+__device__ inline void mt_load2_commit(uint32_t *lds0, uint32_t *lds1, const uint4 (&v)[5], int lane, MtStream &a, MtStream &b) {
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const int w = 4 * (lane + 64 * k);
@@ -347,6 +349,20 @@ __device__ inline void mt_load2(uint32_t *lds0, uint32_t *lds1, const uint32_t *
   wave_sync();
   a.st = lds0; a.gen = lds0[DRLGX_MT_N]; a.cons = lds0[DRLGX_MT_N + 1];
   b.st = lds1; b.gen = lds1[DRLGX_MT_N]; b.cons = lds1[DRLGX_MT_N + 1];
+}
+__device__ inline void mt_load2(uint32_t *lds0, uint32_t *lds1, const uint32_t *g, int lane, MtStream &a, MtStream &b) {
+  uint4 v[5];
+  mt_load2_issue(g, lane, v);
+  mt_load2_commit(lds0, lds1, v, lane, a, b);
+}
+// the stream's counters into the two spare words of its LDS image (as mt_store writes them): the image can then be copied
+// to HBM by anyone, 626 words per stream
+__device__ inline void mt_park(const MtStream &s, int lane) {
+  if (lane == 0) {
+    const uint32_t k = (s.cons / DRLGX_MT_N) * DRLGX_MT_N;
+    s.st[DRLGX_MT_N] = s.gen - k;
+    s.st[DRLGX_MT_N + 1] = s.cons - k;
+  }
 }
 __device__ inline void mt_store(const MtStream &s, uint32_t *g, int lane) {
   wave_sync();
@@ -488,16 +504,17 @@ __device__ inline double normal01(MtStream &s, NormalState &ns, int lane) {
   ns.has = 1;
   return y * mult;
 }
-// The next `count` variates of std::normal_distribution<double>(0,1) on this stream, written to out[0..count)
-// (LDS, count + 1 doubles), all lanes cooperating: lane i examines candidate pair i of the Marsaglia polar loop
-// speculatively (words cons+4i .. cons+4i+3), a ballot ranks the accepted pairs, the j-th accepted pair yields variates
-// 2j (y*mult) and 2j+1 (x*mult, libstdc++'s saved value), and exactly the words up to the last pair that the sequential
-// loop would have examined are consumed.  Bit-identical to `count` successive normal01() calls.
-__device__ inline void draw_normals(MtStream &s, NormalState &ns, int count, double *out, int lane, bool values = true) {
+// The next `count` variates of std::normal_distribution<double>(0,1) on this stream, all lanes cooperating: lane i examines
+// candidate pair i of the Marsaglia polar loop speculatively (words cons+4i .. cons+4i+3), a ballot ranks the accepted
+// pairs, the j-th accepted pair yields variates 2j (y*mult) and 2j+1 (x*mult, libstdc++'s saved value), and exactly the
+// words up to the last pair that the sequential loop would have examined are consumed.  Bit-identical to `count`
+// successive normal01() calls.  The VALUES of the first `skip` variates are not wanted (the caller only advances the
+// stream over them): variate number i >= skip goes to out[i - skip] (LDS, count - skip + 1 doubles).
+__device__ inline void draw_normals(MtStream &s, NormalState &ns, int count, double *out, int lane, int skip = 0) {
   if (count <= 0) return;
   int offset = 0;
   if (ns.has) {
-    if (lane == 0) out[0] = ns.saved;
+    if (lane == 0 && skip == 0) out[0] = ns.saved;
     offset = 1;
     ns.has = 0;
   }
@@ -514,11 +531,11 @@ __device__ inline void draw_normals(MtStream &s, NormalState &ns, int count, dou
     const unsigned long long m = __ballot(acc);
     const int rank = __popcll(m & ((1ull << lane) - 1ull));
     const int j = have + rank;
-    // `values == false`: the caller only advances the stream; the one variate that survives the call is libstdc++'s saved one
-    if (acc && j < Np && (values || (j == Np - 1 && (R & 1)))) {
+    const int i0 = offset + 2 * j;  // numbers of this pair's two variates (the second one may be the saved extra: i0 + 1 == count)
+    if (acc && j < Np && i0 + 1 >= skip) {
       const double mult = sqrt(-2 * log(r2) / r2);
-      out[offset + 2 * j] = y * mult;
-      out[offset + 2 * j + 1] = x * mult;
+      if (i0 >= skip) out[i0 - skip] = y * mult;
+      out[i0 + 1 - skip] = x * mult;
     }
     const int A = __popcll(m);
     if (have + A >= Np) {
@@ -533,7 +550,7 @@ __device__ inline void draw_normals(MtStream &s, NormalState &ns, int count, dou
   }
   wave_sync();
   if (R & 1) {
-    ns.saved = out[count];
+    ns.saved = out[count - skip];
     ns.has = 1;
   }
 }

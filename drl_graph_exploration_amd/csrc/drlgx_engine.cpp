@@ -1046,10 +1046,11 @@ int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]) {
   if (!e) return DRLGX_E_INVALID;
   HIPCHK(e, hipStreamSynchronize(e->stream));
   // (arm & 2: the second bank of 64 stamps - per-wave stamps of one sweep block step)
-  if (out && e->S.prof) HIPCHK(e, hipMemcpy(out, e->S.prof + ((arm & 2) ? 64 : 0), 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  // (arm & 4: 1024 stamps - out must hold them: banks 0, 1 and the per-workgroup start / end stamps of k_step from 128 on)
+  if (out && e->S.prof) HIPCHK(e, hipMemcpy(out, e->S.prof + ((arm & 2) ? 64 : 0), ((arm & 4) ? 1024 : 64) * sizeof(long long), hipMemcpyDeviceToHost));
   if (arm && !e->S.prof) {
     long long *p = nullptr;
-    int r = dev_alloc(e, &p, 128);
+    int r = dev_alloc(e, &p, 1024);
     if (r) return r;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     e->S.prof = p;

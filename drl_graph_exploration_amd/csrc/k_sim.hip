@@ -30,13 +30,46 @@ struct SimCtx {
 // `record == false` is SS2D.simulate's first measure() (obstacle logic, inert at safe_distance = 0): only the RNG advances.
 // in-range ground-truth landmarks in libstdc++'s hash iteration order (ballot + prefix rank) -> inr[0..n_in); the set only
 // depends on the vehicle pose, so the two measure() calls of a real step share one scan
-__device__ inline int scan_in_range(SimCtx &c, int *inr) {
+// (GtPrefetch: up to 128 ground-truth landmarks - two per lane - fetched by the caller while it was waiting for other data)
+struct GtPrefetch {
+  bool ok;
+  int key[2];
+  double x[2], y[2];
+};
+__device__ inline void gt_prefetch_keys(const SimCtx &c, GtPrefetch &g) {
+  const int n_gt = c.S.cfg.num_landmarks;
+  g.ok = n_gt <= 128;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) g.key[r] = (g.ok && 64 * r + c.lane < n_gt) ? c.S.lm_order[64 * r + c.lane] : 0;
+}
+__device__ inline void gt_prefetch_points(const SimCtx &c, GtPrefetch &g) {
+  const double *gl = c.S.gt_lm + (size_t)c.S.parent[c.inst] * c.S.LG * 2;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    g.x[r] = g.ok ? gl[2 * g.key[r]] : 0.0;
+    g.y[r] = g.ok ? gl[2 * g.key[r] + 1] : 0.0;
+  }
+}
+__device__ inline int scan_in_range(SimCtx &c, int *inr, const GtPrefetch *pf = nullptr) {
   const DrlgxState &S = c.S;
   const drlgx_config &cfg = S.cfg;
   const double *gl = S.gt_lm + (size_t)S.parent[c.inst] * S.LG * 2;
   const int n_gt = cfg.num_landmarks;
   const unsigned long long below = (1ull << c.lane) - 1ull;
   int n_in = 0;
+  if (pf && pf->ok) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const bool valid = 64 * r + c.lane < n_gt;
+      const double dx = pf->x[r] - c.veh.x, dy = pf->y[r] - c.veh.y;
+      const bool in = valid && (dx * dx + dy * dy < S.r2_max_lt);
+      const unsigned long long mask = __ballot(in);
+      if (in) inr[n_in + __popcll(mask & below)] = pf->key[r];
+      n_in += __popcll(mask);
+    }
+    wave_sync();
+    return n_in;
+  }
   for (int base = 0; base < n_gt; base += 64) {
     const int idx = base + c.lane;
     const bool valid = idx < n_gt;
@@ -53,13 +86,14 @@ __device__ inline int scan_in_range(SimCtx &c, int *inr) {
 }
 // exp_*: the staged interface (drlgx_stage_measure) exports the valid measurements (key, bearing, range) in order instead
 // of appending them: Simulator2D::measure as the object-level API sees it
+// `lead`: variates of earlier measure() calls that are drawn (and dropped) together with this call's
 __device__ inline void measure(SimCtx &c, bool record, double *nrm, const int *inr, int n_in, int32_t *exp_keys = nullptr,
-                               double *exp_br = nullptr, int32_t *exp_count = nullptr) {
+                               double *exp_br = nullptr, int32_t *exp_count = nullptr, int lead = 0) {
   const DrlgxState &S = c.S;
   const drlgx_config &cfg = S.cfg;
   const double *gl = S.gt_lm + (size_t)S.parent[c.inst] * S.LG * 2;
   const unsigned long long below = (1ull << c.lane) - 1ull;
-  draw_normals(c.sensor, c.ns_sensor, 2 * n_in, nrm, c.lane, record || exp_keys);
+  draw_normals(c.sensor, c.ns_sensor, lead + 2 * n_in, nrm, c.lane, (record || exp_keys) ? lead : lead + 2 * n_in);
   if (exp_keys) {
     int n_out = 0;
     for (int base = 0; base < n_in; base += 64) {
@@ -132,10 +166,18 @@ __device__ inline void measure(SimCtx &c, bool record, double *nrm, const int *i
   }
 }
 
-__device__ inline void store_ctx(SimCtx &c) {
+// park: the caller copies the LDS images of the two streams (2 x 626 words, contiguous) to S.mt itself, later and with
+// more than one wave (k_step); the counters are put into the images here
+// mail: LDS words that receive the final counts (P, L, M) for the waves that wait for this one (k_step)
+__device__ inline void store_ctx(SimCtx &c, bool park = false, int *mail = nullptr) {
   const DrlgxState &S = c.S;
-  mt_store(c.sensor, S.mt + ((size_t)c.inst * 2 + 0) * DRLGX_MT_STRIDE, c.lane);
-  mt_store(c.control, S.mt + ((size_t)c.inst * 2 + 1) * DRLGX_MT_STRIDE, c.lane);
+  if (park) {
+    mt_park(c.sensor, c.lane);
+    mt_park(c.control, c.lane);
+  } else {
+    mt_store(c.sensor, S.mt + ((size_t)c.inst * 2 + 0) * DRLGX_MT_STRIDE, c.lane);
+    mt_store(c.control, S.mt + ((size_t)c.inst * 2 + 1) * DRLGX_MT_STRIDE, c.lane);
+  }
   if (c.lane == 0) {
     S.nrm_saved[c.inst * 2 + 0] = c.ns_sensor.saved;
     S.nrm_has[c.inst * 2 + 0] = c.ns_sensor.has;
@@ -147,6 +189,11 @@ __device__ inline void store_ctx(SimCtx &c) {
     cnt[C_P] = c.P;
     cnt[C_L] = c.L;
     cnt[C_M] = c.M;
+    if (mail) {
+      mail[0] = c.P;
+      mail[1] = c.L;
+      mail[2] = c.M;
+    }
     if (c.err) atomicMin(S.status, c.err);
   }
 }
@@ -228,7 +275,8 @@ __global__ __launch_bounds__(64) void k_reset(DrlgxState S, int first_measure, c
 template <bool kMove = true>
 __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchSel &sel, const double *odom, int odom_stride,
                                               int n_measure, uint32_t *lds0, uint32_t *lds1, double *dyn, int lane,
-                                              int32_t *exp_keys = nullptr, double *exp_br = nullptr, int32_t *exp_count = nullptr) {
+                                              int32_t *exp_keys = nullptr, double *exp_br = nullptr, int32_t *exp_count = nullptr,
+                                              bool park_streams = false, int *mail = nullptr) {
   uint32_t *lds[2] = {lds0, lds1};
   double *nrm = dyn;
   int *inr = reinterpret_cast<int *>(dyn + 2 * S.LG + 2);
@@ -256,51 +304,75 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
     return;
   }
   DRLGX_PROF(S, 8);
-  mt_load2(lds[0], lds[1], S.mt + (size_t)inst * 2 * DRLGX_MT_STRIDE, lane, c.sensor, c.control);
-  c.ns_sensor = NormalState{S.nrm_saved[inst * 2 + 0], S.nrm_has[inst * 2 + 0]};
-  c.ns_control = NormalState{S.nrm_saved[inst * 2 + 1], S.nrm_has[inst * 2 + 1]};
+  // Loads first, in the order of their first use (vmcnt counts in order): the small ones, the two random streams, the
+  // ground-truth landmarks of the range scan.  The part of the move that needs no random numbers is evaluated while the
+  // streams are on their way from HBM.
+  const double ns_s = S.nrm_saved[inst * 2 + 0], ns_c = S.nrm_saved[inst * 2 + 1];
+  const int nh_s = S.nrm_has[inst * 2 + 0], nh_c = S.nrm_has[inst * 2 + 1];
   const double *gp = S.gt_pose + (size_t)inst * 4;
   c.veh = Pose{gp[0], gp[1], gp[2], gp[3]};
+  const double *ep = S.est_pose + ((size_t)inst * S.P_max + (c.P - 1)) * 4;
+  const Pose last_est{ep[0], ep[1], ep[2], ep[3]};
+  const int step0 = cnt[C_STEP];
+  const double dist0 = S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST];
+  uint4 mtv[5];
+  mt_load2_issue(S.mt + (size_t)inst * 2 * DRLGX_MT_STRIDE, lane, mtv);
+  GtPrefetch gtp;
+  gtp.ok = false;
+  if (n_measure > 0) gt_prefetch_keys(c, gtp);
+  c.ns_sensor = NormalState{ns_s, nh_s};
+  c.ns_control = NormalState{ns_c, nh_c};
+  Pose odomP{0, 0, 1, 0};
+  if constexpr (kMove) {
+    odomP = make_pose(ox, oy, oth);
+    // SLAM2D::addOdometry (SLAM2D.cpp:70-89): initial guess = last estimate * odom
+    Pose p2 = compose(last_est, odomP);
+    if (lane == 0) {
+      double *tp = S.th_pose + ((size_t)inst * S.P_max + c.P) * 4;
+      tp[0] = p2.x; tp[1] = p2.y; tp[2] = p2.c; tp[3] = p2.s;
+      double *dp = S.d_pose + ((size_t)inst * S.P_max + c.P) * 3;
+      dp[0] = dp[1] = dp[2] = 0;
+      double *oo = S.odo + ((size_t)inst * S.P_max + (c.P - 1)) * 4;
+      oo[0] = odomP.x; oo[1] = odomP.y; oo[2] = odomP.c; oo[3] = odomP.s;
+      cnt[C_NEWP] = c.P;
+      cnt[C_NEWL] = c.L;
+      cnt[C_FLAG] = 0;
+      cnt[C_STEP] = step0 + 1;
+      // Planner2D.cpp:1440: dist += sqrt(x^2 + y^2 + angle_weight * theta^2), theta = Pose2::theta()
+      double th = theta_of(odomP);
+      S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST] = dist0 + sqrt(ox * ox + oy * oy + cfg.angle_weight * (th * th));
+    }
+  }
+  mt_load2_commit(lds[0], lds[1], mtv, lane, c.sensor, c.control);
+  if (n_measure > 0) gt_prefetch_points(c, gtp);  // (the keys arrived with the streams; the points travel during the move)
   DRLGX_PROF(S, 9);
   if constexpr (kMove) {
-  const Pose odomP = make_pose(ox, oy, oth);
   // SimpleControlModel::evolve (Simulator2D.cpp:161-182)
   draw_normals(c.control, c.ns_control, 3, nrm, lane);
   const double xn = nrm[0] * cfg.translation_noise + 0.0;
   const double yn = nrm[1] * cfg.translation_noise + 0.0;
   const double tn = nrm[2] * cfg.rotation_noise + 0.0;
-  wave_sync();
+  wave_sync();  // (also: lane 0's writes above - the initial guess of the new pose - are read by every lane below)
   c.veh = compose(compose(c.veh, odomP), make_pose(xn, yn, tn));
-  // SLAM2D::addOdometry (SLAM2D.cpp:70-89): initial guess = last estimate * odom
-  const double *ep = S.est_pose + ((size_t)inst * S.P_max + (c.P - 1)) * 4;
-  Pose p2 = compose(Pose{ep[0], ep[1], ep[2], ep[3]}, odomP);
-  if (lane == 0) {
-    double *tp = S.th_pose + ((size_t)inst * S.P_max + c.P) * 4;
-    tp[0] = p2.x; tp[1] = p2.y; tp[2] = p2.c; tp[3] = p2.s;
-    double *dp = S.d_pose + ((size_t)inst * S.P_max + c.P) * 3;
-    dp[0] = dp[1] = dp[2] = 0;
-    double *oo = S.odo + ((size_t)inst * S.P_max + (c.P - 1)) * 4;
-    oo[0] = odomP.x; oo[1] = odomP.y; oo[2] = odomP.c; oo[3] = odomP.s;
-    cnt[C_NEWP] = c.P;
-    cnt[C_NEWL] = c.L;
-    cnt[C_FLAG] = 0;
-    cnt[C_STEP] += 1;
-    // Planner2D.cpp:1440: dist += sqrt(x^2 + y^2 + angle_weight * theta^2), theta = Pose2::theta()
-    double th = theta_of(odomP);
-    S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST] += sqrt(ox * ox + oy * oy + cfg.angle_weight * (th * th));
-  }
-  wave_sync();  // lane 0's writes (initial guess of the new pose) are read by every lane below
   c.P += 1;
   }
   DRLGX_PROF(S, 10);
   if (n_measure > 0) {
-    const int n_in = scan_in_range(c, inr);
-    for (int m = 0; m < n_measure; ++m) {
-      measure(c, m == n_measure - 1 && !exp_keys, nrm, inr, n_in, exp_keys, exp_br, exp_count);
-      DRLGX_PROF(S, 11 + m);
+    const int n_in = scan_in_range(c, inr, &gtp);
+    if (n_measure == 2 && !exp_keys) {
+      // SS2D.simulate's two measure() calls (pyss2d.py:171-206): the first one only advances the sensor stream (obstacle
+      // logic, inert at safe_distance = 0) - its 2 n_in variates are drawn and dropped together with the second call's
+      DRLGX_PROF(S, 11);
+      measure(c, true, nrm, inr, n_in, nullptr, nullptr, nullptr, 2 * n_in);
+      DRLGX_PROF(S, 12);
+    } else {
+      for (int m = 0; m < n_measure; ++m) {
+        measure(c, m == n_measure - 1 && !exp_keys, nrm, inr, n_in, exp_keys, exp_br, exp_count);
+        DRLGX_PROF(S, 11 + m);
+      }
     }
   }
-  store_ctx(c);
+  store_ctx(c, park_streams, mail);
   DRLGX_PROF(S, 13);
 }
 
@@ -334,6 +406,10 @@ __global__ void k_add_measurements(DrlgxState S, LaunchSel sel, const int32_t *k
   int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
   int P = cnt[C_P], L = cnt[C_L], M = cnt[C_M];
   int *key_slot = S.key_slot + (size_t)inst * S.LG;
+  if (count[i] < 0 || count[i] > S.LG) {  // the lists have LG entries per instance
+    atomicMin(S.status, DRLGX_E_INVALID);
+    return;
+  }
   for (int k = 0; k < count[i]; ++k) {
     const int key = keys[(size_t)i * S.LG + k];
     const double bearing = br[((size_t)i * S.LG + k) * 2], range = br[((size_t)i * S.LG + k) * 2 + 1];

@@ -881,8 +881,18 @@ struct SlamCtx {
 
   __device__ __forceinline__ int AT(int i, int j) const { return i * (i + 1) / 2 + j; }
 
-  // LDS carve from byte offset `off` of the dynamic shared memory: small arrays first, then the dense system; the factor
-  // records and the observation table go to the HBM workspace when they do not fit
+  // LDS carve from byte offset `off` of the dynamic shared memory: small arrays first, then the dense system, then - kBigLds -
+  // the factor records and the observation table, which otherwise go to the HBM workspace
+  __device__ __forceinline__ static size_t small_bytes(int P, int Lb, int Mb) {
+    const size_t MW = (size_t)(P + 63) >> 6;
+    return up8((size_t)P * 32) * 2 + up8((size_t)Lb * 16) + up8((size_t)Lb * 64) + up8((size_t)(P + 2) * 4) + up8((size_t)(Lb + 2) * 4) +
+           up8((size_t)Mb * 2) * 3 + 8 + up8((size_t)Lb * MW * 8) + 32;
+  }
+  __device__ __forceinline__ static bool big_fits(size_t off, int lds_bytes, int P, int Lb, int Mb) {
+    const size_t N = 16 * (((size_t)3 * P + 1 + 15) / 16);
+    return off + small_bytes(P, Lb, Mb) + sweep_region_doubles(N) * 8 + (size_t)Mb * REC * 8 + up8((size_t)Lb * P * 2) <= (size_t)lds_bytes;
+  }
+  template <bool kBigLds>
   __device__ __forceinline__ void setup(const DrlgxState &S, unsigned char *smem_raw, size_t off, int lds_bytes, int inst_, int P_, int Lb_, int Mb_) {
     inst = inst_; P = P_; Lb = Lb_; Mb = Mb_;
     np = 3 * P;
@@ -905,15 +915,19 @@ struct SlamCtx {
     lmask = reinterpret_cast<unsigned long long *>(take((size_t)Lb * MW * 8));
     off = (off + 31) & ~(size_t)31;
     A = reinterpret_cast<double *>(smem_raw + off); off += sweep_region_doubles(N) * 8;  // (reused for the sweep panels)
-    double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
-    const size_t big = (size_t)Mb * REC * 8 + up8((size_t)Lb * P * 2);
-    if (off + big <= (size_t)lds_bytes) {
+    if constexpr (kBigLds) {
       rec = reinterpret_cast<double *>(smem_raw + off); off += (size_t)Mb * REC * 8;
       obs = reinterpret_cast<unsigned short *>(smem_raw + off);
     } else {
+      double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
       rec = wsd; wsd += (size_t)S.M_max * REC;
       obs = reinterpret_cast<unsigned short *>(wsd);
     }
+    // Both are used through `flat` instructions whatever their placement: with pointers the compiler knows to be LDS the
+    // record-walking phases measured SLOWER (landmark marginals 3.9 -> 6.6 us, the loads are scheduled as short-latency
+    // ones), so the address space is hidden from it
+    asm volatile("" : "+v"(rec));
+    asm volatile("" : "+v"(obs));
   }
 
   // tables + the (expensive) linearisation of the factors [m0, m1), one thread each
@@ -1046,17 +1060,18 @@ struct SlamCtx {
         A[AT(np, 3 * i + r)] = -g[r];  // rhs lives in the augmented row
       }
     }
+    if (S.prof && blockIdx.x == 0 && ft == 0) S.prof[14] = wall_clock64();  // (dev aid: end of the front end)
   }
 
   // everything after the simulator: all kThreads threads, hardware barriers.  Lfin / Mfin: the final counts (>= the front's).
   template <int FT>
   __device__ __forceinline__ void back(const DrlgxState &S, int tid, int Lfin, int Mfin, bool full, bool refresh) {
-    const drlgx_config &cfg = S.cfg;
-    const double wb = 1.0 / (cfg.bearing_noise * cfg.bearing_noise), wr = 1.0 / (cfg.range_noise * cfg.range_noise);
     int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
     double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
-    double *th_lm = S.th_lm + (size_t)inst * S.L_max * 2;
     double *d_lm = S.d_lm + (size_t)inst * S.L_max * 2;
+    const drlgx_config &cfg = S.cfg;
+    const double wb = 1.0 / (cfg.bearing_noise * cfg.bearing_noise), wr = 1.0 / (cfg.range_noise * cfg.range_noise);
+    double *th_lm = S.th_lm + (size_t)inst * S.L_max * 2;
     const int L0 = L, M0 = M;
     L = Lfin; M = Mfin;
     // ---- this step's landmarks and factors (all of them observed from the newest pose) ----
@@ -1164,6 +1179,8 @@ struct SlamCtx {
         while ((p + 1) * (p + 2) / 2 <= e) ++p;
         while (p * (p + 1) / 2 > e) --p;
         const int q = e - p * (p + 1) / 2;
+        // (a variant that walks the landmarks COMMON to both poses - the AND of per-pose landmark masks - instead of the
+        // factors of p measured slower: 5.7 against 4.4 us)
         double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         bool any = false;
         for (int m = mstart[p]; m < mstart[p + 1]; ++m) {
@@ -1307,9 +1324,10 @@ struct SlamCtx {
 };
 
 // The SLAM stage after the simulator.  `pre` (have_pre): the context whose front() already ran beside the simulator (k_step)
-// for the counts before the step.  smem_off: first byte of the dynamic LDS the stage may use.
+// for the counts before the step (records in LDS).  smem_off: first byte of the dynamic LDS the stage may use.
 template <int FT>
-__device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel &sel, int lds_bytes, size_t smem_off, const SlamCtx &pre, bool have_pre) {
+__device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel &sel, int lds_bytes, size_t smem_off, const SlamCtx &pre, bool have_pre,
+                                            const int *mail = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int bi = blockIdx.x;
@@ -1320,9 +1338,11 @@ __device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel
   // rebuilt there and nowhere else): the steps before it solve for the estimates only.  If that last action was rejected
   // (nothing was appended) the marginals of the unchanged system are recomputed without counting as an update.
   const bool full = sel.map_on(bi);
-  const bool refresh = cnt[C_FLAG] != 0;
+  // (mail: the counts after the step as the simulator wave left them in LDS - no round trip to HBM; -1: it appended nothing)
+  const bool mailed = mail && mail[0] >= 0;
+  const bool refresh = mailed ? false : cnt[C_FLAG] != 0;
   if (refresh && !(sel.map_last_only && sel.n_act && full)) return;
-  const int P = cnt[C_P], L = cnt[C_L], M = cnt[C_M];
+  const int P = mailed ? mail[0] : cnt[C_P], L = mailed ? mail[1] : cnt[C_L], M = mailed ? mail[2] : cnt[C_M];
   if ((3 * P + 1 + 15) / 16 > FT) {
     // more poses than this kernel was launched for (the host's bound was wrong): flag it, touch nothing
     if (tid == 0) atomicMin(S.status, DRLGX_E_CAPACITY);
@@ -1334,8 +1354,10 @@ __device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel
     c = pre;
   } else {
     // stand-alone kernel, a rejected move, or more new landmarks / factors than the front reserved room for: everything now
-    c.setup(S, smem_raw, smem_off, lds_bytes, inst, P, L, M);
-    c.front<false>(S, tid, P, L, M, cnt[C_NEWP], cnt[C_NEWL], cnt[C_ISAM] + (refresh ? 0 : 1), refresh, nullptr, SubBarrier{nullptr, 0, 0});
+    const int n_old_p = cnt[C_NEWP], n_old_l = cnt[C_NEWL], count = cnt[C_ISAM] + (refresh ? 0 : 1);
+    if (SlamCtx::big_fits(smem_off, lds_bytes, P, L, M)) c.setup<true>(S, smem_raw, smem_off, lds_bytes, inst, P, L, M);
+    else c.setup<false>(S, smem_raw, smem_off, lds_bytes, inst, P, L, M);
+    c.front<false>(S, tid, P, L, M, n_old_p, n_old_l, count, refresh, nullptr, SubBarrier{nullptr, 0, 0});
     __syncthreads();
   }
   c.back<FT>(S, tid, L, M, full, refresh);
@@ -1362,8 +1384,8 @@ constexpr int kArrowRegTiles = 20;  // ... beyond: up to 20 register tiles per w
 // LDS needed by the always-resident small arrays of the fast path
 size_t slam_dim(int P_max) { return 16 * (((size_t)3 * P_max + 1 + 15) / 16); }
 size_t slam_small_bytes(int P_max, int L_max, int M_max) {  // (SlamCtx::setup)
-  return (size_t)P_max * 64 + (size_t)L_max * 16 + (size_t)L_max * 64 + (size_t)L_max * 8 * ((P_max + 63) / 64) + (size_t)(P_max + 2) * 4 +
-         (size_t)(L_max + 2) * 4 + (size_t)M_max * 6 + 160;
+  return (size_t)P_max * 64 + (size_t)L_max * 16 + (size_t)L_max * 64 + (size_t)L_max * 8 * ((P_max + 63) / 64) +
+         (size_t)(P_max + 2) * 4 + (size_t)(L_max + 2) * 4 + (size_t)M_max * 6 + 192;
 }
 // LDS the arrow path cannot do without at full capacity: tables + the packed landmark system or the panels of the
 // workspace variant (factor records and the observation table overflow to the workspace)

@@ -29,11 +29,12 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
   extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
   const int tid = threadIdx.x;
   const int bi = blockIdx.x;
+  if (S.prof && tid == 0 && bi < 448) S.prof[128 + 2 * bi] = wall_clock64();  // (dev aid: per-workgroup start / end)
   // ---- what the SLAM front end needs is read before the simulator wave starts to change it ----
   const size_t sim_bytes = sim_lds_bytes(S.LG);
   int *sub_cnt = reinterpret_cast<int *>(step_smem + sim_bytes - 16);
   kslam::SlamCtx ctx;
-  bool pre = false;
+  bool pre = false, accepted = false;
   double od3[3] = {0, 0, 0};
   int P0 = 0, L0 = 0, M0 = 0, isam = 0;
   if (sel.on(bi)) {
@@ -44,26 +45,39 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
     od3[0] = od[0]; od3[1] = od[1]; od3[2] = od[2];
     const drlgx_config &cfg = S.cfg;
     // the simulator's own acceptance test (sim_step_body): a rejected move appends nothing - no front end then
-    const bool accepted = (cfg.map_min_x < od3[0] && od3[0] < cfg.map_max_x) && (cfg.map_min_y < od3[1] && od3[1] < cfg.map_max_y) && P0 < S.P_max;
-    pre = accepted && (3 * (P0 + 1) + 1 + 15) / 16 <= FT;
-    if (pre)  // room for the landmarks / factors a step may add (more: slam_finish starts over)
-      ctx.setup(S, step_smem, sim_bytes, lds_bytes, inst, P0 + 1, min(S.L_max, L0 + 48), min(S.M_max, M0 + 48));
+    accepted = (cfg.map_min_x < od3[0] && od3[0] < cfg.map_max_x) && (cfg.map_min_y < od3[1] && od3[1] < cfg.map_max_y) && P0 < S.P_max;
+    // room for the landmarks / factors a step may add (more: slam_finish starts over); the front end only runs ahead when
+    // the factor records fit the LDS (else slam_finish takes the workspace variant after the simulator)
+    const int Lb = min(S.L_max, L0 + 48), Mb = min(S.M_max, M0 + 48);
+    pre = accepted && (3 * (P0 + 1) + 1 + 15) / 16 <= FT && kslam::SlamCtx::big_fits(sim_bytes, lds_bytes, P0 + 1, Lb, Mb);
+    if (pre) ctx.setup<true>(S, step_smem, sim_bytes, lds_bytes, inst, P0 + 1, Lb, Mb);
   }
-  if (tid == 0) *sub_cnt = 0;
+  if (tid == 0) {
+    sub_cnt[0] = 0;
+    sub_cnt[1] = -1;  // [1..3]: the simulator wave's final counts (stay -1 when it rejects the move)
+  }
   __syncthreads();
   if (tid < 64) {
     // wave 0: the (single-wave) simulator; the other seven waves: the part of the SLAM update that does not depend on it
     uint32_t *l0 = reinterpret_cast<uint32_t *>(step_smem);
     uint32_t *l1 = l0 + DRLGX_MT_STRIDE;
     double *dyn = reinterpret_cast<double *>(step_smem + 2 * DRLGX_MT_STRIDE * sizeof(uint32_t));  // 5008 B: 16-aligned
-    ksim::sim_step_body(S, sel, odom, odom_stride, n_measure, l0, l1, dyn, tid);
+    ksim::sim_step_body(S, sel, odom, odom_stride, n_measure, l0, l1, dyn, tid, nullptr, nullptr, nullptr, true, sub_cnt + 1);
   } else if (pre) {
     ctx.front<true>(S, tid, P0, L0, M0, P0, L0, isam + 1, false, od3, kslam::SubBarrier{sub_cnt, kslam::kThreads / 64 - 1, 0});
   }
   __syncthreads();
-  kslam::slam_finish<FT>(S, sel, lds_bytes, sim_bytes, ctx, pre);
+  if (accepted && tid >= 64) {
+    // the two random streams go back to HBM from their LDS images (the simulator wave left the counters in them): seven
+    // waves, in the shadow of the few threads that linearise this step's factors
+    uint32_t *g = S.mt + (size_t)(sel.base + bi) * 2 * DRLGX_MT_STRIDE;
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(step_smem);
+    for (int i = tid - 64; i < 2 * DRLGX_MT_STRIDE; i += kslam::kThreads - 64) g[i] = img[i];
+  }
+  kslam::slam_finish<FT>(S, sel, lds_bytes, sim_bytes, ctx, pre, sub_cnt + 1);
   __syncthreads();
   kmap::map_body(S, sel, 1, map_chunk);
+  if (S.prof && tid == 0 && bi < 448) S.prof[129 + 2 * bi] = wall_clock64();
 }
 
 // The same fusion around the pose-chain solver (trajectories beyond the LDS-resident dense solve): simulate -> k_slam_arrow's

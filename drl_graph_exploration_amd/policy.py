@@ -252,9 +252,10 @@ class DeepQ(object):
             y_batch[pos] = t
         return a_batch, y_batch
 
-    def _train_minibatch(self, device, policy_net, target_net, optimizer, prepared=None):
+    def _train_minibatch(self, device, policy_net, target_net, optimizer, prepared=None, minibatch=None):
         if prepared is None:
-            minibatch = random.sample(self.buffer, self.BATCH)
+            if minibatch is None:  # (a caller that sampled already - _prepare_updates' fallback - hands its sample in)
+                minibatch = random.sample(self.buffer, self.BATCH)
             s_j = GraphData.collate([d[0] for d in minibatch])
             s_j1 = GraphData.collate([d[3] for d in minibatch])
             with torch.no_grad():
@@ -409,9 +410,10 @@ class DeepQ(object):
                 if self.step_t // self.TARGET_UPDATE > (self.step_t - n_envs) // self.TARGET_UPDATE:
                     target_net.load_state_dict(policy_net.state_dict())
                     self._target_version = self.__dict__.get("_target_version", 0) + 1  # cached target read-outs are stale
-                prepared, _ = self._prepare_updates(n_upd, device, target_net)
+                prepared, batches = self._prepare_updates(n_upd, device, target_net)
                 for u in range(n_upd):
-                    self._train_minibatch(device, policy_net, target_net, optimizer, None if prepared is None else prepared[u])
+                    self._train_minibatch(device, policy_net, target_net, optimizer, None if prepared is None else prepared[u],
+                                          None if prepared is not None else batches[u])
                 temp_loss_data.append([self.step_t, self.temp_loss])
 
             if log_every and (self.step_t // n_envs) % log_every == 0:
@@ -419,7 +421,9 @@ class DeepQ(object):
                       "/ EXPLORED", float(env.status().mean()), "/ REWARD", float(r_h.mean()))
             rows.extend([self.step_t, float(x)] for x in r_h)
             recent.extend(float(x) for x in r_h)
-            if self.step_t > 1000 and (self.step_t // n_envs) % max(100 // n_envs, 1) == 0:
+            if self.step_t // 5e4 > (self.step_t - n_envs) // 5e4:  # every 50000 iterations (policy.py:197-199)
+                torch.save(policy_net.state_dict(), os.path.join(self.weights_path, "MyModel.pt"))
+            if self.step_t > 1000 and self.step_t // 100 > (self.step_t - n_envs) // 100:  # every 100 (policy.py:200-203)
                 temp_reward_data.append([self.step_t, float(np.average(recent))])
 
         self.total_reward = np.append(self.total_reward, np.array([r[1] for r in rows]))
@@ -602,9 +606,11 @@ class A2C(object):
         for k in range(pool.n_slots):
             pool.ref[k] = 0
         for b in self.buffer:  # (a window carried over from an earlier call keeps its own graphs)
-            for d in b[0]:
+            for k, d in enumerate(b[0]):
                 if isinstance(d, PoolRef) and d.pool is pool:
                     pool.ref[d.slot] = 1
+                else:  # re-loaded from saved_training.pkl (host graphs) or pooled elsewhere: onto this device, once
+                    b[0][k] = d.to(device)
         g = self._host_offsets(env.graph_matrix())
         slot = pool.put(g)
         pool.ref[slot] = 1
@@ -631,13 +637,16 @@ class A2C(object):
             r_h = r_t.cpu().numpy()
             val_h = val.cpu().numpy()
             # envs out of pose capacity are re-created like finished ones, but stay non-terminal (VecExplorationEnv.truncated)
-            renew = done_h | env.truncated().cpu().numpy()
+            trunc_h = env.truncated().cpu().numpy()
+            renew = done_h | trunc_h
             if renew.any():
                 env.reset(np.nonzero(renew)[0])
             g1 = self._host_offsets(env.graph_matrix())
             slot1 = pool.put(g1)
             pool.ref[slot1] = 1
-            self.buffer.append((s_t, a_loc, r_h, current_done | done_h, nfr_h.copy(), val_h))
+            # (a truncated env is re-created, so in the n-step return - and only there - its trajectory ends here: the
+            # bootstrap value and the next state would belong to another episode)
+            self.buffer.append((s_t, a_loc, r_h, current_done | done_h | trunc_h, nfr_h.copy(), val_h))
             self.step_t += n_envs
             temp_i += n_envs
 
@@ -676,9 +685,9 @@ class A2C(object):
                       "/ EXPLORED", float(env.status().mean()), "/ REWARD", float(r_h.mean()))
             rows.extend([self.step_t, float(x)] for x in r_h)
             self.total_reward = np.append(self.total_reward, r_h)
-            if self.step_t % 5e4 < n_envs and self.step_t >= 5e4:
+            if self.step_t // 5e4 > (self.step_t - n_envs) // 5e4:
                 torch.save(policy_net.state_dict(), os.path.join(self.weights_path, "MyModel.pt"))
-            if self.step_t > 1000 and (self.step_t // n_envs) % max(100 // n_envs, 1) == 0:
+            if self.step_t > 1000 and self.step_t // 100 > (self.step_t - n_envs) // 100:
                 temp_reward_data.append([self.step_t, float(np.average(self.total_reward[-1000:]))])
 
         np.savetxt(os.path.join(self.object_path, "temp_reward.csv"), np.array(temp_reward_data).reshape(-1, 2), delimiter=",")

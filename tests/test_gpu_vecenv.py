@@ -228,6 +228,29 @@ def test_a2c_running_smoke(tmp_path):
     assert rows[0] == "Step,Reward" and len(rows) == 25
 
 
+def test_a2c_resumes_from_a_pickle_taken_mid_window(tmp_path):
+    """run_training.py re-loads saved_training.pkl between epochs (train.py:85-94).  An epoch rarely ends on a multiple of
+    nstep, so the pickled trainer carries a partial n-step window whose graphs are host copies: the next epoch must move
+    them back to the device and train on the mixed window (pooled + carried-over graphs)."""
+    import pickle
+    from drl_graph_exploration_amd.networks import PolicyGCN, ValueGCN
+    from drl_graph_exploration_amd.policy import A2C
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    a2c = A2C("resume_a2c/", data_root=str(tmp_path))
+    a2c.nstep, a2c.epoch, a2c.graphs_per_pass = 3, 16, 5  # 4 vector steps of 4 envs: one update, ONE step left in the window
+    actor, critic = PolicyGCN().to(dev), ValueGCN().to(dev)
+    a2c.running(actor, critic, test=True, n_envs=4)
+    assert a2c.step_t == 16 and len(a2c.buffer) == 1
+    again = pickle.loads(pickle.dumps(a2c))
+    assert len(again.buffer) == 1 and all(not d.x.is_cuda for d in again.buffer[0][0])
+    again.temp_loss = 0.0
+    again.running(actor, critic, test=True, n_envs=4)  # 4 more vector steps: the window fills after two of them
+    assert again.step_t == 32 and len(again.buffer) == 2
+    assert math.isfinite(again.temp_loss) and again.temp_loss != 0
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the reference's own golden data through the PRODUCT path: data/test_result/40_DQN_GCN.csv (fixture csv_pin.json)
 # ---------------------------------------------------------------------------------------------------------------------
