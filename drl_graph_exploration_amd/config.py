@@ -38,7 +38,9 @@ def default_config(map_size=40, num_landmarks=None, algorithm=0, max_poses=41, m
     """exploration_env.ini + ExplorationEnv.reset overrides + read_map_params(ext=20).
 
     Capacities (engine-side, no counterpart in the reference): max_poses per trajectory (any value the LDS tables of
-    k_slam_arrow hold, a few hundred), max_landmarks <= 127, max_actions = the longest line plan the map can produce
+    k_slam_arrow hold, a few hundred), max_landmarks (any count whose tables fit the LDS; the default caps it at 127 because up
+    to there the landmark system of the pose-chain solver stays in registers / LDS - pass it explicitly for worlds where an
+    episode observes more, e.g. BASELINE config 5), max_actions = the longest line plan the map can produce
     (1-2 rotations + floor(d / max_edge_length) + 1 translations with d <= the diagonal of the vehicle's box)."""
     c = DrlgxConfig()
     c.bearing_noise = _rot2_theta(math.radians(0.5))

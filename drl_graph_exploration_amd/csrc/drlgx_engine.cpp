@@ -155,8 +155,8 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   if (cfg->max_poses < 2 || cfg->max_landmarks < 1 || cfg->max_factors < 1 || cfg->num_landmarks < 0 ||
       cfg->max_actions < 1 || cfg->num_samples < 1 || !(cfg->resolution > 0))
     return DRLGX_E_INVALID;
-  // kernel limits: 16-bit pose / landmark / factor indices in LDS tables; the landmark system of k_slam_arrow (<= 127
-  // landmarks) and its per-pose tables must fit the LDS
+  // kernel limits: 16-bit pose / landmark / factor indices in LDS tables; the per-pose / per-landmark tables of k_slam_arrow
+  // must fit the LDS (its landmark system is streamed from the workspace beyond 127 landmarks)
   if (cfg->max_poses > 65535 || cfg->max_landmarks > 65535 || cfg->max_factors > 65534) return DRLGX_E_INVALID;
   if (!drlgx_slam_capacity_ok(cfg->max_poses, cfg->max_landmarks, cfg->max_factors)) return DRLGX_E_INVALID;
   int ndev = 0;

@@ -840,6 +840,120 @@ __device__ __forceinline__ void sweep_regtiles(double *A, double *pbase, int np,
   }
 }
 
+// 16-wide block steps with EVERYTHING in the HBM / L2 workspace: the square matrix A (leading dimension N, lower triangle
+// valid), the pivot-column panel and W (pws: 32 N doubles); LDS holds the two E tiles and the look-ahead scratch only
+// (lds_s: 1280 doubles).  This is the landmark system of k_slam_arrow beyond what its register-tile sweep holds (> 127
+// landmarks - the reference has no cap, SLAM2D.cpp:103-124): every lower tile is read, updated on the matrix cores and
+// written back once per block step (8 bytes x N^2 / 2 of traffic per step - a few hundred MB per update at 500 landmarks;
+// this path exists so that such worlds RUN, not to be fast).  Same update / replacement rules as sweep_regtiles.
+__device__ __forceinline__ void sweep_streamed(double *A, double *pws, double *lds_s, int np, int N, int Tn, int *bad, int tid) {
+  const int ld = N;
+  constexpr int TW = kWaves - 1;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int lc = lane & 15, lr = lane >> 4;
+  const bool ewave = wave == TW;
+  double *pan = pws, *wt = pws + 16 * (size_t)N;
+  double *einv0 = lds_s, *dscr = lds_s + 512, *es = dscr + 256;
+  const SweepCtx x{0, lane, lc, lr, np, N, true, ewave, bad, nullptr};
+  const int ntiles = Tn * (Tn + 1) / 2;
+  // element (i, j) of the symmetric matrix from its stored lower triangle
+  auto sym = [&](int i, int j) -> double { return A[(size_t)max(i, j) * ld + min(i, j)]; };
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dscr[4 * lane + r] = sym(lr + 4 * r, lc);
+  }
+  __syncthreads();
+  if (ewave) {
+    double t4[4];
+    ld4(dscr + 4 * lane, t4);
+    v4d d = {t4[0], t4[1], t4[2], t4[3]};
+    inv16(x, 0, d);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) einv0[(lr + 4 * r) * 16 + ks16(lc)] = d[r];
+  }
+  __syncthreads();
+  for (int K = 0; 16 * K < np; ++K) {
+    const int kb = 16 * K;
+    const bool have_next = kb + 16 < np;
+    double *einv = einv0 + 256 * (K & 1), *enext = einv0 + 256 * ((K + 1) & 1);
+    // P: the pivot column panel PAN[i][.] = A[i][16 K + .] (masked rows / columns as zeros) from the tiles of column K and,
+    // transposed, of row K
+    if (!ewave) {
+      for (int I = wave; I < Tn; I += TW) {
+        if (I >= K) {
+          const bool colact = kb + lc < np;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * I + lr + 4 * r;
+            pan[(size_t)i * 16 + ks16(lc)] = colact ? sym(i, kb + lc) : 0.0;
+          }
+        } else {  // PAN[16 I + lc][c = lr + 4 r] = A[kb + lr + 4 r][16 I + lc]
+          double *o = pan + (size_t)(16 * I + lc) * 16 + lr * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (kb + lr + 4 * r < np) ? A[(size_t)(kb + lr + 4 * r) * ld + 16 * I + lc] : 0.0;
+        }
+      }
+    } else if (have_next) {  // current values of the next diagonal tile, for the look-ahead
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dscr[4 * lane + r] = sym(kb + 16 + lr + 4 * r, kb + 16 + lc);
+    }
+    __syncthreads();
+    v4d dn = {0.0, 0.0, 0.0, 0.0};
+    if (!ewave) {
+      for (int I = wave; I < Tn; I += TW) {  // W_I = PAN_I E_K
+        double aP[4], eB[4];
+        ld4(pan + (size_t)(16 * I + lc) * 16 + lr * 4, aP);
+        ld4(einv + lc * 16 + lr * 4, eB);
+        v4d w = {0.0, 0.0, 0.0, 0.0};
+        w = mfma4(aP, eB, w);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wt[(size_t)(16 * I + lr + 4 * r) * 16 + ks16(lc)] = w[r];
+      }
+    } else if (have_next) {  // look-ahead: D'_{K+1} (the E-wave forms W_{K+1} itself)
+      double aP[4], eB[4], aW[4], t4[4];
+      ld4(pan + (size_t)(16 * (K + 1) + lc) * 16 + lr * 4, aP);  // also the B operand of the update (PAN_{K+1}^T)
+      ld4(einv + lc * 16 + lr * 4, eB);
+      v4d w1 = {0.0, 0.0, 0.0, 0.0};
+      w1 = mfma4(aP, eB, w1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) es[(lr + 4 * r) * 16 + ks16(lc)] = w1[r];  // accumulator -> A-operand layout
+      wave_lds_sync();
+      ld4(es + lc * 16 + lr * 4, aW);
+      ld4(dscr + 4 * lane, t4);
+      dn = v4d{t4[0], t4[1], t4[2], t4[3]};
+      dn = mfma4(aW, aP, dn);
+    }
+    __syncthreads();
+    if (ewave) {
+      if (have_next) {
+        inv16(x, K + 1, dn);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) enext[(lr + 4 * r) * 16 + ks16(lc)] = dn[r];
+      }
+    } else {
+      for (int t = wave; t < ntiles; t += TW) {
+        int ib = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+        while ((ib + 1) * (ib + 2) / 2 <= t) ++ib;
+        while (ib * (ib + 1) / 2 > t) --ib;
+        const int jb = t - ib * (ib + 1) / 2;
+        v4d acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ib + lr + 4 * r, j = 16 * jb + lc;
+          acc[r] = sym(i, j);  // (diagonal tiles are kept fully symmetric in registers)
+        }
+        tile_step16(ib, jb, K, np, lc, lr, pan, wt, einv, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ib + lr + 4 * r, j = 16 * jb + lc;
+          if (j <= i) A[(size_t)i * ld + j] = acc[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- software barrier among the waves that run the SLAM front end beside the simulator wave (k_step) ----
 // A monotonic LDS counter: every participating wave adds one and waits (lane 0, s_sleep) until all have arrived.  The
 // hardware barrier cannot be used there: the simulator wave does not take part.
@@ -1391,7 +1505,10 @@ size_t slam_small_bytes(int P_max, int L_max, int M_max) {  // (SlamCtx::setup)
 // workspace variant (factor records and the observation table overflow to the workspace)
 size_t arrow_lds_bytes(int P_max, int L_max, int M_max) {
   const size_t N = 16 * (((size_t)2 * L_max + 1 + 15) / 16);
-  const size_t sys = N <= 16 * kFastTilesArrow ? sweep_region_doubles(N) : 32 * N + 1280;
+  const size_t Tn = N / 16;
+  // packed in LDS; register tiles + panels in LDS; or everything streamed from the workspace (E tiles + scratch in LDS)
+  const size_t sys = N <= 16 * kFastTilesArrow ? sweep_region_doubles(N)
+                     : Tn * (Tn + 1) / 2 <= (size_t)kArrowRegTiles * (kWaves - 1) ? 32 * N + 1280 : 1280;
   return arrow_small_bytes(P_max, L_max, M_max) + sys * 8 + 64;
 }
 
@@ -1405,17 +1522,15 @@ bool drlgx_slam_in_lds(int P_max, int L_max, int M_max) {
 }
 // capacities the SLAM kernels can serve at all (checked by drlgx_create)
 bool drlgx_slam_capacity_ok(int P_max, int L_max, int M_max) {
-  const size_t N = 16 * (((size_t)2 * L_max + 1 + 15) / 16);
-  const size_t Tn = N / 16;
-  if (Tn > (size_t)kslam::kFastTilesArrow && Tn * (Tn + 1) / 2 > (size_t)kslam::kArrowRegTiles * (kslam::kWaves - 1)) return false;
-  return kslam::arrow_lds_bytes(P_max, L_max, M_max) <= (size_t)kslam::kLdsBudget && 2 * L_max + 1 <= kslam::kThreads;
+  // (any number of landmarks: beyond the register-tile sweep the landmark system is streamed from the workspace)
+  return kslam::arrow_lds_bytes(P_max, L_max, M_max) <= (size_t)kslam::kLdsBudget;
 }
 // doubles of HBM workspace per instance: X (3 P x (2 L + 1), row stride rounded up to 4), the selected-inverse blocks of the
 // chain (6 + 9 + 9 per pose), the leaf -> right-separator rhs scratch, the square landmark system of the workspace variant, the factor records and the observation
 // table when they do not fit the LDS
 size_t drlgx_slam_ws_doubles(int P_max, int L_max, int M_max) {
   const size_t ldx = (size_t)((2 * L_max + 1 + 3) & ~3);
-  const size_t n = (size_t)3 * P_max * ldx + (size_t)24 * P_max + (size_t)(P_max / kslam::kSeg + 2) * 3 * ldx + (size_t)(2 * L_max + 17) * (2 * L_max + 17) +
+  const size_t n = (size_t)3 * P_max * ldx + (size_t)24 * P_max + (size_t)(P_max / kslam::kSeg + 2) * 3 * ldx + (size_t)(2 * L_max + 17) * (2 * L_max + 17) + (size_t)32 * (2 * L_max + 17) +
                    (size_t)M_max * kslam::REC + ((size_t)L_max * P_max * 2 + 7) / 8 + 16;
   return (n + 31) & ~(size_t)31;  // instances stay 256-byte aligned: 32-byte row loads of X
 }

@@ -102,7 +102,8 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   const int ntiles = Tn * (Tn + 1) / 2;
   const bool c_lds = Tn <= kFastTilesArrow;          // <= 63 landmarks: packed system + sweep panels in LDS
   const int ldx = (ncol + 3) & ~3;                   // row stride of X
-  if (!c_lds && (NTW == 0 || ntiles > NTW * (kWaves - 1))) {
+  const bool c_reg = !c_lds && NTW > 0 && ntiles <= NTW * (kWaves - 1);  // lower tiles in registers, panels in LDS
+  if (!c_lds && NTW == 0) {  // (this instantiation serves engines whose landmark capacity always fits the LDS)
     if (tid == 0) atomicMin(S.status, DRLGX_E_CAPACITY);
     return;
   }
@@ -137,7 +138,8 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   unsigned short *obs;
   double *rec_ws = wsd; wsd += (size_t)S.M_max * REC;
   double *Aws = wsd; wsd += (size_t)(2 * S.L_max + 17) * (2 * S.L_max + 17);
-  const size_t sys_bytes = (c_lds ? sweep_region_doubles(N) : (size_t)32 * N + 1280) * 8;
+  double *pws = wsd; wsd += (size_t)32 * (2 * S.L_max + 17);  // panels of the streamed sweep
+  const size_t sys_bytes = (c_lds ? sweep_region_doubles(N) : c_reg ? (size_t)32 * N + 1280 : (size_t)1280) * 8;
   if (off + sys_bytes + up8((size_t)L * P * 2) + 32 <= (size_t)lds_bytes) {
     obs = reinterpret_cast<unsigned short *>(smem_raw + off); off += (up8((size_t)L * P * 2) + 31) & ~(size_t)31;
   } else {
@@ -758,8 +760,10 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   // ---- 8. sweep: A <- -C^-1 (lower triangle), row np <- delta_l ----
   if (c_lds)
     sweep_packed_fast<kFastTilesArrow>(S, A, np, N, Tn, bad, tid);
-  else if constexpr (NTW > 0)
-    sweep_regtiles<false, NTW>(A, panels, np, N, Tn, ntiles, bad, tid);
+  else if constexpr (NTW > 0) {
+    if (c_reg) sweep_regtiles<false, NTW>(A, panels, np, N, Tn, ntiles, bad, tid);
+    else sweep_streamed(A, pws, panels, np, N, Tn, bad, tid);
+  }
   __syncthreads();
   DRLGX_PROF(S, 7);
   // ---- 9. landmark outputs ----

@@ -59,8 +59,8 @@ typedef struct drlgx_config {
   double angle_weight, distance_weight0, distance_weight1, occupancy_threshold, max_edge_length;
   int32_t algorithm; /* DRLGX_ALG_* */
   /* capacities (new: the reference grows std::vectors) */
-  int32_t max_poses;     /* P_max per instance (2 .. 127) */
-  int32_t max_landmarks; /* L_max observed landmarks per instance */
+  int32_t max_poses;     /* P_max per instance (>= 2; any value whose tables fit the 160 KB LDS: drlgx_create checks) */
+  int32_t max_landmarks; /* L_max observed landmarks per instance (likewise; no fixed cap) */
   int32_t max_factors;   /* M_max bearing-range factors per instance */
   int32_t max_actions;   /* A_max actions per look-ahead candidate */
   int32_t max_snapshots; /* device-resident snapshot slots of the live environments (0..16) */

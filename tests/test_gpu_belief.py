@@ -418,11 +418,11 @@ def test_larger_capacities_use_the_pose_chain_solver(max_poses, monkeypatch):
 
 
 def test_capacities_beyond_the_kernels_are_refused():
-    """More than 127 landmarks (the landmark system of the pose-chain solver is at most 256 x 256) or per-pose tables
-    beyond the LDS: drlgx_create says so instead of overrunning."""
+    """Per-landmark / per-pose tables beyond the LDS: drlgx_create says so instead of overrunning.  (Hundreds of landmarks
+    are fine: test_more_than_127_landmarks_per_instance.)"""
     from drl_graph_exploration_amd import _lib, default_config
     from drl_graph_exploration_amd.engine import Engine
-    for kw in (dict(num_landmarks=400, max_landmarks=400), dict(max_poses=2000)):
+    for kw in (dict(num_landmarks=4000, max_landmarks=4000), dict(max_poses=2000)):
         with pytest.raises(_lib.DrlgxError):
             Engine(default_config(MAP, **kw), 2, 0)
 
@@ -519,6 +519,36 @@ def test_config5_scale_120_pose_graphs():
             for i in range(n):
                 assert eng.counts(i)["poses"] == s + 2
                 compare_state(eng, i, sims[i], "config-5 env %d step %d" % (i, s), mask_knife_edge=True)
+    eng.close()
+
+
+def test_more_than_127_landmarks_per_instance():
+    """The reference has no landmark cap (SLAM2D.cpp:103-124 grows its map; exploration_env.py:399 sets the count).
+    BASELINE config 5's world (50 m, 500 landmarks) observed along a lawn-mower sweep: > 200 landmarks per instance, i.e.
+    a landmark system beyond the register-tile sweep of k_slam_arrow (streamed from the workspace), and before that - up to
+    42 poses - the dense pose solve with hundreds of landmarks eliminated analytically."""
+    from drl_graph_exploration_amd import default_config
+    from drl_graph_exploration_amd.engine import Engine
+    n, msize = 2, 50
+    cfg = default_config(msize, num_landmarks=500, max_poses=80, max_landmarks=500, max_factors=3600)
+    eng = Engine(cfg, n, 0)
+    ocfg = O.default_config(msize, num_landmarks=500)
+    starts = np.array([[-21.3183, -19.2718, 0.1234], [20.1, 17.7, 3.3]])
+    sims = [O.OracleSim(ocfg, lo, lo, start=tuple(starts[lo])) for lo in range(n)]
+    eng.reset(np.arange(n), np.arange(n), starts=starts)
+    lane = [(2, 0, 0)] * 16 + [(0.5, 0, math.pi / 2)] + [(2, 0, 0)] * 4 + [(0.5, 0, math.pi / 2)]
+    script = (lane + [(2, 0, 0)] * 16 + [(0.5, 0, -math.pi / 2)] + [(2, 0, 0)] * 4 + [(0.5, 0, -math.pi / 2)] + lane)[:66]
+    for s, act in enumerate(script):
+        eng.step(torch.tensor([act] * n, dtype=torch.float64, device=eng.device))
+        for sim in sims:
+            sim.simulate(act)
+        if s in (30, 47, 65):  # 32 poses: dense pose solve; 49 / 67 poses: pose-chain solver
+            assert eng.status() == 0
+            for i in range(n):
+                assert eng.counts(i)["poses"] == s + 2
+                compare_state(eng, i, sims[i], "many landmarks env %d step %d" % (i, s), mask_knife_edge=True)
+    seen = [eng.counts(i)["landmarks"] for i in range(n)]
+    assert min(seen) > 200, seen
     eng.close()
 
 

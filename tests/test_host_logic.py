@@ -41,7 +41,7 @@ def test_error_strings_and_create_without_device():
     h = C.c_void_p()
     # argument validation comes before the device: capacities beyond what the SLAM kernels' LDS tables hold are refused
     assert L.drlgx_create(C.byref(default_config(40, max_poses=4096)), 4, 0, 0, C.byref(h)) == -1 and not h.value
-    assert L.drlgx_create(C.byref(default_config(40, num_landmarks=200, max_landmarks=128)), 4, 0, 0, C.byref(h)) == -1
+    assert L.drlgx_create(C.byref(default_config(40, num_landmarks=4000, max_landmarks=4000)), 4, 0, 0, C.byref(h)) == -1
     assert L.drlgx_create(C.byref(default_config(40, max_poses=1)), 4, 0, 0, C.byref(h)) == -1 and not h.value
     if torch.cuda.is_available():
         pytest.skip("needs a box without a GPU")
