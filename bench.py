@@ -314,7 +314,7 @@ def spawn_command(args_list, n):
             "--master-port", str(port), os.path.abspath(__file__)] + list(args_list)
 
 
-def make_train_step(model, d64, dev):
+def make_train_step(model, d64, dev, split=False):
     """The reference's DQN update on one collated mini-batch as the product issues it (`DeepQ.train` with the fused
     optimiser: trunk forward with dropout, float64 cost + gradient, trunk backward, [gradient all-reduce over the ranks,]
     clamp + Adam): synthetic targets, one action node per graph."""
@@ -329,6 +329,9 @@ def make_train_step(model, d64, dev):
     action[last] = 1.0
     y = torch.zeros(n, dtype=torch.float64, device=dev)
     y[last] = torch.randn(last.numel(), dtype=torch.float64, device=dev)
+    if split:  # (begin: forward / cost / backward + the gradient exchange issued; end: wait for it, clamp + Adam)
+        model.train()
+        return (lambda: dq._train_begin(d64, action, y, dev, model, opt)), dq._train_end
     return lambda: dq.train(d64, action, y, dev, model, opt)
 
 
@@ -374,6 +377,15 @@ def train_allreduce_bench(eng, dev, dist, world, iters=20, env_steps_per_iter=8)
 
     t_train = bracket(train_step, iters)
     t_coll = bracket((lambda: dist.all_reduce(flat)) if dist is not None else (lambda: None), iters)
+    # the trainer's own loop shape (DeepQ._train_minibatches): the next mini-batch is collated between an update's backward
+    # pass and its Adam step, i.e. while that update's all-reduce travels (stand-in for the collation: a copy of the batch)
+    begin, end = make_train_step(model, d64, dev, split=True)
+
+    def pipelined():
+        h = begin()
+        _ = (d64.x.clone(), d64.edge_index.clone(), d64.edge_attr.clone())
+        end(h)
+    t_pipe = bracket(pipelined, iters)
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream())
 
@@ -390,6 +402,7 @@ def train_allreduce_bench(eng, dev, dist, world, iters=20, env_steps_per_iter=8)
                         "elements (%.2f MB) per train step" % (n64, n_param, n_param * 4 / 1e6),
             "ranks": world, "backend": (dist.get_backend() if dist is not None else "none"),
             "train_step_ms": t_train * 1e3, "allreduce_ms": t_coll * 1e3 if dist is not None else 0.0,
+            "train_step_with_next_batch_collated_under_the_exchange_ms": t_pipe * 1e3,
             "overlapped_iteration_ms": t_ov * 1e3, "env_steps_per_iteration": env_steps_per_iter * N_ENVS,
             "env_steps_per_sec_while_training": env_steps_per_iter * N_ENVS * world / t_ov,
             "train_steps_per_sec": world / t_ov}

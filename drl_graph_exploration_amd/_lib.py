@@ -31,7 +31,7 @@ SYMBOLS = [
     "drlgx_get_virtual_map_host", "drlgx_get_ground_truth_host", "drlgx_get_adjacency_host", "drlgx_get_factors_host",
     "drlgx_get_landmark_order_host", "drlgx_snapshot", "drlgx_restore", "drlgx_timing_enable",
     "drlgx_timing_read_host", "drlgx_debug_phase_clocks_host", "drlgx_gcn_workspace_bytes", "drlgx_gcn_forward", "drlgx_gcn_forward_batched", "drlgx_gcn_backward",
-    "drlgx_replay_collate", "drlgx_dqn_targets", "drlgx_dqn_loss_grad", "drlgx_adam_step", "drlgx_normalise_rewards",
+    "drlgx_replay_collate", "drlgx_dqn_targets", "drlgx_dqn_loss_grad", "drlgx_adam_step", "drlgx_adam_step_scaled", "drlgx_normalise_rewards",
     "drlgx_segment_softmax", "drlgx_segment_softmax_backward", "drlgx_mean_pool", "drlgx_mean_pool_backward",
 ]
 
@@ -111,6 +111,8 @@ def lib():
     L.drlgx_mean_pool_backward.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     L.drlgx_adam_step.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64),
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_double]
+    L.drlgx_adam_step_scaled.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64),
+                                  C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_double, C.c_double]
     _lib = L
     return L
 

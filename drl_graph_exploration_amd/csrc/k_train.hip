@@ -130,8 +130,8 @@ struct AdamTensors {
   long long n[kAdamMaxTensors];
   int count;
 };
-__global__ __launch_bounds__(256) void k_adam(AdamTensors T, float clamp, float b1w, float b2, float b2w, float neg_step, float bc2_sqrt,
-                                              float eps) {
+__global__ __launch_bounds__(256) void k_adam(AdamTensors T, float gscale, float clamp, float b1w, float b2, float b2w, float neg_step,
+                                              float bc2_sqrt, float eps) {
   const long long blk = blockIdx.x;
   int t = 0;
   while (t + 1 < T.count && blk >= T.first_block[t + 1]) ++t;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamTensors T, float clamp, float 
   for (int u = 0; u < 4; ++u) {
     const long long i = base + u * 256 + threadIdx.x;
     if (i < n) {
-      float gi = g[i];
+      float gi = g[i] * gscale;  // (1 / world size of the summed gradient; 1 otherwise: exact)
       if (clamp > 0.f) gi = fminf(fmaxf(gi, -clamp), clamp);
       const float mi = m[i] + b1w * (gi - m[i]);
       const float vi = v[i] * b2 + b2w * gi * gi;
@@ -350,9 +350,9 @@ int drlgx_dqn_loss_grad(void *hip_stream, int n_nodes, const float *pred, const 
   return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
 }
 
-int drlgx_adam_step(void *hip_stream, int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
-                    float *const *exp_avg_sq, const int64_t *sizes, double lr, double beta1, double beta2, double eps, int64_t step,
-                    double grad_clamp) {
+int drlgx_adam_step_scaled(void *hip_stream, int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                           float *const *exp_avg_sq, const int64_t *sizes, double lr, double beta1, double beta2, double eps, int64_t step,
+                           double grad_clamp, double grad_scale) {
   if (n_tensors <= 0 || n_tensors > kAdamMaxTensors || !params || !grads || !exp_avg || !exp_avg_sq || !sizes || step <= 0)
     return DRLGX_E_INVALID;
   AdamTensors T;
@@ -377,9 +377,15 @@ int drlgx_adam_step(void *hip_stream, int n_tensors, float *const *params, const
   const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
   const double step_size = lr / bc1, bc2_sqrt = std::sqrt(bc2);
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-  hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, st, T, (float)grad_clamp, (float)(1.0 - beta1), (float)beta2,
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, st, T, (float)grad_scale, (float)grad_clamp, (float)(1.0 - beta1), (float)beta2,
                      (float)(1.0 - beta2), (float)(-step_size), (float)bc2_sqrt, (float)eps);
   return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
+}
+
+int drlgx_adam_step(void *hip_stream, int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                    float *const *exp_avg_sq, const int64_t *sizes, double lr, double beta1, double beta2, double eps, int64_t step,
+                    double grad_clamp) {
+  return drlgx_adam_step_scaled(hip_stream, n_tensors, params, grads, exp_avg, exp_avg_sq, sizes, lr, beta1, beta2, eps, step, grad_clamp, 1.0);
 }
 
 }  // extern "C"

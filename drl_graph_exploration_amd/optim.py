@@ -8,8 +8,57 @@ must be fp32 HIP tensors (at most 8 of them - the GCN has six).
 import ctypes as C
 
 import torch
+import torch.distributed as dist
 
 from . import _lib
+
+
+class GradientBucket(object):
+    """The gradients of a list of parameters as VIEWS into one flat tensor, and the data-parallel exchange on it
+    (one all-reduce of the flattened gradient per optimiser step): `start()` issues ONE in-place SUM
+    all-reduce of the flat tensor without blocking (on NCCL/RCCL it runs on the backend's own stream), `finish()` makes the
+    current stream wait for it and returns the factor 1 / world that turns the sum into the mean - for the optimiser to fold
+    into its update (`FusedAdam.step(grad_scale=...)`) or, with `apply=True`, multiplied in here.  No concatenation, no
+    copies back, nothing at all without a process group.  Works on any device (the multi-process tests run it over gloo)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        n = sum(p.numel() for p in self.params)
+        p0 = self.params[0]
+        self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
+        self.attach()
+        self._work = None
+
+    def attach(self):
+        """(Re-)bind every parameter's .grad to its slice of the flat tensor (after a zero_grad(set_to_none=True))."""
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            view = self.flat[off:off + k].view_as(p)
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                if p.grad is not None:
+                    view.copy_(p.grad)
+                p.grad = view
+            off += k
+
+    @staticmethod
+    def world(group=None):
+        return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    def start(self, group=None):
+        if self.world(group) > 1:
+            self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+    def finish(self, group=None, apply=False):
+        ws = self.world(group)
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        scale = 1.0 / ws
+        if apply and ws > 1:
+            self.flat.mul_(scale)
+            return 1.0
+        return scale
 
 
 class FusedAdam(object):
@@ -23,25 +72,25 @@ class FusedAdam(object):
         self.lr, self.betas, self.eps, self.grad_clamp = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(grad_clamp)
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self.bucket = GradientBucket(self.params)  # the gradients are views of ONE flat tensor: all-reduced in place
         self.step_count = 0
         self.param_groups = [{"params": self.params, "lr": self.lr, "betas": self.betas, "eps": self.eps}]
 
     def grads(self):
-        """The gradient tensors (allocated on first use), in parameter order - `gcn_backward_raw` writes into them."""
-        for p in self.params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
+        """The gradient tensors (views of the bucket's flat tensor), in parameter order - `gcn_backward_raw` writes into them."""
+        self.bucket.attach()
         return [p.grad for p in self.params]
 
     def zero_grad(self, set_to_none=False):
         for p in self.params:
-            if p.grad is not None:
-                if set_to_none:
-                    p.grad = None
-                else:
-                    p.grad.zero_()
+            if p.grad is not None and set_to_none:
+                p.grad = None
+        if not set_to_none:
+            self.bucket.attach()
+            self.bucket.flat.zero_()
 
-    def step(self):
+    def step(self, grad_scale=1.0):
+        """grad_scale: factor on the gradient in front of the clamp (GradientBucket.finish: 1 / world size)."""
         n = len(self.params)
         self.step_count += 1
         vp = C.c_void_p
@@ -50,9 +99,9 @@ class FusedAdam(object):
         sizes = (C.c_int64 * n)(*[p.numel() for p in self.params])
         dev = self.params[0].device
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(_lib.lib().drlgx_adam_step(vp(stream), n, arr([p.data for p in self.params]), arr(grads), arr(self.exp_avg),
-                                              arr(self.exp_avg_sq), sizes, self.param_groups[0]["lr"], self.betas[0], self.betas[1],
-                                              self.eps, self.step_count, self.grad_clamp))
+        _lib.check(_lib.lib().drlgx_adam_step_scaled(vp(stream), n, arr([p.data for p in self.params]), arr(grads), arr(self.exp_avg),
+                                                     arr(self.exp_avg_sq), sizes, self.param_groups[0]["lr"], self.betas[0],
+                                                     self.betas[1], self.eps, self.step_count, self.grad_clamp, float(grad_scale)))
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": [t.clone() for t in self.exp_avg], "exp_avg_sq": [t.clone() for t in self.exp_avg_sq],

@@ -25,7 +25,7 @@ import ctypes as C
 from . import _lib
 from . import networks as NW
 from .networks import GCN, GraphData, GraphSlice, PoolRef, ReplayPool
-from .optim import FusedAdam
+from .optim import FusedAdam, GradientBucket
 from .vecenv import VecExplorationEnv
 
 
@@ -36,13 +36,21 @@ def _graph_to_host(d):
     return GraphData(d.x.detach().cpu().clone(), d.edge_index.detach().cpu().clone(), d.edge_attr.detach().cpu().clone())
 
 
-def allreduce_gradients(model, group=None):
+def allreduce_gradients(model, group=None, optimizer=None):
     """Average the gradients of `model` over all ranks with ONE flat all-reduce (3 MB..4 MB for the GCN: far below
-    the xGMI per-link bandwidth-delay product, so a single bucket is optimal). No-op without a process group."""
+    the xGMI per-link bandwidth-delay product, so a single bucket is optimal).  No-op without a process group.
+    With a `FusedAdam` the gradients already are views of one flat tensor: it is reduced in place (no concatenation, no
+    copies back).  The trainers' hot path does not call this at all: it issues the exchange asynchronously right after
+    the backward pass and folds the 1 / world into the Adam kernel (`DeepQ._train_begin / _train_end`)."""
     if not (dist.is_available() and dist.is_initialized()):
         return
     ws = dist.get_world_size(group)
     if ws == 1:
+        return
+    if isinstance(optimizer, FusedAdam):
+        optimizer.grads()
+        optimizer.bucket.start(group)
+        optimizer.bucket.finish(group, apply=True)
         return
     grads = [p.grad for p in model.parameters() if p.grad is not None]
     if not grads:
@@ -150,28 +158,7 @@ class DeepQ(object):
         model.train()
         data = data.to(device)
         if type(model) is GCN and isinstance(optimizer, FusedAdam) and data.x.is_cuda:
-            # the same update as below as a fixed sequence of HIP launches, no autograd graph: trunk forward, cost and its
-            # gradient (drlgx_dqn_loss_grad), trunk backward straight into the gradient buffers, [all-reduce,] clamp + Adam
-            # in one kernel (drlgx_adam_step)
-            x = data.x
-            n = x.shape[0]
-            mask = NW._dropout_mask(n, 1000, 0.5, x.device)
-            out, saved = NW.gcn_forward_raw(x, data.edge_index, data.edge_attr, model.trunk_parameters(), mask, NW.graph_segments(data))
-            y = torch.as_tensor(y, dtype=torch.float64, device=device)
-            action = torch.as_tensor(action, dtype=torch.float64, device=device)
-            loss = torch.empty(1, dtype=torch.float64, device=x.device)
-            d_out = torch.empty(n, 1, dtype=torch.float32, device=x.device)
-            vp = C.c_void_p
-            stream = torch.cuda.current_stream(x.device).cuda_stream
-            _lib.check(_lib.lib().drlgx_dqn_loss_grad(vp(stream), n, vp(out.data_ptr()), vp(action.data_ptr()), vp(y.data_ptr()),
-                                                      float(self.BATCH), vp(loss.data_ptr()), vp(d_out.data_ptr())))
-            self._loss_t = loss
-            NW.gcn_backward_raw(saved, d_out, optimizer.grads())
-            allreduce_gradients(model)
-            if optimizer.grad_clamp != self.max_grad_norm:
-                for param in model.parameters():
-                    param.grad.data.clamp_(-self.max_grad_norm, self.max_grad_norm)
-            optimizer.step()
+            self._train_end(self._train_begin(data, action, y, device, model, optimizer))
             return
         optimizer.zero_grad()
         out = model(data, 0.5, batch=data.batch)
@@ -182,10 +169,42 @@ class DeepQ(object):
         loss = self.cost(out, y, action)
         self._loss_t = loss.detach()  # read lazily (`temp_loss`): a `.item()` here would stall the host on every update
         loss.backward()
-        allreduce_gradients(model)
+        allreduce_gradients(model, optimizer=optimizer)
         for param in model.parameters():
             param.grad.data.clamp_(-self.max_grad_norm, self.max_grad_norm)
         optimizer.step()
+
+    def _train_begin(self, data, action, y, device, model, optimizer):
+        """First half of the fused update: the same arithmetic as `train`'s framework path as a fixed sequence of HIP
+        launches without an autograd graph - trunk forward, cost and its gradient (drlgx_dqn_loss_grad), trunk backward
+        straight into the optimiser's flat gradient buffer - and, with several ranks, the gradient all-reduce ISSUED (one
+        in-place SUM over the flat buffer, on the backend's own stream).  Returns the handle for `_train_end`."""
+        x = data.x
+        n = x.shape[0]
+        mask = NW._dropout_mask(n, 1000, 0.5, x.device)
+        out, saved = NW.gcn_forward_raw(x, data.edge_index, data.edge_attr, model.trunk_parameters(), mask, NW.graph_segments(data))
+        y = torch.as_tensor(y, dtype=torch.float64, device=device)
+        action = torch.as_tensor(action, dtype=torch.float64, device=device)
+        loss = torch.empty(1, dtype=torch.float64, device=x.device)
+        d_out = torch.empty(n, 1, dtype=torch.float32, device=x.device)
+        vp = C.c_void_p
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(_lib.lib().drlgx_dqn_loss_grad(vp(stream), n, vp(out.data_ptr()), vp(action.data_ptr()), vp(y.data_ptr()),
+                                                  float(self.BATCH), vp(loss.data_ptr()), vp(d_out.data_ptr())))
+        self._loss_t = loss
+        NW.gcn_backward_raw(saved, d_out, optimizer.grads())
+        optimizer.bucket.start()
+        return model, optimizer
+
+    def _train_end(self, handle):
+        """Second half: wait for the exchange (a stream dependency, the host does not block on NCCL/RCCL), then clamp + Adam
+        in one kernel with the 1 / world of the averaged gradient folded in (drlgx_adam_step_scaled)."""
+        model, optimizer = handle
+        scale = optimizer.bucket.finish()
+        if optimizer.grad_clamp != self.max_grad_norm:
+            optimizer.bucket.flat.mul_(scale).clamp_(-self.max_grad_norm, self.max_grad_norm)
+            scale = 1.0
+        optimizer.step(grad_scale=scale)
 
     def test(self, data, prob, device, model):
         model.eval()
@@ -252,7 +271,9 @@ class DeepQ(object):
             y_batch[pos] = t
         return a_batch, y_batch
 
-    def _train_minibatch(self, device, policy_net, target_net, optimizer, prepared=None, minibatch=None):
+    def _collate_minibatch(self, device, target_net, prepared=None, minibatch=None):
+        """(s_j batch, a_batch, y_batch) of one mini-batch.  Nothing here reads the POLICY weights (the targets come from the
+        target network), so the loop may run it while the previous update's gradient exchange is still in flight."""
         if prepared is None:
             if minibatch is None:  # (a caller that sampled already - _prepare_updates' fallback - hands its sample in)
                 minibatch = random.sample(self.buffer, self.BATCH)
@@ -269,7 +290,31 @@ class DeepQ(object):
             # (_refresh_target_readout) and gathered here
             q1 = pool.gather_q(prepared["desc_j1"], B, prepared["N1"])
             a_batch, y_batch = self._td_apply(q1, prepared["meta"], prepared["r"], B, prepared["N"])
+        return s_j, a_batch, y_batch
+
+    def _train_minibatch(self, device, policy_net, target_net, optimizer, prepared=None, minibatch=None):
+        s_j, a_batch, y_batch = self._collate_minibatch(device, target_net, prepared, minibatch)
         self.train(s_j, a_batch, y_batch, device, policy_net, optimizer)
+
+    def _train_minibatches(self, device, policy_net, target_net, optimizer, prepared, batches, n_upd):
+        """`n_upd` updates.  On the fused path the next mini-batch is collated (and its targets gathered) between an update's
+        backward pass and its Adam step, i.e. while that update's gradient all-reduce travels: the collective is hidden
+        behind work that does not depend on it."""
+        fused = type(policy_net) is GCN and isinstance(optimizer, FusedAdam)
+        pending = None
+        for u in range(n_upd):
+            s_j, a_batch, y_batch = self._collate_minibatch(device, target_net, None if prepared is None else prepared[u],
+                                                            None if prepared is not None else batches[u])
+            if pending is not None:
+                self._train_end(pending)
+                pending = None
+            if fused and s_j.x.is_cuda:
+                policy_net.train()
+                pending = self._train_begin(s_j.to(device), a_batch, y_batch, device, policy_net, optimizer)
+            else:
+                self.train(s_j, a_batch, y_batch, device, policy_net, optimizer)
+        if pending is not None:
+            self._train_end(pending)
 
     def _refresh_target_readout(self, pool, slots, device, target_net):
         """Target-network read-out (dropout off) of every export in `slots` whose cached values are older than the current
@@ -411,9 +456,7 @@ class DeepQ(object):
                     target_net.load_state_dict(policy_net.state_dict())
                     self._target_version = self.__dict__.get("_target_version", 0) + 1  # cached target read-outs are stale
                 prepared, batches = self._prepare_updates(n_upd, device, target_net)
-                for u in range(n_upd):
-                    self._train_minibatch(device, policy_net, target_net, optimizer, None if prepared is None else prepared[u],
-                                          None if prepared is not None else batches[u])
+                self._train_minibatches(device, policy_net, target_net, optimizer, prepared, batches, n_upd)
                 temp_loss_data.append([self.step_t, self.temp_loss])
 
             if log_every and (self.step_t // n_envs) % log_every == 0:

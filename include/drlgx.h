@@ -322,6 +322,11 @@ int drlgx_dqn_loss_grad(void *hip_stream, int n_nodes, const float *pred, const 
 int drlgx_adam_step(void *hip_stream, int n_tensors, float *const *params, const float *const *grads,
                     float *const *exp_avg, float *const *exp_avg_sq, const int64_t *sizes, double lr, double beta1,
                     double beta2, double eps, int64_t step, double grad_clamp);
+/* ... with the gradient multiplied by grad_scale in front of the clamp: the 1 / world-size of a SUM all-reduced gradient
+ * (scripts/policy.py has one process; the build's data-parallel trainer averages over ranks - SURVEY.md 8e) folded in. */
+int drlgx_adam_step_scaled(void *hip_stream, int n_tensors, float *const *params, const float *const *grads,
+                    float *const *exp_avg, float *const *exp_avg_sq, const int64_t *sizes, double lr, double beta1,
+                    double beta2, double eps, int64_t step, double grad_clamp, double grad_scale);
 
 /* ---- env wrapper / actor-critic heads ------------------------------------------------------------------------- */
 

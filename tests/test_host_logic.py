@@ -254,6 +254,69 @@ def test_gradient_allreduce_gloo_world_size_2():
         assert torch.allclose(a, (x + y) / 2, rtol=1e-6, atol=1e-7)
 
 
+def _bucket_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from drl_graph_exploration_amd.optim import GradientBucket
+    from drl_graph_exploration_amd.policy import broadcast_parameters
+    torch.manual_seed(100 + rank)
+    m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 1)).double()
+    broadcast_parameters(m)
+    bucket = GradientBucket(list(m.parameters()))
+    views = [p.grad.data_ptr() for p in m.parameters()]
+    gen = torch.Generator().manual_seed(11)
+    data = torch.randn(3, world, 16, 5, generator=gen, dtype=torch.float64)  # update, rank, sample, feature
+    for u in range(3):
+        bucket.flat.zero_()
+        (m(data[u, rank]).pow(2).sum() / 16).backward()      # autograd accumulates INTO the flat buffer's views
+        assert [p.grad.data_ptr() for p in m.parameters()] == views
+        bucket.start()                                         # one in-place SUM all-reduce, asynchronous
+        _ = data[(u + 1) % 3, rank].sum()                      # (what the trainer does meanwhile: the next mini-batch)
+        scale = bucket.finish()                                # 1 / world, to be folded into the optimiser
+        assert scale == 1.0 / world
+        with torch.no_grad():
+            for p in m.parameters():
+                p -= 0.05 * (p.grad * scale)
+    q.put((rank, [p.detach().numpy().copy() for p in m.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_three_updates_gloo_world_size_2():
+    """The trainer's exchange (optim.GradientBucket: gradients as views of ONE flat tensor, asynchronous in-place all-reduce,
+    1 / world folded into the update) over three updates on two ranks: the replicas stay bit-identical, and equal a single
+    process that trains on the concatenation of both ranks' mini-batches (mean loss), up to summation order."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w0, w1 = [[torch.from_numpy(a) for a in r[1]] for r in res]
+    for a, b in zip(w0, w1):
+        assert torch.equal(a, b)
+    torch.manual_seed(100)
+    m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 1)).double()
+    gen = torch.Generator().manual_seed(11)
+    data = torch.randn(3, 2, 16, 5, generator=gen, dtype=torch.float64)
+    for u in range(3):
+        m.zero_grad()
+        (m(data[u].reshape(32, 5)).pow(2).sum() / 32).backward()
+        with torch.no_grad():
+            for p in m.parameters():
+                p -= 0.05 * p.grad
+    for a, p in zip(w0, m.parameters()):
+        assert torch.allclose(a, p.detach(), rtol=1e-12, atol=1e-14)
+
+
 def test_vectorised_action_sampling_equals_per_env_choice():
     """A2C samples one frontier per env with np.random.choice(fro, 1, p=p / p.sum()) (scripts/policy.py:392-394);
     `sample_frontiers` does it for all envs at once from the same stream: same actions, same stream position afterwards."""
