@@ -192,11 +192,11 @@ class _Sim(object):
 class SS2D(object):
     """scripts/envs/pyss2d.py:56-330 (construction + simulate + getters).
 
-    Default: one fused device step per `simulate` (`drlgx_step`).  `staged=True` builds the simulation from the `ss2d`
-    module's own classes and drives them call by call in the reference's order (pyss2d.py:102-138, :140-206) - the same
-    kernels launched stage by stage, bit-identical state."""
+    One fused device step per `simulate` (`drlgx_step`).  (The same simulation driven call by call through the `ss2d`
+    module's own classes, in the reference's order, lives in tests/staged_facade.py - the module classes are the API, that
+    driver is test code.)"""
 
-    def __init__(self, config, verbose=False, device=0, max_poses=256, start=None, staged=False):
+    def __init__(self, config, verbose=False, device=0, max_poses=256, start=None):
         self._config = load_config(config) if isinstance(config, str) else config
         cfg, prm = config_from_ini(self._config, max_poses=max_poses)
         self._sensor_params, self._control_params = prm["sensor"], prm["control"]
@@ -206,48 +206,11 @@ class SS2D(object):
         seed = self._config.getint("Simulator", "seed")
         # `start` (x, y, theta) overrides the reference's integer start pose (extension used by tests)
         x0, y0, theta0 = start_pose(lo, cfg.map_max_x) if start is None else start
-        self.verbose, self._staged = verbose, staged
-        if not staged:
-            self.engine = Engine(cfg, 1, max(cfg.max_landmarks, 1), device)
-            self.engine.reset([0], [seed], starts=np.array([[x0, y0, theta0]]))
-            self.engine.check_status()
-            self._slam, self._virtual_map, self._sim = _Slam(self), _VirtualMap(self), _Sim(self)
-            return
-        # pyss2d.py:102-138, statement by statement
-        self._sim = ss2d.Simulator2D(self._sensor_params, self._control_params, seed, device=device)
-        self._sim._ses.max_poses = max_poses
-        self._sim._ses.planner_params = self._planner_params
-        self._sim.initialize_vehicle(ss2d.Pose2(x0, y0, theta0))
-        self._slam = ss2d.SLAM2D(self._map_params)
-        self._virtual_map = ss2d.VirtualMap(self._virtual_map_params, seed)
-        self._sim.random_landmarks([], self._config.getint("Simulator", "num"), self._environment_params)
-        sx0, sy0 = self._config.getfloat("Simulator", "sigma_x0"), self._config.getfloat("Simulator", "sigma_y0")
-        st0 = math.radians(self._config.getfloat("Simulator", "sigma_theta0"))
-        initial_state = ss2d.VehicleBeliefState(self._sim.vehicle, np.diag([1.0 / sx0 ** 2, 1.0 / sy0 ** 2, 1.0 / st0 ** 2]))
-        self._cleared = True
-        self._slam.add_prior(initial_state)
-        self.engine = self._sim._ses.engine
-        self.measure()
-        self.optimize()
-
-    # ---- pyss2d.py:140-169 (staged mode)
-    def move(self, odom):
-        _, self._control_state = self._sim.move(ss2d.Pose2(odom[0], odom[1], odom[2]), True)
-        self._slam.add_odometry(self._control_state)
-
-    def measure(self):
-        self._measurements = self._sim.measure()
-        for key, m in self._measurements:
-            self._slam.add_measurement(key, m)
-
-    def optimize(self):
-        self._slam.optimize(update_covariance=True)
-
-    def update_virtual_map(self, update_probability=False, update_information=True):
-        if update_probability:
-            self._virtual_map.update_probability(self._slam, self._sim.sensor_model)
-        if update_information:
-            self._virtual_map.update_information(self._slam.map, self._sim.sensor_model)
+        self.verbose = verbose
+        self.engine = Engine(cfg, 1, max(cfg.max_landmarks, 1), device)
+        self.engine.reset([0], [seed], starts=np.array([[x0, y0, theta0]]))
+        self.engine.check_status()
+        self._slam, self._virtual_map, self._sim = _Slam(self), _VirtualMap(self), _Sim(self)
 
     @property
     def step(self):
@@ -260,28 +223,9 @@ class SS2D(object):
         mp = self._map_params
         if not mp.min_x < odom[0] < mp.max_x or not mp.min_y < odom[1] < mp.max_y:
             return True
-        if not self._staged:
-            self.engine.step(torch.tensor([[odom[0], odom[1], odom[2]]], dtype=torch.float64, device=self.engine.device))
-            self.engine.check_status()
-            return False
-        self.move(odom)
-        obstacle = False
-        measurements = self._sim.measure()
-        landmarks = [key for key, landmark in self._slam.map.iter_landmarks()]
-        for key, m in measurements:  # (inert at the shipped safe_distance = 0, but the measure() consumes sensor noise)
-            if self._cleared:
-                if m.range < self._environment_params.safe_distance:
-                    obstacle, self._cleared = True, False
-                    break
-            elif key not in landmarks and m.range < self._environment_params.safe_distance:
-                obstacle, self._cleared = True, False
-                break
-        if not obstacle:
-            self._cleared = True
-        self.measure()
-        self.optimize()
-        self.update_virtual_map(True, True)
-        return obstacle
+        self.engine.step(torch.tensor([[odom[0], odom[1], odom[2]]], dtype=torch.float64, device=self.engine.device))
+        self.engine.check_status()
+        return False
 
     @property
     def vehicle_position(self):
@@ -303,20 +247,11 @@ class SS2D(object):
 class EMExplorer(SS2D):
     """scripts/envs/pyplanner2d.py:57-84."""
 
-    def __init__(self, config, verbose=False, device=0, max_poses=256, start=None, staged=False):
-        super().__init__(config, verbose, device, max_poses, start, staged)
-        if staged:
-            self._planner = planner2d.EMPlanner2D(self._planner_params, self._sim.sensor_model, self._sim.control_model)
-
     def calculate_utility(self, distance):
-        if self._staged:
-            return planner2d.EMPlanner2D.calculate_utility(self._virtual_map, distance, self._planner_params)
         d = torch.tensor([float(distance)], dtype=torch.float64, device=self.engine.device)
         return float(self.engine.utility(d)[0])
 
     def line_plan(self, goal_key, fron):
-        if self._staged:
-            return self._planner.line_planner(self._slam, self._virtual_map, goal_key, fron[0], fron[1])
         ce = torch.zeros(1, dtype=torch.int32, device=self.engine.device)
         goal = torch.tensor([[fron[0], fron[1]]], dtype=torch.float64, device=self.engine.device)
         acts, n = self.engine.line_plan(ce, goal)
@@ -324,8 +259,6 @@ class EMExplorer(SS2D):
         return [ss2d.Pose2(*a) for a in acts[0, :int(n[0])].cpu().numpy()]
 
     def simulations_reward(self, actions):
-        if self._staged:
-            return self._planner.simulations_reward(self._slam, self._virtual_map, self._sim, actions)
         A = self.engine.cfg.max_actions
         acts = torch.zeros(1, A, 3, dtype=torch.float64, device=self.engine.device)
         for k, a in enumerate(actions):

@@ -116,11 +116,12 @@ def test_exploration_env_member_accesses_through_the_facade():
     """The member accesses ExplorationEnv makes on its EMExplorer (scripts/envs/exploration_env.py:82-162, :196-348):
     `_virtual_map.to_cov_array / to_array / to_cov_trace / explored`, `_slam.key_size / adjacency_degree_get /
     adjacency_out / features_out / get_key_points / map.*`, `line_plan`, `simulations_reward`, `calculate_utility`,
-    `vehicle_position`, `simulate` - through the staged facade, with the oracle's ExplorationEnv as the expected values."""
-    from drl_graph_exploration_amd.pyplanner2d import EMExplorer
+    `vehicle_position`, `simulate` - through the module classes driven in the reference's order (tests/staged_facade.py),
+    with the oracle's ExplorationEnv as the expected values."""
+    from staged_facade import StagedEMExplorer
     lo = 6
     start = tuple(np.array(O.start_pose(lo, MAP / 2 + 20)) + np.array([0.3113, 0.2291, -0.0517]))
-    ex = EMExplorer(ini(lo), start=start, staged=True)
+    ex = StagedEMExplorer(ini(lo), start=start)
     ref = O.OracleEnv(MAP, lo, start=start)
     for _ in range(4):
         ex.simulate((1, 1, math.pi / 2.0))  # ExplorationEnv.reset (:404-405)
