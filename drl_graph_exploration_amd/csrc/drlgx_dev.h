@@ -89,13 +89,14 @@ struct DrlgxState {
   int *slam_iws;  // [n_inst][slam_iws_stride] observation table + per-pose factor ranges
   size_t slam_iws_stride;
   int *status;  // [1]
-  long long *prof;  // [1024] development aid: wall_clock64() stamps of the phases of block 0 (or null)
+  long long *prof;  // [1024] development aid: wall_clock64() stamps of the phases of ONE workgroup (or null)
+  int prof_block;   // ... this one
 };
 
 // phase stamp (100 MHz constant clock) — only block 0 / thread 0, only when profiling is armed
 #define DRLGX_PROF(S, slot)                                                        \
   do {                                                                             \
-    if ((S).prof && threadIdx.x == 0 && blockIdx.x == 0) (S).prof[slot] = wall_clock64(); \
+    if ((S).prof && threadIdx.x == 0 && blockIdx.x == (S).prof_block) (S).prof[slot] = wall_clock64(); \
   } while (0)
 
 struct LaunchSel {

@@ -1045,6 +1045,7 @@ int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]) {
   DRLGX_ENTER(e);
   if (!e) return DRLGX_E_INVALID;
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->S.prof_block = (arm >> 8) & 0xffff;  // (arm >> 8: the workgroup whose phases are stamped; 0 by default)
   // (arm & 2: the second bank of 64 stamps - per-wave stamps of one sweep block step)
   // (arm & 4: 1024 stamps - out must hold them: banks 0, 1 and the per-workgroup start / end stamps of k_step from 128 on)
   if (out && e->S.prof) HIPCHK(e, hipMemcpy(out, e->S.prof + ((arm & 2) ? 64 : 0), ((arm & 4) ? 1024 : 64) * sizeof(long long), hipMemcpyDeviceToHost));

@@ -161,7 +161,11 @@ __device__ __forceinline__ double block_sum(double v, double *scratch, int tid) 
   return s;
 }
 
-__device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &sel, int rebuild, int chunk) {
+// handed (k_step): est_pose / pose_info of this instance already are in the LDS where this stage keeps them (sp, si) and
+// lm_lds holds the landmark estimates (LDS of the SLAM stage that this stage does not overwrite before it has read them):
+// nothing is fetched back from HBM
+__device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &sel, int rebuild, int chunk, bool handed = false,
+                                         const double *lm_lds = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bi = blockIdx.x;
@@ -200,9 +204,11 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
   if (rebuild) {
     const double *ep = S.est_pose + (size_t)inst * S.P_max * 4;
     const double *pin = S.pose_info + (size_t)inst * S.P_max * 6;
-    for (int e = tid; e < P * 4; e += kThreads) sp[e] = ep[e];
-    for (int e = tid; e < P * 6; e += kThreads) si[e] = pin[e];
-    const double *el = S.est_lm + (size_t)inst * S.L_max * 2;
+    if (!handed) {
+      for (int e = tid; e < P * 4; e += kThreads) sp[e] = ep[e];
+      for (int e = tid; e < P * 6; e += kThreads) si[e] = pin[e];
+    }
+    const double *el = (handed && lm_lds) ? lm_lds : S.est_lm + (size_t)inst * S.L_max * 2;
     for (int v = tid; v < V; v += kThreads) {  // (the first chunk's masks too, while the loads above are in flight)
       lmc[v] = 0;
       mask[v] = 0ull;
@@ -386,11 +392,16 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
       }
       __syncthreads();
       if (c0 == 0) DRLGX_PROF(S, 21);
-      const bool wprof = S.prof && blockIdx.x == 0 && lane == 0 && c0 == 0;
+      const bool wprof = S.prof && blockIdx.x == S.prof_block && lane == 0 && c0 == 0;
       long long ci_clk = 0;
       // cell pass: one 8 x 8 tile of cells per wave and round (lane = 8 (row mod 8) + (col mod 8)).  Cells of a tile
       // are seen by nearly the same poses, so the lanes' covariance-intersection chains have similar lengths and tiles
       // away from the trajectory skip the loop altogether (row-major strips of 64 cells cross the whole map instead).
+      // (Tiles on the trajectory cost several times the others and the round-robin deal leaves some waves idle from 2.2 us
+      // while others work until 6.5 us; a tile queue - with the utility terms summed per tile, or parked per cell and summed
+      // afterwards, to keep the sums reproducible - and a deal by ranked cost both evened the waves out and both made the
+      // kernel slower: ranking costs more than it saves, and with the queue the barrier after the pass completed 1.9 us
+      // after the last wave instead of 0.2 us.)
       const int tiles_c = (cols + 7) >> 3, ntiles = ((rows + 7) >> 3) * tiles_c;
       for (int t = wave; t < ntiles; t += kWaves) {
         const int trow = t / tiles_c, tcol = t - trow * tiles_c;

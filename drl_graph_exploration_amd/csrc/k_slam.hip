@@ -47,9 +47,7 @@ __device__ __forceinline__ size_t up8(size_t b) { return (b + 7) & ~(size_t)7; }
 __device__ __forceinline__ double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
   r = r * (2.0 - x * r);
-#ifndef DRLGX_EXP_N1
   r = r * (2.0 - x * r);
-#endif
   return r;
 }
 
@@ -412,9 +410,7 @@ __device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &
         v4d dn = {t[0], t[1], t[2], t[3]};
         dn = mfma4(aW, aP, dn);
         if (trg) x.tr[2] = clock64();
-#ifndef DRLGX_EXP_NOINV
         inv16_blk(x, min(16, np - kb - 16), dn);
-#endif
         st_op(L.einv((K + 1) & 1), lane, dn[0], dn[1], dn[2], dn[3]);
         __builtin_amdgcn_s_setprio(0);
         if (trg) x.tr[3] = clock64();
@@ -444,7 +440,6 @@ __device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &
           const int h = (u >> 1) & 1, u1 = u + 1 <= I1 ? u + 1 : u;
           if (u + 2 <= I) ld_op(pan + 256 * (u + 2), lane, bP[h ^ 1][0]);
           if (u + 3 <= I) ld_op(pan + 256 * (u + 3), lane, bP[h ^ 1][1]);
-#ifndef DRLGX_EXP_NOU
           const bool d0 = u != K || K == I, d1 = u + 1 <= I && (u + 1 != K || K == I);
           if (d0 && d1) {
 #pragma unroll
@@ -457,7 +452,6 @@ __device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &
           } else if (d1) {
             acc[u1] = mfma4(aW, bP[h][1], acc[u1]);
           }
-#endif
         }
       }
       if (K <= I) {
@@ -691,7 +685,7 @@ __device__ __forceinline__ void sweep_packed_fast(const DrlgxState &S, double *A
   }
   const bool live = trow < Tn, ewave = trow == (Tn < FT ? FT - 1 : 0);
   const SweepCtx x{trow, lane, lane & 15, lane >> 4, np, N, live, ewave, bad,
-                   (S.prof && blockIdx.x == 0 && lane == 0) ? S.prof + 64 + 5 * wv : nullptr};
+                   (S.prof && blockIdx.x == S.prof_block && lane == 0) ? S.prof + 64 + 5 * wv : nullptr};
   if (!live) {
     if (ewave) sweep_role<-1, true>(S, x, A, N);
     else sweep_role<-1, false>(S, x, A, N);
@@ -989,8 +983,8 @@ struct SlamCtx {
   bool relin;
   // LDS
   double *thp, *odl, *thl, *lamb, *A, *rec;
-  int *mstart, *bad, *lstart;
-  unsigned short *mp, *ml, *lfac, *obs;
+  int *mstart, *bad, *lstart, *pstart;
+  unsigned short *mp, *ml, *lfac, *obs, *pairlm;
   unsigned long long *lmask;
 
   __device__ __forceinline__ int AT(int i, int j) const { return i * (i + 1) / 2 + j; }
@@ -999,8 +993,8 @@ struct SlamCtx {
   // the factor records and the observation table, which otherwise go to the HBM workspace
   __device__ __forceinline__ static size_t small_bytes(int P, int Lb, int Mb) {
     const size_t MW = (size_t)(P + 63) >> 6;
-    return up8((size_t)P * 32) * 2 + up8((size_t)Lb * 16) + up8((size_t)Lb * 64) + up8((size_t)(P + 2) * 4) + up8((size_t)(Lb + 2) * 4) +
-           up8((size_t)Mb * 2) * 3 + 8 + up8((size_t)Lb * MW * 8) + 32;
+    return up8((size_t)P * 32) * 2 + up8((size_t)Lb * 16) + up8((size_t)Lb * 64) + up8((size_t)(P + 2) * 4) + up8((size_t)(Lb + 2) * 4) * 2 +
+           up8((size_t)Mb * 2) * 3 + up8((size_t)(Mb / 2 + Lb + 2) * 2) + 8 + up8((size_t)Lb * MW * 8) + 32;
   }
   __device__ __forceinline__ static bool big_fits(size_t off, int lds_bytes, int P, int Lb, int Mb) {
     const size_t N = 16 * (((size_t)3 * P + 1 + 15) / 16);
@@ -1021,9 +1015,11 @@ struct SlamCtx {
     lamb = reinterpret_cast<double *>(take((size_t)Lb * 8 * 8));
     mstart = reinterpret_cast<int *>(take((size_t)(P + 2) * 4));
     lstart = reinterpret_cast<int *>(take((size_t)(Lb + 2) * 4));
+    pstart = reinterpret_cast<int *>(take((size_t)(Lb + 2) * 4));
     mp = reinterpret_cast<unsigned short *>(take((size_t)Mb * 2));
     ml = reinterpret_cast<unsigned short *>(take((size_t)Mb * 2));
     lfac = reinterpret_cast<unsigned short *>(take((size_t)Mb * 2));
+    pairlm = reinterpret_cast<unsigned short *>(take((size_t)(Mb / 2 + Lb + 2) * 2));
     bad = reinterpret_cast<int *>(take(8));
     // poses observing each landmark as bit masks (MW 64-bit words): the per-landmark loops visit only those poses
     lmask = reinterpret_cast<unsigned long long *>(take((size_t)Lb * MW * 8));
@@ -1174,12 +1170,15 @@ struct SlamCtx {
         A[AT(np, 3 * i + r)] = -g[r];  // rhs lives in the augmented row
       }
     }
-    if (S.prof && blockIdx.x == 0 && ft == 0) S.prof[14] = wall_clock64();  // (dev aid: end of the front end)
+    if (S.prof && blockIdx.x == S.prof_block && ft == 0) S.prof[14] = wall_clock64();  // (dev aid: end of the front end)
   }
 
   // everything after the simulator: all kThreads threads, hardware barriers.  Lfin / Mfin: the final counts (>= the front's).
+  // hand: LDS (or null) that receives what the map stage of k_step reads next - est_pose [P][4] and, behind it at
+  // hand + 4 P_max, pose_info [P][6] - so that it does not fetch them back from HBM; the landmark estimates are left in
+  // `thl` for the same reason (the linearisation points are dead by then)
   template <int FT>
-  __device__ __forceinline__ void back(const DrlgxState &S, int tid, int Lfin, int Mfin, bool full, bool refresh) {
+  __device__ __forceinline__ void back(const DrlgxState &S, int tid, int Lfin, int Mfin, bool full, bool refresh, double *hand = nullptr) {
     int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
     double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
     double *d_lm = S.d_lm + (size_t)inst * S.L_max * 2;
@@ -1221,22 +1220,30 @@ struct SlamCtx {
     }
     if (tid >= kThreads - 64) {  // exclusive scan of the observation counts -> lstart[0 .. L]
       const int ln = tid - (kThreads - 64);
-      int carry = 0;
+      unsigned carry = 0;
       for (int base = 0; base < L; base += 64) {
         const int j = base + ln;
         int k = 0;
         if (j < L)
           for (int w = 0; w < MW; ++w) k += __popcll(lmask[MW * j + w]);
-        int v = k;
+        // (two scans in one: observations in the low half, pairs of observations - ceil(k / 2) - in the high half)
+        const int k2 = (k + 1) >> 1;
+        unsigned v = (unsigned)k | ((unsigned)k2 << 16);
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-          const int u = __shfl_up(v, o);
+          const unsigned u = (unsigned)__shfl_up((int)v, o);
           if (ln >= o) v += u;
         }
-        if (j < L) lstart[j] = carry + v - k;
-        carry += __shfl(v, 63);
+        if (j < L) {
+          lstart[j] = (int)((carry & 0xffffu) + (v & 0xffffu)) - k;
+          pstart[j] = (int)((carry >> 16) + (v >> 16)) - k2;
+        }
+        carry += (unsigned)__shfl((int)v, 63);
       }
-      if (ln == 0) lstart[L] = carry;
+      if (ln == 0) {
+        lstart[L] = (int)(carry & 0xffffu);
+        pstart[L] = (int)(carry >> 16);
+      }
     }
     if (M > M0 && tid == kThreads / 2) {
       // pose_block's own-factor loop for the factors appended after the front ran (same expressions, same order)
@@ -1261,7 +1268,7 @@ struct SlamCtx {
     DRLGX_PROF(S, 2);
     // ---- 4. landmark elimination: rec[0..5] <- G_m = Lambda_pl Lambda_ll^-1 (3x2), rec[6..11] <- H_m = G_m Lambda_jj
     //         (= Lambda_pl; the Jacobian of the landmark and the residual are not needed any more);
-    //         per-landmark factor lists lfac[lstart[j] ..] in pose order ----
+    //         per-landmark factor lists lfac[lstart[j] ..] in pose order, and the pair table of phase 6 ----
     for (int m = tid; m < M; m += kThreads) {
       double *l = rec + (size_t)REC * m;
       const double *lb = lamb + 8 * ml[m];
@@ -1278,11 +1285,15 @@ struct SlamCtx {
       }
       for (int k = 0; k < 6; ++k) l[k] = g[k];
       for (int k = 0; k < 6; ++k) l[6 + k] = h[k];
+      // the factor's place in its landmark's list = the rank of its pose among the observers (no list walk)
+      const int j = ml[m], p = mp[m];
+      int rank = 0;
+      for (int w = 0; w < (p >> 6); ++w) rank += __popcll(lmask[MW * j + w]);
+      rank += __popcll(lmask[MW * j + (p >> 6)] & ((1ull << (p & 63)) - 1ull));
+      lfac[lstart[j] + rank] = (unsigned short)m;
+      if (rank < pstart[j + 1] - pstart[j]) pairlm[pstart[j] + rank] = (unsigned short)j;
     }
-    for (int j = (tid + kThreads / 2) % kThreads; j < L; j += kThreads) {
-      int t = lstart[j];
-      FOR_EACH_OBSERVING_POSE(lmask + MW * j, MW, p) lfac[t++] = (unsigned short)(obs[j * P + p] - 1);
-    }
+
     __syncthreads();
     DRLGX_PROF(S, 3);
     //      Schur complement: S_pq -= sum_j G_m Lambda_jj G_mq^T   (Lambda_pl = G Lambda_jj = H)
@@ -1293,8 +1304,11 @@ struct SlamCtx {
         while ((p + 1) * (p + 2) / 2 <= e) ++p;
         while (p * (p + 1) / 2 > e) --p;
         const int q = e - p * (p + 1) / 2;
-        // (a variant that walks the landmarks COMMON to both poses - the AND of per-pose landmark masks - instead of the
-        // factors of p measured slower: 5.7 against 4.4 us)
+        // Row-major pairs: the lanes of a wave share p (one factor list, one trip count).  Measured and dropped - none
+        // faster than this plain loop (5.2 us; 9.1 us for the instances with the most factors, of which 2.1 / 4.3 us are
+        // the look-ups and the rest the terms): four look-ups per round issued together; look-ups software-pipelined one
+        // factor ahead; the landmarks common to both poses from per-pose bit masks; diagonal-major pair order (lanes of
+        // similar hit counts, but different factor lists: 6.2 / 9.8 us).
         double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         bool any = false;
         for (int m = mstart[p]; m < mstart[p + 1]; ++m) {
@@ -1332,51 +1346,81 @@ struct SlamCtx {
     __syncthreads();
     DRLGX_PROF(S, 5);
     for (int k = tid; k < np; k += kThreads) d_pose[k] = A[AT(np, k)];
-    // ---- 6. landmark marginals: rec[6..9] <- G_m^T ( sum_{m' of the same landmark} Sigma[p_m][p_m'] G_m' ).  The factors
-    //         m' of the landmark come from its list; a factor's sum is split over S6 adjacent lanes (the longest list is
-    //         the latency of this phase) and combined by a butterfly (a fixed tree: deterministic) ----
+    // ---- 6. landmark marginals: Sigma_jj = Lambda_jj^-1 + sum_{a, b} G_a^T Sigma[p_a][p_b] G_b over the landmark's factor list
+    //         (ascending poses).  By symmetry only b <= a is evaluated: factor a gets
+    //             rec[6..9] <- Y_a + X_a + X_a^T,   Y_a = G_a^T Sigma_aa G_a,   X_a = sum_{b < a} G_a^T Sigma_ab G_b,
+    //         whose sum over the list is the full double sum.  One work item = the list entries a and k-1-a of a landmark
+    //         (a + (k-1-a) = k-1 block products whatever a: balanced), split over S6 adjacent lanes and combined by a
+    //         butterfly (a fixed tree: deterministic).  The longest list sets the latency of this phase: (k-1) / S6 rounds. ----
     if (full) {
-      const int sh6 = 4 * M <= kThreads ? 2 : 2 * M <= kThreads ? 1 : 0, S6 = 1 << sh6;
+      const int NP = pstart[L];
+      const int sh6 = 4 * NP <= kThreads ? 2 : 2 * NP <= kThreads ? 1 : 0, S6 = 1 << sh6;
       const int per_pass = kThreads >> sh6;
-      for (int m0 = 0; m0 < M; m0 += per_pass) {
-        const int m = m0 + (tid >> sh6), s6 = tid & (S6 - 1);
-        const bool work = m < M;
-        double Wm[6] = {0, 0, 0, 0, 0, 0};
+      for (int pid0 = 0; pid0 < NP; pid0 += per_pass) {
+        const int pid = pid0 + (tid >> sh6), s6 = tid & (S6 - 1);
+        const bool work = pid < NP;
+        double X[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // X_a of the two entries (row major 2 x 2)
+        int ma[2] = {0, 0};
+        bool two = false;
         if (work) {
-          const int j = ml[m], p = mp[m];
-          const int t0 = lstart[j], t1 = lstart[j + 1];
-          for (int t = t0 + s6; t < t1; t += S6) {
-            const int mq = lfac[t], q = mp[mq];
-            const double *gq = rec + (size_t)REC * mq;
-            // Sigma[p][q] = -(swept block): the packed triangle holds the block as rows of the later pose
-            const int hi = max(p, q), lo = min(p, q);
-            double tb[9];
-            for (int a = 0; a < 3; ++a)
-              for (int b = 0; b < 3; ++b) {
-                const int ra = (hi == lo) ? max(a, b) : a, cb = (hi == lo) ? min(a, b) : b;
-                tb[a * 3 + b] = A[AT(3 * hi + ra, 3 * lo + cb)];
+          const int j = pairlm[pid], t0 = lstart[j], k = lstart[j + 1] - t0;
+          const int a0 = pid - pstart[j], a1 = k - 1 - a0;  // a0 <= a1
+          two = a1 > a0;
+          ma[0] = lfac[t0 + a0];
+          ma[1] = lfac[t0 + a1];
+          const int pa0 = mp[ma[0]], pa1 = mp[ma[1]];
+          double W[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+          // the earlier entries b of the list: Sigma[p_a][p_b] = -(swept block), stored as rows of the later pose p_a
+          for (int b = s6; b < a1; b += S6) {
+            const int mb = lfac[t0 + b], pb = mp[mb];
+            const double *gb = rec + (size_t)REC * mb;
+            const double g0 = gb[0], g1 = gb[1], g2 = gb[2], g3 = gb[3], g4 = gb[4], g5 = gb[5];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              if (e == 0 && (b >= a0 || !two)) continue;
+              const int pa = e ? pa1 : pa0;
+#pragma unroll
+              for (int r = 0; r < 3; ++r) {
+                const int row = AT(3 * pa + r, 3 * pb);
+                const double t0v = A[row], t1v = A[row + 1], t2v = A[row + 2];
+                W[e][r * 2] -= t0v * g0 + t1v * g2 + t2v * g4;
+                W[e][r * 2 + 1] -= t0v * g1 + t1v * g3 + t2v * g5;
               }
-            for (int r = 0; r < 3; ++r) {
-              double s0 = 0, s1 = 0;
-              for (int c = 0; c < 3; ++c) {
-                const double sg = -((p >= q) ? tb[r * 3 + c] : tb[c * 3 + r]);
-                s0 += sg * gq[c * 2];
-                s1 += sg * gq[c * 2 + 1];
-              }
-              Wm[r * 2] += s0;
-              Wm[r * 2 + 1] += s1;
             }
+          }
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const double *ga = rec + (size_t)REC * ma[e];
+            X[e][0] = ga[0] * W[e][0] + ga[2] * W[e][2] + ga[4] * W[e][4];
+            X[e][1] = ga[0] * W[e][1] + ga[2] * W[e][3] + ga[4] * W[e][5];
+            X[e][2] = ga[1] * W[e][0] + ga[3] * W[e][2] + ga[5] * W[e][4];
+            X[e][3] = ga[1] * W[e][1] + ga[3] * W[e][3] + ga[5] * W[e][5];
           }
         }
         for (int o = S6 >> 1; o > 0; o >>= 1)
 #pragma unroll
-          for (int k = 0; k < 6; ++k) Wm[k] += __shfl_xor(Wm[k], o);
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) X[e][q4] += __shfl_xor(X[e][q4], o);
         if (work && s6 == 0) {
-          double *g = rec + (size_t)REC * m;
-          g[6] = g[0] * Wm[0] + g[2] * Wm[2] + g[4] * Wm[4];
-          g[7] = g[0] * Wm[1] + g[2] * Wm[3] + g[4] * Wm[5];
-          g[8] = g[1] * Wm[0] + g[3] * Wm[2] + g[5] * Wm[4];
-          g[9] = g[1] * Wm[1] + g[3] * Wm[3] + g[5] * Wm[5];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            if (e == 0 && !two) continue;  // (a0 == a1: the middle entry of an odd list, handled as e = 1)
+            double *g = rec + (size_t)REC * ma[e];
+            const int pa = mp[ma[e]];
+            // Y = G^T Sigma_aa G with the symmetric diagonal block
+            const double s00 = -A[AT(3 * pa, 3 * pa)], s10 = -A[AT(3 * pa + 1, 3 * pa)], s11 = -A[AT(3 * pa + 1, 3 * pa + 1)];
+            const double s20 = -A[AT(3 * pa + 2, 3 * pa)], s21 = -A[AT(3 * pa + 2, 3 * pa + 1)], s22 = -A[AT(3 * pa + 2, 3 * pa + 2)];
+            const double d00 = s00 * g[0] + s10 * g[2] + s20 * g[4], d01 = s00 * g[1] + s10 * g[3] + s20 * g[5];
+            const double d10 = s10 * g[0] + s11 * g[2] + s21 * g[4], d11 = s10 * g[1] + s11 * g[3] + s21 * g[5];
+            const double d20 = s20 * g[0] + s21 * g[2] + s22 * g[4], d21 = s20 * g[1] + s21 * g[3] + s22 * g[5];
+            const double y00 = g[0] * d00 + g[2] * d10 + g[4] * d20, y01 = g[0] * d01 + g[2] * d11 + g[4] * d21;
+            const double y10 = g[1] * d00 + g[3] * d10 + g[5] * d20, y11 = g[1] * d01 + g[3] * d11 + g[5] * d21;
+            g[6] = y00 + 2.0 * X[e][0];
+            g[7] = y01 + (X[e][1] + X[e][2]);
+            g[8] = y10 + (X[e][1] + X[e][2]);
+            g[9] = y11 + 2.0 * X[e][3];
+          }
         }
       }
     }
@@ -1385,23 +1429,41 @@ struct SlamCtx {
     double *est_lm = S.est_lm + (size_t)inst * S.L_max * 2;
     double *lm_info = S.lm_info + (size_t)inst * S.L_max * 3;
     double *lm_tr = S.lm_tr + (size_t)inst * S.L_max;
-    for (int j = tid; j < L; j += kThreads) {
-      const double *lb = lamb + 8 * j;
-      double c00 = lb[3], c01 = lb[4], c10 = lb[4], c11 = lb[5];
-      // delta_j = Lambda^-1 eta_j - sum_m G_m^T delta_p
-      double dx = lb[3] * lb[6] + lb[4] * lb[7], dy = lb[4] * lb[6] + lb[5] * lb[7];
-      for (int t = lstart[j]; t < lstart[j + 1]; ++t) {
-        const int mq = lfac[t], p = mp[mq];
-        const double *g = rec + (size_t)REC * mq;
-        c00 += g[6]; c01 += g[7]; c10 += g[8]; c11 += g[9];
-        const double dp0 = A[AT(np, 3 * p)], dp1 = A[AT(np, 3 * p + 1)], dp2 = A[AT(np, 3 * p + 2)];
-        dx -= g[0] * dp0 + g[2] * dp1 + g[4] * dp2;
-        dy -= g[1] * dp0 + g[3] * dp1 + g[5] * dp2;
+    // (a landmark's list is split over S7 adjacent lanes - the first half of the workgroup; the poses below take the second -
+    // and combined by a butterfly)
+    const int sh7 = 4 * L <= kThreads / 2 ? 2 : 2 * L <= kThreads / 2 ? 1 : 0, S7 = 1 << sh7;
+    for (int j0 = 0; j0 < L; j0 += kThreads >> sh7) {
+      const int j = j0 + (tid >> sh7), s7 = tid & (S7 - 1);
+      const bool lwork = j < L;
+      double c00 = 0, c01 = 0, c10 = 0, c11 = 0, dx = 0, dy = 0;
+      if (lwork) {
+        for (int t = lstart[j] + s7; t < lstart[j + 1]; t += S7) {
+          const int mq = lfac[t], p = mp[mq];
+          const double *g = rec + (size_t)REC * mq;
+          c00 += g[6]; c01 += g[7]; c10 += g[8]; c11 += g[9];
+          const double dp0 = A[AT(np, 3 * p)], dp1 = A[AT(np, 3 * p + 1)], dp2 = A[AT(np, 3 * p + 2)];
+          dx -= g[0] * dp0 + g[2] * dp1 + g[4] * dp2;
+          dy -= g[1] * dp0 + g[3] * dp1 + g[5] * dp2;
+        }
       }
+      for (int o = S7 >> 1; o > 0; o >>= 1) {
+        c00 += __shfl_xor(c00, o); c01 += __shfl_xor(c01, o); c10 += __shfl_xor(c10, o); c11 += __shfl_xor(c11, o);
+        dx += __shfl_xor(dx, o); dy += __shfl_xor(dy, o);
+      }
+      if (!lwork || s7 != 0) continue;
+      const double *lb = lamb + 8 * j;
+      c00 += lb[3]; c01 += lb[4]; c10 += lb[4]; c11 += lb[5];
+      // delta_j = Lambda^-1 eta_j - sum_m G_m^T delta_p
+      dx += lb[3] * lb[6] + lb[4] * lb[7];
+      dy += lb[4] * lb[6] + lb[5] * lb[7];
       d_lm[2 * j] = dx;
       d_lm[2 * j + 1] = dy;
       est_lm[2 * j] = thl[2 * j] + dx;
       est_lm[2 * j + 1] = thl[2 * j + 1] + dy;
+      if (hand) {
+        thl[2 * j] = thl[2 * j] + dx;
+        thl[2 * j + 1] = thl[2 * j + 1] + dy;
+      }
       if (!full) continue;
       const double cs = 0.5 * (c01 + c10);
       lm_tr[j] = c00 + c11;
@@ -1419,11 +1481,18 @@ struct SlamCtx {
       const Pose t{thp[4 * i], thp[4 * i + 1], thp[4 * i + 2], thp[4 * i + 3]};
       const Pose e = compose(t, make_pose(A[AT(np, k0)], A[AT(np, k0 + 1)], A[AT(np, k0 + 2)]));
       est_pose[4 * i] = e.x; est_pose[4 * i + 1] = e.y; est_pose[4 * i + 2] = e.c; est_pose[4 * i + 3] = e.s;
+      if (hand) {
+        hand[4 * i] = e.x; hand[4 * i + 1] = e.y; hand[4 * i + 2] = e.c; hand[4 * i + 3] = e.s;
+      }
       if (!full) continue;
       const double c00 = -A[AT(k0, k0)], c10 = -A[AT((k0 + 1), k0)], c11 = -A[AT((k0 + 1), k0 + 1)];
       const double c20 = -A[AT((k0 + 2), k0)], c21 = -A[AT((k0 + 2), k0 + 1)], c22 = -A[AT((k0 + 2), k0 + 2)];
       pose_tr[i] = c00 + c11 + c22;
-      inv3_sym_fast(c00, c10, c20, c11, c21, c22, pose_info + 6 * i);
+      double info[6];
+      inv3_sym_fast(c00, c10, c20, c11, c21, c22, info);
+      for (int k = 0; k < 6; ++k) pose_info[6 * i + k] = info[k];
+      if (hand)
+        for (int k = 0; k < 6; ++k) hand[4 * S.P_max + 6 * i + k] = info[k];
     }
     DRLGX_PROF(S, 7);
     if (tid == 0) {
@@ -1441,7 +1510,7 @@ struct SlamCtx {
 // for the counts before the step (records in LDS).  smem_off: first byte of the dynamic LDS the stage may use.
 template <int FT>
 __device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel &sel, int lds_bytes, size_t smem_off, const SlamCtx &pre, bool have_pre,
-                                            const int *mail = nullptr) {
+                                            const int *mail = nullptr, double *hand = nullptr, const double **lm_out = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int bi = blockIdx.x;
@@ -1474,7 +1543,8 @@ __device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel
     c.front<false>(S, tid, P, L, M, n_old_p, n_old_l, count, refresh, nullptr, SubBarrier{nullptr, 0, 0});
     __syncthreads();
   }
-  c.back<FT>(S, tid, L, M, full, refresh);
+  c.back<FT>(S, tid, L, M, full, refresh, hand);
+  if (lm_out) *lm_out = c.thl;
 }
 
 template <int FT>
@@ -1499,7 +1569,7 @@ constexpr int kArrowRegTiles = 20;  // ... beyond: up to 20 register tiles per w
 size_t slam_dim(int P_max) { return 16 * (((size_t)3 * P_max + 1 + 15) / 16); }
 size_t slam_small_bytes(int P_max, int L_max, int M_max) {  // (SlamCtx::setup)
   return (size_t)P_max * 64 + (size_t)L_max * 16 + (size_t)L_max * 64 + (size_t)L_max * 8 * ((P_max + 63) / 64) +
-         (size_t)(P_max + 2) * 4 + (size_t)(L_max + 2) * 4 + (size_t)M_max * 6 + 192;
+         (size_t)(P_max + 2) * 4 + (size_t)(L_max + 2) * 8 + (size_t)M_max * 7 + (size_t)L_max * 2 + 224;
 }
 // LDS the arrow path cannot do without at full capacity: tables + the packed landmark system or the panels of the
 // workspace variant (factor records and the observation table overflow to the workspace)

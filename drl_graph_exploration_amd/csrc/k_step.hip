@@ -18,8 +18,12 @@ namespace kstep {
 
 // LDS of the simulator wave (two mt19937 streams, the normal variates and the in-range list of a measure() call); the SLAM
 // stage of k_step carves behind it because its front end runs WHILE the simulator wave works
-__host__ __device__ inline size_t sim_lds_bytes(int LG) {
-  return ((size_t)2 * DRLGX_MT_STRIDE * 4 + (size_t)(2 * LG + 2) * 8 + (size_t)LG * 4 + 16 + 31) & ~(size_t)31;
+__host__ __device__ inline size_t sim_lds_bytes(int LG, int P_max) {
+  size_t b = (size_t)2 * DRLGX_MT_STRIDE * 4 + (size_t)(2 * LG + 2) * 8 + (size_t)LG * 4 + 16;
+  // ... and, when that costs little, wide enough for the map stage's pose tables (19 P_max doubles), so that the SLAM stage
+  // can leave its outputs in them (see k_step)
+  if (P_max <= 64) b = b > (size_t)P_max * 19 * 8 + 32 ? b : (size_t)P_max * 19 * 8 + 32;
+  return (b + 31) & ~(size_t)31;
 }
 
 template <int FT>
@@ -31,7 +35,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
   const int bi = blockIdx.x;
   if (S.prof && tid == 0 && bi < 448) S.prof[128 + 2 * bi] = wall_clock64();  // (dev aid: per-workgroup start / end)
   // ---- what the SLAM front end needs is read before the simulator wave starts to change it ----
-  const size_t sim_bytes = sim_lds_bytes(S.LG);
+  const size_t sim_bytes = sim_lds_bytes(S.LG, S.P_max);
   int *sub_cnt = reinterpret_cast<int *>(step_smem + sim_bytes - 16);
   kslam::SlamCtx ctx;
   bool pre = false, accepted = false;
@@ -74,9 +78,19 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
     const uint32_t *img = reinterpret_cast<const uint32_t *>(step_smem);
     for (int i = tid - 64; i < 2 * DRLGX_MT_STRIDE; i += kslam::kThreads - 64) g[i] = img[i];
   }
-  kslam::slam_finish<FT>(S, sel, lds_bytes, sim_bytes, ctx, pre, sub_cnt + 1);
+  // The pose estimates / information blocks go straight to where the map stage keeps them (its first 10 P_max doubles; its
+  // pose tables - 19 P_max doubles - must end inside the simulator's region, free by now, because the map stage fills the
+  // last of them while it reads the landmarks).  The landmark estimates stay in the SLAM stage's LDS: the map stage reads
+  // them before the first array it writes beyond its pose tables (the information stage, in its phase A) is touched - as
+  // long as they lie below its cell masks, which it clears first.
+  const bool hand = (size_t)S.P_max * 19 * sizeof(double) + 16 <= sim_bytes - 16;
+  const double *lm_lds = nullptr;
+  kslam::slam_finish<FT>(S, sel, lds_bytes, sim_bytes, ctx, pre, sub_cnt + 1, hand ? reinterpret_cast<double *>(step_smem) : nullptr, &lm_lds);
   __syncthreads();
-  kmap::map_body(S, sel, 1, map_chunk);
+  const bool handed = hand && lm_lds != nullptr;  // (lm_lds: set once the SLAM stage ran to its end)
+  const unsigned char *map_masks = step_smem + ((size_t)S.P_max * 19 + (size_t)map_chunk * 64 * 3) * sizeof(double);
+  if (!handed || reinterpret_cast<const unsigned char *>(lm_lds + 2 * (size_t)S.L_max) > map_masks) lm_lds = nullptr;
+  kmap::map_body(S, sel, 1, map_chunk, handed, lm_lds);
   if (S.prof && tid == 0 && bi < 448) S.prof[129 + 2 * bi] = wall_clock64();
 }
 
@@ -106,7 +120,7 @@ bool drlgx_step_fusable(const DrlgxState &S, int p_bound) {
   const size_t nf = 16 * kslam::kFastTiles;
   // (the SLAM stage sits behind the simulator's LDS: its front end runs beside the simulator wave)
   return drlgx_slam_in_lds(Pb, S.L_max, S.M_max) &&
-         kstep::sim_lds_bytes(S.LG) + kslam::slam_small_bytes(Pb, S.L_max, S.M_max) + kslam::sweep_region_doubles(nf) * 8 <= (size_t)kslam::kLdsBudget &&
+         kstep::sim_lds_bytes(S.LG, S.P_max) + kslam::slam_small_bytes(Pb, S.L_max, S.M_max) + kslam::sweep_region_doubles(nf) * 8 <= (size_t)kslam::kLdsBudget &&
          drlgx_map_lds_bytes(S, &chunk) <= (size_t)kslam::kLdsBudget;
 }
 

@@ -1,4 +1,4 @@
-"""Dev tool: in-kernel phase breakdown (block 0) of k_slam / k_map at the bench workload."""
+"""Dev tool: in-kernel phase breakdown of k_slam / k_sim at the bench workload:  phase_profile.py [workgroup = env index, default 0]"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,11 +9,14 @@ if os.environ.get('DRLGX_LIB_DEV'):
 eng, cfg = bench.make_engine(0, 0)
 odom = torch.tensor([bench.STEP_ACTION] * bench.N_ENVS, dtype=torch.float64, device=eng.device)
 out = (C.c_int64 * 64)()
-eng.L.drlgx_debug_phase_clocks_host(eng.h, 1, None)
+BLK = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ARM = 1 | (BLK << 8)
+eng.L.drlgx_debug_phase_clocks_host(eng.h, ARM, None)
+print('workgroup %d:' % BLK, eng.counts(BLK) if hasattr(eng, 'counts') else '')
 acc = np.zeros(64); n = 0
 for it in range(20):
     eng.restore(0); eng.step(odom)
-    eng.L.drlgx_debug_phase_clocks_host(eng.h, 1, out)
+    eng.L.drlgx_debug_phase_clocks_host(eng.h, ARM, out)
     a = np.array(out[:], dtype=np.float64)
     if it >= 5:
         acc += a; n += 1
