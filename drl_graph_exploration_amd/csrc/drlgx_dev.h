@@ -49,6 +49,7 @@ struct DrlgxState {
   unsigned long long lo_tocc, lo_tfree;  // lo_tr packed for <= 16 states: 4 bits per next state (occupied / free)
   unsigned int lo_tflag;                 // 2 bits of flags per state
   double vm_i0;                          // 1 / sigma0^2 (host pow, like the reference's initialisation)
+  double w_trans, w_rot, w_bear, w_range;  // 1 / noise^2 of the odometry (translation, rotation) and bearing-range factors
   const int *lm_order;                                 // [LG] libstdc++ unordered_map iteration order of GT keys
   // --- simulator
   double *gt_pose;    // [n_inst][4] x,y,c,s

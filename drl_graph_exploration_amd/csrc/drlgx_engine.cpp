@@ -224,6 +224,10 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   S.lo_max = l2p(0.95);  // sic: MAX_LOGODDS = LOGODDS2PROB(0.95)
   S.occ_thresh = p2l(0.5);
   S.vm_i0 = 1.0 / std::pow(cfg->sigma0, 2);
+  S.w_trans = 1.0 / (cfg->translation_noise * cfg->translation_noise);
+  S.w_rot = 1.0 / (cfg->rotation_noise * cfg->rotation_noise);
+  S.w_bear = 1.0 / (cfg->bearing_noise * cfg->bearing_noise);
+  S.w_range = 1.0 / (cfg->range_noise * cfg->range_noise);
   S.lo_tocc = S.lo_tfree = 0ull;
   S.lo_tflag = 0u;
   // occupancy ladder closure (see DrlgxState::lo_tr)

@@ -87,8 +87,12 @@ __device__ inline int scan_in_range(SimCtx &c, int *inr, const GtPrefetch *pf = 
 // exp_*: the staged interface (drlgx_stage_measure) exports the valid measurements (key, bearing, range) in order instead
 // of appending them: Simulator2D::measure as the object-level API sees it
 // `lead`: variates of earlier measure() calls that are drawn (and dropped) together with this call's
+// `lmbox` (k_step): LDS for 2 LG doubles.  The appended factors are then ALSO left in LDS for the SLAM stage of the same
+// workgroup, which would otherwise wait for them to come back from HBM: factor M0 + r has its bearing / range in
+// nrm[2 r], nrm[2 r + 1] and its landmark slot in inr[r] (in place: r <= the index a lane read its own inputs from), new
+// landmark L0 + r its initial estimate in lmbox[2 r], lmbox[2 r + 1].
 __device__ inline void measure(SimCtx &c, bool record, double *nrm, const int *inr, int n_in, int32_t *exp_keys = nullptr,
-                               double *exp_br = nullptr, int32_t *exp_count = nullptr, int lead = 0) {
+                               double *exp_br = nullptr, int32_t *exp_count = nullptr, int lead = 0, double *lmbox = nullptr) {
   const DrlgxState &S = c.S;
   const drlgx_config &cfg = S.cfg;
   const double *gl = S.gt_lm + (size_t)S.parent[c.inst] * S.LG * 2;
@@ -120,6 +124,7 @@ __device__ inline void measure(SimCtx &c, bool record, double *nrm, const int *i
   }
   if (!record) return;
   int *key_slot = S.key_slot + (size_t)c.inst * S.LG;
+  const int L_first = c.L, M_first = c.M;
   for (int base = 0; base < n_in; base += 64) {
     const int k = base + c.lane;
     const bool v = k < n_in;
@@ -152,6 +157,10 @@ __device__ inline void measure(SimCtx &c, bool record, double *nrm, const int *i
       dl[1] = 0;
       S.lm_key[(size_t)c.inst * S.L_max + slot] = key;
       key_slot[key] = slot;
+      if (lmbox) {
+        lmbox[2 * (slot - L_first)] = g.x;
+        lmbox[2 * (slot - L_first) + 1] = g.y;
+      }
     }
     if (ok) {
       const int f = c.M + __popcll(okm & below);
@@ -160,6 +169,11 @@ __device__ inline void measure(SimCtx &c, bool record, double *nrm, const int *i
       double *br = S.meas_br + ((size_t)c.inst * S.M_max + f) * 2;
       br[0] = bearing;
       br[1] = range;
+      if (lmbox) {
+        nrm[2 * (f - M_first)] = bearing;
+        nrm[2 * (f - M_first) + 1] = range;
+        const_cast<int *>(inr)[f - M_first] = slot;
+      }
     }
     c.L += n_new;
     c.M += n_ok;
@@ -276,7 +290,7 @@ template <bool kMove = true>
 __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchSel &sel, const double *odom, int odom_stride,
                                               int n_measure, uint32_t *lds0, uint32_t *lds1, double *dyn, int lane,
                                               int32_t *exp_keys = nullptr, double *exp_br = nullptr, int32_t *exp_count = nullptr,
-                                              bool park_streams = false, int *mail = nullptr) {
+                                              bool park_streams = false, int *mail = nullptr, double *lmbox = nullptr) {
   uint32_t *lds[2] = {lds0, lds1};
   double *nrm = dyn;
   int *inr = reinterpret_cast<int *>(dyn + 2 * S.LG + 2);
@@ -363,7 +377,7 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
       // SS2D.simulate's two measure() calls (pyss2d.py:171-206): the first one only advances the sensor stream (obstacle
       // logic, inert at safe_distance = 0) - its 2 n_in variates are drawn and dropped together with the second call's
       DRLGX_PROF(S, 11);
-      measure(c, true, nrm, inr, n_in, nullptr, nullptr, nullptr, 2 * n_in);
+      measure(c, true, nrm, inr, n_in, nullptr, nullptr, nullptr, 2 * n_in, lmbox);
       DRLGX_PROF(S, 12);
     } else {
       for (int m = 0; m < n_measure; ++m) {

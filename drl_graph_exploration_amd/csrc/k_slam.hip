@@ -27,18 +27,44 @@ namespace kslam {
 constexpr int kThreads = 512;
 constexpr int REC = 12;  // per-factor record: [0..5] Jx (2x3) -> later G (3x2); [6..9] Jl (2x2) -> later partial; [10..11] e
 
-// BearingRangeFactor linearised at (pose, landmark) (SLAM2D.cpp:91-124; gtsam BearingRangeFactor)
+// BearingRangeFactor linearised at (pose, landmark) (SLAM2D.cpp:91-124; gtsam BearingRangeFactor).  d = the landmark in the
+// pose frame, n = |d|, (c, s) = d / n: the predicted bearing is atan2(s, c) and never needed as an angle - the error
+// Rot2 Local(measured, predicted) is taken from (c, s) directly - and the predicted range is n; the range Jacobians are
+// (-c, -s, 0) for the pose and R (c, s) for the landmark.  One square root, one division, one sincos, one atan2 (the
+// composition of bearing_of / range_of - two atan2, four trigonometric calls, two roots, six divisions - took most of the
+// 2.9 us the factor tables cost).
 __device__ __forceinline__ void linearize_br(const double *tp, const double *tl, double bm, double rm, double *rec) {
   Pose ps{tp[0], tp[1], tp[2], tp[3]};
   P2 lm{tl[0], tl[1]};
-  double Jx[6], Jl[4];
-  const double bp = bearing_of<true>(ps, lm, Jx, Jl);
-  const double rp = range_of<true>(ps, lm, Jx + 3, Jl + 2);
-  const double cm = cos(bm), sm = sin(bm), cp = cos(bp), sp = sin(bp);
-  for (int k = 0; k < 6; ++k) rec[k] = Jx[k];
-  for (int k = 0; k < 4; ++k) rec[6 + k] = Jl[k];
-  rec[10] = atan2(-sm * cp + cm * sp, cm * cp + sm * sp);  // Rot2 Local(measured, predicted)
-  rec[11] = rp - rm;
+  const P2 d = transform_to(ps, lm);
+  const double d2 = d.x * d.x + d.y * d.y, n = sqrt(d2);
+  double sm, cm;
+  sincos(bm, &sm, &cm);
+  if (n > 1e-5) {
+    const double in = 1.0 / n;
+    const double c = d.x * in, s = d.y * in;
+    const double a = -s * in, b = c * in;  // -d.y / d2, d.x / d2
+    rec[0] = -a;
+    rec[1] = -b;
+    rec[2] = a * d.y - b * d.x;
+    rec[3] = -c;
+    rec[4] = -s;
+    rec[5] = 0.0;
+    rec[6] = a * ps.c - b * ps.s;
+    rec[7] = a * ps.s + b * ps.c;
+    rec[8] = ps.c * c - ps.s * s;
+    rec[9] = ps.s * c + ps.c * s;
+    rec[10] = atan2(-sm * c + cm * s, cm * c + sm * s);
+    rec[11] = n - rm;
+  } else {  // (a landmark on top of the pose: the conventions of bearing_of / range_of)
+    double Jx[6], Jl[4];
+    (void)bearing_of<true>(ps, lm, Jx, Jl);
+    const double rp = range_of<true>(ps, lm, Jx + 3, Jl + 2);
+    for (int k = 0; k < 6; ++k) rec[k] = Jx[k];
+    for (int k = 0; k < 4; ++k) rec[6 + k] = Jl[k];
+    rec[10] = atan2(-sm, cm);
+    rec[11] = rp - rm;
+  }
 }
 
 __device__ __forceinline__ size_t up8(size_t b) { return (b + 7) & ~(size_t)7; }
@@ -666,6 +692,85 @@ __device__ __forceinline__ void pose_block(const DrlgxState &S, int inst, const 
   }
 }
 
+// ---- pose_block in pieces, for the LDS-resident solver's front end (one thread per pose ran the whole of it: ~3 us of
+// serial fp64 per pose - two atan2 among it - plus ~0.3 us per own factor, in ONE wave, while the others idled) ----
+// lower triangle (xx, yx, yy, tx, ty, tt) + gradient of one bearing-range factor seen from its pose, added to B6 / g
+__device__ __forceinline__ void own_factor_add(const double *l, double wb, double wr, double *B6, double *g) {
+  for (int r = 0, q = 0; r < 3; ++r) {
+    for (int c = 0; c <= r; ++c, ++q) B6[q] += l[r] * wb * l[c] + l[3 + r] * wr * l[3 + c];
+    g[r] += l[r] * wb * l[10] + l[3 + r] * wr * l[11];
+  }
+}
+// the prior on pose 0 (SLAM2D.cpp:44-57): its block (lower triangle) and gradient
+__device__ __forceinline__ void prior_factor(const DrlgxState &S, int inst, const double *thp, double *B6, double *g) {
+  const Pose t0{thp[0], thp[1], thp[2], thp[3]};
+  const double *pr = S.prior + (size_t)inst * DRLGX_PRIOR_STRIDE;
+  const Pose h = between(Pose{pr[0], pr[1], pr[2], pr[3]}, t0, nullptr);
+  const double e[3] = {h.x, h.y, theta_of(h)};
+  const double J[9] = {h.c, h.s, 0, -h.s, h.c, 0, 0, 0, 1};
+  const double *W = pr + 4;
+  double WJ[9], We[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) WJ[r * 3 + c] = W[r * 3] * J[c] + W[r * 3 + 1] * J[3 + c] + W[r * 3 + 2] * J[6 + c];
+    We[r] = W[r * 3] * e[0] + W[r * 3 + 1] * e[1] + W[r * 3 + 2] * e[2];
+  }
+  for (int r = 0, q = 0; r < 3; ++r) {
+    for (int c = 0; c <= r; ++c, ++q) B6[q] = J[r] * WJ[c] + J[3 + r] * WJ[3 + c] + J[6 + r] * WJ[6 + c];
+    g[r] = J[r] * We[0] + J[3 + r] * We[1] + J[6 + r] * We[2];
+  }
+}
+// odometry factor i (poses i, i + 1; SLAM2D.cpp:59-89) linearised ONCE: what it adds to the block / gradient of its first
+// key (C1, g1) and of its second key (C2, g2), and the off-diagonal block O = (i + 1, i)
+__device__ __forceinline__ void odo_factor(const DrlgxState &S, const double *thp, const double *odo, int i, double *C1, double *g1,
+                                           double *C2, double *g2, double *O) {
+  const double wt = S.w_trans, wr = S.w_rot;  // W = diag(wt, wt, wr)
+  const Pose ti{thp[4 * i], thp[4 * i + 1], thp[4 * i + 2], thp[4 * i + 3]};
+  const Pose tn{thp[4 * (i + 1)], thp[4 * (i + 1) + 1], thp[4 * (i + 1) + 2], thp[4 * (i + 1) + 3]};
+  const double *oo = odo + 4 * i;
+  double H1[9];
+  const Pose hx = between(ti, tn, H1);
+  const Pose h = between(Pose{oo[0], oo[1], oo[2], oo[3]}, hx, nullptr);
+  const double e0 = h.x, e1 = h.y, e2 = theta_of(h);
+  // Jacobians: second key Hl = [h.c h.s 0; -h.s h.c 0; 0 0 1], first key J1 = Hl H1 with H1 = [. . .; . . .; 0 0 -1] - the
+  // zero / unit entries are written out (the generic 3x3 products spend two thirds of their operations on them)
+  const double j00 = h.c * H1[0] + h.s * H1[3], j01 = h.c * H1[1] + h.s * H1[4], j02 = h.c * H1[2] + h.s * H1[5];
+  const double j10 = h.c * H1[3] - h.s * H1[0], j11 = h.c * H1[4] - h.s * H1[1], j12 = h.c * H1[5] - h.s * H1[2];
+  // C1 = J1^T W J1 (lower: xx yx yy tx ty tt), g1 = J1^T W e;  row 2 of J1 = (0, 0, -1)
+  C1[0] = wt * (j00 * j00 + j10 * j10);
+  C1[1] = wt * (j01 * j00 + j11 * j10);
+  C1[2] = wt * (j01 * j01 + j11 * j11);
+  C1[3] = wt * (j02 * j00 + j12 * j10);
+  C1[4] = wt * (j02 * j01 + j12 * j11);
+  C1[5] = wt * (j02 * j02 + j12 * j12) + wr;
+  g1[0] = wt * (j00 * e0 + j10 * e1);
+  g1[1] = wt * (j01 * e0 + j11 * e1);
+  g1[2] = wt * (j02 * e0 + j12 * e1) - wr * e2;
+  // C2 = Hl^T W Hl, g2 = Hl^T W e
+  const double n2 = h.c * h.c + h.s * h.s;
+  C2[0] = wt * n2; C2[1] = 0.0; C2[2] = wt * n2; C2[3] = 0.0; C2[4] = 0.0; C2[5] = wr;
+  g2[0] = wt * (h.c * e0 - h.s * e1);
+  g2[1] = wt * (h.s * e0 + h.c * e1);
+  g2[2] = wr * e2;
+  // O = Hl^T W J1 = block (i + 1, i)
+  O[0] = wt * (h.c * j00 - h.s * j10); O[1] = wt * (h.c * j01 - h.s * j11); O[2] = wt * (h.c * j02 - h.s * j12);
+  O[3] = wt * (h.s * j00 + h.c * j10); O[4] = wt * (h.s * j01 + h.c * j11); O[5] = wt * (h.s * j02 + h.c * j12);
+  O[6] = 0.0; O[7] = 0.0; O[8] = -wr;
+}
+// sum over the aligned groups of 8 lanes, in the lane with (lane & 7) == 7: DPP row shifts, no LDS traffic
+template <int kCtrl>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, kCtrl, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), kCtrl, 0xf, 0xf, true);
+  return v + __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double sum8_lane7(double v) {
+  v = dpp_add_f64<0x111>(v);  // row_shr:1
+  v = dpp_add_f64<0x112>(v);  // row_shr:2
+  v = dpp_add_f64<0x114>(v);  // row_shr:4
+  return v;
+}
+
 // Symmetric Gauss-Jordan sweep of the packed lower triangle `A` (LDS, row i at i (i + 1) / 2, N = 16 Tn <= 16 FT rows; the
 // region must hold sweep_region_doubles(N) doubles: the sweep panels alias it while the tiles are in registers) on
 // the pivots [0, np); rows >= np (the rhs row np, pads) are carried along.  Afterwards A holds -A_pp^-1 and row np the
@@ -966,6 +1071,14 @@ struct SubBarrier {
   }
 };
 
+// What the simulator wave of k_step appended in this step, left in LDS (ksim::measure): factor M0 + r = (newest pose,
+// landmark slot[r], bearing br[2 r], range br[2 r + 1]), new landmark L0 + r at lm[2 r], lm[2 r + 1].  br == null: not there.
+struct SimBox {
+  const double *br;
+  const int *slot;
+  const double *lm;
+};
+
 // The fast path: <= 42 poses (N <= 16 FT = 128), the whole problem in LDS.  Longer trajectories: arrow_body (k_slam_arrow.hip).
 //
 // The update is split in two so that the fused step kernel can run the first part BESIDE the simulator wave:
@@ -1041,10 +1154,23 @@ struct SlamCtx {
   }
 
   // tables + the (expensive) linearisation of the factors [m0, m1), one thread each
-  __device__ __forceinline__ void factor_tables(const DrlgxState &S, int m0, int m1, int t, int nt) const {
+  __device__ __forceinline__ void factor_tables(const DrlgxState &S, int m0, int m1, int t, int nt, const SimBox &box = SimBox{nullptr, nullptr, nullptr}) const {
     const int *meas_pose = S.meas_pose + (size_t)inst * S.M_max;
     const int *meas_lm = S.meas_lm + (size_t)inst * S.M_max;
     const double *meas_br = S.meas_br + (size_t)inst * S.M_max * 2;
+    if (box.br) {  // this step's factors from the simulator wave's LDS: all of them observed from the newest pose
+      const int p = P - 1;
+      for (int m = m0 + t; m < m1; m += nt) {
+        const int j = box.slot[m - m0];
+        mp[m] = (unsigned short)p;
+        ml[m] = (unsigned short)j;
+        if (m == m0) mstart[p] = m;
+        obs[j * P + p] = (unsigned short)(m + 1);
+        atomicOr(&lmask[MW * j + (p >> 6)], 1ull << (p & 63));
+        linearize_br(thp + 4 * p, thl + 2 * j, box.br[2 * (m - m0)], box.br[2 * (m - m0) + 1], rec + (size_t)REC * m);
+      }
+      return;
+    }
     for (int m = m0 + t; m < m1; m += nt) {
       const int p = meas_pose[m], j = meas_lm[m];
       mp[m] = (unsigned short)p;
@@ -1123,8 +1249,10 @@ struct SlamCtx {
     for (int e = ft; e <= P; e += fn) mstart[e] = 0x7fffffff;
     if (ft == 0) bad[0] = 0;
     bar();
+    if (S.prof && blockIdx.x == S.prof_block && ft == 0) S.prof[33] = wall_clock64();
     factor_tables(S, 0, Mf, ft, fn);
     bar();
+    if (S.prof && blockIdx.x == S.prof_block && ft == 0) S.prof[34] = wall_clock64();
     // poses without factors get the empty range [next pose's start, same): the first assigned start at or after p, i.e.
     // the suffix minimum of the raw starts (they increase with the pose); one wave, top chunk first
     if (ft < 64) {
@@ -1143,9 +1271,9 @@ struct SlamCtx {
       }
     }
     bar();
+    if (S.prof && blockIdx.x == S.prof_block && ft == 0) S.prof[35] = wall_clock64();
     // ---- 3. block assembly.  first waves: one thread per landmark; following waves: one thread per pose ----
-    const double wb = 1.0 / (cfg.bearing_noise * cfg.bearing_noise), wr = 1.0 / (cfg.range_noise * cfg.range_noise);
-    const int pose_t0 = ((Lf + 63) & ~63) % fn;  // poses start on a fresh wave so both roles overlap
+    const double wb = S.w_bear, wr = S.w_range;
     for (int j = ft; j < Lf; j += fn) {
       double a = 0, b = 0, d = 0, g0 = 0, g1 = 0;
       FOR_EACH_OBSERVING_POSE(lmask + MW * j, MW, p) {
@@ -1159,18 +1287,65 @@ struct SlamCtx {
       double *lb = lamb + 8 * j;
       lb[0] = a; lb[1] = b; lb[2] = d; lb[3] = g0; lb[4] = g1;  // (sums so far; back() appends this step's terms)
     }
-    for (int i = (ft - pose_t0 + fn) % fn; i < P; i += fn) {
-      double B[9], g[3], O[9];
-      pose_block(S, inst, thp, odl, rec, mstart, i, P, wb, wr, B, g, O);
-      if (i + 1 < P)
+    // Pose blocks (pose_block in pieces).  The LAST wave: lane i linearises odometry factor i once - for both of its keys -
+    // and lane P - 1, which has none, the prior; the contributions to the second key travel through LDS (`c2buf`, 9 doubles
+    // per pose; slot 0 = the prior).  The threads below it, eight per pose from the top down (the landmark loop above
+    // occupies the first ones): the own bearing-range factors, every eighth factor per lane, summed over the eight lanes.
+    // The newest pose is the exception: its own factors are added one by one, afterwards - as back() does it when this
+    // front end ran before they existed (k_step), so that both ways round alike.
+    double *c2buf = A + (size_t)N * (N + 1) / 2;  // (the sweep region is larger than the packed triangle: >= 18 P doubles)
+    double *ownsum = c2buf + 9 * P;
+    const int la = ft - (fn - 64);
+    double B6[6] = {0, 0, 0, 0, 0, 0}, g3[3] = {0, 0, 0};
+    if (la >= 0) {
+      if (la + 1 < P) {
+        double C2[6], g2[3], O[9];
+        odo_factor(S, thp, odl, la, B6, g3, C2, g2, O);
+        double *o2 = c2buf + 9 * (la + 1);
+        for (int q = 0; q < 6; ++q) o2[q] = C2[q];
+        for (int r = 0; r < 3; ++r) o2[6 + r] = g2[r];
         for (int r = 0; r < 3; ++r)
-          for (int c = 0; c < 3; ++c) A[AT((3 * (i + 1) + r), 3 * i + c)] = O[r * 3 + c];
-      for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c <= r; ++c) A[AT((3 * i + r), 3 * i + c)] = B[r * 3 + c];
-        A[AT(np, 3 * i + r)] = -g[r];  // rhs lives in the augmented row
+          for (int c = 0; c < 3; ++c) A[AT((3 * (la + 1) + r), 3 * la + c)] = O[r * 3 + c];
+      } else if (la == P - 1) {
+        double PB[6], pg[3];
+        prior_factor(S, inst, thp, PB, pg);
+        for (int q = 0; q < 6; ++q) c2buf[q] = PB[q];
+        for (int r = 0; r < 3; ++r) c2buf[6 + r] = pg[r];
+      }
+    } else {
+      const int idx = fn - 65 - ft, grp = idx >> 3, part = idx & 7, ngrp = (fn - 64) >> 3;
+      for (int i0 = 0; i0 < P; i0 += ngrp) {  // (uniform trip count: the lane sums run on whole waves)
+        const int i = i0 + grp;
+        double s6[6] = {0, 0, 0, 0, 0, 0}, sg[3] = {0, 0, 0};
+        if (i < P - 1 || (i == P - 1 && kSub))  // (kSub: the newest pose has no factors yet; else they follow one by one)
+          for (int m = mstart[i] + part; m < mstart[i + 1]; m += 8) own_factor_add(rec + (size_t)REC * m, wb, wr, s6, sg);
+        for (int q = 0; q < 6; ++q) s6[q] = sum8_lane7(s6[q]);
+        for (int r = 0; r < 3; ++r) sg[r] = sum8_lane7(sg[r]);
+        if (i < P && (lane & 7) == 7) {
+          double *o = ownsum + 9 * i;
+          for (int q = 0; q < 6; ++q) o[q] = s6[q];
+          for (int r = 0; r < 3; ++r) o[6 + r] = sg[r];
+        }
       }
     }
-    if (S.prof && blockIdx.x == S.prof_block && ft == 0) S.prof[14] = wall_clock64();  // (dev aid: end of the front end)
+    bar();
+    if (la >= 0 && la < P) {
+      // prior / second key, first key, own factors: the order pose_block adds them in
+      const double *c2 = c2buf + 9 * la, *own = ownsum + 9 * la;
+      double B[6], g[3];
+      for (int q = 0; q < 6; ++q) B[q] = (c2[q] + B6[q]) + own[q];
+      for (int r = 0; r < 3; ++r) g[r] = (c2[6 + r] + g3[r]) + own[6 + r];
+      if (!kSub && la == P - 1)
+        for (int m = mstart[la]; m < mstart[la + 1]; ++m) own_factor_add(rec + (size_t)REC * m, wb, wr, B, g);
+      for (int r = 0, q = 0; r < 3; ++r) {
+        for (int c = 0; c <= r; ++c, ++q) A[AT((3 * la + r), 3 * la + c)] = B[q];
+        A[AT(np, 3 * la + r)] = -g[r];  // rhs lives in the augmented row
+      }
+    }
+    if (S.prof && blockIdx.x == S.prof_block) {  // (dev aid: end of the front end, first thread and per wave)
+      if (ft == 0) S.prof[14] = wall_clock64();
+      if (lane == 0) S.prof[24 + (tid >> 6)] = wall_clock64();
+    }
   }
 
   // everything after the simulator: all kThreads threads, hardware barriers.  Lfin / Mfin: the final counts (>= the front's).
@@ -1178,25 +1353,26 @@ struct SlamCtx {
   // hand + 4 P_max, pose_info [P][6] - so that it does not fetch them back from HBM; the landmark estimates are left in
   // `thl` for the same reason (the linearisation points are dead by then)
   template <int FT>
-  __device__ __forceinline__ void back(const DrlgxState &S, int tid, int Lfin, int Mfin, bool full, bool refresh, double *hand = nullptr) {
+  __device__ __forceinline__ void back(const DrlgxState &S, int tid, int Lfin, int Mfin, bool full, bool refresh, double *hand = nullptr,
+                                       const SimBox &box = SimBox{nullptr, nullptr, nullptr}) {
     int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
     double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
     double *d_lm = S.d_lm + (size_t)inst * S.L_max * 2;
     const drlgx_config &cfg = S.cfg;
-    const double wb = 1.0 / (cfg.bearing_noise * cfg.bearing_noise), wr = 1.0 / (cfg.range_noise * cfg.range_noise);
+    const double wb = S.w_bear, wr = S.w_range;
     double *th_lm = S.th_lm + (size_t)inst * S.L_max * 2;
     const int L0 = L, M0 = M;
     L = Lfin; M = Mfin;
     // ---- this step's landmarks and factors (all of them observed from the newest pose) ----
     for (int j = L0 + tid; j < L; j += kThreads) {
-      thl[2 * j] = th_lm[2 * j];
-      thl[2 * j + 1] = th_lm[2 * j + 1];
+      thl[2 * j] = box.br ? box.lm[2 * (j - L0)] : th_lm[2 * j];
+      thl[2 * j + 1] = box.br ? box.lm[2 * (j - L0) + 1] : th_lm[2 * j + 1];
       double *lb = lamb + 8 * j;
       lb[0] = lb[1] = lb[2] = lb[3] = lb[4] = 0.0;
     }
     if (tid == 0) mstart[P] = M;
     __syncthreads();
-    factor_tables(S, M0, M, tid, kThreads);
+    factor_tables(S, M0, M, tid, kThreads, box);
     __syncthreads();
     DRLGX_PROF(S, 1);
     // ---- landmark blocks: this step's term (at most one per landmark) closes the sum, then Lambda_jj^-1 and eta_j;
@@ -1246,19 +1422,13 @@ struct SlamCtx {
       }
     }
     if (M > M0 && tid == kThreads / 2) {
-      // pose_block's own-factor loop for the factors appended after the front ran (same expressions, same order)
+      // the own factors of the newest pose, appended after the front ran (front(): the same loop when it runs after them)
       const int i = P - 1;
       double B[6], g[3];
       for (int r = 0, q = 0; r < 3; ++r)
         for (int c = 0; c <= r; ++c, ++q) B[q] = A[AT(3 * i + r, 3 * i + c)];
       for (int r = 0; r < 3; ++r) g[r] = -A[AT(np, 3 * i + r)];
-      for (int m = M0; m < M; ++m) {
-        const double *l = rec + (size_t)REC * m;
-        for (int r = 0, q = 0; r < 3; ++r) {
-          for (int c = 0; c <= r; ++c, ++q) B[q] += l[r] * wb * l[c] + l[3 + r] * wr * l[3 + c];
-          g[r] += l[r] * wb * l[10] + l[3 + r] * wr * l[11];
-        }
-      }
+      for (int m = M0; m < M; ++m) own_factor_add(rec + (size_t)REC * m, wb, wr, B, g);
       for (int r = 0, q = 0; r < 3; ++r) {
         for (int c = 0; c <= r; ++c, ++q) A[AT(3 * i + r, 3 * i + c)] = B[q];
         A[AT(np, 3 * i + r)] = -g[r];
@@ -1510,7 +1680,8 @@ struct SlamCtx {
 // for the counts before the step (records in LDS).  smem_off: first byte of the dynamic LDS the stage may use.
 template <int FT>
 __device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel &sel, int lds_bytes, size_t smem_off, const SlamCtx &pre, bool have_pre,
-                                            const int *mail = nullptr, double *hand = nullptr, const double **lm_out = nullptr) {
+                                            const int *mail = nullptr, double *hand = nullptr, const double **lm_out = nullptr,
+                                            SimBox box = SimBox{nullptr, nullptr, nullptr}) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int bi = blockIdx.x;
@@ -1533,7 +1704,8 @@ __device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel
   }
   DRLGX_PROF(S, 0);
   SlamCtx c;
-  if (have_pre && !refresh && pre.P == P && L <= pre.Lb && M <= pre.Mb) {
+  const bool from_pre = have_pre && !refresh && pre.P == P && L <= pre.Lb && M <= pre.Mb;
+  if (from_pre) {
     c = pre;
   } else {
     // stand-alone kernel, a rejected move, or more new landmarks / factors than the front reserved room for: everything now
@@ -1543,7 +1715,7 @@ __device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel
     c.front<false>(S, tid, P, L, M, n_old_p, n_old_l, count, refresh, nullptr, SubBarrier{nullptr, 0, 0});
     __syncthreads();
   }
-  c.back<FT>(S, tid, L, M, full, refresh, hand);
+  c.back<FT>(S, tid, L, M, full, refresh, hand, (from_pre && mailed) ? box : SimBox{nullptr, nullptr, nullptr});
   if (lm_out) *lm_out = c.thl;
 }
 

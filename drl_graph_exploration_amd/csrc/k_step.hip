@@ -20,6 +20,7 @@ namespace kstep {
 // stage of k_step carves behind it because its front end runs WHILE the simulator wave works
 __host__ __device__ inline size_t sim_lds_bytes(int LG, int P_max) {
   size_t b = (size_t)2 * DRLGX_MT_STRIDE * 4 + (size_t)(2 * LG + 2) * 8 + (size_t)LG * 4 + 16;
+  b = ((b + 7) & ~(size_t)7) + (size_t)2 * LG * 8;  // the new landmarks' initial estimates, for the SLAM stage (ksim::measure)
   // ... and, when that costs little, wide enough for the map stage's pose tables (19 P_max doubles), so that the SLAM stage
   // can leave its outputs in them (see k_step)
   if (P_max <= 64) b = b > (size_t)P_max * 19 * 8 + 32 ? b : (size_t)P_max * 19 * 8 + 32;
@@ -37,6 +38,10 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
   // ---- what the SLAM front end needs is read before the simulator wave starts to change it ----
   const size_t sim_bytes = sim_lds_bytes(S.LG, S.P_max);
   int *sub_cnt = reinterpret_cast<int *>(step_smem + sim_bytes - 16);
+  // what the simulator wave appends, left in LDS for the SLAM stage (ksim::measure)
+  double *sim_dyn = reinterpret_cast<double *>(step_smem + 2 * DRLGX_MT_STRIDE * sizeof(uint32_t));
+  double *lmbox = reinterpret_cast<double *>(step_smem + sim_bytes - 16 - (size_t)2 * S.LG * 8);
+  const kslam::SimBox box{n_measure == 2 ? sim_dyn : nullptr, reinterpret_cast<const int *>(sim_dyn + 2 * S.LG + 2), lmbox};
   kslam::SlamCtx ctx;
   bool pre = false, accepted = false;
   double od3[3] = {0, 0, 0};
@@ -65,12 +70,14 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
     // wave 0: the (single-wave) simulator; the other seven waves: the part of the SLAM update that does not depend on it
     uint32_t *l0 = reinterpret_cast<uint32_t *>(step_smem);
     uint32_t *l1 = l0 + DRLGX_MT_STRIDE;
-    double *dyn = reinterpret_cast<double *>(step_smem + 2 * DRLGX_MT_STRIDE * sizeof(uint32_t));  // 5008 B: 16-aligned
-    ksim::sim_step_body(S, sel, odom, odom_stride, n_measure, l0, l1, dyn, tid, nullptr, nullptr, nullptr, true, sub_cnt + 1);
+    double *dyn = sim_dyn;  // 5008 B: 16-aligned
+    ksim::sim_step_body(S, sel, odom, odom_stride, n_measure, l0, l1, dyn, tid, nullptr, nullptr, nullptr, true, sub_cnt + 1,
+                        n_measure == 2 ? lmbox : nullptr);
   } else if (pre) {
     ctx.front<true>(S, tid, P0, L0, M0, P0, L0, isam + 1, false, od3, kslam::SubBarrier{sub_cnt, kslam::kThreads / 64 - 1, 0});
   }
   __syncthreads();
+  DRLGX_PROF(S, 32);
   if (accepted && tid >= 64) {
     // the two random streams go back to HBM from their LDS images (the simulator wave left the counters in them): seven
     // waves, in the shadow of the few threads that linearise this step's factors
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
   // long as they lie below its cell masks, which it clears first.
   const bool hand = (size_t)S.P_max * 19 * sizeof(double) + 16 <= sim_bytes - 16;
   const double *lm_lds = nullptr;
-  kslam::slam_finish<FT>(S, sel, lds_bytes, sim_bytes, ctx, pre, sub_cnt + 1, hand ? reinterpret_cast<double *>(step_smem) : nullptr, &lm_lds);
+  kslam::slam_finish<FT>(S, sel, lds_bytes, sim_bytes, ctx, pre, sub_cnt + 1, hand ? reinterpret_cast<double *>(step_smem) : nullptr, &lm_lds, box);
   __syncthreads();
   const bool handed = hand && lm_lds != nullptr;  // (lm_lds: set once the SLAM stage ran to its end)
   const unsigned char *map_masks = step_smem + ((size_t)S.P_max * 19 + (size_t)map_chunk * 64 * 3) * sizeof(double);

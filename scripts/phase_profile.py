@@ -26,6 +26,7 @@ print("k_slam phases after the simulator (us, block 0; the front end runs beside
 for k in range(1, 8): print("  %-24s %8.2f" % (names[k], (a[k]-a[k-1]) / 100.0))
 print("  total %.2f" % ((a[7]-a[0]) / 100.0))
 print("simulator start -> SLAM back start: %.2f us; -> end of the SLAM front end (first front thread): %.2f us" % ((a[0] - a[8]) / 100.0, (a[14] - a[8]) / 100.0))
+print("SLAM front end beside the simulator (us after the simulator's start): staged %.2f, factor tables %.2f, list starts %.2f; block assembly ends per wave 1..7: %s; barrier after both: %.2f" % ((a[33]-a[8])/100.0, (a[34]-a[8])/100.0, (a[35]-a[8])/100.0, " ".join("%.2f" % ((a[24+w]-a[8])/100.0) for w in range(1, 8)), (a[32]-a[8])/100.0))
 print("k_sim phases (us, block 0): load %.2f, move %.2f, measure-1 %.2f, measure-2 %.2f, store %.2f, total %.2f" % (tuple((a[i+1]-a[i])/100.0 for i in (8,9,10,11,12)) + ((a[13]-a[8])/100.0,)))
 print("k_map phases: see scripts/phase_profile_map.py")
 eng.timing_enable(True); eng.timing_read()
