@@ -164,8 +164,16 @@ __device__ __forceinline__ double block_sum(double v, double *scratch, int tid) 
 // handed (k_step): est_pose / pose_info of this instance already are in the LDS where this stage keeps them (sp, si) and
 // lm_lds holds the landmark estimates (LDS of the SLAM stage that this stage does not overwrite before it has read them):
 // nothing is fetched back from HBM
+// lo: entry threadIdx.x of the ladder tables (k_step fetches them before the SLAM stage: one HBM round trip less here)
+// P >= 0: the instance's counts and rejected-move flag as k_step knows them from the simulator wave (else read from S.cnt)
+struct LadderEntry {
+  bool have;
+  double pv;
+  uint32_t tr;
+  int P, L, flag;
+};
 __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &sel, int rebuild, int chunk, bool handed = false,
-                                         const double *lm_lds = nullptr) {
+                                         const double *lm_lds = nullptr, LadderEntry lo = LadderEntry{false, 0.0, 0u, -1, 0, 0}) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bi = blockIdx.x;
@@ -173,9 +181,9 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
   const int inst = sel.base + bi;
   const int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
   // a rejected move leaves the belief as it was: nothing to rebuild, unless this is the one rebuild of a rollout
-  if (cnt[C_FLAG] && !sel.map_last_only) return;
+  if ((lo.P >= 0 ? lo.flag : cnt[C_FLAG]) && !sel.map_last_only) return;
   const drlgx_config &cfg = S.cfg;
-  const int P = cnt[C_P], L = cnt[C_L];
+  const int P = lo.P >= 0 ? lo.P : cnt[C_P], L = lo.P >= 0 ? lo.L : cnt[C_L];
   const int V = S.V, cols = S.cols, rows = S.rows, W = S.win;
   // LDS carve
   double *sp = smem;                       // [P_max][4]
@@ -215,9 +223,16 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
       omask[v] = 0ull;
     }
     if (tid == 0) *pcount = 0;
-    for (int t = tid; t < S.lo_ntab; t += kThreads) {
-      lpv[t] = S.lo_pv[t];
-      reinterpret_cast<uint32_t *>(ltr)[t] = reinterpret_cast<const uint32_t *>(S.lo_tr)[t];
+    if (lo.have) {
+      if (tid < S.lo_ntab) {
+        lpv[tid] = lo.pv;
+        reinterpret_cast<uint32_t *>(ltr)[tid] = lo.tr;
+      }
+    } else {
+      for (int t = tid; t < S.lo_ntab; t += kThreads) {
+        lpv[t] = S.lo_pv[t];
+        reinterpret_cast<uint32_t *>(ltr)[t] = reinterpret_cast<const uint32_t *>(S.lo_tr)[t];
+      }
     }
     __syncthreads();
     DRLGX_PROF(S, 40);

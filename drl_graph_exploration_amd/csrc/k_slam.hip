@@ -243,7 +243,7 @@ struct Inv16Lane {  // lane constants of the block inversion
   }
 };
 template <int Kb>
-__device__ __forceinline__ void inv16_blk_step(const SweepCtx &x, const Inv16Lane &q, v4d &d) {
+__device__ __forceinline__ void inv16_blk_step(const SweepCtx &x, const Inv16Lane &q, v4d &d, bool &spd) {
   constexpr int c0 = 4 * Kb;
   const double a00 = readlane_f64(d[Kb], c0);
   const double a10 = readlane_f64(d[Kb], 16 + c0), a11 = readlane_f64(d[Kb], 16 + c0 + 1);
@@ -267,7 +267,7 @@ __device__ __forceinline__ void inv16_blk_step(const SweepCtx &x, const Inv16Lan
   const double r00 = s11 * is, r10 = -s10 * is, r11 = s00 * is;           // S^-1
   const double u00 = r00 * t00 + r10 * t10, u01 = r00 * t01 + r10 * t11;  // U = S^-1 T
   const double u10 = r10 * t00 + r11 * t10, u11 = r10 * t01 + r11 * t11;
-  if (x.lane == 0 && (!(a00 > 0) || !(detp > 0) || !(s00 > 0) || !(dets > 0))) x.bad[0] = 1;
+  spd = spd && (a00 > 0) && (detp > 0) && (s00 > 0) && (dets > 0);  // (tested once per tile: off the dependent chain)
   // this lane's entry E4[lr][lc & 3] of  E4 = -D^-1 = -[P^-1 + T^T U, -U^T; -U, S^-1]
   const double t0x = q.lr1 ? t01 : t00, t1x = q.lr1 ? t11 : t10;  // T[.][lr & 1]
   const double u0c = q.c1 ? u01 : u00, u1c = q.c1 ? u11 : u10;    // U[.][lc & 1]
@@ -299,10 +299,12 @@ __device__ __forceinline__ void inv16_blk(const SweepCtx &x, int nact, v4d &d) {
     }
   }
   const Inv16Lane q(x.lr, x.lc);
-  inv16_blk_step<0>(x, q, d);
-  inv16_blk_step<1>(x, q, d);
-  inv16_blk_step<2>(x, q, d);
-  inv16_blk_step<3>(x, q, d);
+  bool spd = true;
+  inv16_blk_step<0>(x, q, d, spd);
+  inv16_blk_step<1>(x, q, d, spd);
+  inv16_blk_step<2>(x, q, d, spd);
+  inv16_blk_step<3>(x, q, d, spd);
+  if (!spd && x.lane == 0) x.bad[0] = 1;
 }
 
 // ---- the fast sweep as ONE runtime loop over the block steps ----

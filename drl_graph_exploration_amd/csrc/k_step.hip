@@ -42,6 +42,12 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
   double *sim_dyn = reinterpret_cast<double *>(step_smem + 2 * DRLGX_MT_STRIDE * sizeof(uint32_t));
   double *lmbox = reinterpret_cast<double *>(step_smem + sim_bytes - 16 - (size_t)2 * S.LG * 8);
   const kslam::SimBox box{n_measure == 2 ? sim_dyn : nullptr, reinterpret_cast<const int *>(sim_dyn + 2 * S.LG + 2), lmbox};
+  // (the map stage's ladder tables: fetched now, stored to its LDS after the SLAM stage)
+  kmap::LadderEntry lo{S.lo_ntab <= kslam::kThreads, 0.0, 0u, -1, 0, 0};
+  if (lo.have && tid < S.lo_ntab) {
+    lo.pv = S.lo_pv[tid];
+    lo.tr = reinterpret_cast<const uint32_t *>(S.lo_tr)[tid];
+  }
   kslam::SlamCtx ctx;
   bool pre = false, accepted = false;
   double od3[3] = {0, 0, 0};
@@ -95,9 +101,15 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
   kslam::slam_finish<FT>(S, sel, lds_bytes, sim_bytes, ctx, pre, sub_cnt + 1, hand ? reinterpret_cast<double *>(step_smem) : nullptr, &lm_lds, box);
   __syncthreads();
   const bool handed = hand && lm_lds != nullptr;  // (lm_lds: set once the SLAM stage ran to its end)
+  if (sel.on(bi)) {  // the counts as the simulator wave left them (nothing appended: those before the step)
+    const bool appended = sub_cnt[1] >= 0;
+    lo.P = appended ? sub_cnt[1] : P0;
+    lo.L = appended ? sub_cnt[2] : L0;
+    lo.flag = appended ? 0 : 1;
+  }
   const unsigned char *map_masks = step_smem + ((size_t)S.P_max * 19 + (size_t)map_chunk * 64 * 3) * sizeof(double);
   if (!handed || reinterpret_cast<const unsigned char *>(lm_lds + 2 * (size_t)S.L_max) > map_masks) lm_lds = nullptr;
-  kmap::map_body(S, sel, 1, map_chunk, handed, lm_lds);
+  kmap::map_body(S, sel, 1, map_chunk, handed, lm_lds, lo);
   if (S.prof && tid == 0 && bi < 448) S.prof[129 + 2 * bi] = wall_clock64();
 }
 
