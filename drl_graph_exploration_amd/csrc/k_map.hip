@@ -418,18 +418,37 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
       // kernel slower: ranking costs more than it saves, and with the queue the barrier after the pass completed 1.9 us
       // after the last wave instead of 0.2 us.)
       const int tiles_c = (cols + 7) >> 3, ntiles = ((rows + 7) >> 3) * tiles_c;
-      for (int t = wave; t < ntiles; t += kWaves) {
+      // the three per-cell LDS words of a tile (update mask, sees-me mask, landmark count) are fetched one tile ahead: each
+      // is the head of a dependent chain and a wave has nothing else to cover the LDS latency with
+      auto cell_of = [&](int t, int &row, int &col) -> int {
         const int trow = t / tiles_c, tcol = t - trow * tiles_c;
-        const int row = 8 * trow + (lane >> 3), col = 8 * tcol + (lane & 7);
-        const bool ok = row < rows && col < cols;
-        const int v = ok ? row * cols + col : 0;
+        row = 8 * trow + (lane >> 3);
+        col = 8 * tcol + (lane & 7);
+        return (row < rows && col < cols) ? row * cols + col : -1;
+      };
+      int nrow = 0, ncol = 0;
+      int nv = wave < ntiles ? cell_of(wave, nrow, ncol) : -1;
+      unsigned long long nm = nv >= 0 ? mask[nv] : 0ull, nom = nv >= 0 ? omask[nv] : 0ull;
+      int nlmc = nv >= 0 ? lmc[nv] : 0;
+      for (int t = wave; t < ntiles; t += kWaves) {
+        const int row = nrow, col = ncol;
+        const bool ok = nv >= 0;
+        const int v = ok ? nv : 0;
+        unsigned long long m = nm;
+        const unsigned long long om_cell = nom;
+        const int lmc_cell = nlmc;
+        if (t + kWaves < ntiles) {
+          nv = cell_of(t + kWaves, nrow, ncol);
+          nm = nv >= 0 ? mask[nv] : 0ull;
+          nom = nv >= 0 ? omask[nv] : 0ull;
+          nlmc = nv >= 0 ? lmc[nv] : 0;
+        }
         double axx = i0, axy = 0.0, ayy = i0;
         int u = 0;
         if (c0 > 0) {
           axx = ixx[v]; axy = ixy[v]; ayy = iyy[v];
           u = upd[v];
         }
-        unsigned long long m = ok ? mask[v] : 0ull;
         const double *nx = stage + lane * 3;  // + 192 * (pose within the chunk): the slot is the lane
         const long long tc0 = wprof ? wall_clock64() : 0;
         if (m && !u) {  // the first update of an untouched cell replaces the prior (VirtualMap.cpp:300-304)
@@ -466,7 +485,7 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
           int st = 0;      // ... as a state of the precomputed ladder (DrlgxState::lo_tr) when it is closed
           const bool fsm = S.lo_ntab > 0;
           if (c0 == 0) {
-            for (int n = lmc[v]; n > 0; --n) {
+            for (int n = lmc_cell; n > 0; --n) {
               l = fmin(S.lo_max, fmax(S.lo_min, l + S.lo_occ));
               st = ltr[4 * st];
             }
@@ -474,7 +493,7 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
             l = prob[v];
             st = (int)l;
           }
-          m = omask[v];
+          m = om_cell;
           if (fsm_reg) {
             // a state that maps to itself is absorbing (the transition depends on the state only): the remaining bits
             // cannot change it (cells at the clamped minimum / maximum, i.e. every cell seen more than a few times)
