@@ -1295,9 +1295,8 @@ struct SlamCtx {
     // Pose blocks (pose_block in pieces).  The LAST wave: lane i linearises odometry factor i once - for both of its keys -
     // and lane P - 1, which has none, the prior; the contributions to the second key travel through LDS (`c2buf`, 9 doubles
     // per pose; slot 0 = the prior).  The threads below it, eight per pose from the top down (the landmark loop above
-    // occupies the first ones): the own bearing-range factors, every eighth factor per lane, summed over the eight lanes.
-    // The newest pose is the exception: its own factors are added one by one, afterwards - as back() does it when this
-    // front end ran before they existed (k_step), so that both ways round alike.
+    // occupies the first ones): the own bearing-range factors, every eighth factor per lane, summed over the eight lanes
+    // (back() adds the newest pose's the same way when this front end ran before they existed: both ways round alike).
     double *c2buf = A + (size_t)N * (N + 1) / 2;  // (the sweep region is larger than the packed triangle: >= 18 P doubles)
     double *ownsum = c2buf + 9 * P;
     const int la = ft - (fn - 64);
@@ -1322,7 +1321,7 @@ struct SlamCtx {
       for (int i0 = 0; i0 < P; i0 += ngrp) {  // (uniform trip count: the lane sums run on whole waves)
         const int i = i0 + grp;
         double s6[6] = {0, 0, 0, 0, 0, 0}, sg[3] = {0, 0, 0};
-        if (i < P - 1 || (i == P - 1 && kSub))  // (kSub: the newest pose has no factors yet; else they follow one by one)
+        if (i < P)
           for (int m = mstart[i] + part; m < mstart[i + 1]; m += 8) own_factor_add(rec + (size_t)REC * m, wb, wr, s6, sg);
         for (int q = 0; q < 6; ++q) s6[q] = sum8_lane7(s6[q]);
         for (int r = 0; r < 3; ++r) sg[r] = sum8_lane7(sg[r]);
@@ -1340,8 +1339,6 @@ struct SlamCtx {
       double B[6], g[3];
       for (int q = 0; q < 6; ++q) B[q] = (c2[q] + B6[q]) + own[q];
       for (int r = 0; r < 3; ++r) g[r] = (c2[6 + r] + g3[r]) + own[6 + r];
-      if (!kSub && la == P - 1)
-        for (int m = mstart[la]; m < mstart[la + 1]; ++m) own_factor_add(rec + (size_t)REC * m, wb, wr, B, g);
       for (int r = 0, q = 0; r < 3; ++r) {
         for (int c = 0; c <= r; ++c, ++q) A[AT((3 * la + r), 3 * la + c)] = B[q];
         A[AT(np, 3 * la + r)] = -g[r];  // rhs lives in the augmented row
@@ -1426,17 +1423,19 @@ struct SlamCtx {
         pstart[L] = (int)(carry >> 16);
       }
     }
-    if (M > M0 && tid == kThreads / 2) {
-      // the own factors of the newest pose, appended after the front ran (front(): the same loop when it runs after them)
-      const int i = P - 1;
-      double B[6], g[3];
-      for (int r = 0, q = 0; r < 3; ++r)
-        for (int c = 0; c <= r; ++c, ++q) B[q] = A[AT(3 * i + r, 3 * i + c)];
-      for (int r = 0; r < 3; ++r) g[r] = -A[AT(np, 3 * i + r)];
-      for (int m = M0; m < M; ++m) own_factor_add(rec + (size_t)REC * m, wb, wr, B, g);
-      for (int r = 0, q = 0; r < 3; ++r) {
-        for (int c = 0; c <= r; ++c, ++q) A[AT(3 * i + r, 3 * i + c)] = B[q];
-        A[AT(np, 3 * i + r)] = -g[r];
+    if (M > M0 && (tid >> 3) == kThreads / 16) {
+      // the own factors of the newest pose, appended after the front ran: eight lanes, every eighth factor each, like the
+      // front end sums the own factors of every pose (so that (front + this) == the front alone when it runs after them)
+      const int i = P - 1, part = 7 - (tid & 7);
+      double s6[6] = {0, 0, 0, 0, 0, 0}, sg[3] = {0, 0, 0};
+      for (int m = M0 + part; m < M; m += 8) own_factor_add(rec + (size_t)REC * m, wb, wr, s6, sg);
+      for (int q = 0; q < 6; ++q) s6[q] = sum8_lane7(s6[q]);
+      for (int r = 0; r < 3; ++r) sg[r] = sum8_lane7(sg[r]);
+      if ((tid & 7) == 7) {
+        for (int r = 0, q = 0; r < 3; ++r) {
+          for (int c = 0; c <= r; ++c, ++q) A[AT(3 * i + r, 3 * i + c)] += s6[q];
+          A[AT(np, 3 * i + r)] = -(-A[AT(np, 3 * i + r)] + sg[r]);
+        }
       }
     }
     __syncthreads();
