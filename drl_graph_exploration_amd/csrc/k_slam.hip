@@ -1482,7 +1482,9 @@ struct SlamCtx {
         // faster than this plain loop (5.2 us; 9.1 us for the instances with the most factors, of which 2.1 / 4.3 us are
         // the look-ups and the rest the terms): four look-ups per round issued together; look-ups software-pipelined one
         // factor ahead; the landmarks common to both poses from per-pose bit masks; diagonal-major pair order (lanes of
-        // similar hit counts, but different factor lists: 6.2 / 9.8 us).
+        // similar hit counts, but different factor lists: 6.2 / 9.8 us); two lanes per pair on the even / odd factors with a
+        // DPP sum (three rounds of half the length instead of 1.3 of the full one: 6.9 / 9.9 us - the per-pair overhead,
+        // index decode and the nine read-modify-writes, is worth ~2.5 loop iterations).
         double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         bool any = false;
         for (int m = mstart[p]; m < mstart[p + 1]; ++m) {
