@@ -353,8 +353,9 @@ __device__ __forceinline__ int acc_off(int lr, int lc, int r) {
 // branches - and the block steps are a runtime loop, so each wave runs ~2-5 KB of code that stays in the instruction cache.
 // A: the packed lower triangle (LDS); the panels alias it once the tiles are in registers.  Every role executes the same
 // sequence of workgroup barriers.
+// e0 (kE only, may be null): E_0 = -D_0^-1 as the caller inverted it already (SlamCtx::back does, under the Schur phase)
 template <int I, bool kE>
-__device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &x, double *A, int N) {
+__device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &x, double *A, int N, const v4d *e0 = nullptr) {
   constexpr int NT = I >= 0 ? I + 1 : 1;
   auto AT = [&](int i, int j) -> int { return i * (i + 1) / 2 + j; };
   const int lane = x.lane, lc = x.lc, lr = x.lr, np = x.np;
@@ -374,11 +375,15 @@ __device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &
   if constexpr (I == 0) st_op(L.dscr(0), lane, acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
   __syncthreads();
   if constexpr (kE) {  // E_0
-    double t[4];
-    ld_op(L.dscr(0), lane, t);
-    v4d d = {t[0], t[1], t[2], t[3]};
-    inv16_blk(x, min(16, np), d);
-    st_op(L.einv(0), lane, d[0], d[1], d[2], d[3]);
+    if (e0) {
+      st_op(L.einv(0), lane, (*e0)[0], (*e0)[1], (*e0)[2], (*e0)[3]);
+    } else {
+      double t[4];
+      ld_op(L.dscr(0), lane, t);
+      v4d d = {t[0], t[1], t[2], t[3]};
+      inv16_blk(x, min(16, np), d);
+      st_op(L.einv(0), lane, d[0], d[1], d[2], d[3]);
+    }
   }
   const int aoff[4] = {acc_off(lr, lc, 0), acc_off(lr, lc, 1), acc_off(lr, lc, 2), acc_off(lr, lc, 3)};
 #pragma clang loop unroll(disable)
@@ -781,7 +786,7 @@ __device__ __forceinline__ double sum8_lane7(double v) {
 // the pivots [0, np); rows >= np (the rhs row np, pads) are carried along.  Afterwards A holds -A_pp^-1 and row np the
 // solution.  All kThreads threads of the workgroup call it (block barriers inside).
 template <int FT>
-__device__ __forceinline__ void sweep_packed_fast(const DrlgxState &S, double *A, int np, int N, int Tn, int *bad, int tid) {
+__device__ __forceinline__ void sweep_packed_fast(const DrlgxState &S, double *A, int np, int N, int Tn, int *bad, int tid, const v4d *e0 = nullptr) {
   static_assert(FT == 8, "one role per wave of the 512-thread workgroup");
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -797,7 +802,7 @@ __device__ __forceinline__ void sweep_packed_fast(const DrlgxState &S, double *A
   const SweepCtx x{trow, lane, lane & 15, lane >> 4, np, N, live, ewave, bad,
                    (S.prof && blockIdx.x == S.prof_block && lane == 0) ? S.prof + 64 + 5 * wv : nullptr};
   if (!live) {
-    if (ewave) sweep_role<-1, true>(S, x, A, N);
+    if (ewave) sweep_role<-1, true>(S, x, A, N, e0);
     else sweep_role<-1, false>(S, x, A, N);
     return;
   }
@@ -1252,7 +1257,10 @@ struct SlamCtx {
     for (int e = ft; e < Lb * P; e += fn) obs[e] = 0;
     for (int e = ft; e < MW * Lb; e += fn) lmask[e] = 0ull;
     for (int e = ft; e <= P; e += fn) mstart[e] = 0x7fffffff;
-    if (ft == 0) bad[0] = 0;
+    if (ft == 0) {
+      bad[0] = 0;
+      bad[1] = 0;  // (pairs of tile (0, 0) subtracted so far: back(), Schur phase)
+    }
     bar();
     if (S.prof && blockIdx.x == S.prof_block && ft == 0) S.prof[33] = wall_clock64();
     factor_tables(S, 0, Mf, ft, fn);
@@ -1471,9 +1479,30 @@ struct SlamCtx {
     __syncthreads();
     DRLGX_PROF(S, 3);
     //      Schur complement: S_pq -= sum_j G_m Lambda_jj G_mq^T   (Lambda_pl = G Lambda_jj = H)
-    {
+    // While the other seven waves do that, the wave that inverts the diagonal tiles in the sweep (an idle tile row's wave
+    // when the system has fewer than FT tile rows: <= 37 poses) already inverts the FIRST one: tile (0, 0) is complete as
+    // soon as the pairs of the poses 0..5 are subtracted - the first 21 pairs, counted in an LDS flag by their threads -
+    // and its inversion (2.2 us) used to run after this phase with every other wave waiting at a barrier.
+    const bool pre_e0 = Tn < FT;
+    const int ewave_first = 64 * (FT / 2);  // first thread of that wave (sweep_packed_fast: wave FT / 2 owns tile row FT - 1)
+    const bool is_ewave = pre_e0 && tid >= ewave_first && tid < ewave_first + 64;
+    v4d e0 = {0.0, 0.0, 0.0, 0.0};
+    if (is_ewave) {
+      const int p6 = min(P, 6), need = p6 * (p6 + 1) / 2;
+      while (__hip_atomic_load(bad + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(2);
+      __threadfence_block();
+      const int lane = tid & 63, lc = lane & 15, lr = lane >> 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = lr + 4 * r;
+        e0[r] = A[AT(max(i, lc), min(i, lc))];  // (N >= 16: the whole tile is inside the triangle)
+      }
+      const SweepCtx x{FT - 1, lane, lc, lr, np, N, false, true, bad, nullptr};
+      inv16_blk(x, min(16, np), e0);
+    } else {
       const int npairs = P * (P + 1) / 2;
-      for (int e = tid; e < npairs; e += kThreads) {
+      const int sidx = (pre_e0 && tid >= ewave_first) ? tid - 64 : tid, sn = pre_e0 ? kThreads - 64 : kThreads;
+      for (int e = sidx; e < npairs; e += sn) {
         int p = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
         while ((p + 1) * (p + 2) / 2 <= e) ++p;
         while (p * (p + 1) / 2 > e) --p;
@@ -1501,8 +1530,12 @@ struct SlamCtx {
               if (p == q && c > r) continue;
               A[AT((3 * p + r), 3 * q + c)] -= acc[r * 3 + c];
             }
+        if (pre_e0 && p < 6) {  // a pair of tile (0, 0): done (release: the subtractions above are visible before the count)
+          __threadfence_block();
+          atomicAdd(bad + 1, 1);
+        }
       }
-      for (int p = (tid + kThreads / 2) % kThreads; p < P; p += kThreads) {  // rhs_p -= sum_m G_m eta_j (idle waves)
+      for (int p = (tid + kThreads - 64 * (FT / 2 + 1)) % kThreads; p < P; p += kThreads) {  // rhs_p -= sum_m G_m eta_j (idle waves)
         double s0 = 0, s1 = 0, s2 = 0;
         for (int m = mstart[p]; m < mstart[p + 1]; ++m) {
           const double *g = rec + (size_t)REC * m, *lb = lamb + 8 * ml[m];
@@ -1518,7 +1551,7 @@ struct SlamCtx {
     __syncthreads();
     DRLGX_PROF(S, 4);
     // ---- 5. sweep: one tile row per wave (sweep_packed_fast) ----
-    sweep_packed_fast<FT>(S, A, np, N, Tn, bad, tid);
+    sweep_packed_fast<FT>(S, A, np, N, Tn, bad, tid, pre_e0 ? &e0 : nullptr);
     __syncthreads();
     DRLGX_PROF(S, 5);
     for (int k = tid; k < np; k += kThreads) d_pose[k] = A[AT(np, k)];
