@@ -142,6 +142,47 @@ class DeepQ(object):
         e0, e1 = int(g["edge_off_h"][i]), int(g["edge_off_h"][i + 1])
         return GraphSlice(g, n0, n1, e0, e1)  # views: the replay buffer keeps the export alive, nothing is copied
 
+    def _repool(self, pool, device):
+        """Replace the host GraphData of a re-loaded replay buffer by PoolRefs into `pool` (see running)."""
+        todo = [(k, j) for k, t in enumerate(self.buffer) for j in (0, 3) if not isinstance(t[j], PoolRef)]
+        if not todo:
+            return
+        buf = list(self.buffer)
+        new = {}
+        pos = 0
+        while pos < len(todo) and any(r == 0 for r in pool.ref):
+            # as many graphs as one slot holds
+            n_nodes = n_edges = 0
+            end = pos
+            while end < len(todo):
+                d = buf[todo[end][0]][todo[end][1]]
+                nn, ne = int(d.x.shape[0]), int(d.edge_index.shape[1])
+                if n_nodes + nn > pool.cap_nodes or n_edges + ne > pool.cap_edges:
+                    break
+                n_nodes += nn
+                n_edges += ne
+                end += 1
+            if end == pos:
+                break  # (a graph larger than a slot: cannot happen for graphs exported with the same capacities)
+            ds = [buf[k][j] for k, j in todo[pos:end]]
+            node_off = np.concatenate([[0], np.cumsum([int(d.x.shape[0]) for d in ds])]).astype(np.int64)
+            edge_off = np.concatenate([[0], np.cumsum([int(d.edge_index.shape[1]) for d in ds])]).astype(np.int64)
+            g = {"x": torch.cat([d.x.cpu() for d in ds]).to(device),
+                 "edge_index": torch.cat([d.edge_index.cpu() + int(o) for d, o in zip(ds, node_off[:-1])], dim=1).to(device),
+                 "edge_attr": torch.cat([d.edge_attr.cpu() for d in ds]).to(device),
+                 "node_off_h": node_off, "edge_off_h": edge_off}
+            slot = pool.put(g)
+            for i, kj in enumerate(todo[pos:end]):
+                new[kj] = PoolRef(pool, slot, i)
+                pool.ref[slot] += 1
+            pos = end
+        for k, t in enumerate(buf):
+            if (k, 0) in new or (k, 3) in new:
+                buf[k] = (new.get((k, 0), t[0]), t[1], t[2], new.get((k, 3), t[3])) + tuple(t[4:])
+        for k, j in todo[pos:]:  # no free slot left for these
+            buf[k][j].to(device)
+        self.buffer = ReplayList(buf)
+
     @staticmethod
     def _host_offsets(g):
         g["node_off_h"] = g["node_off"].cpu().numpy()
@@ -367,16 +408,16 @@ class DeepQ(object):
         device = env.device
         policy_net, target_net = model, modelTarget
         target_net.eval()
-        for t in self.buffer:  # a replay buffer re-loaded from saved_training.pkl holds host graphs: back to the device, once
-            if not isinstance(t[0], PoolRef):
-                t[0].to(device)
-                t[3].to(device)
         # graphs of new transitions live in a device pool (one slot per batched export, recycled when unreferenced)
         mn, me, _ = env.engine.graph_capacity()
         n_slots = 2 * (int(math.ceil(self.REPLAY_MEMORY / n_envs)) + 2)
         pool = getattr(self, "_pool", None)
         if pool is None or pool.device != device or pool.cap_nodes < mn or pool.cap_edges < me or pool.n_slots < n_slots:
             pool = self._pool = ReplayPool(device, n_slots, mn, me)
+        # a replay buffer re-loaded from saved_training.pkl holds host graphs: they go into the pool too (packed into
+        # slot-sized synthetic exports, a few large copies), so that the updates after a reload take the same one-gather
+        # collation and cached target read-out as before it; what does not fit stays a device GraphData (generic path)
+        self._repool(pool, device)
 
         def release(t):
             for d in (t[0], t[3]):

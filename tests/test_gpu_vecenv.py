@@ -206,6 +206,43 @@ def test_deepq_running_smoke(tmp_path):
     assert (tmp_path / "training_object_data" / "smoke" / "Model_Policy.pt").exists()
 
 
+def test_deepq_reload_repools_the_replay_buffer(tmp_path):
+    """run_training.py re-loads saved_training.pkl between epochs (train.py:85-94): the pickled replay buffer carries its
+    graphs as host tensors.  The next epoch puts them back into the device pool (DeepQ._repool), so that its updates take
+    the pooled collation and the cached target read-out like the ones before the reload - and give the same mini-batches:
+    a graph read back through its PoolRef equals the host graph it was made from."""
+    import pickle
+    from drl_graph_exploration_amd.networks import GCN, PoolRef
+    from drl_graph_exploration_amd.policy import DeepQ
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    dq = DeepQ("reload/", "GCN", data_root=str(tmp_path))
+    dq.OBSERVE, dq.epoch, dq.BATCH = 16, 48, 16
+    pol, tgt = GCN().to(dev), GCN().to(dev)
+    tgt.load_state_dict(pol.state_dict())
+    dq.running(pol, tgt, test=True, n_envs=8)
+    dq2 = pickle.loads(pickle.dumps(dq))
+    assert len(dq2.buffer) == 48 and not any(isinstance(t[0], PoolRef) or isinstance(t[3], PoolRef) for t in dq2.buffer)
+    host = [(t[0].x.clone(), t[0].edge_index.clone(), t[0].edge_attr.clone(), t[3].x.clone(), t[3].edge_index.clone()) for t in dq2.buffer]
+    from drl_graph_exploration_amd.networks import ReplayPool
+    from drl_graph_exploration_amd.vecenv import VecExplorationEnv
+    env = VecExplorationEnv(40, 8, env_index=0, test=True, device=0, seed=0)
+    mn, me, _ = env.engine.graph_capacity()
+    pool = ReplayPool(dev, 20, mn, me)
+    dq2._repool(pool, dev)
+    assert all(isinstance(t[0], PoolRef) and isinstance(t[3], PoolRef) for t in dq2.buffer)
+    for t, h in zip(dq2.buffer, host):
+        assert torch.equal(t[0].x.cpu(), h[0]) and torch.equal(t[0].edge_index.cpu(), h[1]) and torch.equal(t[0].edge_attr.cpu(), h[2])
+        assert torch.equal(t[3].x.cpu(), h[3]) and torch.equal(t[3].edge_index.cpu(), h[4])
+    env.close()
+    # ... and the trainer carries on from the pickle (its own pool, its own re-pooling)
+    dq3 = pickle.loads(pickle.dumps(dq))
+    dq3.epoch = 24
+    dq3.running(pol, tgt, test=True, n_envs=8)
+    assert dq3.step_t == 72 and all(isinstance(t[0], PoolRef) for t in dq3.buffer)
+    assert dq3.temp_loss > 0 and math.isfinite(dq3.temp_loss)
+
+
 def test_a2c_running_smoke(tmp_path):
     """A2C (scripts/policy.py:262-503) over the vectorised env: n-step returns per env, actor + critic on the HIP GCN,
     one optimiser step per `nstep` vector steps."""
