@@ -353,9 +353,11 @@ __device__ __forceinline__ int acc_off(int lr, int lc, int r) {
 // branches - and the block steps are a runtime loop, so each wave runs ~2-5 KB of code that stays in the instruction cache.
 // A: the packed lower triangle (LDS); the panels alias it once the tiles are in registers.  Every role executes the same
 // sequence of workgroup barriers.
-// e0 (kE only, may be null): E_0 = -D_0^-1 as the caller inverted it already (SlamCtx::back does, under the Schur phase)
+// have_e0 (kE only): e0 = E_0 = -D_0^-1 as the caller inverted it already (SlamCtx::back does, under the Schur phase); by
+// value - a pointer to it would put it into scratch memory
 template <int I, bool kE>
-__device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &x, double *A, int N, const v4d *e0 = nullptr) {
+__device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &x, double *A, int N, bool have_e0 = false,
+                                           v4d e0 = v4d{0.0, 0.0, 0.0, 0.0}) {
   constexpr int NT = I >= 0 ? I + 1 : 1;
   auto AT = [&](int i, int j) -> int { return i * (i + 1) / 2 + j; };
   const int lane = x.lane, lc = x.lc, lr = x.lr, np = x.np;
@@ -375,8 +377,8 @@ __device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &
   if constexpr (I == 0) st_op(L.dscr(0), lane, acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
   __syncthreads();
   if constexpr (kE) {  // E_0
-    if (e0) {
-      st_op(L.einv(0), lane, (*e0)[0], (*e0)[1], (*e0)[2], (*e0)[3]);
+    if (have_e0) {
+      st_op(L.einv(0), lane, e0[0], e0[1], e0[2], e0[3]);
     } else {
       double t[4];
       ld_op(L.dscr(0), lane, t);
@@ -786,7 +788,8 @@ __device__ __forceinline__ double sum8_lane7(double v) {
 // the pivots [0, np); rows >= np (the rhs row np, pads) are carried along.  Afterwards A holds -A_pp^-1 and row np the
 // solution.  All kThreads threads of the workgroup call it (block barriers inside).
 template <int FT>
-__device__ __forceinline__ void sweep_packed_fast(const DrlgxState &S, double *A, int np, int N, int Tn, int *bad, int tid, const v4d *e0 = nullptr) {
+__device__ __forceinline__ void sweep_packed_fast(const DrlgxState &S, double *A, int np, int N, int Tn, int *bad, int tid, bool have_e0 = false,
+                                                  v4d e0 = v4d{0.0, 0.0, 0.0, 0.0}) {
   static_assert(FT == 8, "one role per wave of the 512-thread workgroup");
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -802,7 +805,7 @@ __device__ __forceinline__ void sweep_packed_fast(const DrlgxState &S, double *A
   const SweepCtx x{trow, lane, lane & 15, lane >> 4, np, N, live, ewave, bad,
                    (S.prof && blockIdx.x == S.prof_block && lane == 0) ? S.prof + 64 + 5 * wv : nullptr};
   if (!live) {
-    if (ewave) sweep_role<-1, true>(S, x, A, N, e0);
+    if (ewave) sweep_role<-1, true>(S, x, A, N, have_e0, e0);
     else sweep_role<-1, false>(S, x, A, N);
     return;
   }
@@ -1551,7 +1554,7 @@ struct SlamCtx {
     __syncthreads();
     DRLGX_PROF(S, 4);
     // ---- 5. sweep: one tile row per wave (sweep_packed_fast) ----
-    sweep_packed_fast<FT>(S, A, np, N, Tn, bad, tid, pre_e0 ? &e0 : nullptr);
+    sweep_packed_fast<FT>(S, A, np, N, Tn, bad, tid, pre_e0, e0);
     __syncthreads();
     DRLGX_PROF(S, 5);
     for (int k = tid; k < np; k += kThreads) d_pose[k] = A[AT(np, k)];
