@@ -291,6 +291,47 @@ def config5_bench(device_index, n_envs=256, warm=108, timed=8):
             "env_steps_per_sec": n_envs / dt}
 
 
+def full_fill_bench(device_index, n_envs=2048, steps=40):
+    """The headline workload with EIGHT workgroups per CU's worth of instances (2 048 envs on one GPU): the per-launch
+    figure at 256 envs is the latency of the slowest instance; here the workgroups are dispatched as CUs free up, so the
+    launch lasts ~8 average instances - the throughput the step reaches when there are more belief states than CUs (more
+    envs per GPU; the look-ahead's rollouts).  Same state (36 poses), same restore + step loop, fused kernel events."""
+    from drl_graph_exploration_amd import default_config
+    from drl_graph_exploration_amd.engine import Engine
+    cfg = default_config(MAP, num_landmarks=NUM_LM, max_poses=41, max_landmarks=100, max_factors=12 * 41 + 20, max_snapshots=1)
+    eng = Engine(cfg, n_envs, 0, device=device_index)
+    ids = np.arange(n_envs)
+    eng.reset(ids, ids, los=ids)
+    for act in WARM_SCRIPT:
+        eng.step(torch.tensor([act] * n_envs, dtype=torch.float64, device=eng.device))
+    eng.check_status()
+    eng.snapshot(0)
+    odom = torch.tensor([STEP_ACTION] * n_envs, dtype=torch.float64, device=eng.device)
+    for _ in range(5):
+        eng.restore(0); eng.step(odom)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.restore(0); eng.step(odom)
+    eng.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    eng.timing_enable(True); eng.timing_read()
+    for _ in range(steps):
+        eng.restore(0); eng.step(odom)
+    tm = eng.timing_read()
+    eng.check_status()
+    eng_counts = eng.counts_dev().cpu().numpy()[:, :3].astype(np.float64).mean(axis=0)  # poses, landmarks, factors
+    V = eng.rows * eng.cols
+    eng.close()
+    step_us = tm["step"][0] * 1e3 / max(tm["step"][1], 1)
+    c = eng_counts
+    bytes_per_env = sum(algorithmic_bytes(c[0], c[1], c[2], V).values())
+    return {"workload": "configs[1]'s state with %d envs on one GPU (8 workgroups per CU in one launch)" % n_envs,
+            "ms_per_step": dt * 1e3, "env_steps_per_sec": n_envs / dt, "k_step_us_per_launch_incl_event_overhead": step_us,
+            "k_step_env_steps_per_sec": n_envs / (step_us * 1e-6),
+            "k_step_frac_hbm_peak": bytes_per_env * n_envs / (step_us * 1e-6) / 8e12}
+
+
 BELIEF_STEP_SOURCES = ("drlgx_dev.h", "drlgx_fields.h", "k_sim.hip", "k_slam.hip", "k_slam_arrow.hip", "k_map.hip", "k_step.hip",
                        "drlgx_engine.cpp")
 
@@ -603,6 +644,7 @@ def main():
         if not args.no_policy and world == 1:
             out["policy_path"] = policy_bench(eng, dev)
             out["config5_scale"] = config5_bench(local_rank)
+            out["full_fill"] = full_fill_bench(local_rank)
             out["dqn_loop"] = dqn_loop_bench(local_rank)
             out["a2c_loop"] = a2c_loop_bench(local_rank)
         if not args.no_cpu_baseline and world == 1:
