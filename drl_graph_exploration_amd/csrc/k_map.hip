@@ -151,16 +151,6 @@ __device__ __forceinline__ double wave_sum63(double v) {
   return v;
 }
 
-__device__ __forceinline__ double block_sum(double v, double *scratch, int tid) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-  __syncthreads();
-  if ((tid & 63) == 0) scratch[tid >> 6] = v;
-  __syncthreads();
-  double s = 0;
-  for (int w = 0; w < kWaves; ++w) s += scratch[w];
-  return s;
-}
-
 // handed (k_step): est_pose / pose_info of this instance already are in the LDS where this stage keeps them (sp, si) and
 // lm_lds holds the landmark estimates (LDS of the SLAM stage that this stage does not overwrite before it has read them):
 // nothing is fetched back from HBM

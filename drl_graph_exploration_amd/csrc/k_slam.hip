@@ -3,22 +3,24 @@
 // Restates SLAM2D::optimize / copy_optimize (src/em_exploration/SLAM2D.cpp:374-488) — one iSAM2
 // update (gtsam ISAM2::update, third-party; policy in SURVEY.md App. A.3) followed by the block
 // marginals of FastMarginals (src/em_exploration/FastMarginals.cpp:130-186):
+//   front end (SlamCtx::front; in k_step it runs beside the simulator wave, on the state before the step):
 //   1. relinearisation policy (every 10th update, |delta|_inf >= 0.1), theta staged in LDS
-//   2. every bearing-range factor is linearised ONCE by its own thread into a 12-double LDS record
-//      (the fp64 atan2/sincos chains are the expensive part); landmark 2x2 blocks (thread per
-//      landmark) and pose 3x3 blocks (thread per pose) are summed deterministically in factor order
-//   3. landmarks are eliminated analytically -> Schur complement S on the poses (3P x 3P, LDS)
+//   2. every bearing-range factor is linearised ONCE by its own thread into a 12-double LDS record (linearize_br); landmark
+//      2x2 blocks (thread per landmark, walking a bit mask of the observing poses), pose 3x3 blocks by roles: odometry
+//      factors linearised once for both keys, own factors summed eight lanes per pose
+//   back end (SlamCtx::back; after the simulator):
+//   3. this step's factors; landmarks are eliminated analytically -> Schur complement S on the poses (3P x 3P, LDS)
 //   4. symmetric Gauss-Jordan SWEEP of the augmented system [S rhs] on the fp64 matrix cores
 //      (v_mfma_f64_16x16x4_f64): the lower triangle lives in 16 x 16 accumulator tiles in registers for the whole
 //      factorisation; afterwards the triangle holds -S^-1 (every pose marginal and cross block) and the augmented row
-//      holds delta_p.  Fast path (<= 42 poses, everything in LDS): 16-wide block pivots, one tile row per wave, the next
-//      diagonal tile inverted in registers by an otherwise idle wave (sweep16_block).  Larger systems (<= 127 poses,
-//      dense matrix in an HBM/L2 workspace): the same block steps per lower tile (tile_step16), tiles in registers up
-//      to 85 poses (5e) or streamed per step (5d); 4-wide streamed sweeps (5c) when the 16-wide panels do not fit.
+//      holds delta_p.  Fast path (<= 42 poses, everything in LDS): sweep_packed_fast - 16-wide block pivots, one role per
+//      wave (sweep_role), the next diagonal tile inverted in registers by an otherwise idle wave (inv16_blk).
+//      sweep_regtiles / sweep_streamed are the same block steps for the landmark systems of k_slam_arrow.hip that do not
+//      fit that scheme (tiles in registers with panels in LDS; everything in the HBM/L2 workspace).
 //   5. landmark deltas and 2x2 landmark marginals by back-substitution through G = Lambda_pl Lambda_ll^-1
-//   6. estimates theta (+) delta, information blocks (3x3 LLT inverse / 2x2 inverse), traces
-// Per-landmark loops walk a bit mask of the observing poses.  LDS: the padded system + per-factor records when they
-// fit; the records (and, for the larger capacities, the system itself) fall back to an HBM/L2 workspace.
+//   6. estimates theta (+) delta, information blocks (3x3 cofactor inverse / 2x2 inverse), traces
+// LDS: the packed system + per-factor records when they fit; the records fall back to an HBM/L2 workspace otherwise.
+// Trajectories beyond 42 poses: k_slam_arrow.hip (pose chain eliminated first).
 #include "drlgx_dev.h"
 #pragma clang fp contract(fast)  // (the unity build k_step.hip is compiled with -ffp-contract=off)
 
@@ -98,21 +100,18 @@ struct SweepCtx {
 };
 
 // ------------------------------------------------------------------------------------------------------------------
-// Fast sweep path (N <= 128, i.e. <= 42 poses): 16-wide block Gauss-Jordan with one tile row per wave (lower tiles
-// u <= I in MFMA accumulators, diagonal tile kept fully symmetric).  Scalar branches cost ~20-30 cycles here and a block
-// barrier ~50 plus the arrival skew, so a step pivots on a whole 16 x 16 tile column K (7 steps at 37 poses) and every
-// wave runs the same straight-line code (sweep16_block<K> is instantiated per tile column):
-//   P  wave I >= K publishes tile (I, K), wave K also the transposed tiles (K, u < K): panel PAN[i][.] = A[i][16 K + .]
-//      barrier
-//   W  every wave: W_I = PAN_I E_K  (4 chained MFMAs, E_K = -D_K^-1 from the look-ahead below), published to WT
-//      barrier
-//   U  every wave: A_Iu += W_I PAN_u^T for its tiles u <= I (4 MFMAs each); tile column K <- -W_I;
-//      wave K: its pivot rows <- -W_u^T, pivot block <- E_K
-//   look-ahead: the diagonal tile D_{K+1} = A_{K+1,K+1} + W_{K+1} PAN_{K+1}^T is formed and inverted (four 4-wide
-//      sub-sweeps inside ONE wave, wave-local LDS only) by a wave with little or no matrix work while the others run U.
-// Panels live in the LDS region of the dense matrix A, which is dead while the tiles are in registers.  Operand layout
-// "KS": a 16-vector v is stored as v[(c & 3) * 4 + (c >> 2)] so that the 4 K-steps of an MFMA operand lane are one
-// 32-byte read.
+// 16-wide block Gauss-Jordan on lower tiles in MFMA accumulators (diagonal tiles kept fully symmetric).  Scalar branches
+// cost ~20-30 cycles here and a block barrier ~50 plus the arrival skew, so a step pivots on a whole 16 x 16 tile column K
+// (7 steps at 37 poses):
+//   P  the pivot tile column is published to LDS: panel PAN[i][.] = A[i][16 K + .]
+//   W  every wave: W_I = PAN_I E_K  (4 chained MFMAs, E_K = -D_K^-1 from the look-ahead below)
+//   U  every wave: A_Iu += W_I PAN_u^T for its tiles u <= I (4 MFMAs each); tile column K <- -W_I; pivot rows <- -W_u^T,
+//      pivot block <- E_K
+//   look-ahead: the diagonal tile D_{K+1} = A_{K+1,K+1} + W_{K+1} PAN_{K+1}^T is formed and inverted inside ONE wave with
+//      little or no matrix work while the others run U.
+// The fast path (sweep_role, below) keeps the panels as MFMA operand images and needs one barrier per step; the helpers
+// here (row-major "KS" panels: a 16-vector v is stored as v[(c & 3) * 4 + (c >> 2)] so that the 4 K-steps of an MFMA
+// operand lane are one 32-byte read; tile_step16 / tile_replace16) serve sweep_regtiles and sweep_streamed.
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int ks16(int c) { return (c & 3) * 4 + (c >> 2); }
 
@@ -552,7 +551,7 @@ __device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &
       if (const int p = 64 * _w + __ffsll((long long)_m) - 1; true)
 
 // the part of a block step that overwrites instead of updating: tile column K takes -W, the pivot rows -(W)^T, the pivot
-// block E_K (masked rows / columns excepted); see sweep16_block
+// block E_K (masked rows / columns excepted)
 __device__ __forceinline__ void tile_replace16(int I, int J, int K, int np, int lc, int lr, const double *wt, const double *einv,
                                                v4d &acc) {
   const int kb = 16 * K;
@@ -582,7 +581,7 @@ __device__ __forceinline__ void tile_replace16(int I, int J, int K, int np, int 
 }
 
 // One lower tile (I, J) of block step K of the 16-wide symmetric sweep, for the variants that do not keep a whole tile row
-// per wave: the same update / replacement rules as sweep16_block, from the LDS panels PAN (pivot column), WT = PAN E_K
+// per wave: the update / replacement rules above, from the LDS panels PAN (pivot column), WT = PAN E_K
 // and E_K.  acc: accumulator layout (row lr + 4 r, column lc of the tile; diagonal tiles fully symmetric).
 __device__ __forceinline__ void tile_step16(int I, int J, int K, int np, int lc, int lr, const double *pan, const double *wt,
                                             const double *einv, v4d &acc) {
@@ -596,45 +595,6 @@ __device__ __forceinline__ void tile_step16(int I, int J, int K, int np, int lc,
   }
   tile_replace16(I, J, K, np, lc, lr, wt, einv, acc);
 }
-// E = -D^-1 of the 4x4 SPD pivot block at index q0i, read from `dscr` (16 doubles, row major, lower triangle valid), by
-// 2x2 block inversion (two reciprocals on the critical path instead of four; indices >= np act as identity); every
-// lane computes it redundantly, lanes 0-15 write `eout` (16 doubles, row major).
-__device__ __forceinline__ void pivot_inverse_from(int np, int q0i, const double *dscr, double *eout, int *bad, int lane) {
-      const bool m1 = q0i + 1 < np, m2 = q0i + 2 < np, m3 = q0i + 3 < np;
-      const double a00 = dscr[0];
-      const double a10 = m1 ? dscr[4] : 0.0, a11 = m1 ? dscr[5] : 1.0;
-      const double a20 = m2 ? dscr[8] : 0.0, a21 = (m2 && m1) ? dscr[9] : 0.0, a22 = m2 ? dscr[10] : 1.0;
-      const double a30 = m3 ? dscr[12] : 0.0, a31 = (m3 && m1) ? dscr[13] : 0.0, a32 = (m3 && m2) ? dscr[14] : 0.0;
-      const double a33 = m3 ? dscr[15] : 1.0;
-      // P = [a00 a10; a10 a11], Q = [a20 a21; a30 a31], R = [a22 a32; a32 a33]
-      const double detp = a00 * a11 - a10 * a10;
-      const double ip = fast_rcp(detp);
-      const double p00 = a11 * ip, p10 = -a10 * ip, p11 = a00 * ip;           // P^-1
-      const double t00 = a20 * p00 + a21 * p10, t01 = a20 * p10 + a21 * p11;  // T = Q P^-1
-      const double t10 = a30 * p00 + a31 * p10, t11 = a30 * p10 + a31 * p11;
-      const double s00 = a22 - (t00 * a20 + t01 * a21);                       // S = R - T Q^T
-      const double s10 = a32 - (t10 * a20 + t11 * a21);
-      const double s11 = a33 - (t10 * a30 + t11 * a31);
-      const double dets = s00 * s11 - s10 * s10;
-      const double is = fast_rcp(dets);
-      const double r00 = s11 * is, r10 = -s10 * is, r11 = s00 * is;           // S^-1
-      const double u00 = r00 * t00 + r10 * t10, u01 = r00 * t01 + r10 * t11;  // U = S^-1 T
-      const double u10 = r10 * t00 + r11 * t10, u11 = r10 * t01 + r11 * t11;
-      if (lane == 0 && (!(a00 > 0) || !(detp > 0) || !(s00 > 0) || !(dets > 0))) bad[0] = 1;
-      // D^-1 = [P^-1 + T^T U, -U^T; -U, S^-1];  E = -D^-1
-      const double e00 = -(p00 + t00 * u00 + t10 * u10), e10 = -(p10 + t01 * u00 + t11 * u10);
-      const double e11 = -(p11 + t01 * u01 + t11 * u11);
-      if (lane < 16) {
-        const int r = lane >> 2, c = lane & 3;
-        const int hi = max(r, c), lo = min(r, c);
-        double v;
-        if (hi < 2) v = (hi == 0) ? e00 : (lo == 0 ? e10 : e11);
-        else if (lo >= 2) v = -((lo == 3) ? r11 : (hi == 2 ? r00 : r10));
-        else v = (hi == 2) ? (lo == 0 ? u00 : u01) : (lo == 0 ? u10 : u11);
-        eout[lane] = v;
-      }
-}
-
 // Pose i's diagonal block B (3x3, full) and gradient g of the prior / odometry (odo[i] = measured odometry between the
 // poses i and i + 1: x, y, cos, sin) / own bearing-range factors linearised at thp, and - for i + 1 < P - the block O = (i + 1, i) of the odometry factor i (SLAM2D.cpp:44-89; records: linearize_br)
 __device__ __forceinline__ void pose_block(const DrlgxState &S, int inst, const double *thp, const double *odo, const double *rec, const int *mstart,
@@ -824,7 +784,7 @@ __device__ __forceinline__ void sweep_packed_fast(const DrlgxState &S, double *A
   }
 }
 
-// 16-wide block steps with the lower tiles in registers (see 5e in slam_body): `A` is the packed lower triangle in LDS
+// 16-wide block steps with the lower tiles in registers: `A` is the packed lower triangle in LDS
 // (kPackedA, the panels `pbase` may alias it: every tile is in registers before the first panel is written) or the square
 // matrix with leading dimension N in the HBM/L2 workspace (panels `pbase` in LDS, 32 N + 1280 doubles).
 template <bool kPackedA, int NTW>

@@ -1,8 +1,14 @@
 // Fused belief step: simulate -> SLAM -> virtual map for one instance in ONE kernel (one 512-thread workgroup per
 // instance).  The three stages are independent between instances, so fusing them removes two launches per step and,
 // more importantly, the two grid-wide joins: an instance no longer waits for the slowest workgroup of the previous stage
-// (launch + ramp + tail cost ~3-5 us per kernel at 256 workgroups).  Wave 0 runs the (single-wave) simulator while the
-// other waves wait at the barrier they would otherwise have spent between kernels.
+// (launch + ramp + tail cost ~3-5 us per kernel at 256 workgroups).  Inside the workgroup nothing one stage hands the
+// next goes through HBM:
+//   * wave 0 runs the (single-wave) simulator; waves 1-7 run the SLAM FRONT END on the state before the step beside it
+//     (old factors linearised, tables, block assembly; kslam::SlamCtx::front behind a 7-wave software barrier);
+//   * the simulator leaves what it appends (factors, landmarks, counts) in LDS for the SLAM back end (kslam::SimBox, the
+//     mailbox `sub_cnt`), its two random streams are written back by the other seven waves;
+//   * the SLAM stage writes the pose estimates / information blocks into the map stage's LDS pose tables and leaves the
+//     landmark estimates where the map stage reads them; the map stage's ladder tables are fetched before the SLAM stage.
 //
 // This translation unit is a unity build of the three stage files (their kernels stay available for the paths that use
 // them alone: reset, the look-ahead base solve, capacities beyond the LDS-resident SLAM kernel).  It is compiled with
