@@ -433,6 +433,9 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
           nom = nv >= 0 ? omask[nv] : 0ull;
           nlmc = nv >= 0 ? lmc[nv] : 0;
         }
+        // a middle chunk of poses (trajectories beyond 128 poses) that neither updates nor sees any cell of the tile leaves
+        // it as it is: no read-modify-write of its planes
+        if (c0 > 0 && !last && __ballot((m | om_cell) != 0ull) == 0ull) continue;
         double axx = i0, axy = 0.0, ayy = i0;
         int u = 0;
         if (c0 > 0) {
