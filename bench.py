@@ -319,17 +319,24 @@ def full_fill_bench(device_index, n_envs=2048, steps=40):
     for _ in range(steps):
         eng.restore(0); eng.step(odom)
     tm = eng.timing_read()
+    eng.timing_enable(2)  # ... and as the three stage kernels, for the map stage's own figure at this fill
+    for _ in range(steps):
+        eng.restore(0); eng.step(odom)
+    tm3 = eng.timing_read()
     eng.check_status()
     eng_counts = eng.counts_dev().cpu().numpy()[:, :3].astype(np.float64).mean(axis=0)  # poses, landmarks, factors
     V = eng.rows * eng.cols
     eng.close()
     step_us = tm["step"][0] * 1e3 / max(tm["step"][1], 1)
     c = eng_counts
-    bytes_per_env = sum(algorithmic_bytes(c[0], c[1], c[2], V).values())
+    ab = algorithmic_bytes(c[0], c[1], c[2], V)
+    bytes_per_env = sum(ab.values())
+    map_us = tm3["map"][0] * 1e3 / max(tm3["map"][1], 1)
     return {"workload": "configs[1]'s state with %d envs on one GPU (8 workgroups per CU in one launch)" % n_envs,
             "ms_per_step": dt * 1e3, "env_steps_per_sec": n_envs / dt, "k_step_us_per_launch_incl_event_overhead": step_us,
             "k_step_env_steps_per_sec": n_envs / (step_us * 1e-6),
-            "k_step_frac_hbm_peak": bytes_per_env * n_envs / (step_us * 1e-6) / 8e12}
+            "k_step_frac_hbm_peak": bytes_per_env * n_envs / (step_us * 1e-6) / 8e12,
+            "k_map_us_per_launch_incl_event_overhead": map_us, "k_map_frac_hbm_peak": ab["map"] * n_envs / (map_us * 1e-6) / 8e12}
 
 
 BELIEF_STEP_SOURCES = ("drlgx_dev.h", "drlgx_fields.h", "k_sim.hip", "k_slam.hip", "k_slam_arrow.hip", "k_map.hip", "k_step.hip",
