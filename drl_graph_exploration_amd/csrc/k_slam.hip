@@ -736,6 +736,14 @@ __device__ __forceinline__ double dpp_add_f64(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), kCtrl, 0xf, 0xf, true);
   return v + __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// the value of another lane of the same quad: kCtrl = DPP quad_perm (0xB1: lane ^ 1, 0x4E: lane ^ 2)
+template <int kCtrl>
+__device__ __forceinline__ double dpp_quad_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, kCtrl, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), kCtrl, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double sum8_lane7(double v) {
   v = dpp_add_f64<0x111>(v);  // row_shr:1
   v = dpp_add_f64<0x112>(v);  // row_shr:2
@@ -1569,11 +1577,17 @@ struct SlamCtx {
             X[e][3] = ga[1] * W[e][1] + ga[3] * W[e][3] + ga[5] * W[e][5];
           }
         }
-        for (int o = S6 >> 1; o > 0; o >>= 1)
+        // (butterfly over the S6 <= 4 adjacent lanes of an item: DPP quad permutes, no trip through the LDS crossbar)
+        if (S6 >= 4)
 #pragma unroll
           for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) X[e][q4] += __shfl_xor(X[e][q4], o);
+            for (int q4 = 0; q4 < 4; ++q4) X[e][q4] += dpp_quad_f64<0x4E>(X[e][q4]);  // lane ^ 2
+        if (S6 >= 2)
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) X[e][q4] += dpp_quad_f64<0xB1>(X[e][q4]);  // lane ^ 1
         if (work && s6 == 0) {
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
@@ -1618,9 +1632,13 @@ struct SlamCtx {
           dy -= g[1] * dp0 + g[3] * dp1 + g[5] * dp2;
         }
       }
-      for (int o = S7 >> 1; o > 0; o >>= 1) {
-        c00 += __shfl_xor(c00, o); c01 += __shfl_xor(c01, o); c10 += __shfl_xor(c10, o); c11 += __shfl_xor(c11, o);
-        dx += __shfl_xor(dx, o); dy += __shfl_xor(dy, o);
+      if (S7 >= 4) {
+        c00 += dpp_quad_f64<0x4E>(c00); c01 += dpp_quad_f64<0x4E>(c01); c10 += dpp_quad_f64<0x4E>(c10); c11 += dpp_quad_f64<0x4E>(c11);
+        dx += dpp_quad_f64<0x4E>(dx); dy += dpp_quad_f64<0x4E>(dy);
+      }
+      if (S7 >= 2) {
+        c00 += dpp_quad_f64<0xB1>(c00); c01 += dpp_quad_f64<0xB1>(c01); c10 += dpp_quad_f64<0xB1>(c10); c11 += dpp_quad_f64<0xB1>(c11);
+        dx += dpp_quad_f64<0xB1>(dx); dy += dpp_quad_f64<0xB1>(dy);
       }
       if (!lwork || s7 != 0) continue;
       const double *lb = lamb + 8 * j;
