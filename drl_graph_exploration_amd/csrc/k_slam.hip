@@ -1386,16 +1386,18 @@ struct SlamCtx {
         // (two scans in one: observations in the low half, pairs of observations - ceil(k / 2) - in the high half)
         const int k2 = (k + 1) >> 1;
         unsigned v = (unsigned)k | ((unsigned)k2 << 16);
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const unsigned u = (unsigned)__shfl_up((int)v, o);
-          if (ln >= o) v += u;
-        }
+        // inclusive scan over the wave on DPP: row shifts inside the 16-lane rows, then the two row broadcasts
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1, 3
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2, 3
         if (j < L) {
           lstart[j] = (int)((carry & 0xffffu) + (v & 0xffffu)) - k;
           pstart[j] = (int)((carry >> 16) + (v >> 16)) - k2;
         }
-        carry += (unsigned)__shfl((int)v, 63);
+        carry += (unsigned)__builtin_amdgcn_readlane((int)v, 63);
       }
       if (ln == 0) {
         lstart[L] = (int)(carry & 0xffffu);
