@@ -290,7 +290,8 @@ template <bool kMove = true>
 __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchSel &sel, const double *odom, int odom_stride,
                                               int n_measure, uint32_t *lds0, uint32_t *lds1, double *dyn, int lane,
                                               int32_t *exp_keys = nullptr, double *exp_br = nullptr, int32_t *exp_count = nullptr,
-                                              bool park_streams = false, int *mail = nullptr, double *lmbox = nullptr) {
+                                              bool park_streams = false, int *mail = nullptr, double *lmbox = nullptr,
+                                              int known_P = -1, int known_L = 0, int known_M = 0) {
   uint32_t *lds[2] = {lds0, lds1};
   double *nrm = dyn;
   int *inr = reinterpret_cast<int *>(dyn + 2 * S.LG + 2);
@@ -309,7 +310,10 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
       return;
     }
   }
-  SimCtx c{S, inst, lane, {}, {}, {0, 0}, {0, 0}, {}, cnt[C_P], cnt[C_L], cnt[C_M], 0};
+  // (known_*: the counts as the caller read them already - k_step's prelude - so that the loads that depend on the pose
+  // count do not wait for a second round trip to the counters)
+  SimCtx c{S, inst, lane, {}, {}, {0, 0}, {0, 0}, {}, known_P >= 0 ? known_P : cnt[C_P], known_P >= 0 ? known_L : cnt[C_L],
+           known_P >= 0 ? known_M : cnt[C_M], 0};
   if (kMove && c.P >= S.P_max) {
     if (lane == 0) {
       cnt[C_FLAG] = 1;

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
     uint32_t *l1 = l0 + DRLGX_MT_STRIDE;
     double *dyn = sim_dyn;  // 5008 B: 16-aligned
     ksim::sim_step_body(S, sel, odom, odom_stride, n_measure, l0, l1, dyn, tid, nullptr, nullptr, nullptr, true, sub_cnt + 1,
-                        n_measure == 2 ? lmbox : nullptr);
+                        n_measure == 2 ? lmbox : nullptr, sel.on(bi) ? P0 : -1, L0, M0);
   } else if (pre) {
     ctx.front<true>(S, tid, P0, L0, M0, P0, L0, isam + 1, false, od3, kslam::SubBarrier{sub_cnt, kslam::kThreads / 64 - 1, 0});
   }
