@@ -881,6 +881,25 @@ __global__ __launch_bounds__(256) void k_linear_out(int N, int hidden, int out_d
 __global__ __launch_bounds__(256) void k_dz2(int N, int hidden, int out_dim, const float *dOut, const float *Wf, const float *mask,
                                              const float *H2, float *dZ2) {
   const int n = blockIdx.x;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(Wf) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(H2) | reinterpret_cast<uintptr_t>(dZ2);
+  if ((hidden & 3) == 0 && (al & 15) == 0) {  // four columns per lane, 16-byte accesses
+    for (int c4 = threadIdx.x; c4 < (hidden >> 2); c4 += 256) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int o = 0; o < out_dim; ++o) {
+        const float d = dOut[(size_t)n * out_dim + o];
+        const float4 w = reinterpret_cast<const float4 *>(Wf + (size_t)o * hidden)[c4];
+        s.x += d * w.x; s.y += d * w.y; s.z += d * w.z; s.w += d * w.w;
+      }
+      const float4 h = reinterpret_cast<const float4 *>(H2 + (size_t)n * hidden)[c4];
+      float4 g = make_float4(h.x > 0.f ? 1.f : 0.f, h.y > 0.f ? 1.f : 0.f, h.z > 0.f ? 1.f : 0.f, h.w > 0.f ? 1.f : 0.f);
+      if (mask) {
+        const float4 m = reinterpret_cast<const float4 *>(mask + (size_t)n * hidden)[c4];
+        g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
+      }
+      reinterpret_cast<float4 *>(dZ2 + (size_t)n * hidden)[c4] = make_float4(s.x * g.x, s.y * g.y, s.z * g.z, s.w * g.w);
+    }
+    return;
+  }
   for (int c = threadIdx.x; c < hidden; c += 256) {
     float s = 0.f;
     for (int o = 0; o < out_dim; ++o) s += dOut[(size_t)n * out_dim + o] * Wf[(size_t)o * hidden + c];
