@@ -256,9 +256,12 @@ int drlgx_restore(drlgx_engine *e, int slot);
 int drlgx_timing_enable(drlgx_engine *e, int on);
 int drlgx_timing_read_host(drlgx_engine *e, double ms[DRLGX_N_TIMERS], int64_t launches[DRLGX_N_TIMERS]);
 
-/* Development aid: arm (1) / disarm (0) in-kernel phase stamps (wall_clock64, 100 MHz) written by block 0
- * of k_slam (slots 0-10) and k_map (slots 16-22); out (may be NULL) receives the last stamps (arm & 2: the second
- * bank of 64 - per-wave cycle stamps of one block step of the sweep). */
+/* Development aid: in-kernel phase stamps (wall_clock64, 100 MHz) of ONE workgroup of the belief kernels.  arm = 0 disarms;
+ * arm & 1 arms; arm >> 8 = the workgroup (instance index inside the launch) that stamps, 0 by default.  Slots: 0-7 the SLAM
+ * back end, 8-13 the simulator, 14 / 24-35 the SLAM front end, 16-21 / 40-43 / 48-63 the map stage.  out (may be NULL)
+ * receives the last stamps: 64 values - the first bank; with arm & 2 the second bank (per-wave cycle stamps of one block
+ * step of the sweep); with arm & 4 all 1024 values (out must hold them): both banks and, from 128 on, the start / end stamp
+ * of every workgroup of the last k_step launch (scripts/phase_profile*.py). */
 int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]);
 
 /* ---- GCN policy (scripts/Networks.py:12-70 over PyG GCNConv(improved=True)) ------------------- */
