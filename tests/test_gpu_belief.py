@@ -370,7 +370,11 @@ def test_fused_step_kernel_equals_stage_kernels():
     starts = generic_starts(n)
     for e in (fused, staged):
         e.reset(np.arange(n), np.arange(n), starts=starts)
-    for s, act in enumerate(SCRIPT):
+    # ... up to the capacity of the fused kernel's dense solver (41 poses: every tile-row count of the sweep, with and
+    # without an idle tile row for the wave that inverts the diagonal tiles - the first one under the Schur phase)
+    loop = [(2, 0, 0)] * 3 + [(0, 0, math.pi / 2)] + [(2, 0, 0)] * 2 + [(0.7, 0, 0.4)]
+    script = SCRIPT + [loop[k % len(loop)] for k in range(cfg.max_poses - 1 - len(SCRIPT))]
+    for s, act in enumerate(script):
         odom = torch.tensor([act] * n, dtype=torch.float64, device=fused.device)
         fused.step(odom)
         staged.step(odom)
@@ -385,7 +389,8 @@ def test_fused_step_kernel_equals_stage_kernels():
         np.testing.assert_array_equal(fused.utility().cpu().numpy(), staged.utility().cpu().numpy())
     assert fused.status() == 0 and staged.status() == 0
     tm = staged.timing_read()
-    assert tm["slam"][1] == len(SCRIPT) and tm["step"][1] == 0  # the staged engine really ran the stage kernels
+    assert tm["slam"][1] == len(script) and tm["step"][1] == 0  # the staged engine really ran the stage kernels
+    assert max(fused.counts(i)["poses"] for i in range(n)) == cfg.max_poses
     fused.close()
     staged.close()
 
