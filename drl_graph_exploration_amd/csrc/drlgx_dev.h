@@ -90,6 +90,17 @@ struct DrlgxState {
   int *slam_iws;  // [n_inst][slam_iws_stride] observation table + per-pose factor ranges
   size_t slam_iws_stride;
   int *status;  // [1]
+  // --- incremental belief update (k_inc.hip): the columns of the joint covariance that later updates can touch - every
+  // variable against the ACTIVE set (current pose, landmarks) - plus the 3x3 marginal of every pose.  Null: disabled.
+  //   jc[inst][row][jc_ld]: rows 3 i + r = pose i, 3 P_max + 2 j + e = landmark j; columns 0..2 = the current (newest) pose,
+  //   3 + 2 j + e = landmark j.  jd[inst][P_max][6]: pose marginal covariance (xx yx yy tx ty tt).
+  //   jc_meta[inst][4] = {valid, P, L, M at the update that left the panel}.  inc_stats[2] = {incremental, full} updates.
+  double *jc;
+  size_t jc_stride;
+  int jc_ld;
+  double *jd;
+  int *jc_meta;
+  unsigned long long *inc_stats;
   long long *prof;  // [1024] development aid: wall_clock64() stamps of the phases of ONE workgroup (or null)
   int prof_block;   // ... this one
 };
@@ -574,6 +585,17 @@ inline void drlgx_ensure_lds_attr(bool (&done)[32], const void *const *fns, int 
   done[dev] = true;
 }
 
+// LDS of the simulator wave inside the fused step kernel (two mt19937 streams, the normal variates and the in-range list of
+// a measure() call, the new landmarks' initial estimates); the SLAM stage of k_step carves behind it (k_step.hip)
+__host__ __device__ inline size_t drlgx_sim_lds_bytes(int LG, int P_max) {
+  size_t b = (size_t)2 * DRLGX_MT_STRIDE * 4 + (size_t)(2 * LG + 2) * 8 + (size_t)LG * 4 + 16;
+  b = ((b + 7) & ~(size_t)7) + (size_t)2 * LG * 8;  // the new landmarks' initial estimates, for the SLAM stage (ksim::measure)
+  // ... and, when that costs little, wide enough for the map stage's pose tables (19 P_max doubles), so that the SLAM stage
+  // can leave its outputs in them (see k_step)
+  if (P_max <= 64) b = b > (size_t)P_max * 19 * 8 + 32 ? b : (size_t)P_max * 19 * 8 + 32;
+  return (b + 31) & ~(size_t)31;
+}
+
 // ---- launchers implemented in the kernel translation units ------------------------------------
 struct DrlgxField;
 void drlgx_launch_reset(const DrlgxState &S, hipStream_t st, int n, const int32_t *env_ids_dev, const uint32_t *seeds_dev,
@@ -598,6 +620,9 @@ void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel);  // s
 void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
                        const int32_t *dst, int src_off, int dst_off, int skip_mask);  // skip fields with cls & mask
 void drlgx_launch_rebase(const DrlgxState &S, hipStream_t st, int base0, int n);
+// the incremental update's covariance panel of instance src[i] -> dst[i] (live rows / columns only; k_inc.hip)
+void drlgx_launch_copy_panel(const DrlgxState &S, hipStream_t st, int n, const int32_t *src, const int32_t *dst, int src_off,
+                             int dst_off);
 void drlgx_launch_fix_rollouts(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0);
 void drlgx_launch_rewards(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0,
                           double *rewards);

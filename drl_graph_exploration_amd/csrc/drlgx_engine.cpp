@@ -385,6 +385,22 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
     TRY(dev_alloc(e, &S.slam_ws, S.slam_ws_stride * (size_t)S.n_inst));
     TRY(dev_alloc(e, &S.slam_iws, S.slam_iws_stride * (size_t)S.n_inst));
   }
+  // Covariance panel of the incremental belief update (k_inc.hip): on unless DRLGX_INCREMENTAL=0 or the panels of all
+  // instances would not fit the budget (DRLGX_INC_MAX_GB, 32 GB by default) - then every update is a full solve.
+  {
+    const char *v = getenv("DRLGX_INCREMENTAL");
+    const char *g = getenv("DRLGX_INC_MAX_GB");
+    const double max_gb = g ? atof(g) : 32.0;
+    S.jc_ld = (3 + 2 * S.L_max + 15) & ~15;  // rows start on 128-byte lines: the 16-column tiles of the rank-k update are whole lines
+    S.jc_stride = (size_t)(3 * S.P_max + 2 * S.L_max) * (size_t)S.jc_ld;
+    const double gb = (double)S.jc_stride * 8.0 * (double)S.n_inst / 1073741824.0;
+    if (!(v && v[0] == '0') && gb <= max_gb) {
+      TRY(dev_alloc(e, &S.jc, S.jc_stride * (size_t)S.n_inst));
+      TRY(dev_alloc(e, &S.jd, (size_t)S.P_max * 6 * (size_t)S.n_inst));
+      TRY(dev_alloc(e, &S.jc_meta, (size_t)4 * (size_t)S.n_inst));
+      TRY(dev_alloc(e, &S.inc_stats, 2));
+    }
+  }
   TRY(dev_alloc(e, &S.status, 1));
   TRY(dev_alloc(e, &e->fields_dev, e->fields.size()));
   hipMemcpyAsync(e->fields_dev, e->fields.data(), e->fields.size() * sizeof(DrlgxField), hipMemcpyHostToDevice, e->stream);
@@ -727,6 +743,7 @@ int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env
     {
       ScopedTimer t(e, 3);
       drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, nc, ce, nullptr, base0, roll0, 3);
+      drlgx_launch_copy_panel(S, e->stream, nc, ce, nullptr, base0, roll0);  // (the base solve's covariance panel)
       drlgx_launch_fix_rollouts(S, e->stream, nc, ce, roll0);
     }
     for (int a = 0; a < max_n_actions; ++a) {
@@ -1029,6 +1046,7 @@ int drlgx_snapshot(drlgx_engine *e, int slot) {
   ScopedTimer t(e, 3);
   drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr, 0,
                     2 * S.n_envs + S.n_roll + slot * S.n_envs, 0);
+  drlgx_launch_copy_panel(S, e->stream, S.n_envs, nullptr, nullptr, 0, 2 * S.n_envs + S.n_roll + slot * S.n_envs);
   e->snap_pbound[slot] = e->pbound;
   return check_launch(e);
 }
@@ -1040,6 +1058,7 @@ int drlgx_restore(drlgx_engine *e, int slot) {
   ScopedTimer t(e, 3);
   drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr,
                     2 * S.n_envs + S.n_roll + slot * S.n_envs, 0, 0);
+  drlgx_launch_copy_panel(S, e->stream, S.n_envs, nullptr, nullptr, 2 * S.n_envs + S.n_roll + slot * S.n_envs, 0);
   e->pbound = e->snap_pbound[slot];
   return check_launch(e);
 }
@@ -1052,7 +1071,9 @@ int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]) {
   e->S.prof_block = (arm >> 8) & 0xffff;  // (arm >> 8: the workgroup whose phases are stamped; 0 by default)
   // (arm & 2: the second bank of 64 stamps - per-wave stamps of one sweep block step)
   // (arm & 4: 1024 stamps - out must hold them: banks 0, 1 and the per-workgroup start / end stamps of k_step from 128 on)
-  if (out && e->S.prof) HIPCHK(e, hipMemcpy(out, e->S.prof + ((arm & 2) ? 64 : 0), ((arm & 4) ? 1024 : 64) * sizeof(long long), hipMemcpyDeviceToHost));
+  // (arm & 4 reads the whole buffer from its start, whatever arm & 2 says: the buffer holds exactly 1024 stamps)
+  if (out && e->S.prof)
+    HIPCHK(e, hipMemcpy(out, e->S.prof + ((arm & 4) ? 0 : ((arm & 2) ? 64 : 0)), ((arm & 4) ? 1024 : 64) * sizeof(long long), hipMemcpyDeviceToHost));
   if (arm && !e->S.prof) {
     long long *p = nullptr;
     int r = dev_alloc(e, &p, 1024);
@@ -1062,6 +1083,21 @@ int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]) {
   } else if (!arm) {
     e->S.prof = nullptr;
   }
+  return DRLGX_OK;
+}
+
+// ---- incremental belief update: how many SLAM updates took the rank-k path / the full solve ------------------
+int drlgx_inc_stats_host(drlgx_engine *e, int64_t out[2], int reset) {
+  DRLGX_ENTER(e);
+  if (!e || !out) return DRLGX_E_INVALID;
+  out[0] = out[1] = -1;  // -1: the incremental path is disabled (DRLGX_INCREMENTAL=0 or the panels exceed the memory budget)
+  if (!e->S.inc_stats) return DRLGX_OK;
+  unsigned long long v[2] = {0, 0};
+  HIPCHK(e, hipMemcpyAsync(v, e->S.inc_stats, sizeof(v), hipMemcpyDeviceToHost, e->stream));
+  if (reset) HIPCHK(e, hipMemsetAsync(e->S.inc_stats, 0, sizeof(v), e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  out[0] = (int64_t)v[0];
+  out[1] = (int64_t)v[1];
   return DRLGX_OK;
 }
 

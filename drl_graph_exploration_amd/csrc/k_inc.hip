@@ -1,0 +1,632 @@
+// Incremental belief update between relinearisations: the SLAM stage as a rank-k covariance update instead of a re-solve.
+// Included by k_slam.hip (namespace kslam, after SlamCtx): it shares linearize_br, the fp64-MFMA helpers and inv16_blk.
+//
+// Reference arithmetic: FastMarginals2::propagate / update (src/em_exploration/FastMarginals.cpp:188-321) - the covariance-form
+// (EKF) update the reference's EM planner applies to candidate trajectories - applied here to SLAM2D::optimize
+// (SLAM2D.cpp:374-430) itself.  One iSAM2 update (gtsam ISAM2, policy in SURVEY.md App. A.3) keeps the linearisation point of
+// every variable it does not relinearise, so between relinearisations the normal equations only GAIN the new pose's
+// odometry factor and this step's bearing-range factors: with Sigma = Lambda^-1 and delta = Sigma eta of the previous update,
+//     new pose x' (odometry factor e0 + J1 d_x + J2 d_x', J2 orthogonal):   d_x' = F d_x + c,  F = -J2^T J1,  c = -J2^T e0
+//                                                Sigma[x', .] = F Sigma[x, .],  Sigma[x', x'] = F Sigma[x, x] F^T + Q
+//     re-observed landmarks (rows A = [Jx at x', Jl at l], noise R):         T = R + A Sigma A^T
+//                                                Sigma' = Sigma - Sigma A^T T^-1 A Sigma,   d' = d + Sigma A^T T^-1 (-e - A d)
+//     a landmark seen for the first time (square Jl):                          d_l = G d_x' + c,  G = -Jl^-1 Jx,  rows like the pose
+// which is exactly the re-solve of the grown system (scripts/emul/inc_update_emul.py holds the numpy form and the measured
+// drift against the CPU oracle: estimates 1e-12, information blocks 3 % of the parity tolerance over 120-step runs).
+//
+// Only part of Sigma can ever be touched again: a factor always joins the NEWEST pose and a landmark, old poses are never
+// revisited.  The state kept per instance is therefore the "panel" Sigma[:, active] - every variable (rows) against the active
+// set (columns: the current pose, all landmarks) - and the 3x3 marginal of every pose: (3P + 2L) x (3 + 2L) + 6P doubles
+// (59 KB at 37 poses / 22 landmarks against 97 KB for the packed joint covariance), DrlgxState::jc / jd / jc_meta.  All steps
+// are row-local except the k x k system T (k = 2 x re-observed landmarks, in batches of <= 8 landmarks = one 16 x 16 tile inverted in
+// registers by inv16_blk) and the rank-k update itself, which runs on the fp64 matrix cores:
+//     U'^T = W' Y^T,  C <- C + U' Ya^T         (Y = Sigma A^T row by row, W' = -T^-1, Ya = the Y rows of the active variables)
+// The panel lives in LDS for the step when it fits (flat pointers: the same code updates it in place in HBM / L2 otherwise).
+//
+// Who may take this path is decided per instance and per update (inc_precheck / inc_body's own checks): a valid panel, exactly
+// one new pose since it was left, every new factor on that pose, no landmark twice, and no relinearisation due (update count
+// % 10 == 0 with some |delta| >= 0.1).  Everything else - and every update that relinearises - runs the full solve, which
+// leaves a fresh panel behind (panel_from_dense); the pose-chain solver for long trajectories invalidates it.
+
+// Contraction is decided in the front end here (a * b + c written in one expression becomes an fma, nothing else does): with
+// contract(fast) the back end fuses differently in the fused step kernel and in the stage kernel, and the two must agree bit
+// for bit (test_fused_step_kernel_equals_stage_kernels).
+#pragma clang fp contract(on)
+
+constexpr int IYS = 18;  // row stride (doubles) of the Y / U' / W' images: 16 columns in ks16 order + 2 pad (144 B)
+constexpr int INF = 64;  // most bearing-range factors one step may add on this path
+
+__device__ __forceinline__ int *inc_meta(const DrlgxState &S, int inst) { return S.jc_meta + (size_t)inst * 4; }
+
+// Can the update that brings instance `inst` to P_after poses be incremental?  Uniform over the workgroup; every thread calls.
+// scratch: one int of LDS nobody else uses at this point (the library's __syncthreads_or brings 256 B of STATIC LDS with it,
+// which on top of the 160 KB of dynamic LDS these kernels request makes the launch fail).
+__device__ __forceinline__ bool inc_precheck(const DrlgxState &S, int inst, int P_after, int tid, int *scratch) {
+  if (!S.jc) return false;
+  const int *meta = inc_meta(S, inst);
+  if (meta[0] != 1 || meta[1] + 1 != P_after || P_after < 2) return false;
+  const int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
+  const int count = cnt[C_ISAM] + 1;
+  if (count % 10 != 0) return true;
+  // relinearizeSkip = 10: the variables that existed at the previous update are checked against relinearizeThreshold = 0.1
+  const double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
+  const double *d_lm = S.d_lm + (size_t)inst * S.L_max * 2;
+  int any = 0;
+  for (int k = tid; k < 3 * meta[1]; k += kThreads) any |= fabs(d_pose[k]) >= 0.1;
+  for (int k = tid; k < 2 * meta[2]; k += kThreads) any |= fabs(d_lm[k]) >= 0.1;
+  if (tid == 0) *scratch = 0;
+  __syncthreads();
+  if (any) atomicOr(scratch, 1);
+  __syncthreads();
+  const int r = *scratch;
+  __syncthreads();
+  return r == 0;
+}
+
+// value of the lane 16 or 32 lanes away (lane ^ kDist) - the other 16-lane rows of the wave - by the gfx950 permlane swaps
+template <int kDist>
+__device__ __forceinline__ double rowgroup_xor(double v) {
+  const long long b = __double_as_longlong(v);
+  unsigned w[2] = {(unsigned)b, (unsigned)(b >> 32)};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if constexpr (kDist == 16) {
+      const auto p = __builtin_amdgcn_permlane16_swap(w[h], w[h], false, false);  // [x0 x0 x2 x2], [x1 x1 x3 x3]
+      // rows 0 and 2 want their odd neighbour (x1, x3), rows 1 and 3 their even one (x0, x2)
+      w[h] = ((threadIdx.x >> 4) & 1) ? p[0] : p[1];
+    } else {
+      const auto p = __builtin_amdgcn_permlane32_swap(w[h], w[h], false, false);  // [x0 x1 x0 x1], [x2 x3 x2 x3]
+      w[h] = ((threadIdx.x >> 5) & 1) ? p[0] : p[1];
+    }
+  }
+  return __longlong_as_double(((long long)w[1] << 32) | w[0]);
+}
+
+// LDS carve of one incremental update.  Sizes follow what is known BEFORE the step (the pose count after it, the landmark
+// count L0 of the previous update) plus room for up to INEW landmarks seen for the first time, so that the first half of the
+// update can run beside the simulator wave of the fused step kernel.
+constexpr int INEW = 12;
+struct IncCtx {
+  int inst, P, pn, pp, L0, M0, Lcap, n1, n1p, a0, ldw;
+  int *fre, *fnew, *fslot, *ictl;
+  double *fq, *recs, *gs, *vvec, *wks, *thp, *thl, *dl, *Dl, *Y, *cwl;
+};
+// false: the step cannot take this path (LDS).  lds_panel: the panel is staged in LDS for the step (else updated in place in
+// HBM / L2).  The decision is taken for the SAME LDS offset in every kernel (the fused step's: behind the simulator's region),
+// so that the fused kernel and the stage kernels always run the same instantiation.
+__device__ __forceinline__ bool inc_plan(const DrlgxState &S, int inst, int P, int lds_bytes, size_t smem_off, IncCtx &x, bool &lds_panel) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int *meta = inc_meta(S, inst);
+  x.inst = inst; x.P = P; x.pn = P - 1; x.pp = P - 2;
+  x.L0 = meta[2]; x.M0 = meta[3];
+  x.Lcap = min(S.L_max, x.L0 + INEW);
+  x.n1 = 3 * P + 2 * x.L0; x.n1p = (x.n1 + 15) & ~15;
+  x.a0 = 3 + 2 * x.L0;
+  x.ldw = (3 + 2 * x.Lcap + 1) & ~1;
+  const int ncap = 3 * P + 2 * x.Lcap;
+  size_t plan_off = drlgx_sim_lds_bytes(S.LG, S.P_max);
+  if (smem_off > plan_off) plan_off = smem_off;
+  size_t off = (smem_off + 15) & ~(size_t)15;
+  const size_t off0 = off;
+  auto take = [&](size_t bytes) { unsigned char *q = smem_raw + off; off += (bytes + 15) & ~(size_t)15; return q; };
+  x.fre = reinterpret_cast<int *>(take(INF * 4));    // re-observed: index (0 .. nf-1) of the factor, in factor order
+  x.fnew = reinterpret_cast<int *>(take(INF * 4));   // new landmark L0 + j: index of its factor
+  x.fslot = reinterpret_cast<int *>(take(INF * 4));  // landmark slot of factor t
+  x.ictl = reinterpret_cast<int *>(take(16));        // [0] re-observed count, [1] numerical flag (inv16_blk), [2] structure flag
+  x.fq = reinterpret_cast<double *>(take(32 * 8));            // F (9), c (3), theta of the new pose (4), measured odometry (4)
+  x.recs = reinterpret_cast<double *>(take(INF * REC * 8));   // linearised new factors
+  x.gs = reinterpret_cast<double *>(take(INEW * 12 * 8));     // per new landmark: G (6), c (2), Q (xx xy yy), pad
+  x.vvec = reinterpret_cast<double *>(take(16 * 8));
+  x.wks = reinterpret_cast<double *>(take(16 * IYS * 8));
+  x.thp = reinterpret_cast<double *>(take((size_t)P * 4 * 8));
+  x.thl = reinterpret_cast<double *>(take((size_t)x.Lcap * 2 * 8));
+  x.dl = reinterpret_cast<double *>(take((size_t)ncap * 8));  // delta, logical row order
+  x.Dl = reinterpret_cast<double *>(take((size_t)P * 6 * 8));
+  x.Y = reinterpret_cast<double *>(take((size_t)(x.n1p + 1) * IYS * 8));  // (+ one row of zeros: the pad columns' operand)
+  x.cwl = reinterpret_cast<double *>(smem_raw + off);
+  const size_t fixed = ((plan_off + 15) & ~(size_t)15) + (off - off0);
+  if (fixed > (size_t)lds_bytes) return false;
+  lds_panel = fixed + (size_t)ncap * x.ldw * 8 <= (size_t)lds_bytes;
+  return true;
+}
+
+// First half: everything that does not depend on this step's measurements - loads, the new pose (odometry factor between the
+// last two poses, SLAM2D.cpp:59-89).  kSub: called by the threads 64 .. kThreads-1 while wave 0 simulates (k_step); the new
+// pose's theta is then formed from the commanded odometry with the expressions the simulator evaluates (as SlamCtx::front).
+// kLds: the panel is staged in LDS (two instantiations rather than one body on generic pointers: flat accesses count on both
+// memory counters, so every LDS read waited for all panel loads in flight).
+template <bool kLds, bool kSub>
+__device__ __forceinline__ void inc_pre(const DrlgxState &S, const IncCtx &x, int tid, const double *odom3, SubBarrier sb) {
+  const int ft = kSub ? tid - 64 : tid, fn = kSub ? kThreads - 64 : kThreads, lane = tid & 63;
+  auto bar = [&]() {
+    if constexpr (kSub) sb.sync(lane);
+    else __syncthreads();
+  };
+  const int inst = x.inst, P = x.P, pn = x.pn, pp = x.pp, L0 = x.L0, n1 = x.n1, a0 = x.a0;
+  double *gpan = S.jc + (size_t)inst * S.jc_stride;
+  auto growp = [&](int q) -> double * { return gpan + (size_t)(q < 3 * P ? q : q + 3 * (S.P_max - P)) * S.jc_ld; };
+  auto rowp = [&](int q) -> double * {
+    if constexpr (kLds) return x.cwl + (size_t)q * x.ldw;
+    else return gpan + (size_t)(q < 3 * P ? q : q + 3 * (S.P_max - P)) * S.jc_ld;
+  };
+  const double *th_pose = S.th_pose + (size_t)inst * S.P_max * 4;
+  const double *th_lm = S.th_lm + (size_t)inst * S.L_max * 2;
+  const double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
+  const double *d_lm = S.d_lm + (size_t)inst * S.L_max * 2;
+  const double *jd = S.jd + (size_t)inst * S.P_max * 6;
+  if (S.prof && blockIdx.x == S.prof_block && ft == 0) S.prof[0] = wall_clock64();
+  if (ft < 4) x.ictl[ft] = 0;
+  // the thread that linearises the odometry factor starts with its own loads
+  if (ft == fn - 1) {
+    const double *t1 = th_pose + 4 * pp;
+    Pose p1{t1[0], t1[1], t1[2], t1[3]}, p2, om;
+    if constexpr (kSub) {
+      om = make_pose(odom3[0], odom3[1], odom3[2]);
+      const double *ep = S.est_pose + ((size_t)inst * S.P_max + pp) * 4;
+      p2 = compose(Pose{ep[0], ep[1], ep[2], ep[3]}, om);  // SLAM2D::addOdometry's initial guess (SLAM2D.cpp:70-89)
+    } else {
+      const double *t2 = th_pose + 4 * pn, *oo = S.odo + ((size_t)inst * S.P_max + pp) * 4;
+      p2 = Pose{t2[0], t2[1], t2[2], t2[3]};
+      om = Pose{oo[0], oo[1], oo[2], oo[3]};
+    }
+    // e = Local(measured, between(x1, x2)), J2 = Hlocal (a rotation), J1 = Hlocal H1  =>  F = -J2^T J1 = -H1, c = -J2^T e
+    double H1[9];
+    const Pose hx = between(p1, p2, H1);
+    const Pose h = between(om, hx, nullptr);
+    const double e0 = h.x, e1 = h.y, e2 = theta_of(h);
+    double *fq = x.fq;
+    for (int k = 0; k < 9; ++k) fq[k] = -H1[k];
+    fq[9] = -(h.c * e0 - h.s * e1);
+    fq[10] = -(h.s * e0 + h.c * e1);
+    fq[11] = -e2;
+    x.thp[4 * pn] = p2.x; x.thp[4 * pn + 1] = p2.y; x.thp[4 * pn + 2] = p2.c; x.thp[4 * pn + 3] = p2.s;
+  }
+  for (int e = ft; e < 4 * pn; e += fn) x.thp[e] = th_pose[e];
+  for (int e = ft; e < 2 * L0; e += fn) x.thl[e] = th_lm[e];
+  for (int e = ft; e < 3 * pn; e += fn) x.dl[e] = d_pose[e];
+  for (int e = ft; e < 2 * L0; e += fn) x.dl[3 * P + e] = d_lm[e];
+  for (int e = ft; e < 6 * pn; e += fn) x.Dl[e] = jd[e];
+  if constexpr (kLds) {
+    // (the rows of the new pose and of the new landmarks are made below; columns [0, a0) are live.)  32 threads x 16 bytes per
+    // row, four rows' loads in flight per thread before the first store
+    const int npair = (a0 + 1) >> 1, nr = n1 - 3;
+    const int cp0 = ft & 31, r0 = ft >> 5, rs = fn >> 5;
+    for (int cp = cp0; cp < npair; cp += 32)
+      for (int qq = r0; qq < nr; qq += 4 * rs) {
+        // (clamped row indices: the loads are unconditional, the stores are not)
+        const int q0 = qq, q1 = qq + rs, q2 = qq + 2 * rs, q3 = qq + 3 * rs;
+        auto src = [&](int q) { const int c = min(q, nr - 1); return reinterpret_cast<const double2 *>(growp(c < 3 * pn ? c : c + 3))[cp]; };
+        const double2 v0 = src(q0), v1 = src(q1), v2 = src(q2), v3 = src(q3);
+        auto dst = [&](int q, const double2 &v) { if (q < nr) reinterpret_cast<double2 *>(rowp(q < 3 * pn ? q : q + 3))[cp] = v; };
+        dst(q0, v0); dst(q1, v1); dst(q2, v2); dst(q3, v3);
+      }
+  }
+  for (int e = ft; e < (x.n1p + 1 - n1) * IYS; e += fn) x.Y[(size_t)n1 * IYS + e] = 0.0;  // pad rows + the zero row
+  bar();
+  if (S.prof && blockIdx.x == S.prof_block && ft == 0) S.prof[1] = wall_clock64();
+  // ---- A. the new pose: every row's covariance with the current pose moves through F; the new pose's own rows ----
+  const double *fq = x.fq;
+  {
+    const double f00 = fq[0], f01 = fq[1], f02 = fq[2], f10 = fq[3], f11 = fq[4], f12 = fq[5], f20 = fq[6], f21 = fq[7], f22 = fq[8];
+    for (int qq = ft; qq < n1 - 3; qq += fn) {
+      const int q = qq < 3 * pn ? qq : qq + 3;
+      double *r = rowp(q);
+      const double t0 = r[0], t1 = r[1], t2 = r[2];
+      r[0] = f00 * t0 + f01 * t1 + f02 * t2;
+      r[1] = f10 * t0 + f11 * t1 + f12 * t2;
+      r[2] = f20 * t0 + f21 * t1 + f22 * t2;
+    }
+  }
+  bar();
+  for (int e = ft; e < 3 * a0; e += fn) {
+    const int r = e / a0, c = e - r * a0;
+    double v = fq[3 * r] * rowp(3 * pp)[c] + fq[3 * r + 1] * rowp(3 * pp + 1)[c] + fq[3 * r + 2] * rowp(3 * pp + 2)[c];
+    if (c == r) v += 1.0 / (c < 2 ? S.w_trans : S.w_rot);  // Q = J2^T W^-1 J2 = diag(sigma_t^2, sigma_t^2, sigma_r^2)
+    rowp(3 * pn + r)[c] = v;
+  }
+  if (ft < 3) x.dl[3 * pn + ft] = fq[3 * ft] * x.dl[3 * pp] + fq[3 * ft + 1] * x.dl[3 * pp + 1] + fq[3 * ft + 2] * x.dl[3 * pp + 2] + fq[9 + ft];
+  if (S.prof && blockIdx.x == S.prof_block && ft == 0) S.prof[2] = wall_clock64();
+}
+
+// Second half (all kThreads threads, after the simulator and a workgroup barrier): this step's factors.  L, M: the final
+// counts.  box: what the simulator wave left in LDS (k_step), else read from the instance's arrays in HBM.  The structure of
+// the new factors is verified either way (the staged C ABI can append anything; the fused step's own simulator cannot, but
+// it runs the same code).  Returns false when the step does not fit this path after all: the caller runs the full solve
+// (the HBM panel, if inc_pre already moved it, is marked invalid); uniform over the workgroup.
+template <bool kLds>
+__device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, int L, int M, const SimBox &box, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, lc = lane & 15, lr = lane >> 4;
+  const int inst = x.inst, P = x.P, pn = x.pn, L0 = x.L0, M0 = x.M0, n1 = x.n1, n1p = x.n1p, a0 = x.a0;
+  int *meta = inc_meta(S, inst);
+  const int nf = M - M0, nn = L - L0;
+  const int n = 3 * P + 2 * L, a = 3 + 2 * L;
+  int *fre = x.fre, *fnew = x.fnew, *fslot = x.fslot, *ictl = x.ictl;
+  double *recs = x.recs, *gs = x.gs, *vvec = x.vvec, *wks = x.wks, *thp = x.thp, *thl = x.thl, *dl = x.dl, *Dl = x.Dl, *Y = x.Y;
+  double *gpan = S.jc + (size_t)inst * S.jc_stride;
+  auto growp = [&](int q) -> double * { return gpan + (size_t)(q < 3 * P ? q : q + 3 * (S.P_max - P)) * S.jc_ld; };
+  auto rowp = [&](int q) -> double * {
+    if constexpr (kLds) return x.cwl + (size_t)q * x.ldw;
+    else return gpan + (size_t)(q < 3 * P ? q : q + 3 * (S.P_max - P)) * S.jc_ld;
+  };
+  int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
+  double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
+  double *d_lm = S.d_lm + (size_t)inst * S.L_max * 2;
+  double *jd = S.jd + (size_t)inst * S.P_max * 6;
+  const bool feasible = nf >= 0 && nf <= INF && nn >= 0 && nn <= nf && L <= x.Lcap;
+  // ---- 0. the new factors: structure, lists, linearisation at (theta of the new pose, theta of the landmark) ----
+  const int *slot_src = box.br ? box.slot : S.meas_lm + (size_t)inst * S.M_max + M0;
+  const double *br_src = box.br ? box.br : S.meas_br + ((size_t)inst * S.M_max + M0) * 2;
+  const double *nl_src = box.br ? box.lm : S.th_lm + ((size_t)inst * S.L_max + L0) * 2;
+  if (feasible && tid < 64) {  // (nf <= 64: one wave ranks them in factor order)
+    const bool have = tid < nf;
+    const int slot = have ? slot_src[tid] : -1;
+    if (have) fslot[tid] = slot;
+    bool bad = have && (slot < 0 || slot >= L);
+    if (have && !box.br) bad |= S.meas_pose[(size_t)inst * S.M_max + M0 + tid] != pn;
+    for (int t = 0; t < nf; ++t) {  // a landmark twice in one step: not this path
+      const int st = __builtin_amdgcn_readlane(slot, t);
+      bad |= have && t < tid && st == slot;
+    }
+    const bool re = have && slot < L0, nw = have && slot >= L0;
+    const unsigned long long mre = __ballot(re), mnw = __ballot(nw);
+    if (re) fre[__popcll(mre & ((1ull << lane) - 1ull))] = tid;
+    if (nw && !bad) fnew[slot - L0] = tid;
+    if ((__ballot(bad) || __popcll(mnw) != nn) && lane == 0) ictl[2] = 1;
+    if (lane == 0) ictl[0] = __popcll(mre);
+  }
+  for (int e = tid - 64; e >= 0 && e < 2 * nn && feasible; e += kThreads - 64) thl[2 * L0 + e] = nl_src[e];
+  __syncthreads();
+  if (!feasible || ictl[2]) {
+    if (!kLds && tid == 0) meta[0] = 0;
+    return false;
+  }
+  const int n_re = ictl[0];
+  if (tid < nf) linearize_br(thp + 4 * pn, thl + 2 * fslot[tid], br_src[2 * tid], br_src[2 * tid + 1], recs + (size_t)REC * tid);
+  __syncthreads();
+  DRLGX_PROF(S, 35);
+  // ---- B. the re-observed landmarks, <= 8 at a time (independent measurement noise: sequential batches are exact) ----
+  const double Rb = S.cfg.bearing_noise * S.cfg.bearing_noise, Rr = S.cfg.range_noise * S.cfg.range_noise;
+  const int ntr = n1p >> 4, ntc = (a0 + 15) >> 4;
+  for (int b0 = 0; b0 < n_re; b0 += 8) {
+    const int nb = min(8, n_re - b0), k = 2 * nb;
+    // B1. Y = Sigma A^T, row by row: a thread serves ONE factor of the batch (its Jacobians in registers) for every 64th row
+    {
+      const int f = tid & 7;
+      double j0 = 0, j1 = 0, j2 = 0, j3 = 0, j4 = 0, j5 = 0, l0c = 0, l1c = 0, l2c = 0, l3c = 0;
+      int cl = 3;
+      if (f < nb) {
+        const int t = fre[b0 + f];
+        const double *rc = recs + (size_t)REC * t;
+        j0 = rc[0]; j1 = rc[1]; j2 = rc[2]; j3 = rc[3]; j4 = rc[4]; j5 = rc[5];
+        l0c = rc[6]; l1c = rc[7]; l2c = rc[8]; l3c = rc[9];
+        cl = 3 + 2 * fslot[t];
+      }
+      const int k0 = ks16(2 * f), k1 = ks16(2 * f + 1);
+      for (int q = tid >> 3; q < n1; q += kThreads >> 3) {
+        const double *r = rowp(q);
+        const double c0 = r[0], c1 = r[1], c2 = r[2], l0 = r[cl], l1 = r[cl + 1];
+        // (factors beyond the batch: all-zero Jacobians, zero columns)
+        Y[(size_t)q * IYS + k0] = c0 * j0 + c1 * j1 + c2 * j2 + l0 * l0c + l1 * l1c;
+        Y[(size_t)q * IYS + k1] = c0 * j3 + c1 * j4 + c2 * j5 + l0 * l2c + l1 * l3c;
+      }
+    }
+    __syncthreads();
+    if (b0 == 0) DRLGX_PROF(S, 36);
+    // B2. T = R + A Y (symmetric by construction), v = -e - A delta, W' = -T^-1: one wave
+    if (wave == 0) {
+      v4d d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = lr + 4 * r, hi = max(i, lc), lo = min(i, lc);
+        if (hi < k) {
+          const int t = fre[b0 + (hi >> 1)], u = hi & 1;
+          const double *rc = recs + (size_t)REC * t;
+          const int col = ks16(lo);
+          const double *yp = Y + (size_t)(3 * pn) * IYS + col, *yl = Y + (size_t)(3 * P + 2 * fslot[t]) * IYS + col;
+          double s = rc[3 * u] * yp[0] + rc[3 * u + 1] * yp[IYS] + rc[3 * u + 2] * yp[2 * IYS] + rc[6 + 2 * u] * yl[0] + rc[7 + 2 * u] * yl[IYS];
+          if (hi == lo) s += u ? Rr : Rb;
+          d[r] = s;
+        }
+      }
+      if (lane < 16) {
+        double v = 0.0;
+        if (lane < k) {
+          const int t = fre[b0 + (lane >> 1)], u = lane & 1;
+          const double *rc = recs + (size_t)REC * t;
+          const double *dp = dl + 3 * pn, *dq = dl + 3 * P + 2 * fslot[t];
+          v = -rc[10 + u] - (rc[3 * u] * dp[0] + rc[3 * u + 1] * dp[1] + rc[3 * u + 2] * dp[2] + rc[6 + 2 * u] * dq[0] + rc[7 + 2 * u] * dq[1]);
+        }
+        vvec[ks16(lane)] = v;  // (ks16 order, like the rows of Y)
+      }
+      const SweepCtx sx{0, lane, lc, lr, k, 16, true, true, ictl + 1, nullptr};
+      inv16_blk(sx, k, d);
+      // image of W' for the matrix cores: row lc, columns lr + 4 r at ks16 positions 4 lr + r (W' is symmetric)
+      double *o = wks + lc * IYS + 4 * lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (lc < k && lr + 4 * r < k) ? d[r] : 0.0;
+    }
+    __syncthreads();
+    if (b0 == 0) DRLGX_PROF(S, 37);
+    // B3. U'^T = W' Y^T per 16-row tile; delta and the pose marginals; every column tile of the panel: C += U' Ya^T
+    for (int I = wave; I < ntr; I += kWaves) {
+      double w4[4], yI[4];
+      ld4(wks + lc * IYS + 4 * lr, w4);
+      ld4(Y + (size_t)(16 * I + lc) * IYS + 4 * lr, yI);
+      v4d ut = {0.0, 0.0, 0.0, 0.0};
+      ut = mfma4(w4, yI, ut);  // lane (lr, lc), register r: U'[16 I + lc][lr + 4 r]
+      double ua[4] = {ut[0], ut[1], ut[2], ut[3]};
+      {
+        // this row's delta and - pose rows - its entries of the pose marginal, from the U' registers: a lane holds the columns
+        // lr + 4 r of row q = 16 I + lc; the four lanes of a row (lc, lc + 16, lc + 32, lc + 48) are summed with the gfx950
+        // permlane swaps (no trip through LDS):  delta' = delta - U' v  (U' = -Sigma A^T T^-1, v = -e - A delta),  D_i += U'_i Y_i^T
+        const int q = 16 * I + lc;
+        auto rowdot = [&](const double *vec) -> double {
+          double y4[4];
+          ld4(vec + 4 * lr, y4);
+          double sdot = ua[0] * y4[0] + ua[1] * y4[1] + ua[2] * y4[2] + ua[3] * y4[3];
+          sdot += rowgroup_xor<16>(sdot);
+          sdot += rowgroup_xor<32>(sdot);
+          return sdot;
+        };
+        const double sv = rowdot(vvec);
+        const bool prow = q < 3 * pn;
+        const int qc = prow ? q : 0, pi = qc / 3, rp = qc - 3 * pi;
+        const double s0 = rowdot(Y + (size_t)(3 * pi) * IYS), s1 = rowdot(Y + (size_t)(3 * pi + 1) * IYS), s2 = rowdot(Y + (size_t)(3 * pi + 2) * IYS);
+        if (lr == 0 && q < n1) {
+          dl[q] -= sv;
+          if (prow) {
+            double *D = Dl + 6 * pi + (rp * (rp + 1)) / 2;
+            D[0] += s0;
+            if (rp >= 1) D[1] += s1;
+            if (rp >= 2) D[2] += s2;
+          }
+        }
+      }
+      // four column tiles at a time: their loads are issued together (the panel may live in HBM / L2), the four accumulation
+      // chains interleave on the matrix cores
+      for (int J0 = 0; J0 < ntc; J0 += 4) {
+        v4d acc[4];
+        double yJ[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int col = 16 * (J0 + t) + lc;
+          const bool cok = col < a0;  // (also false for tiles beyond ntc)
+          const int yrow = col < 3 ? 3 * pn + col : (cok ? 3 * P + col - 3 : n1p);
+          ld4(Y + (size_t)yrow * IYS + 4 * lr, yJ[t]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = 16 * I + lr + 4 * r;
+            acc[t][r] = (q < n1 && cok) ? rowp(q)[col] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[ks], yJ[t][ks], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int col = 16 * (J0 + t) + lc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = 16 * I + lr + 4 * r;
+            if (q < n1 && col < a0) rowp(q)[col] = acc[t][r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (b0 == 0) DRLGX_PROF(S, 38);
+  }
+  DRLGX_PROF(S, 3);
+  // ---- C. landmarks seen for the first time ----
+  if (nn > 0) {
+    if (tid < nn) {
+      const double *rc = recs + (size_t)REC * fnew[tid];
+      const double det = rc[6] * rc[9] - rc[7] * rc[8], id = 1.0 / det;
+      const double i00 = rc[9] * id, i01 = -rc[7] * id, i10 = -rc[8] * id, i11 = rc[6] * id;  // Jl^-1
+      double *g = gs + 12 * tid;
+      for (int c = 0; c < 3; ++c) {
+        g[c] = -(i00 * rc[c] + i01 * rc[3 + c]);
+        g[3 + c] = -(i10 * rc[c] + i11 * rc[3 + c]);
+      }
+      g[6] = -(i00 * rc[10] + i01 * rc[11]);
+      g[7] = -(i10 * rc[10] + i11 * rc[11]);
+      g[8] = i00 * Rb * i00 + i01 * Rr * i01;  // Jl^-1 R Jl^-T
+      g[9] = i00 * Rb * i10 + i01 * Rr * i11;
+      g[10] = i10 * Rb * i10 + i11 * Rr * i11;
+    }
+    __syncthreads();
+    // C1. the new rows against the old columns; delta_l
+    for (int e = tid; e < 2 * nn * a0; e += kThreads) {
+      const int rr = e / a0, c = e - rr * a0;
+      const double *g = gs + 12 * (rr >> 1) + 3 * (rr & 1);
+      rowp(n1 + rr)[c] = g[0] * rowp(3 * pn)[c] + g[1] * rowp(3 * pn + 1)[c] + g[2] * rowp(3 * pn + 2)[c];
+    }
+    if (tid < 2 * nn) {
+      const double *g = gs + 12 * (tid >> 1);
+      dl[n1 + tid] = g[3 * (tid & 1)] * dl[3 * pn] + g[3 * (tid & 1) + 1] * dl[3 * pn + 1] + g[3 * (tid & 1) + 2] * dl[3 * pn + 2] + g[6 + (tid & 1)];
+    }
+    __syncthreads();
+    // C2. the new columns of every row (Sigma[., l] = Sigma[., x'] G^T), + the landmark's own noise on its diagonal block
+    for (int e = tid; e < n * 2 * nn; e += kThreads) {
+      const int q = e / (2 * nn), cc = e - q * 2 * nn;
+      const double *g = gs + 12 * (cc >> 1);
+      const double *r = rowp(q);
+      double v = r[0] * g[3 * (cc & 1)] + r[1] * g[3 * (cc & 1) + 1] + r[2] * g[3 * (cc & 1) + 2];
+      if (q >= n1 && ((q - n1) >> 1) == (cc >> 1)) {
+        const int er = (q - n1) & 1, ec = cc & 1;
+        v += er == ec ? (er ? g[10] : g[8]) : g[9];
+      }
+      rowp(q)[a0 + cc] = v;
+    }
+    __syncthreads();
+  }
+  DRLGX_PROF(S, 4);
+  // ---- D. outputs: estimates theta (+) delta, information = inverse(marginal covariance) (SLAM2D.cpp:395-417), the panel ----
+  double *est_pose = S.est_pose + (size_t)inst * S.P_max * 4;
+  double *pose_info = S.pose_info + (size_t)inst * S.P_max * 6;
+  double *pose_tr = S.pose_tr + (size_t)inst * S.P_max;
+  for (int i = tid; i < P; i += kThreads) {
+    const Pose t{thp[4 * i], thp[4 * i + 1], thp[4 * i + 2], thp[4 * i + 3]};
+    const double d0 = dl[3 * i], d1 = dl[3 * i + 1], d2 = dl[3 * i + 2];
+    const Pose e = compose(t, make_pose(d0, d1, d2));
+    est_pose[4 * i] = e.x; est_pose[4 * i + 1] = e.y; est_pose[4 * i + 2] = e.c; est_pose[4 * i + 3] = e.s;
+    d_pose[3 * i] = d0; d_pose[3 * i + 1] = d1; d_pose[3 * i + 2] = d2;
+    double c00, c10, c11, c20, c21, c22;
+    if (i == pn) {  // the current pose's marginal is its block of the panel
+      const double *r0 = rowp(3 * pn), *r1 = rowp(3 * pn + 1), *r2 = rowp(3 * pn + 2);
+      c00 = r0[0]; c10 = 0.5 * (r1[0] + r0[1]); c11 = r1[1]; c20 = 0.5 * (r2[0] + r0[2]); c21 = 0.5 * (r2[1] + r1[2]); c22 = r2[2];
+    } else {
+      const double *D = Dl + 6 * i;
+      c00 = D[0]; c10 = D[1]; c11 = D[2]; c20 = D[3]; c21 = D[4]; c22 = D[5];
+    }
+    double *go = jd + 6 * i;
+    go[0] = c00; go[1] = c10; go[2] = c11; go[3] = c20; go[4] = c21; go[5] = c22;
+    pose_tr[i] = c00 + c11 + c22;
+    inv3_sym_fast(c00, c10, c20, c11, c21, c22, pose_info + 6 * i);
+  }
+  {
+    double *est_lm = S.est_lm + (size_t)inst * S.L_max * 2;
+    double *lm_info = S.lm_info + (size_t)inst * S.L_max * 3;
+    double *lm_tr = S.lm_tr + (size_t)inst * S.L_max;
+    for (int j = kThreads - 1 - tid; j < L; j += kThreads) {
+      const double dx = dl[3 * P + 2 * j], dy = dl[3 * P + 2 * j + 1];
+      d_lm[2 * j] = dx; d_lm[2 * j + 1] = dy;
+      est_lm[2 * j] = thl[2 * j] + dx;
+      est_lm[2 * j + 1] = thl[2 * j + 1] + dy;
+      const double *r0 = rowp(3 * P + 2 * j), *r1 = rowp(3 * P + 2 * j + 1);
+      const double c00 = r0[3 + 2 * j], c11 = r1[3 + 2 * j + 1], cs = 0.5 * (r0[3 + 2 * j + 1] + r1[3 + 2 * j]);
+      lm_tr[j] = c00 + c11;
+      const double id = 1.0 / (c00 * c11 - cs * cs);  // marginalCovariance(l).inverse() (SLAM2D.cpp:417)
+      lm_info[3 * j] = c11 * id;
+      lm_info[3 * j + 1] = -cs * id;
+      lm_info[3 * j + 2] = c00 * id;
+    }
+  }
+  DRLGX_PROF(S, 5);
+  if constexpr (kLds) {
+    const int npair = (a + 1) >> 1;
+    const int cp0 = tid & 31, r0 = tid >> 5;
+    for (int cp = cp0; cp < npair; cp += 32)
+      for (int q = r0; q < n; q += 16) reinterpret_cast<double2 *>(growp(q))[cp] = reinterpret_cast<const double2 *>(rowp(q))[cp];
+  }
+  if (tid == 0) {
+    meta[0] = 1; meta[1] = P; meta[2] = L; meta[3] = M;
+    cnt[C_ISAM] = cnt[C_ISAM] + 1;
+    cnt[C_NEWP] = P;
+    cnt[C_NEWL] = L;
+    if (ictl[1]) atomicMin(S.status, DRLGX_E_NUMERIC);
+    if (S.inc_stats) atomicAdd(S.inc_stats, 1ull);
+  }
+  DRLGX_PROF(S, 7);
+  return true;
+}
+
+// The panel after a full (dense) solve: Sigma[:, active] from what SlamCtx::back leaves in LDS - A = -Sigma_pp (packed lower
+// triangle), the per-factor G_m = Lambda_pl Lambda_ll^-1 blocks, the per-landmark factor lists:
+//     Sigma_pl = -Sigma_pp G          (column block of landmark j: the sum over its factor list)
+//     Sigma_ll = Lambda_ll^-1 + G^T Sigma_pp G = Lambda_ll^-1 - G^T Sigma_pl
+// written to the HBM panel (the second stage reads the first one's rows back through L2).
+__device__ __forceinline__ void panel_from_dense(const DrlgxState &S, const SlamCtx &c, int tid) {
+  if (!S.jc) return;
+  const int inst = c.inst, P = c.P, L = c.L, pn = P - 1;
+  double *gpan = S.jc + (size_t)inst * S.jc_stride;
+  const int ldg = S.jc_ld;
+  auto prow = [&](int q) -> double * { return gpan + (size_t)q * ldg; };                           // pose rows
+  auto lrow = [&](int q) -> double * { return gpan + (size_t)(3 * S.P_max + q) * ldg; };           // landmark rows
+  auto asym = [&](int i, int j) -> double { return c.A[c.AT(max(i, j), min(i, j))]; };
+  double *jd = S.jd + (size_t)inst * S.P_max * 6;
+  // pose rows: columns of the current pose, the marginal, the landmark blocks
+  for (int e = tid; e < 3 * P * 3; e += kThreads) {
+    const int q = e / 3, cc = e - 3 * q;
+    prow(q)[cc] = -asym(q, 3 * pn + cc);
+  }
+  for (int e = tid; e < 6 * P; e += kThreads) {
+    const int i = e / 6, t = e - 6 * i;
+    const int r = t < 1 ? 0 : (t < 3 ? 1 : 2), cc = t - (r * (r + 1)) / 2;
+    jd[e] = -c.A[c.AT(3 * i + r, 3 * i + cc)];
+  }
+  for (int e = tid; e < P * L; e += kThreads) {
+    const int i = e / L, j = e - i * L;
+    double b[6] = {0, 0, 0, 0, 0, 0};
+    for (int t = c.lstart[j]; t < c.lstart[j + 1]; ++t) {
+      const int m = c.lfac[t], p = c.mp[m];
+      const double *g = c.rec + (size_t)REC * m;
+      const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4], g5 = g[5];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double a0 = asym(3 * i + r, 3 * p), a1 = asym(3 * i + r, 3 * p + 1), a2 = asym(3 * i + r, 3 * p + 2);
+        b[2 * r] += a0 * g0 + a1 * g2 + a2 * g4;
+        b[2 * r + 1] += a0 * g1 + a1 * g3 + a2 * g5;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      prow(3 * i + r)[3 + 2 * j] = b[2 * r];
+      prow(3 * i + r)[3 + 2 * j + 1] = b[2 * r + 1];
+    }
+  }
+  __syncthreads();
+  // landmark rows
+  for (int e = tid; e < 2 * L * 3; e += kThreads) {
+    const int q = e / 3, cc = e - 3 * q;
+    lrow(q)[cc] = prow(3 * pn + cc)[3 + q];
+  }
+  for (int e = tid; e < L * L; e += kThreads) {
+    const int j = e / L, j2 = e - j * L;
+    double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+    if (j == j2) {
+      const double *lb = c.lamb + 8 * j;
+      s00 = lb[3]; s01 = lb[4]; s10 = lb[4]; s11 = lb[5];
+    }
+    for (int t = c.lstart[j]; t < c.lstart[j + 1]; ++t) {
+      const int m = c.lfac[t], p = c.mp[m];
+      const double *g = c.rec + (size_t)REC * m;
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const double *pr = prow(3 * p + kk) + 3 + 2 * j2;
+        const double x0 = pr[0], x1 = pr[1];
+        s00 -= g[2 * kk] * x0; s01 -= g[2 * kk] * x1;
+        s10 -= g[2 * kk + 1] * x0; s11 -= g[2 * kk + 1] * x1;
+      }
+    }
+    lrow(2 * j)[3 + 2 * j2] = s00; lrow(2 * j)[3 + 2 * j2 + 1] = s01;
+    lrow(2 * j + 1)[3 + 2 * j2] = s10; lrow(2 * j + 1)[3 + 2 * j2 + 1] = s11;
+  }
+  if (tid == 0) {
+    int *meta = inc_meta(S, inst);
+    meta[0] = 1; meta[1] = P; meta[2] = L; meta[3] = c.M;
+    if (S.inc_stats) atomicAdd(S.inc_stats + 1, 1ull);
+  }
+}
+
+// an update by a solver that leaves no panel (the pose-chain solver of long trajectories)
+__device__ __forceinline__ void panel_invalidate(const DrlgxState &S, int inst, int tid) {
+  if (S.jc && tid == 0) {
+    inc_meta(S, inst)[0] = 0;
+    if (S.inc_stats) atomicAdd(S.inc_stats + 1, 1ull);
+  }
+}
+
+// panel of instance src -> dst: the live rows / columns only
+__global__ __launch_bounds__(256) void k_copy_panel(DrlgxState S, const int32_t *src, const int32_t *dst, int src_off, int dst_off) {
+  const int i = blockIdx.x;
+  const int s = (src ? src[i] : i) + src_off, d = (dst ? dst[i] : i) + dst_off;
+  const int *ms = S.jc_meta + (size_t)s * 4;
+  int *md = S.jc_meta + (size_t)d * 4;
+  const int valid = ms[0], P = ms[1], L = ms[2], M = ms[3];
+  if (threadIdx.x == 0) {
+    md[0] = valid; md[1] = P; md[2] = L; md[3] = M;
+  }
+  if (valid != 1) return;
+  const double *ps = S.jc + (size_t)s * S.jc_stride;
+  double *pd = S.jc + (size_t)d * S.jc_stride;
+  const int npair = (3 + 2 * L + 1) >> 1, rows = 3 * P + 2 * L;
+  for (int e = threadIdx.x; e < rows * npair; e += 256) {
+    const int q = e / npair, cp = e - q * npair;
+    const size_t o = (size_t)(q < 3 * P ? q : q - 3 * P + 3 * S.P_max) * S.jc_ld + 2 * cp;
+    *reinterpret_cast<double2 *>(pd + o) = *reinterpret_cast<const double2 *>(ps + o);
+  }
+  for (int e = threadIdx.x; e < 6 * P; e += 256) S.jd[(size_t)d * S.P_max * 6 + e] = S.jd[(size_t)s * S.P_max * 6 + e];
+}
+#pragma clang fp contract(fast)

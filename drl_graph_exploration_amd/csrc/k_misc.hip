@@ -52,6 +52,7 @@ __global__ __launch_bounds__(64) void k_rebase(DrlgxState S, int base0, int n) {
     cnt[C_NEWP] = 0;
     cnt[C_NEWL] = 0;
     cnt[C_FLAG] = 0;
+    if (S.jc_meta) S.jc_meta[(size_t)inst * 4] = 0;  // the re-based system is solved in full (and leaves a fresh covariance panel)
   }
 }
 

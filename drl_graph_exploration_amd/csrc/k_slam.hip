@@ -32,6 +32,9 @@ constexpr int REC = 12;  // per-factor record: [0..5] Jx (2x3) -> later G (3x2);
 // conflict-free and measured SLOWER - G 1.3 -> 2.3 us, Schur 7.8 -> 9.0, landmark marginals 4.4 -> 6.4: the records lose
 // their 16-byte alignment and with it the 128-bit loads)
 
+// (linearize_br, fast_rcp and inv16_blk are shared with the incremental update (k_inc.hip), whose fused and staged forms must
+// round alike although they are inlined into differently shaped code: contraction decided in the front end for them)
+#pragma clang fp contract(on)
 // BearingRangeFactor linearised at (pose, landmark) (SLAM2D.cpp:91-124; gtsam BearingRangeFactor).  d = the landmark in the
 // pose frame, n = |d|, (c, s) = d / n: the predicted bearing is atan2(s, c) and never needed as an angle - the error
 // Rot2 Local(measured, predicted) is taken from (c, s) directly - and the predicted range is n; the range Jacobians are
@@ -82,6 +85,7 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return r;
 }
 
+#pragma clang fp contract(fast)
 typedef double v4d __attribute__((ext_vector_type(4)));
 // doubles of the LDS region of a packed N x N system swept by sweep_packed_fast: the packed lower triangle, or the sweep's
 // panels (two pivot-column panels, two W panels, two E tiles, two diagonal-tile dumps) that alias it
@@ -223,6 +227,7 @@ __device__ __forceinline__ void inv16(const SweepCtx &x, int K, v4d &d) {
   }
 }
 
+#pragma clang fp contract(on)
 // ---- in-wave 16 x 16 SPD inversion by 4 x 4 BLOCK pivots on the fp64 matrix cores ----
 // Same contract as inv16 (d: full symmetric tile in accumulator layout <- -D^-1 on the first `nact` pivots), four block
 // steps instead of sixteen scalar ones.  Block step Kb (rows / columns 4 Kb .. 4 Kb + 3 = accumulator register Kb):
@@ -309,6 +314,7 @@ __device__ __forceinline__ void inv16_blk(const SweepCtx &x, int nact, v4d &d) {
   if (!spd && x.lane == 0) x.bad[0] = 1;
 }
 
+#pragma clang fp contract(fast)
 // ---- the fast sweep as ONE runtime loop over the block steps ----
 // (Round 2 instantiated a block step per tile column: 145 KB of straight-line code for seven steps - more than twice the
 // 64 KB instruction cache, so the wave that inverts the diagonal tiles, alone on the critical path, ran its 16 pivots out
@@ -1698,6 +1704,37 @@ struct SlamCtx {
   }
 };
 
+#include "k_inc.hip"
+
+// The incremental update as a stage (k_slam / k_slam_arrow / k_step_arrow, after the simulator): true when it served the
+// instance - the caller then skips its solver.  Every thread of the workgroup calls it.
+__device__ __forceinline__ bool inc_stage(const DrlgxState &S, const LaunchSel &sel, int lds_bytes, size_t smem_off) {
+  const int tid = threadIdx.x, bi = blockIdx.x;
+  if (!S.jc || !sel.on(bi)) return false;
+  const int inst = sel.base + bi;
+  const int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
+  if (cnt[C_FLAG]) return false;  // (a rejected move appended nothing)
+  const int P = cnt[C_P], L = cnt[C_L], M = cnt[C_M];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (!inc_precheck(S, inst, P, tid, reinterpret_cast<int *>(smem_raw + smem_off))) return false;
+  IncCtx x;
+  bool lds_panel = false;
+  if (!inc_plan(S, inst, P, lds_bytes, smem_off, x, lds_panel)) return false;
+  const SimBox nobox{nullptr, nullptr, nullptr};
+  bool done;
+  if (lds_panel) {
+    inc_pre<true, false>(S, x, tid, nullptr, SubBarrier{nullptr, 0, 0});
+    __syncthreads();
+    done = inc_post<true>(S, x, L, M, nobox, tid);
+  } else {
+    inc_pre<false, false>(S, x, tid, nullptr, SubBarrier{nullptr, 0, 0});
+    __syncthreads();
+    done = inc_post<false>(S, x, L, M, nobox, tid);
+  }
+  if (!done) __syncthreads();  // (the full solve reuses the LDS)
+  return done;
+}
+
 // The SLAM stage after the simulator.  `pre` (have_pre): the context whose front() already ran beside the simulator (k_step)
 // for the counts before the step (records in LDS).  smem_off: first byte of the dynamic LDS the stage may use.
 template <int FT>
@@ -1739,10 +1776,15 @@ __device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel
   }
   c.back<FT>(S, tid, L, M, full, refresh, hand, (from_pre && mailed) ? box : SimBox{nullptr, nullptr, nullptr});
   if (lm_out) *lm_out = c.thl;
+  if (S.jc && !refresh) {  // the covariance panel the incremental updates continue from (k_inc.hip)
+    __syncthreads();
+    panel_from_dense(S, c, tid);
+  }
 }
 
 template <int FT>
 __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &sel, int lds_bytes) {
+  if (inc_stage(S, sel, lds_bytes, 0)) return;
   SlamCtx none;
   slam_finish<FT>(S, sel, lds_bytes, 0, none, false);
 }
@@ -1814,5 +1856,10 @@ void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p
     hipLaunchKernelGGL((kslam::k_slam_arrow<0>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
   else
     hipLaunchKernelGGL((kslam::k_slam_arrow<kslam::kArrowRegTiles>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
+}
+void drlgx_launch_copy_panel(const DrlgxState &S, hipStream_t st, int n, const int32_t *src, const int32_t *dst, int src_off,
+                             int dst_off) {
+  if (!S.jc || n <= 0) return;
+  hipLaunchKernelGGL(kslam::k_copy_panel, dim3(n), dim3(256), 0, st, S, src, dst, src_off, dst_off);
 }
 #pragma clang fp contract(off)

@@ -87,6 +87,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   const int tid = threadIdx.x;
   const int bi = blockIdx.x;
   if (!sel.on(bi)) return;
+  if (inc_stage(S, sel, lds_bytes, 0)) return;  // between relinearisations: the rank-k covariance update (k_inc.hip)
   const int inst = sel.base + bi;
   int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
   // (`full` / `refresh`: see slam_body - intermediate look-ahead steps solve for the estimates only)
@@ -1007,6 +1008,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     }
     if (bad[0]) atomicMin(S.status, DRLGX_E_NUMERIC);
   }
+  if (!refresh) panel_invalidate(S, inst, tid);  // (this solver leaves no covariance panel: full solves from here on)
 }
 
 template <int NTW>

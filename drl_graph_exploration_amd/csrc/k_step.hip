@@ -24,14 +24,7 @@ namespace kstep {
 
 // LDS of the simulator wave (two mt19937 streams, the normal variates and the in-range list of a measure() call); the SLAM
 // stage of k_step carves behind it because its front end runs WHILE the simulator wave works
-__host__ __device__ inline size_t sim_lds_bytes(int LG, int P_max) {
-  size_t b = (size_t)2 * DRLGX_MT_STRIDE * 4 + (size_t)(2 * LG + 2) * 8 + (size_t)LG * 4 + 16;
-  b = ((b + 7) & ~(size_t)7) + (size_t)2 * LG * 8;  // the new landmarks' initial estimates, for the SLAM stage (ksim::measure)
-  // ... and, when that costs little, wide enough for the map stage's pose tables (19 P_max doubles), so that the SLAM stage
-  // can leave its outputs in them (see k_step)
-  if (P_max <= 64) b = b > (size_t)P_max * 19 * 8 + 32 ? b : (size_t)P_max * 19 * 8 + 32;
-  return (b + 31) & ~(size_t)31;
-}
+__host__ __device__ inline size_t sim_lds_bytes(int LG, int P_max) { return drlgx_sim_lds_bytes(LG, P_max); }
 
 template <int FT>
 __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
@@ -55,7 +48,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
     lo.tr = reinterpret_cast<const uint32_t *>(S.lo_tr)[tid];
   }
   kslam::SlamCtx ctx;
-  bool pre = false, accepted = false;
+  bool pre = false, accepted = false, inc_try = false;
   double od3[3] = {0, 0, 0};
   int P0 = 0, L0 = 0, M0 = 0, isam = 0;
   if (sel.on(bi)) {
@@ -67,10 +60,12 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
     const drlgx_config &cfg = S.cfg;
     // the simulator's own acceptance test (sim_step_body): a rejected move appends nothing - no front end then
     accepted = (cfg.map_min_x < od3[0] && od3[0] < cfg.map_max_x) && (cfg.map_min_y < od3[1] && od3[1] < cfg.map_max_y) && P0 < S.P_max;
+    // between relinearisations the SLAM stage is a rank-k covariance update (k_inc.hip): no front end to run ahead
+    inc_try = accepted && kslam::inc_precheck(S, inst, P0 + 1, tid, sub_cnt);
     // room for the landmarks / factors a step may add (more: slam_finish starts over); the front end only runs ahead when
     // the factor records fit the LDS (else slam_finish takes the workspace variant after the simulator)
     const int Lb = min(S.L_max, L0 + 48), Mb = min(S.M_max, M0 + 48);
-    pre = accepted && (3 * (P0 + 1) + 1 + 15) / 16 <= FT && kslam::SlamCtx::big_fits(sim_bytes, lds_bytes, P0 + 1, Lb, Mb);
+    pre = accepted && !inc_try && (3 * (P0 + 1) + 1 + 15) / 16 <= FT && kslam::SlamCtx::big_fits(sim_bytes, lds_bytes, P0 + 1, Lb, Mb);
     if (pre) ctx.setup<true>(S, step_smem, sim_bytes, lds_bytes, inst, P0 + 1, Lb, Mb);
   }
   if (tid == 0) {
@@ -87,6 +82,16 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
                         n_measure == 2 ? lmbox : nullptr, sel.on(bi) ? P0 : -1, L0, M0);
   } else if (pre) {
     ctx.front<true>(S, tid, P0, L0, M0, P0, L0, isam + 1, false, od3, kslam::SubBarrier{sub_cnt, kslam::kThreads / 64 - 1, 0});
+  } else if (inc_try) {
+    // the half of the incremental update that does not need this step's measurements: panel -> LDS, the new pose
+    // (the LDS plan is a few scalar operations: evaluated here and again after the simulator rather than kept in registers)
+    kslam::IncCtx ix;
+    bool inc_lds = false;
+    if (kslam::inc_plan(S, sel.base + bi, P0 + 1, lds_bytes, sim_bytes, ix, inc_lds)) {
+      const kslam::SubBarrier sb{sub_cnt, kslam::kThreads / 64 - 1, 0};
+      if (inc_lds) kslam::inc_pre<true, true>(S, ix, tid, od3, sb);
+      else kslam::inc_pre<false, true>(S, ix, tid, od3, sb);
+    }
   }
   __syncthreads();
   DRLGX_PROF(S, 32);
@@ -104,7 +109,19 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
   // long as they lie below its cell masks, which it clears first.
   const bool hand = (size_t)S.P_max * 19 * sizeof(double) + 16 <= sim_bytes - 16;
   const double *lm_lds = nullptr;
-  kslam::slam_finish<FT>(S, sel, lds_bytes, sim_bytes, ctx, pre, sub_cnt + 1, hand ? reinterpret_cast<double *>(step_smem) : nullptr, &lm_lds, box);
+  bool inc_done = false;
+  if (inc_try) {
+    // (sub_cnt[1] < 0 cannot happen: `accepted` is the simulator's own test; the counts would be the old ones and the
+    // structure check of inc_post would refuse them)
+    kslam::IncCtx ix;
+    bool inc_lds = false;
+    if (kslam::inc_plan(S, sel.base + bi, P0 + 1, lds_bytes, sim_bytes, ix, inc_lds)) {
+      inc_done = inc_lds ? kslam::inc_post<true>(S, ix, sub_cnt[2], sub_cnt[3], box, tid) : kslam::inc_post<false>(S, ix, sub_cnt[2], sub_cnt[3], box, tid);
+      if (!inc_done) __syncthreads();
+    }
+  }
+  if (!inc_done)
+    kslam::slam_finish<FT>(S, sel, lds_bytes, sim_bytes, ctx, pre, sub_cnt + 1, hand ? reinterpret_cast<double *>(step_smem) : nullptr, &lm_lds, box);
   __syncthreads();
   const bool handed = hand && lm_lds != nullptr;  // (lm_lds: set once the SLAM stage ran to its end)
   if (sel.on(bi)) {  // the counts as the simulator wave left them (nothing appended: those before the step)
@@ -132,7 +149,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step_arrow(DrlgxState S, La
     ksim::sim_step_body(S, sel, odom, odom_stride, n_measure, l0, l1, dyn, tid);
   }
   __syncthreads();
-  kslam::arrow_body<0>(S, sel, lds_bytes);
+  kslam::arrow_body<0>(S, sel, lds_bytes);  // (or, between relinearisations, the incremental update: arrow_body's first lines)
   __syncthreads();
   kmap::map_body(S, sel, 1, map_chunk);
 }

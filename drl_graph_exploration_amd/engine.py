@@ -247,6 +247,13 @@ class Engine(object):
         self.use_torch_stream()
         self._chk(self.L.drlgx_restore(self.h, slot))
 
+    def inc_stats(self, reset=False):
+        """(SLAM updates served by the incremental rank-k path, full solves) since creation / the last reset;
+        (-1, -1) when the incremental path is disabled (DRLGX_INCREMENTAL=0 at creation)."""
+        out = (C.c_int64 * 2)()
+        self._chk(self.L.drlgx_inc_stats_host(self.h, out, 1 if reset else 0))
+        return int(out[0]), int(out[1])
+
     def timing_enable(self, on=True):
         """on: False / True (spans around what is launched, fused step = 'step') / 2 (per-stage kernels)."""
         self._chk(self.L.drlgx_timing_enable(self.h, int(on)))

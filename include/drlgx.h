@@ -262,7 +262,17 @@ int drlgx_timing_read_host(drlgx_engine *e, double ms[DRLGX_N_TIMERS], int64_t l
  * receives the last stamps: 64 values - the first bank; with arm & 2 the second bank (per-wave cycle stamps of one block
  * step of the sweep); with arm & 4 all 1024 values (out must hold them): both banks and, from 128 on, the start / end stamp
  * of every workgroup of the last k_step launch (scripts/phase_profile*.py). */
-int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t out[64]);
+int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t *out /* 64 values; 1024 with arm & 4 (read from the buffer's start) */);
+
+/* The incremental belief update (csrc/k_inc.hip): between relinearisations of the iSAM2 policy (SLAM2D.cpp:10-12: every
+ * 10th update, |delta| >= 0.1) SLAM2D::optimize (SLAM2D.cpp:374-430) only gains the new pose's odometry factor and the
+ * step's bearing-range factors, so the engine applies the covariance-form update of FastMarginals2::propagate / update
+ * (FastMarginals.cpp:188-321) to a per-instance covariance panel instead of re-solving; updates that relinearise, re-based
+ * look-ahead copies (SLAM2D::set_copy_isam, SLAM2D.cpp:490-497) and anything the panel cannot serve take the full solve.
+ * On by default; DRLGX_INCREMENTAL=0 in the environment of drlgx_create disables it (every update a full solve), as does a
+ * panel memory need beyond DRLGX_INC_MAX_GB (default 32).  out[0] = updates served by the rank-k path, out[1] = full
+ * solves, since creation or the last call with reset != 0; both -1 when the path is disabled. */
+int drlgx_inc_stats_host(drlgx_engine *e, int64_t out[2], int reset);
 
 /* ---- GCN policy (scripts/Networks.py:12-70 over PyG GCNConv(improved=True)) ------------------- */
 

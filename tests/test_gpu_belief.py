@@ -628,3 +628,60 @@ def test_fm2_covariance_update_matches_the_restatement():
     for i in range(n):
         compare_state(eng, i, sims[i], "after fm2 env %d" % i)
     eng.close()
+
+
+def test_incremental_update_equals_the_full_solve_across_relinearisations(monkeypatch):
+    """The rank-k covariance update between relinearisations (csrc/k_inc.hip; FastMarginals.cpp:188-321 applied to
+    SLAM2D::optimize) against (a) the same engine with every update a full solve (DRLGX_INCREMENTAL=0) and (b) the CPU
+    oracle, over 31 consecutive steps - three 10th-update relinearisation checks (SLAM2D.cpp:10-12) - in the 100-landmark
+    world: estimates 1e-9, information blocks 1e-7 relative, factor topology and the virtual map's update flags exact.
+    The virtual-map information is compared at 1e-6 here: at this many poses the FULL solve itself is 1.5-2.1e-7 away from
+    the oracle in a few cells next to a pose (scripts/inc_drift.py prints both engines' errors side by side - the
+    incremental path is not the less accurate one)."""
+    from drl_graph_exploration_amd import default_config
+    from drl_graph_exploration_amd.engine import Engine
+    n = 6
+    cfg = default_config(MAP, num_landmarks=100, max_poses=41, max_landmarks=100)
+    eng = Engine(cfg, n, 0)
+    monkeypatch.setenv("DRLGX_INCREMENTAL", "0")
+    ref = Engine(cfg, n, 0)
+    monkeypatch.delenv("DRLGX_INCREMENTAL")
+    assert ref.inc_stats() == (-1, -1) and eng.inc_stats()[0] == 0
+    ocfg = O.default_config(MAP, num_landmarks=100)
+    starts = generic_starts(n)
+    sims = [O.OracleSim(ocfg, lo, lo, start=tuple(starts[lo])) for lo in range(n)]
+    for e in (eng, ref):
+        e.reset(np.arange(n), np.arange(n), starts=starts)
+    script = [(1, 1, math.pi / 2)] * 4 + [(2, 0, 0), (2, 0, 0), (0, 0, 0.6)] * 9
+    for s, act in enumerate(script):
+        odom = torch.tensor([act] * n, dtype=torch.float64, device=eng.device)
+        eng.step(odom)
+        ref.step(odom)
+        for sim in sims:
+            sim.simulate(act)
+        assert eng.status() == 0 and ref.status() == 0
+        for i in range(n):
+            name = "incremental, step %d env %d" % (s, i)
+            compare_state(eng, i, sims[i], name, check_vm=False)
+            xyt, info = eng.poses(i)
+            rxyt, rinfo = ref.poses(i)
+            np.testing.assert_allclose(xyt, rxyt, atol=1e-9, err_msg=name)
+            np.testing.assert_allclose(info, rinfo, rtol=1e-7, atol=1e-6, err_msg=name)
+            k, xy, linfo = eng.landmarks(i)
+            rk, rxy, rlinfo = ref.landmarks(i)
+            np.testing.assert_array_equal(k, rk)
+            np.testing.assert_allclose(xy, rxy, atol=1e-9, err_msg=name)
+            np.testing.assert_allclose(linfo, rlinfo, rtol=1e-7, atol=1e-6, err_msg=name)
+            prob, vinfo, tr, upd = eng.virtual_map(i)
+            oprob, ovinfo, otr, oupd = sims[i].virtual_map()
+            np.testing.assert_array_equal(upd, oupd)
+            np.testing.assert_array_equal(upd, ref.virtual_map(i)[3])
+            np.testing.assert_allclose(prob, oprob, rtol=1e-14, err_msg=name)
+            np.testing.assert_allclose(vinfo, ovinfo, rtol=1e-6, atol=1e-9, err_msg=name)
+            np.testing.assert_allclose(tr, otr, rtol=1e-6, err_msg=name)
+    inc, full = eng.inc_stats()
+    # every env: the reset solve and the updates that relinearise are full solves, all the others rank-k updates
+    assert inc + full == n * (len(script) + 1)
+    assert inc >= n * (len(script) - 4) and full >= n
+    eng.close()
+    ref.close()
