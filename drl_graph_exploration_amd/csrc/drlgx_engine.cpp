@@ -391,8 +391,8 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
     const char *v = getenv("DRLGX_INCREMENTAL");
     const char *g = getenv("DRLGX_INC_MAX_GB");
     const double max_gb = g ? atof(g) : 32.0;
-    S.jc_ld = (3 + 2 * S.L_max + 15) & ~15;  // rows start on 128-byte lines: the 16-column tiles of the rank-k update are whole lines
-    S.jc_stride = (size_t)(3 * S.P_max + 2 * S.L_max) * (size_t)S.jc_ld;
+    S.jc_ld = (3 + 2 * S.L_max + 31) & ~31;  // whole pairs of 16-column tiles, rows on 256-byte boundaries (k_inc.hip, B3)
+    S.jc_stride = (size_t)(3 * S.P_max + 2 * S.L_max + 16) * (size_t)S.jc_ld;  // (+ 16: the row tiles are written whole)
     const double gb = (double)S.jc_stride * 8.0 * (double)S.n_inst / 1073741824.0;
     if (!(v && v[0] == '0') && gb <= max_gb) {
       TRY(dev_alloc(e, &S.jc, S.jc_stride * (size_t)S.n_inst));

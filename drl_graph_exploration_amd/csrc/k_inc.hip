@@ -102,8 +102,8 @@ __device__ __forceinline__ bool inc_plan(const DrlgxState &S, int inst, int P, i
   x.Lcap = min(S.L_max, x.L0 + INEW);
   x.n1 = 3 * P + 2 * x.L0; x.n1p = (x.n1 + 15) & ~15;
   x.a0 = 3 + 2 * x.L0;
-  x.ldw = (3 + 2 * x.Lcap + 1) & ~1;
-  const int ncap = 3 * P + 2 * x.Lcap;
+  x.ldw = (3 + 2 * x.Lcap + 31) & ~31;  // (whole pairs of 16-column tiles: inc_post, B3)
+  const int ncap = max(3 * P + 2 * x.Lcap, x.n1p);
   size_t plan_off = drlgx_sim_lds_bytes(S.LG, S.P_max);
   if (smem_off > plan_off) plan_off = smem_off;
   size_t off = (smem_off + 15) & ~(size_t)15;
@@ -302,16 +302,52 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
         cl = 3 + 2 * fslot[t];
       }
       const int k0 = ks16(2 * f), k1 = ks16(2 * f + 1);
-      for (int q = tid >> 3; q < n1; q += kThreads >> 3) {
-        const double *r = rowp(q);
-        const double c0 = r[0], c1 = r[1], c2 = r[2], l0 = r[cl], l1 = r[cl + 1];
-        // (factors beyond the batch: all-zero Jacobians, zero columns)
-        Y[(size_t)q * IYS + k0] = c0 * j0 + c1 * j1 + c2 * j2 + l0 * l0c + l1 * l1c;
-        Y[(size_t)q * IYS + k1] = c0 * j3 + c1 * j4 + c2 * j5 + l0 * l2c + l1 * l3c;
+      // (four rows' loads in flight per thread: in the HBM / L2 form of the panel every load is a round trip)
+      for (int q0 = tid >> 3; q0 < n1; q0 += 4 * (kThreads >> 3)) {
+        double c0[4], c1[4], c2[4], l0[4], l1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double *r = rowp(min(q0 + u * (kThreads >> 3), n1 - 1));
+          c0[u] = r[0]; c1[u] = r[1]; c2[u] = r[2]; l0[u] = r[cl]; l1[u] = r[cl + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = q0 + u * (kThreads >> 3);
+          if (q < n1) {  // (factors beyond the batch: all-zero Jacobians, zero columns)
+            Y[(size_t)q * IYS + k0] = c0[u] * j0 + c1[u] * j1 + c2[u] * j2 + l0[u] * l0c + l1[u] * l1c;
+            Y[(size_t)q * IYS + k1] = c0[u] * j3 + c1[u] * j4 + c2[u] * j5 + l0[u] * l2c + l1[u] * l3c;
+          }
+        }
       }
     }
     __syncthreads();
     if (b0 == 0) DRLGX_PROF(S, 36);
+    // (B3 below) A wave owns the row tiles I = wave, wave + 8, ...; the panel is walked in blocks of 128 columns = four PAIRS
+    // of 16-column tiles: lane lc of a pair holds the adjacent columns 32 u + 2 lc and + 1, so that every panel access is 16
+    // bytes wide.  Loads and stores are unconditional: the rows up to the next multiple of 16 and the columns up to the next
+    // multiple of 32 exist (the future landmarks' rows / columns), their operands are zero rows of Y, so they are written
+    // back unchanged.  (Issuing a wave's first row tile before the
+    // inversion below only moved the latency into that phase: profiles/r04_ab_inc_early_tile_loads.txt.)
+    const int ncb = (a0 + 127) >> 7;
+    v4d acc[8];
+    double ua[4] = {0.0, 0.0, 0.0, 0.0};
+    auto tile_loads = [&](int I, int cb) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (128 * cb + 32 * u < a0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+#ifdef INC_EXP_NOLOAD
+            const double2 v = make_double2(0.0, 0.0);
+#else
+            const double2 v = *reinterpret_cast<const double2 *>(rowp(16 * I + lr + 4 * r) + 128 * cb + 32 * u + 2 * lc);
+#endif
+            acc[2 * u][r] = v.x;
+            acc[2 * u + 1][r] = v.y;
+          }
+        }
+    };
+    int I3 = wave;
     // B2. T = R + A Y (symmetric by construction), v = -e - A delta, W' = -T^-1: one wave
     if (wave == 0) {
       v4d d = {0.0, 0.0, 0.0, 0.0};
@@ -339,7 +375,7 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
         vvec[ks16(lane)] = v;  // (ks16 order, like the rows of Y)
       }
       const SweepCtx sx{0, lane, lc, lr, k, 16, true, true, ictl + 1, nullptr};
-      inv16_blk(sx, k, d);
+      inv16_blk<true>(sx, k, d);
       // image of W' for the matrix cores: row lc, columns lr + 4 r at ks16 positions 4 lr + r (W' is symmetric)
       double *o = wks + lc * IYS + 4 * lr;
 #pragma unroll
@@ -348,68 +384,63 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
     __syncthreads();
     if (b0 == 0) DRLGX_PROF(S, 37);
     // B3. U'^T = W' Y^T per 16-row tile; delta and the pose marginals; every column tile of the panel: C += U' Ya^T
-    for (int I = wave; I < ntr; I += kWaves) {
-      double w4[4], yI[4];
-      ld4(wks + lc * IYS + 4 * lr, w4);
-      ld4(Y + (size_t)(16 * I + lc) * IYS + 4 * lr, yI);
-      v4d ut = {0.0, 0.0, 0.0, 0.0};
-      ut = mfma4(w4, yI, ut);  // lane (lr, lc), register r: U'[16 I + lc][lr + 4 r]
-      double ua[4] = {ut[0], ut[1], ut[2], ut[3]};
-      {
-        // this row's delta and - pose rows - its entries of the pose marginal, from the U' registers: a lane holds the columns
-        // lr + 4 r of row q = 16 I + lc; the four lanes of a row (lc, lc + 16, lc + 32, lc + 48) are summed with the gfx950
-        // permlane swaps (no trip through LDS):  delta' = delta - U' v  (U' = -Sigma A^T T^-1, v = -e - A delta),  D_i += U'_i Y_i^T
-        const int q = 16 * I + lc;
-        auto rowdot = [&](const double *vec) -> double {
-          double y4[4];
-          ld4(vec + 4 * lr, y4);
-          double sdot = ua[0] * y4[0] + ua[1] * y4[1] + ua[2] * y4[2] + ua[3] * y4[3];
-          sdot += rowgroup_xor<16>(sdot);
-          sdot += rowgroup_xor<32>(sdot);
-          return sdot;
-        };
-        const double sv = rowdot(vvec);
-        const bool prow = q < 3 * pn;
-        const int qc = prow ? q : 0, pi = qc / 3, rp = qc - 3 * pi;
-        const double s0 = rowdot(Y + (size_t)(3 * pi) * IYS), s1 = rowdot(Y + (size_t)(3 * pi + 1) * IYS), s2 = rowdot(Y + (size_t)(3 * pi + 2) * IYS);
-        if (lr == 0 && q < n1) {
-          dl[q] -= sv;
-          if (prow) {
-            double *D = Dl + 6 * pi + (rp * (rp + 1)) / 2;
-            D[0] += s0;
-            if (rp >= 1) D[1] += s1;
-            if (rp >= 2) D[2] += s2;
+    for (; I3 < ntr; I3 += kWaves) {
+      for (int cb = 0; cb < ncb; ++cb) {
+        tile_loads(I3, cb);
+        if (cb == 0) {
+          double w4[4], yI[4];
+          ld4(wks + lc * IYS + 4 * lr, w4);
+          ld4(Y + (size_t)(16 * I3 + lc) * IYS + 4 * lr, yI);
+          v4d ut = {0.0, 0.0, 0.0, 0.0};
+          ut = mfma4(w4, yI, ut);  // lane (lr, lc), register r: U'[16 I + lc][lr + 4 r]
+          ua[0] = ut[0]; ua[1] = ut[1]; ua[2] = ut[2]; ua[3] = ut[3];
+          // this row's delta and - pose rows - its entries of the pose marginal, from the U' registers: a lane holds the columns
+          // lr + 4 r of row q = 16 I + lc; the four lanes of a row (lc, lc + 16, lc + 32, lc + 48) are summed with the gfx950
+          // permlane swaps (no trip through LDS):  delta' = delta - U' v  (U' = -Sigma A^T T^-1, v = -e - A delta),  D_i += U'_i Y_i^T
+          const int q = 16 * I3 + lc;
+          auto rowdot = [&](const double *vec) -> double {
+            double y4[4];
+            ld4(vec + 4 * lr, y4);
+            double sdot = ua[0] * y4[0] + ua[1] * y4[1] + ua[2] * y4[2] + ua[3] * y4[3];
+            sdot += rowgroup_xor<16>(sdot);
+            sdot += rowgroup_xor<32>(sdot);
+            return sdot;
+          };
+          const double sv = rowdot(vvec);
+          const bool prow = q < 3 * pn;
+          const int qc = prow ? q : 0, pi = qc / 3, rp = qc - 3 * pi;
+          const double s0 = rowdot(Y + (size_t)(3 * pi) * IYS), s1 = rowdot(Y + (size_t)(3 * pi + 1) * IYS), s2 = rowdot(Y + (size_t)(3 * pi + 2) * IYS);
+          if (lr == 0 && q < n1) {
+            dl[q] -= sv;
+            if (prow) {
+              double *D = Dl + 6 * pi + (rp * (rp + 1)) / 2;
+              D[0] += s0;
+              if (rp >= 1) D[1] += s1;
+              if (rp >= 2) D[2] += s2;
+            }
           }
         }
-      }
-      // four column tiles at a time: their loads are issued together (the panel may live in HBM / L2), the four accumulation
-      // chains interleave on the matrix cores
-      for (int J0 = 0; J0 < ntc; J0 += 4) {
-        v4d acc[4];
-        double yJ[4][4];
+        // the B operands (rows of Y of the columns' variables) come from LDS tile by tile; pad columns take the zero row
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int col = 16 * (J0 + t) + lc;
-          const bool cok = col < a0;  // (also false for tiles beyond ntc)
-          const int yrow = col < 3 ? 3 * pn + col : (cok ? 3 * P + col - 3 : n1p);
-          ld4(Y + (size_t)yrow * IYS + 4 * lr, yJ[t]);
+        for (int u = 0; u < 4; ++u) {
+          if (128 * cb + 32 * u < a0) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int q = 16 * I + lr + 4 * r;
-            acc[t][r] = (q < n1 && cok) ? rowp(q)[col] : 0.0;
-          }
-        }
+            for (int h = 0; h < 2; ++h) {
+              const int col = 128 * cb + 32 * u + 2 * lc + h;
+              const int yrow = col < 3 ? 3 * pn + col : (col < a0 ? 3 * P + col - 3 : n1p);
+              double yJ[4];
+              ld4(Y + (size_t)yrow * IYS + 4 * lr, yJ);
+              // (k = 2 nb columns are live: K steps beyond them would multiply zeros)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+              for (int ks = 0; ks < 4; ++ks)
+                if (4 * ks < k) acc[2 * u + h] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[ks], yJ[ks], acc[2 * u + h], 0, 0, 0);
+            }
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[ks], yJ[t][ks], acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int col = 16 * (J0 + t) + lc;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int q = 16 * I + lr + 4 * r;
-            if (q < n1 && col < a0) rowp(q)[col] = acc[t][r];
+            for (int r = 0; r < 4; ++r) {
+#ifndef INC_EXP_NOSTORE
+              *reinterpret_cast<double2 *>(rowp(16 * I3 + lr + 4 * r) + 128 * cb + 32 * u + 2 * lc) = make_double2(acc[2 * u][r], acc[2 * u + 1][r]);
+#endif
+            }
           }
         }
       }
@@ -608,25 +639,36 @@ __device__ __forceinline__ void panel_invalidate(const DrlgxState &S, int inst, 
   }
 }
 
-// panel of instance src -> dst: the live rows / columns only
+// panel of instance src -> dst: the live rows / columns only.  grid (instances, kCopySplit): a block copies every
+// kCopySplit-th group of 8 rows, 32 threads x 16 bytes per row, four rows' loads in flight per thread
+constexpr int kCopySplit = 4;
 __global__ __launch_bounds__(256) void k_copy_panel(DrlgxState S, const int32_t *src, const int32_t *dst, int src_off, int dst_off) {
-  const int i = blockIdx.x;
+  const int i = blockIdx.x, part = blockIdx.y;
   const int s = (src ? src[i] : i) + src_off, d = (dst ? dst[i] : i) + dst_off;
   const int *ms = S.jc_meta + (size_t)s * 4;
   int *md = S.jc_meta + (size_t)d * 4;
   const int valid = ms[0], P = ms[1], L = ms[2], M = ms[3];
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && part == 0) {
     md[0] = valid; md[1] = P; md[2] = L; md[3] = M;
   }
   if (valid != 1) return;
   const double *ps = S.jc + (size_t)s * S.jc_stride;
   double *pd = S.jc + (size_t)d * S.jc_stride;
   const int npair = (3 + 2 * L + 1) >> 1, rows = 3 * P + 2 * L;
-  for (int e = threadIdx.x; e < rows * npair; e += 256) {
-    const int q = e / npair, cp = e - q * npair;
-    const size_t o = (size_t)(q < 3 * P ? q : q - 3 * P + 3 * S.P_max) * S.jc_ld + 2 * cp;
-    *reinterpret_cast<double2 *>(pd + o) = *reinterpret_cast<const double2 *>(ps + o);
-  }
-  for (int e = threadIdx.x; e < 6 * P; e += 256) S.jd[(size_t)d * S.P_max * 6 + e] = S.jd[(size_t)s * S.P_max * 6 + e];
+  const int cp0 = threadIdx.x & 31, r0 = (threadIdx.x >> 5) + 8 * part, rs = 8 * kCopySplit;
+  auto roff = [&](int q) -> size_t { return (size_t)(q < 3 * P ? q : q - 3 * P + 3 * S.P_max) * S.jc_ld; };
+  for (int cp = cp0; cp < npair; cp += 32)
+    for (int q = r0; q < rows; q += 4 * rs) {
+      const int q1 = q + rs, q2 = q + 2 * rs, q3 = q + 3 * rs;
+      const size_t o0 = roff(q), o1 = roff(min(q1, rows - 1)), o2 = roff(min(q2, rows - 1)), o3 = roff(min(q3, rows - 1));
+      const double2 v0 = reinterpret_cast<const double2 *>(ps + o0)[cp], v1 = reinterpret_cast<const double2 *>(ps + o1)[cp];
+      const double2 v2 = reinterpret_cast<const double2 *>(ps + o2)[cp], v3 = reinterpret_cast<const double2 *>(ps + o3)[cp];
+      reinterpret_cast<double2 *>(pd + o0)[cp] = v0;
+      if (q1 < rows) reinterpret_cast<double2 *>(pd + o1)[cp] = v1;
+      if (q2 < rows) reinterpret_cast<double2 *>(pd + o2)[cp] = v2;
+      if (q3 < rows) reinterpret_cast<double2 *>(pd + o3)[cp] = v3;
+    }
+  if (part == 0)
+    for (int e = threadIdx.x; e < 6 * P; e += 256) S.jd[(size_t)d * S.P_max * 6 + e] = S.jd[(size_t)s * S.P_max * 6 + e];
 }
 #pragma clang fp contract(fast)

@@ -297,6 +297,9 @@ __device__ __forceinline__ void inv16_blk_step(const SweepCtx &x, const Inv16Lan
 }
 // nact: number of pivots of this tile (1 .. 16); the rows / columns beyond are not pivots and their content afterwards is
 // finite but meaningless (every user of E multiplies them by the zeroed panel columns or never reads them)
+// kSkip: block steps whose four pivots are all inactive are left out (the incremental update's k x k systems, k <= 16: the
+// inactive part is an identity block, decoupled from the rest)
+template <bool kSkip = false>
 __device__ __forceinline__ void inv16_blk(const SweepCtx &x, int nact, v4d &d) {
   if (nact < 16) {  // decouple the inactive rows / columns: identity there
 #pragma unroll
@@ -308,9 +311,9 @@ __device__ __forceinline__ void inv16_blk(const SweepCtx &x, int nact, v4d &d) {
   const Inv16Lane q(x.lr, x.lc);
   bool spd = true;
   inv16_blk_step<0>(x, q, d, spd);
-  inv16_blk_step<1>(x, q, d, spd);
-  inv16_blk_step<2>(x, q, d, spd);
-  inv16_blk_step<3>(x, q, d, spd);
+  if (!kSkip || nact > 4) inv16_blk_step<1>(x, q, d, spd);
+  if (!kSkip || nact > 8) inv16_blk_step<2>(x, q, d, spd);
+  if (!kSkip || nact > 12) inv16_blk_step<3>(x, q, d, spd);
   if (!spd && x.lane == 0) x.bad[0] = 1;
 }
 
@@ -1860,6 +1863,6 @@ void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p
 void drlgx_launch_copy_panel(const DrlgxState &S, hipStream_t st, int n, const int32_t *src, const int32_t *dst, int src_off,
                              int dst_off) {
   if (!S.jc || n <= 0) return;
-  hipLaunchKernelGGL(kslam::k_copy_panel, dim3(n), dim3(256), 0, st, S, src, dst, src_off, dst_off);
+  hipLaunchKernelGGL(kslam::k_copy_panel, dim3(n, kslam::kCopySplit), dim3(256), 0, st, S, src, dst, src_off, dst_off);
 }
 #pragma clang fp contract(off)
