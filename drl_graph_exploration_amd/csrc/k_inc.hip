@@ -322,32 +322,6 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
     }
     __syncthreads();
     if (b0 == 0) DRLGX_PROF(S, 36);
-    // (B3 below) A wave owns the row tiles I = wave, wave + 8, ...; the panel is walked in blocks of 128 columns = four PAIRS
-    // of 16-column tiles: lane lc of a pair holds the adjacent columns 32 u + 2 lc and + 1, so that every panel access is 16
-    // bytes wide.  Loads and stores are unconditional: the rows up to the next multiple of 16 and the columns up to the next
-    // multiple of 32 exist (the future landmarks' rows / columns), their operands are zero rows of Y, so they are written
-    // back unchanged.  (Issuing a wave's first row tile before the
-    // inversion below only moved the latency into that phase: profiles/r04_ab_inc_early_tile_loads.txt.)
-    const int ncb = (a0 + 127) >> 7;
-    v4d acc[8];
-    double ua[4] = {0.0, 0.0, 0.0, 0.0};
-    auto tile_loads = [&](int I, int cb) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (128 * cb + 32 * u < a0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-#ifdef INC_EXP_NOLOAD
-            const double2 v = make_double2(0.0, 0.0);
-#else
-            const double2 v = *reinterpret_cast<const double2 *>(rowp(16 * I + lr + 4 * r) + 128 * cb + 32 * u + 2 * lc);
-#endif
-            acc[2 * u][r] = v.x;
-            acc[2 * u + 1][r] = v.y;
-          }
-        }
-    };
-    int I3 = wave;
     // B2. T = R + A Y (symmetric by construction), v = -e - A delta, W' = -T^-1: one wave
     if (wave == 0) {
       v4d d = {0.0, 0.0, 0.0, 0.0};
@@ -383,21 +357,50 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
     }
     __syncthreads();
     if (b0 == 0) DRLGX_PROF(S, 37);
-    // B3. U'^T = W' Y^T per 16-row tile; delta and the pose marginals; every column tile of the panel: C += U' Ya^T
-    for (; I3 < ntr; I3 += kWaves) {
-      for (int cb = 0; cb < ncb; ++cb) {
-        tile_loads(I3, cb);
-        if (cb == 0) {
+    // B3. U'^T = W' Y^T per 16-row tile; delta and the pose marginals; every column tile of the panel: C += U' Ya^T.
+    // A wave owns the row tiles I = wave, wave + 8, ...; the columns are walked in PAIRS of 16-column tiles.  The wave's
+    // (row tile, pair) units form ONE software pipeline: the loads of the next unit are issued before the products of the current one (the
+    // panel may live in HBM / L2: a unit that loads only after the previous one's stores pays a full round trip each time).
+    // Loads and stores are unconditional: the rows up to the next multiple of 16 and the columns up to the next multiple of
+    // 32 exist (the future landmarks' rows / columns), their operands are zero rows of Y: they are written back unchanged.
+    if (wave < ntr) {
+      const int npr = (a0 + 31) >> 5;  // column pairs
+      const int nks = (k + 3) >> 2;    // K steps with live columns (k = 2 nb)
+      const int nun = ((ntr - wave + kWaves - 1) / kWaves) * npr;
+      // the two accumulator tiles of a unit, twice (current / next): element r = row 16 I + lr + 4 r, columns 32 p + lc and
+      // 32 p + 16 + lc - loaded straight into the registers the matrix cores accumulate in (16-byte accesses of adjacent
+      // column pairs were tried: the two halves belong to different accumulator tuples, the compiler copies them apart right
+      // behind the load and waits for it there - no pipeline left)
+      v4d aA0, aA1, aB0, aB1;
+      double ua[4] = {0.0, 0.0, 0.0, 0.0};
+      auto loads = [&](int e, v4d &c0, v4d &c1) {
+        const int it = e / npr, pr = e - it * npr, I = wave + kWaves * it;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#ifdef INC_EXP_NOLOAD
+          c0[r] = 0.0;
+          c1[r] = 0.0;
+#else
+          const double *rw = rowp(16 * I + lr + 4 * r) + 32 * pr + lc;
+          c0[r] = rw[0];
+          c1[r] = rw[16];
+#endif
+        }
+      };
+      auto unit = [&](int e, v4d &acc0, v4d &acc1) {
+        const int it = e / npr, pr = e - it * npr, I = wave + kWaves * it;
+        if (pr == 0) {
+          // U' of this row tile: lane (lr, lc), register r: U'[16 I + lc][lr + 4 r]
           double w4[4], yI[4];
           ld4(wks + lc * IYS + 4 * lr, w4);
-          ld4(Y + (size_t)(16 * I3 + lc) * IYS + 4 * lr, yI);
+          ld4(Y + (size_t)(16 * I + lc) * IYS + 4 * lr, yI);
           v4d ut = {0.0, 0.0, 0.0, 0.0};
-          ut = mfma4(w4, yI, ut);  // lane (lr, lc), register r: U'[16 I + lc][lr + 4 r]
+          ut = mfma4(w4, yI, ut);
           ua[0] = ut[0]; ua[1] = ut[1]; ua[2] = ut[2]; ua[3] = ut[3];
           // this row's delta and - pose rows - its entries of the pose marginal, from the U' registers: a lane holds the columns
           // lr + 4 r of row q = 16 I + lc; the four lanes of a row (lc, lc + 16, lc + 32, lc + 48) are summed with the gfx950
           // permlane swaps (no trip through LDS):  delta' = delta - U' v  (U' = -Sigma A^T T^-1, v = -e - A delta),  D_i += U'_i Y_i^T
-          const int q = 16 * I3 + lc;
+          const int q = 16 * I + lc;
           auto rowdot = [&](const double *vec) -> double {
             double y4[4];
             ld4(vec + 4 * lr, y4);
@@ -420,28 +423,36 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
             }
           }
         }
-        // the B operands (rows of Y of the columns' variables) come from LDS tile by tile; pad columns take the zero row
+        {
+          const int cA = 32 * pr + lc, cB = cA + 16;
+          const int y0 = cA < 3 ? 3 * pn + cA : (cA < a0 ? 3 * P + cA - 3 : n1p);  // (pad columns: the zero row)
+          const int y1 = cB < a0 ? 3 * P + cB - 3 : n1p;
+          double yJ0[4], yJ1[4];
+          ld4(Y + (size_t)y0 * IYS + 4 * lr, yJ0);
+          ld4(Y + (size_t)y1 * IYS + 4 * lr, yJ1);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (128 * cb + 32 * u < a0) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const int col = 128 * cb + 32 * u + 2 * lc + h;
-              const int yrow = col < 3 ? 3 * pn + col : (col < a0 ? 3 * P + col - 3 : n1p);
-              double yJ[4];
-              ld4(Y + (size_t)yrow * IYS + 4 * lr, yJ);
-              // (k = 2 nb columns are live: K steps beyond them would multiply zeros)
-#pragma unroll
-              for (int ks = 0; ks < 4; ++ks)
-                if (4 * ks < k) acc[2 * u + h] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[ks], yJ[ks], acc[2 * u + h], 0, 0, 0);
+          for (int ks = 0; ks < 4; ++ks)
+            if (ks < nks) {
+              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[ks], yJ0[ks], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[ks], yJ1[ks], acc1, 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
+        }
 #ifndef INC_EXP_NOSTORE
-              *reinterpret_cast<double2 *>(rowp(16 * I3 + lr + 4 * r) + 128 * cb + 32 * u + 2 * lc) = make_double2(acc[2 * u][r], acc[2 * u + 1][r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double *rw = rowp(16 * I + lr + 4 * r) + 32 * pr + lc;
+          rw[0] = acc0[r];
+          rw[16] = acc1[r];
+        }
 #endif
-            }
-          }
+      };
+      loads(0, aA0, aA1);
+      for (int e = 0; e < nun; e += 2) {
+        if (e + 1 < nun) loads(e + 1, aB0, aB1);
+        unit(e, aA0, aA1);
+        if (e + 1 < nun) {
+          if (e + 2 < nun) loads(e + 2, aA0, aA1);
+          unit(e + 1, aB0, aB1);
         }
       }
     }
