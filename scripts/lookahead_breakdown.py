@@ -23,6 +23,16 @@ for _ in range(5):
     eng.lookahead(cand_env, acts, nact)
 torch.cuda.synchronize()
 print("lookahead %.3f ms" % ((time.perf_counter() - t0) / 5 * 1e3))
+eng.inc_stats(True)
+eng.lookahead(cand_env, acts, nact)
+print("one look-ahead: SLAM updates served incrementally / by a full solve:", eng.inc_stats(True))
+eng.lookahead(cand_env, acts, nact, int(na.max()))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(5):
+    eng.lookahead(cand_env, acts, nact, int(na.max()))
+torch.cuda.synchronize()
+print("lookahead bounded by the longest plan %.3f ms" % ((time.perf_counter() - t0) / 5 * 1e3))
 eng.timing_enable(True); eng.timing_read()
 for _ in range(5):
     eng.lookahead(cand_env, acts, nact)
