@@ -121,6 +121,11 @@ struct LaunchSel {
   // map), and only the utility after the LAST action enters the reward, so the map stage runs for an instance only
   // when act_idx is its last action
   int map_last_only = 0;
+  // Host-side upper bound of the pose count of every selected instance after this launch (0: the capacity S.P_max).  The
+  // kernels size their per-pose LDS tables with it, so that a large pose capacity costs short trajectories nothing; an
+  // instance that exceeds it raises DRLGX_E_CAPACITY instead of overrunning.
+  int pcap = 0;
+  __host__ __device__ __forceinline__ int cap(int P_max) const { return pcap > 0 && pcap < P_max ? pcap : P_max; }
   __device__ __forceinline__ bool map_on(int i) const {
     return !(map_last_only && n_act) || act_idx == n_act[i] - 1;
   }
@@ -610,7 +615,7 @@ void drlgx_launch_sim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const 
 // p_bound: host-side upper bound of the pose count of every selected instance after this launch (<= P_max); it picks
 // the kernel variant (the kernels flag DRLGX_E_CAPACITY instead of overrunning if the bound is violated)
 void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p_bound);
-size_t drlgx_map_lds_bytes(const DrlgxState &S, int *chunk_out);
+size_t drlgx_map_lds_bytes(const DrlgxState &S, int *chunk_out, int pcap = 0);  // pcap: LaunchSel::cap (0: S.P_max)
 // fused simulate + SLAM + map kernel (k_step.hip); usable when the SLAM system and the map stage fit the LDS
 bool drlgx_step_fusable(const DrlgxState &S, int p_bound);
 bool drlgx_step_arrow_fusable(const DrlgxState &S);

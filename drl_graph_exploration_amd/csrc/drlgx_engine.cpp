@@ -492,6 +492,7 @@ int drlgx_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint3
   LaunchSel sel{0, e->S.n_envs, e->stage_mask, nullptr, 0};
   drlgx_launch_slam(e->S, e->stream, sel, e->by_capacity ? e->S.P_max : 1);
   sel.act_idx = -2;  // reductions only: the virtual map is in its untouched state
+  sel.pcap = max_bound(e);
   drlgx_launch_map(e->S, e->stream, sel);
   int r = check_launch(e);
   if (r) return r;
@@ -504,6 +505,7 @@ int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_de
   if (!e || !odom_dev) return DRLGX_E_INVALID;
   LaunchSel sel{0, e->S.n_envs, active_dev, nullptr, 0};
   const int pb = std::min(max_bound(e) + 1, e->S.P_max);
+  sel.pcap = pb;  // (the kernels size their per-pose LDS tables with the launch's bound, not with the capacity)
   for (int &v : e->pbound) v = std::min(v + 1, e->S.P_max);
   if (drlgx_step_fusable(e->S, pb) && !e->per_stage) {
     // one fused kernel per step (timer 5); timing mode 2 launches the stage kernels separately (timers 0-2)
@@ -542,6 +544,7 @@ int drlgx_step_plan(drlgx_engine *e, const double *actions_dev, const int32_t *n
   LaunchSel sel{0, e->S.n_envs, nullptr, n_actions_dev, action_index};
   sel.map_last_only = map_last_only ? 1 : 0;
   const int pb = std::min(max_bound(e) + 1, e->S.P_max);
+  sel.pcap = pb;
   for (int &v : e->pbound) v = std::min(v + 1, e->S.P_max);
   const int stride = e->S.A_max * 3;
   if (drlgx_step_fusable(e->S, pb) && !e->per_stage) {
@@ -750,6 +753,7 @@ int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env
       LaunchSel sel{roll0, nc, nullptr, na, a};
       sel.map_last_only = 1;
       const int pb = std::min(pbe + a + 1, S.P_max);
+      sel.pcap = pb;
       if (drlgx_step_fusable(S, pb) && !e->per_stage) {
         ScopedTimer t(e, 5);
         drlgx_launch_step(S, e->stream, sel, act, S.A_max * 3, 1);

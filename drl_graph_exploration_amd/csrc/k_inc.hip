@@ -94,7 +94,8 @@ struct IncCtx {
 // false: the step cannot take this path (LDS).  lds_panel: the panel is staged in LDS for the step (else updated in place in
 // HBM / L2).  The decision is taken for the SAME LDS offset in every kernel (the fused step's: behind the simulator's region),
 // so that the fused kernel and the stage kernels always run the same instantiation.
-__device__ __forceinline__ bool inc_plan(const DrlgxState &S, int inst, int P, int lds_bytes, size_t smem_off, IncCtx &x, bool &lds_panel) {
+// pc: the launch's pose bound (LaunchSel::cap): the fused step's simulator region is sized by it.
+__device__ __forceinline__ bool inc_plan(const DrlgxState &S, int inst, int P, int lds_bytes, size_t smem_off, IncCtx &x, bool &lds_panel, int pc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int *meta = inc_meta(S, inst);
   x.inst = inst; x.P = P; x.pn = P - 1; x.pp = P - 2;
@@ -104,7 +105,7 @@ __device__ __forceinline__ bool inc_plan(const DrlgxState &S, int inst, int P, i
   x.a0 = 3 + 2 * x.L0;
   x.ldw = (3 + 2 * x.Lcap + 31) & ~31;  // (whole pairs of 16-column tiles: inc_post, B3)
   const int ncap = max(3 * P + 2 * x.Lcap, x.n1p);
-  size_t plan_off = drlgx_sim_lds_bytes(S.LG, S.P_max);
+  size_t plan_off = drlgx_sim_lds_bytes(S.LG, pc);
   if (smem_off > plan_off) plan_off = smem_off;
   size_t off = (smem_off + 15) & ~(size_t)15;
   const size_t off0 = off;

@@ -175,18 +175,23 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
   const drlgx_config &cfg = S.cfg;
   const int P = lo.P >= 0 ? lo.P : cnt[C_P], L = lo.P >= 0 ? lo.L : cnt[C_L];
   const int V = S.V, cols = S.cols, rows = S.rows, W = S.win;
-  // LDS carve
-  double *sp = smem;                       // [P_max][4]
-  double *si = sp + (size_t)S.P_max * 4;   // [P_max][6]
-  double *sl = si + (size_t)S.P_max * 6;   // [P_max][9] LLT factor of the pose information + reciprocals
-  double *stage = sl + (size_t)S.P_max * 9;  // [chunk][64][3]
+  // LDS carve; the per-pose tables hold pc poses: the launch's pose bound (LaunchSel::pcap), not the engine's capacity
+  const int pc = sel.cap(S.P_max);
+  if (rebuild && P > pc) {  // (the host's bound was wrong: flag it, touch nothing)
+    if (tid == 0) atomicMin(S.status, DRLGX_E_CAPACITY);
+    return;
+  }
+  double *sp = smem;                   // [pc][4]
+  double *si = sp + (size_t)pc * 4;    // [pc][6]
+  double *sl = si + (size_t)pc * 6;    // [pc][9] LLT factor of the pose information + reciprocals
+  double *stage = sl + (size_t)pc * 9;  // [chunk][64][3]
   unsigned long long *mask = reinterpret_cast<unsigned long long *>(stage + (size_t)chunk * 64 * 3);  // [V]
   unsigned long long *omask = mask + V;  // [V] poses that see the cell (occupancy ladder)
   double *scratch = reinterpret_cast<double *>(omask + V);  // [kWaves]
-  int *bbox = reinterpret_cast<int *>(scratch + kWaves + DRLGX_LO_TAB);  // [P_max][4] min_row max_row min_col max_col
-  int *worg = bbox + (size_t)S.P_max * 4;             // [P_max][2] window origin row, col
-  int *pskip = worg + (size_t)S.P_max * 2;            // [P_max]
-  int *lmc = pskip + S.P_max;                         // [V] estimated landmarks per cell
+  int *bbox = reinterpret_cast<int *>(scratch + kWaves + DRLGX_LO_TAB);  // [pc][4] min_row max_row min_col max_col
+  int *worg = bbox + (size_t)pc * 4;                  // [pc][2] window origin row, col
+  int *pskip = worg + (size_t)pc * 2;                 // [pc]
+  int *lmc = pskip + pc;                              // [V] estimated landmarks per cell
   uint8_t *ltr = reinterpret_cast<uint8_t *>(lmc + V);  // [DRLGX_LO_TAB][4] ladder transitions
   double *lpv = scratch + kWaves;                      // [DRLGX_LO_TAB] ladder state -> cell probability
   int *pcount = reinterpret_cast<int *>(ltr + 4 * DRLGX_LO_TAB);  // number of (pose, cell) pairs in range (phase A)
@@ -605,18 +610,24 @@ __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, i
 
 }  // namespace kmap
 
-static size_t map_lds_bytes(const DrlgxState &S, int chunk) {
-  size_t d = (size_t)S.P_max * 19 + (size_t)chunk * 64 * 3 + 2 * (size_t)S.V + kmap::kWaves + DRLGX_LO_TAB;  // + two u64 masks per cell
-  size_t i = (size_t)S.P_max * 7 + (size_t)S.V + DRLGX_LO_TAB + 1 + (size_t)chunk * 32;  // (+ pair counter, pair list)
+static size_t map_lds_bytes(const DrlgxState &S, int chunk, int pc) {
+  size_t d = (size_t)pc * 19 + (size_t)chunk * 64 * 3 + 2 * (size_t)S.V + kmap::kWaves + DRLGX_LO_TAB;  // + two u64 masks per cell
+  size_t i = (size_t)pc * 7 + (size_t)S.V + DRLGX_LO_TAB + 1 + (size_t)chunk * 32;  // (+ pair counter, pair list)
   return d * sizeof(double) + i * sizeof(int) + 16;
 }
+namespace kmap {
+// byte offset of the cell masks inside map_body's LDS carve (k_step checks that what the SLAM stage hands over lies below)
+__host__ __device__ inline size_t masks_offset(int pc, int chunk) { return ((size_t)pc * 19 + (size_t)chunk * 64 * 3) * sizeof(double); }
+}  // namespace kmap
 
 // LDS bytes of k_map and the poses per A/C pass: all of them when the stage fits the LDS (<= 64: one mask bit per pose)
-size_t drlgx_map_lds_bytes(const DrlgxState &S, int *chunk_out) {
-  int chunk = S.P_max < 64 ? S.P_max : 64;
-  while (chunk > 1 && map_lds_bytes(S, chunk) > 160 * 1024) chunk /= 2;
+// (pcap: the launch's pose bound - the tables and the chunk follow it, not the engine's capacity)
+size_t drlgx_map_lds_bytes(const DrlgxState &S, int *chunk_out, int pcap) {
+  const int pc = pcap > 0 && pcap < S.P_max ? pcap : S.P_max;
+  int chunk = pc < 64 ? pc : 64;
+  while (chunk > 1 && map_lds_bytes(S, chunk, pc) > 160 * 1024) chunk /= 2;
   if (chunk_out) *chunk_out = chunk;
-  return map_lds_bytes(S, chunk);
+  return map_lds_bytes(S, chunk, pc);
 }
 
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
@@ -627,7 +638,7 @@ void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
     sel.act_idx = 0;
   }
   int chunk = 0;
-  const size_t lds = drlgx_map_lds_bytes(S, &chunk);
+  const size_t lds = drlgx_map_lds_bytes(S, &chunk, sel.pcap);
   static bool attr_set[32] = {false};
   const void *fns[] = {reinterpret_cast<const void *>(&kmap::k_map)};
   drlgx_ensure_lds_attr(attr_set, fns, 1, 160 * 1024);

@@ -1343,8 +1343,9 @@ struct SlamCtx {
   // hand + 4 P_max, pose_info [P][6] - so that it does not fetch them back from HBM; the landmark estimates are left in
   // `thl` for the same reason (the linearisation points are dead by then)
   template <int FT>
+  // hand_cap: the pose capacity of those tables (the launch's pose bound, LaunchSel::cap)
   __device__ __forceinline__ void back(const DrlgxState &S, int tid, int Lfin, int Mfin, bool full, bool refresh, double *hand = nullptr,
-                                       const SimBox &box = SimBox{nullptr, nullptr, nullptr}) {
+                                       const SimBox &box = SimBox{nullptr, nullptr, nullptr}, int hand_cap = 0) {
     int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
     double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
     double *d_lm = S.d_lm + (size_t)inst * S.L_max * 2;
@@ -1693,7 +1694,7 @@ struct SlamCtx {
       inv3_sym_fast(c00, c10, c20, c11, c21, c22, info);
       for (int k = 0; k < 6; ++k) pose_info[6 * i + k] = info[k];
       if (hand)
-        for (int k = 0; k < 6; ++k) hand[4 * S.P_max + 6 * i + k] = info[k];
+        for (int k = 0; k < 6; ++k) hand[4 * hand_cap + 6 * i + k] = info[k];
     }
     DRLGX_PROF(S, 7);
     if (tid == 0) {
@@ -1722,7 +1723,7 @@ __device__ __forceinline__ bool inc_stage(const DrlgxState &S, const LaunchSel &
   if (!inc_precheck(S, inst, P, tid, reinterpret_cast<int *>(smem_raw + smem_off))) return false;
   IncCtx x;
   bool lds_panel = false;
-  if (!inc_plan(S, inst, P, lds_bytes, smem_off, x, lds_panel)) return false;
+  if (!inc_plan(S, inst, P, lds_bytes, smem_off, x, lds_panel, sel.cap(S.P_max))) return false;
   const SimBox nobox{nullptr, nullptr, nullptr};
   bool done;
   if (lds_panel) {
@@ -1743,7 +1744,7 @@ __device__ __forceinline__ bool inc_stage(const DrlgxState &S, const LaunchSel &
 template <int FT>
 __device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel &sel, int lds_bytes, size_t smem_off, const SlamCtx &pre, bool have_pre,
                                             const int *mail = nullptr, double *hand = nullptr, const double **lm_out = nullptr,
-                                            SimBox box = SimBox{nullptr, nullptr, nullptr}) {
+                                            SimBox box = SimBox{nullptr, nullptr, nullptr}, int hand_cap = 0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int bi = blockIdx.x;
@@ -1777,7 +1778,7 @@ __device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel
     c.front<false>(S, tid, P, L, M, n_old_p, n_old_l, count, refresh, nullptr, SubBarrier{nullptr, 0, 0});
     __syncthreads();
   }
-  c.back<FT>(S, tid, L, M, full, refresh, hand, (from_pre && mailed) ? box : SimBox{nullptr, nullptr, nullptr});
+  c.back<FT>(S, tid, L, M, full, refresh, hand, (from_pre && mailed) ? box : SimBox{nullptr, nullptr, nullptr}, hand_cap);
   if (lm_out) *lm_out = c.thl;
   if (S.jc && !refresh) {  // the covariance panel the incremental updates continue from (k_inc.hip)
     __syncthreads();
@@ -1846,6 +1847,7 @@ size_t drlgx_slam_ws_doubles(int P_max, int L_max, int M_max) {
 
 void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p_bound) {
   const int Pb = p_bound < S.P_max ? p_bound : S.P_max;
+  if (sel.pcap <= 0) sel.pcap = Pb;
   static bool attr_set[32] = {false};
   const void *fns[] = {reinterpret_cast<const void *>(&kslam::k_slam<kslam::kFastTiles>),
                        reinterpret_cast<const void *>(&kslam::k_slam_arrow<0>),

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
   const int bi = blockIdx.x;
   if (S.prof && tid == 0 && bi < 448) S.prof[128 + 2 * bi] = wall_clock64();  // (dev aid: per-workgroup start / end)
   // ---- what the SLAM front end needs is read before the simulator wave starts to change it ----
-  const size_t sim_bytes = sim_lds_bytes(S.LG, S.P_max);
+  const int pc = sel.cap(S.P_max);  // the launch's pose bound sizes the per-pose LDS tables (LaunchSel::pcap)
+  const size_t sim_bytes = sim_lds_bytes(S.LG, pc);
   int *sub_cnt = reinterpret_cast<int *>(step_smem + sim_bytes - 16);
   // what the simulator wave appends, left in LDS for the SLAM stage (ksim::measure)
   double *sim_dyn = reinterpret_cast<double *>(step_smem + 2 * DRLGX_MT_STRIDE * sizeof(uint32_t));
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
     // (the LDS plan is a few scalar operations: evaluated here and again after the simulator rather than kept in registers)
     kslam::IncCtx ix;
     bool inc_lds = false;
-    if (kslam::inc_plan(S, sel.base + bi, P0 + 1, lds_bytes, sim_bytes, ix, inc_lds)) {
+    if (kslam::inc_plan(S, sel.base + bi, P0 + 1, lds_bytes, sim_bytes, ix, inc_lds, pc)) {
       const kslam::SubBarrier sb{sub_cnt, kslam::kThreads / 64 - 1, 0};
       if (inc_lds) kslam::inc_pre<true, true>(S, ix, tid, od3, sb);
       else kslam::inc_pre<false, true>(S, ix, tid, od3, sb);
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
   // last of them while it reads the landmarks).  The landmark estimates stay in the SLAM stage's LDS: the map stage reads
   // them before the first array it writes beyond its pose tables (the information stage, in its phase A) is touched - as
   // long as they lie below its cell masks, which it clears first.
-  const bool hand = (size_t)S.P_max * 19 * sizeof(double) + 16 <= sim_bytes - 16;
+  const bool hand = (size_t)pc * 19 * sizeof(double) + 16 <= sim_bytes - 16;
   const double *lm_lds = nullptr;
   bool inc_done = false;
   if (inc_try) {
@@ -115,13 +116,13 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
     // structure check of inc_post would refuse them)
     kslam::IncCtx ix;
     bool inc_lds = false;
-    if (kslam::inc_plan(S, sel.base + bi, P0 + 1, lds_bytes, sim_bytes, ix, inc_lds)) {
+    if (kslam::inc_plan(S, sel.base + bi, P0 + 1, lds_bytes, sim_bytes, ix, inc_lds, pc)) {
       inc_done = inc_lds ? kslam::inc_post<true>(S, ix, sub_cnt[2], sub_cnt[3], box, tid) : kslam::inc_post<false>(S, ix, sub_cnt[2], sub_cnt[3], box, tid);
       if (!inc_done) __syncthreads();
     }
   }
   if (!inc_done)
-    kslam::slam_finish<FT>(S, sel, lds_bytes, sim_bytes, ctx, pre, sub_cnt + 1, hand ? reinterpret_cast<double *>(step_smem) : nullptr, &lm_lds, box);
+    kslam::slam_finish<FT>(S, sel, lds_bytes, sim_bytes, ctx, pre, sub_cnt + 1, hand ? reinterpret_cast<double *>(step_smem) : nullptr, &lm_lds, box, pc);
   __syncthreads();
   const bool handed = hand && lm_lds != nullptr;  // (lm_lds: set once the SLAM stage ran to its end)
   if (sel.on(bi)) {  // the counts as the simulator wave left them (nothing appended: those before the step)
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
     lo.L = appended ? sub_cnt[2] : L0;
     lo.flag = appended ? 0 : 1;
   }
-  const unsigned char *map_masks = step_smem + ((size_t)S.P_max * 19 + (size_t)map_chunk * 64 * 3) * sizeof(double);
+  const unsigned char *map_masks = step_smem + kmap::masks_offset(pc, map_chunk);
   if (!handed || reinterpret_cast<const unsigned char *>(lm_lds + 2 * (size_t)S.L_max) > map_masks) lm_lds = nullptr;
   kmap::map_body(S, sel, 1, map_chunk, handed, lm_lds, lo);
   if (S.prof && tid == 0 && bi < 448) S.prof[129 + 2 * bi] = wall_clock64();
@@ -162,8 +163,8 @@ bool drlgx_step_fusable(const DrlgxState &S, int p_bound) {
   const size_t nf = 16 * kslam::kFastTiles;
   // (the SLAM stage sits behind the simulator's LDS: its front end runs beside the simulator wave)
   return drlgx_slam_in_lds(Pb, S.L_max, S.M_max) &&
-         kstep::sim_lds_bytes(S.LG, S.P_max) + kslam::slam_small_bytes(Pb, S.L_max, S.M_max) + kslam::sweep_region_doubles(nf) * 8 <= (size_t)kslam::kLdsBudget &&
-         drlgx_map_lds_bytes(S, &chunk) <= (size_t)kslam::kLdsBudget;
+         kstep::sim_lds_bytes(S.LG, Pb) + kslam::slam_small_bytes(Pb, S.L_max, S.M_max) + kslam::sweep_region_doubles(nf) * 8 <= (size_t)kslam::kLdsBudget &&
+         drlgx_map_lds_bytes(S, &chunk, Pb) <= (size_t)kslam::kLdsBudget;
 }
 
 // the fused step around the pose-chain solver: its LDS-swept landmark system (<= 63 landmarks) and the same map / simulator
@@ -176,7 +177,7 @@ bool drlgx_step_arrow_fusable(const DrlgxState &S) {
 
 void drlgx_launch_step_arrow(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure) {
   int chunk = 0;
-  (void)drlgx_map_lds_bytes(S, &chunk);
+  (void)drlgx_map_lds_bytes(S, &chunk, sel.pcap);
   static bool attr_set[32] = {false};
   const void *fns[] = {reinterpret_cast<const void *>(&kstep::k_step_arrow)};
   drlgx_ensure_lds_attr(attr_set, fns, 1, kslam::kLdsBudget);
@@ -186,7 +187,7 @@ void drlgx_launch_step_arrow(const DrlgxState &S, hipStream_t st, LaunchSel sel,
 
 void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure) {
   int chunk = 0;
-  (void)drlgx_map_lds_bytes(S, &chunk);
+  (void)drlgx_map_lds_bytes(S, &chunk, sel.pcap);
   static bool attr_set[32] = {false};
   const void *fns[] = {reinterpret_cast<const void *>(&kstep::k_step<kslam::kFastTiles>)};
   drlgx_ensure_lds_attr(attr_set, fns, 1, kslam::kLdsBudget);
