@@ -623,7 +623,8 @@ void drlgx_launch_step_arrow(const DrlgxState &S, hipStream_t st, LaunchSel sel,
 void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure);  // requires drlgx_step_fusable
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel);  // sel.act_idx == -2: reductions only
 void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
-                       const int32_t *dst, int src_off, int dst_off, int skip_mask);  // skip fields with cls & mask
+                       const int32_t *dst, int src_off, int dst_off, int skip_mask,  // skip fields with cls & mask
+                       const int *cnt = nullptr);  // S.cnt: copy the live part of per-pose / -landmark / -factor fields only
 void drlgx_launch_rebase(const DrlgxState &S, hipStream_t st, int base0, int n);
 // the incremental update's covariance panel of instance src[i] -> dst[i] (live rows / columns only; k_inc.hip)
 void drlgx_launch_copy_panel(const DrlgxState &S, hipStream_t st, int n, const int32_t *src, const int32_t *dst, int src_off,

@@ -86,10 +86,10 @@ int dev_alloc(drlgx_engine *e, T **out, size_t count) {
 }
 
 template <typename T>
-int field_alloc(drlgx_engine *e, T **out, size_t per_inst, int cls = 0) {
+int field_alloc(drlgx_engine *e, T **out, size_t per_inst, int cls = 0, int unit = 0, size_t per_unit = 0) {
   int r = dev_alloc(e, out, per_inst * (size_t)e->S.n_inst);
   if (r) return r;
-  e->fields.push_back(DrlgxField{reinterpret_cast<char *>(*out), per_inst * sizeof(T), cls, 0});
+  e->fields.push_back(DrlgxField{reinterpret_cast<char *>(*out), per_inst * sizeof(T), cls, unit, (int)(per_unit * sizeof(T)), 0});
   return DRLGX_OK;
 }
 
@@ -354,23 +354,23 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   TRY(field_alloc(e, &S.nrm_saved, 2));
   TRY(field_alloc(e, &S.nrm_has, 2));
   TRY(field_alloc(e, &S.cnt, DRLGX_CNT_STRIDE));
-  TRY(field_alloc(e, &S.th_pose, P * 4));
-  TRY(field_alloc(e, &S.d_pose, P * 3));
-  TRY(field_alloc(e, &S.th_lm, L * 2));
-  TRY(field_alloc(e, &S.d_lm, L * 2));
-  TRY(field_alloc(e, &S.lm_key, L));
+  TRY(field_alloc(e, &S.th_pose, P * 4, 0, 1, 4));
+  TRY(field_alloc(e, &S.d_pose, P * 3, 0, 1, 3));
+  TRY(field_alloc(e, &S.th_lm, L * 2, 0, 2, 2));
+  TRY(field_alloc(e, &S.d_lm, L * 2, 0, 2, 2));
+  TRY(field_alloc(e, &S.lm_key, L, 0, 2, 1));
   TRY(field_alloc(e, &S.key_slot, (size_t)S.LG));
   TRY(field_alloc(e, &S.prior, DRLGX_PRIOR_STRIDE));
-  TRY(field_alloc(e, &S.odo, P * 4));
-  TRY(field_alloc(e, &S.meas_pose, M));
-  TRY(field_alloc(e, &S.meas_lm, M));
-  TRY(field_alloc(e, &S.meas_br, M * 2));
-  TRY(field_alloc(e, &S.est_pose, P * 4));
-  TRY(field_alloc(e, &S.est_lm, L * 2));
-  TRY(field_alloc(e, &S.pose_info, P * 6));
-  TRY(field_alloc(e, &S.lm_info, L * 3));
-  TRY(field_alloc(e, &S.pose_tr, P));
-  TRY(field_alloc(e, &S.lm_tr, L));
+  TRY(field_alloc(e, &S.odo, P * 4, 0, 1, 4));
+  TRY(field_alloc(e, &S.meas_pose, M, 0, 3, 1));
+  TRY(field_alloc(e, &S.meas_lm, M, 0, 3, 1));
+  TRY(field_alloc(e, &S.meas_br, M * 2, 0, 3, 2));
+  TRY(field_alloc(e, &S.est_pose, P * 4, 0, 1, 4));
+  TRY(field_alloc(e, &S.est_lm, L * 2, 0, 2, 2));
+  TRY(field_alloc(e, &S.pose_info, P * 6, 0, 1, 6));
+  TRY(field_alloc(e, &S.lm_info, L * 3, 0, 2, 3));
+  TRY(field_alloc(e, &S.pose_tr, P, 0, 1, 1));
+  TRY(field_alloc(e, &S.lm_tr, L, 0, 2, 1));
   TRY(field_alloc(e, &S.red, DRLGX_RED_STRIDE));
   TRY(field_alloc(e, &S.vm_prob, V, 1));
   TRY(field_alloc(e, &S.vm_info, 3 * V, 1));
@@ -730,7 +730,7 @@ int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env
   {
     ScopedTimer t(e, 3);
     // deep copy env -> base, SLAM2D::set_copy_isam (re-base at the best estimate + one batch update)
-    drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr, 0, base0, 3);
+    drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr, 0, base0, 3, e->S.cnt);
     drlgx_launch_rebase(S, e->stream, base0, S.n_envs);
   }
   {
@@ -745,7 +745,7 @@ int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env
     const int32_t *na = n_actions_dev + c0;
     {
       ScopedTimer t(e, 3);
-      drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, nc, ce, nullptr, base0, roll0, 3);
+      drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, nc, ce, nullptr, base0, roll0, 3, e->S.cnt);
       drlgx_launch_copy_panel(S, e->stream, nc, ce, nullptr, base0, roll0);  // (the base solve's covariance panel)
       drlgx_launch_fix_rollouts(S, e->stream, nc, ce, roll0);
     }
@@ -1049,7 +1049,7 @@ int drlgx_snapshot(drlgx_engine *e, int slot) {
   const DrlgxState &S = e->S;
   ScopedTimer t(e, 3);
   drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr, 0,
-                    2 * S.n_envs + S.n_roll + slot * S.n_envs, 0);
+                    2 * S.n_envs + S.n_roll + slot * S.n_envs, 0, e->S.cnt);
   drlgx_launch_copy_panel(S, e->stream, S.n_envs, nullptr, nullptr, 0, 2 * S.n_envs + S.n_roll + slot * S.n_envs);
   e->snap_pbound[slot] = e->pbound;
   return check_launch(e);
@@ -1061,7 +1061,7 @@ int drlgx_restore(drlgx_engine *e, int slot) {
   const DrlgxState &S = e->S;
   ScopedTimer t(e, 3);
   drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr,
-                    2 * S.n_envs + S.n_roll + slot * S.n_envs, 0, 0);
+                    2 * S.n_envs + S.n_roll + slot * S.n_envs, 0, 0, e->S.cnt);
   drlgx_launch_copy_panel(S, e->stream, S.n_envs, nullptr, nullptr, 2 * S.n_envs + S.n_roll + slot * S.n_envs, 0);
   e->pbound = e->snap_pbound[slot];
   return check_launch(e);

@@ -6,5 +6,9 @@ struct DrlgxField {
   char *base;
   size_t stride;  // bytes per instance (multiple of 4)
   int cls;        // 0 = belief/simulator state, 1 = virtual-map planes (rebuilt every step), 2 = ground-truth landmarks
+  // what of the slice is live: 0 = all of it; 1 / 2 / 3 = unit_bytes per pose / landmark / factor of the SOURCE instance
+  // (its counters): the copy moves the live part only, so that a large capacity costs short trajectories nothing
+  int unit;
+  int unit_bytes;
   int pad;
 };

@@ -9,7 +9,7 @@ namespace {
 
 // copy every non-virtual-map field of instance src[i] to dst[i]
 __global__ __launch_bounds__(256) void k_copy_instances(const DrlgxField *fields, int n_fields, const int32_t *src,
-                                                        const int32_t *dst, int src_off, int dst_off, int skip_mask) {
+                                                        const int32_t *dst, int src_off, int dst_off, int skip_mask, const int *cnt) {
   // grid = (instances, fields): every (instance, field) slice is streamed by its own workgroup with
   // 16-byte accesses when the slice is 16-byte aligned (all large fields are)
   const int i = blockIdx.x, f = blockIdx.y;
@@ -18,15 +18,23 @@ __global__ __launch_bounds__(256) void k_copy_instances(const DrlgxField *fields
   const size_t stride = fields[f].stride;
   const char *sb = fields[f].base + (size_t)s * stride;
   char *db = fields[f].base + (size_t)d * stride;
+  // the live part: per-pose / per-landmark / per-factor arrays end at the source instance's counts
+  size_t live = stride;
+  if (fields[f].unit && cnt) {
+    const int *c = cnt + (size_t)s * DRLGX_CNT_STRIDE;
+    const int k = fields[f].unit == 1 ? c[C_P] : fields[f].unit == 2 ? c[C_L] : c[C_M];
+    const size_t b = ((size_t)(k > 0 ? k : 0) * (size_t)fields[f].unit_bytes + 15) & ~(size_t)15;
+    live = b < stride ? b : stride;
+  }
   if ((stride & 15) == 0) {
     const uint4 *sp = reinterpret_cast<const uint4 *>(sb);
     uint4 *dp = reinterpret_cast<uint4 *>(db);
-    const size_t nq = stride / 16;
+    const size_t nq = live / 16;
     for (size_t k = threadIdx.x; k < nq; k += 256) dp[k] = sp[k];
   } else {
     const uint32_t *sp = reinterpret_cast<const uint32_t *>(sb);
     uint32_t *dp = reinterpret_cast<uint32_t *>(db);
-    const size_t nw = stride / 4;
+    const size_t nw = (live < stride ? live : stride) / 4;
     for (size_t k = threadIdx.x; k < nw; k += 256) dp[k] = sp[k];
   }
 }
@@ -229,9 +237,9 @@ void drlgx_launch_cov_array(const DrlgxState &S, hipStream_t st, double *length,
   hipLaunchKernelGGL(k_cov_array, dim3((S.V + 255) / 256, S.n_envs), dim3(256), 0, st, S, length, angle);
 }
 void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
-                       const int32_t *dst, int src_off, int dst_off, int skip_mask) {
+                       const int32_t *dst, int src_off, int dst_off, int skip_mask, const int *cnt) {
   hipLaunchKernelGGL(k_copy_instances, dim3(n, n_fields), dim3(256), 0, st, fields_dev, n_fields, src, dst, src_off,
-                     dst_off, skip_mask);
+                     dst_off, skip_mask, cnt);
 }
 void drlgx_launch_rebase(const DrlgxState &S, hipStream_t st, int base0, int n) {
   hipLaunchKernelGGL(k_rebase, dim3(n), dim3(64), 0, st, S, base0, n);
