@@ -282,6 +282,16 @@ __global__ __launch_bounds__(64) void k_reset(DrlgxState S, int first_measure, c
   }
 }
 
+// SS2D.simulate bounds-checks the odometry increment against the map box (pyss2d.py:173-176): the one predicate both the
+// simulator below and the fused step kernel's prelude (which decides whether a SLAM front end may run ahead) evaluate
+__device__ __forceinline__ bool odom_in_bounds(const drlgx_config &cfg, double ox, double oy) {
+  return (cfg.map_min_x < ox && ox < cfg.map_max_x) && (cfg.map_min_y < oy && oy < cfg.map_max_y);
+}
+// ... and the whole acceptance test of a move for an instance that holds P poses (capacity: DRLGX_E_CAPACITY)
+__device__ __forceinline__ bool move_accepted(const DrlgxState &S, double ox, double oy, int P) {
+  return odom_in_bounds(S.cfg, ox, oy) && P < S.P_max;
+}
+
 // move + addOdometry + measure(s) + addMeasurement for one belief step, executed by ONE wave (lane = 0..63).
 // lds0 / lds1: 626 words each, dyn: (2 LG + 2) doubles + LG ints of LDS scratch.
 // kMove / exp_*: the staged interface runs the move (with addOdometry) and a single exporting measure() as separate
@@ -304,8 +314,7 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
   if constexpr (kMove) {
     const double *od = odom + (size_t)i * odom_stride + (size_t)sel.act_idx * 3;
     ox = od[0]; oy = od[1]; oth = od[2];
-    // SS2D.simulate bounds-checks the odometry increment against the map box (pyss2d.py:173-176)
-    if (!(cfg.map_min_x < ox && ox < cfg.map_max_x) || !(cfg.map_min_y < oy && oy < cfg.map_max_y)) {
+    if (!odom_in_bounds(cfg, ox, oy)) {
       if (lane == 0) cnt[C_FLAG] = 1;
       return;
     }

@@ -58,9 +58,8 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
     P0 = cnt[C_P]; L0 = cnt[C_L]; M0 = cnt[C_M]; isam = cnt[C_ISAM];
     const double *od = odom + (size_t)bi * odom_stride + (size_t)sel.act_idx * 3;
     od3[0] = od[0]; od3[1] = od[1]; od3[2] = od[2];
-    const drlgx_config &cfg = S.cfg;
-    // the simulator's own acceptance test (sim_step_body): a rejected move appends nothing - no front end then
-    accepted = (cfg.map_min_x < od3[0] && od3[0] < cfg.map_max_x) && (cfg.map_min_y < od3[1] && od3[1] < cfg.map_max_y) && P0 < S.P_max;
+    // the simulator's own acceptance test (ksim::move_accepted): a rejected move appends nothing - no front end then
+    accepted = ksim::move_accepted(S, od3[0], od3[1], P0);
     // between relinearisations the SLAM stage is a rank-k covariance update (k_inc.hip): no front end to run ahead
     inc_try = accepted && kslam::inc_precheck(S, inst, P0 + 1, tid, sub_cnt);
     // room for the landmarks / factors a step may add (more: slam_finish starts over); the front end only runs ahead when

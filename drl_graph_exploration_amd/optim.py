@@ -23,29 +23,38 @@ class GradientBucket(object):
 
     def __init__(self, params):
         self.params = [p for p in params]
-        n = sum(p.numel() for p in self.params)
         p0 = self.params[0]
+        if any(p.dtype != p0.dtype or p.device != p0.device for p in self.params):
+            raise ValueError("GradientBucket: every parameter must share one dtype and one device")
+        # every slice starts on a 256-byte boundary: the HIP backward kernels write the gradients with 16-byte accesses
+        self._align = max(1, 256 // p0.element_size())
+        self._offsets = []
+        n = 0
+        for p in self.params:
+            self._offsets.append(n)
+            n += -(-p.numel() // self._align) * self._align
         self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
         self.attach()
         self._work = None
 
     def attach(self):
         """(Re-)bind every parameter's .grad to its slice of the flat tensor (after a zero_grad(set_to_none=True))."""
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self._offsets):
             k = p.numel()
             view = self.flat[off:off + k].view_as(p)
             if p.grad is None or p.grad.data_ptr() != view.data_ptr():
                 if p.grad is not None:
                     view.copy_(p.grad)
                 p.grad = view
-            off += k
 
     @staticmethod
     def world(group=None):
         return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
     def start(self, group=None):
+        if self._work is not None:  # (a start() without finish(), e.g. after an exception in between: settle it first)
+            self._work.wait()
+            self._work = None
         if self.world(group) > 1:
             self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
 

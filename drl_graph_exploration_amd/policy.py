@@ -36,6 +36,21 @@ def _graph_to_host(d):
     return GraphData(d.x.detach().cpu().clone(), d.edge_index.detach().cpu().clone(), d.edge_attr.detach().cpu().clone())
 
 
+def _is_rank0():
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
+def save_state_dict(module, path):
+    """torch.save of a state_dict as the reference writes its artefacts (policy.py:194-199), made safe for the
+    data-parallel trainer: rank 0 only (every rank holds the same parameters), through a temporary file + os.replace, so
+    that a reader such as test.py never sees a truncated or interleaved archive."""
+    if not _is_rank0():
+        return
+    tmp = "%s.tmp.%d" % (path, os.getpid())
+    torch.save(module.state_dict(), tmp)
+    os.replace(tmp, path)
+
+
 def allreduce_gradients(model, group=None, optimizer=None):
     """Average the gradients of `model` over all ranks with ONE flat all-reduce (3 MB..4 MB for the GCN: far below
     the xGMI per-link bandwidth-delay product, so a single bucket is optimal).  No-op without a process group.
@@ -506,18 +521,19 @@ class DeepQ(object):
             rows.extend([self.step_t, float(x)] for x in r_h)
             recent.extend(float(x) for x in r_h)
             if self.step_t // 5e4 > (self.step_t - n_envs) // 5e4:  # every 50000 iterations (policy.py:197-199)
-                torch.save(policy_net.state_dict(), os.path.join(self.weights_path, "MyModel.pt"))
+                save_state_dict(policy_net, os.path.join(self.weights_path, "MyModel.pt"))
             if self.step_t > 1000 and self.step_t // 100 > (self.step_t - n_envs) // 100:  # every 100 (policy.py:200-203)
                 temp_reward_data.append([self.step_t, float(np.average(recent))])
 
         self.total_reward = np.append(self.total_reward, np.array([r[1] for r in rows]))
-        np.savetxt(os.path.join(self.object_path, "temp_reward.csv"), np.array(temp_reward_data).reshape(-1, 2), delimiter=",")
-        np.savetxt(os.path.join(self.object_path, "temp_loss.csv"), np.array(temp_loss_data).reshape(-1, 2), delimiter=",")
-        with open(os.path.join(self.reward_data_path, "reward_data.csv"), "a", newline="") as f:
-            csv.writer(f).writerows(rows)
-        torch.save(policy_net.state_dict(), os.path.join(self.object_path, "Model_Policy.pt"))
-        torch.save(target_net.state_dict(), os.path.join(self.object_path, "Model_Target.pt"))
-        torch.save(policy_net.state_dict(), os.path.join(self.weights_path, "MyModel.pt"))
+        if _is_rank0():  # (data-parallel runs: one writer for the shared artefact files; every rank logs its own envs' rewards in memory)
+            np.savetxt(os.path.join(self.object_path, "temp_reward.csv"), np.array(temp_reward_data).reshape(-1, 2), delimiter=",")
+            np.savetxt(os.path.join(self.object_path, "temp_loss.csv"), np.array(temp_loss_data).reshape(-1, 2), delimiter=",")
+            with open(os.path.join(self.reward_data_path, "reward_data.csv"), "a", newline="") as f:
+                csv.writer(f).writerows(rows)
+        save_state_dict(policy_net, os.path.join(self.object_path, "Model_Policy.pt"))
+        save_state_dict(target_net, os.path.join(self.object_path, "Model_Target.pt"))
+        save_state_dict(policy_net, os.path.join(self.weights_path, "MyModel.pt"))
         pool.ref[slot_t] -= 1
         if own_env:
             env.close()
@@ -770,15 +786,16 @@ class A2C(object):
             rows.extend([self.step_t, float(x)] for x in r_h)
             self.total_reward = np.append(self.total_reward, r_h)
             if self.step_t // 5e4 > (self.step_t - n_envs) // 5e4:
-                torch.save(policy_net.state_dict(), os.path.join(self.weights_path, "MyModel.pt"))
+                save_state_dict(policy_net, os.path.join(self.weights_path, "MyModel.pt"))
             if self.step_t > 1000 and self.step_t // 100 > (self.step_t - n_envs) // 100:
                 temp_reward_data.append([self.step_t, float(np.average(self.total_reward[-1000:]))])
 
-        np.savetxt(os.path.join(self.object_path, "temp_reward.csv"), np.array(temp_reward_data).reshape(-1, 2), delimiter=",")
-        np.savetxt(os.path.join(self.object_path, "temp_loss.csv"), np.array(temp_loss_data).reshape(-1, 2), delimiter=",")
-        with open(os.path.join(self.reward_data_path, "reward_data.csv"), "a", newline="") as f:
-            csv.writer(f).writerows(rows)
-        torch.save(policy_net.state_dict(), os.path.join(self.object_path, "Model_Policy.pt"))
-        torch.save(value_net.state_dict(), os.path.join(self.object_path, "Model_Value.pt"))
+        if _is_rank0():  # (data-parallel runs: one writer for the shared artefact files; every rank logs its own envs' rewards in memory)
+            np.savetxt(os.path.join(self.object_path, "temp_reward.csv"), np.array(temp_reward_data).reshape(-1, 2), delimiter=",")
+            np.savetxt(os.path.join(self.object_path, "temp_loss.csv"), np.array(temp_loss_data).reshape(-1, 2), delimiter=",")
+            with open(os.path.join(self.reward_data_path, "reward_data.csv"), "a", newline="") as f:
+                csv.writer(f).writerows(rows)
+        save_state_dict(policy_net, os.path.join(self.object_path, "Model_Policy.pt"))
+        save_state_dict(value_net, os.path.join(self.object_path, "Model_Value.pt"))
         if own_env:
             env.close()
