@@ -27,6 +27,7 @@
 //     in-range cell, so the sweep (120 sincos per pose) and the box tests are skipped.
 // Compiled with -ffp-contract=off (thresholded decisions must round like the CPU reference).
 #include "drlgx_dev.h"
+#include <stdlib.h>
 
 namespace kmap {
 
@@ -162,6 +163,17 @@ struct LadderEntry {
   uint32_t tr;
   int P, L, flag;
 };
+// kCompact: the LDS-lean form that lets TWO workgroups share a CU (the stand-alone kernel when there are more instances than
+// CUs: look-ahead rollouts, many envs per GPU).  It needs the full-circle sensor (bbox_noop: the poses that update a cell are
+// then exactly the poses that see it, up to cells inside min_range - ONE mask per cell, those rare pairs carry a sentinel
+// in their stage entry) and keeps the stage compact: entry k of the in-range pair list instead of a slot per (pose, window
+// cell), found through a 16-bit index table.  Same arithmetic in the same order: bit-equal results.
+#ifndef KMAPC_WAVES
+#define KMAPC_WAVES 4
+#endif
+constexpr int kPairsPerPose = 40;  // in-range cells per pose the compact stage has room for (the disc of radius max_range
+                                   // holds ~28 cell centres of the 7 x 7 window, never more than 32)
+template <bool kCompact = false>
 __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &sel, int rebuild, int chunk, bool handed = false,
                                          const double *lm_lds = nullptr, LadderEntry lo = LadderEntry{false, 0.0, 0u, -1, 0, 0}) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -184,9 +196,9 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
   double *sp = smem;                   // [pc][4]
   double *si = sp + (size_t)pc * 4;    // [pc][6]
   double *sl = si + (size_t)pc * 6;    // [pc][9] LLT factor of the pose information + reciprocals
-  double *stage = sl + (size_t)pc * 9;  // [chunk][64][3]
-  unsigned long long *mask = reinterpret_cast<unsigned long long *>(stage + (size_t)chunk * 64 * 3);  // [V]
-  unsigned long long *omask = mask + V;  // [V] poses that see the cell (occupancy ladder)
+  double *stage = sl + (size_t)pc * 9;  // [chunk][64][3]; kCompact: [chunk * kPairsPerPose][3]
+  unsigned long long *mask = reinterpret_cast<unsigned long long *>(stage + (size_t)chunk * (kCompact ? kPairsPerPose : 64) * 3);  // [V]
+  unsigned long long *omask = kCompact ? mask : mask + V;  // [V] poses that see the cell (occupancy ladder); kCompact: the same mask
   double *scratch = reinterpret_cast<double *>(omask + V);  // [kWaves]
   int *bbox = reinterpret_cast<int *>(scratch + kWaves + DRLGX_LO_TAB);  // [pc][4] min_row max_row min_col max_col
   int *worg = bbox + (size_t)pc * 4;                  // [pc][2] window origin row, col
@@ -196,6 +208,7 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
   double *lpv = scratch + kWaves;                      // [DRLGX_LO_TAB] ladder state -> cell probability
   int *pcount = reinterpret_cast<int *>(ltr + 4 * DRLGX_LO_TAB);  // number of (pose, cell) pairs in range (phase A)
   unsigned short *plist = reinterpret_cast<unsigned short *>(pcount + 1);  // [chunk * 64] their pair indices
+  unsigned short *sidx = plist + (size_t)chunk * 64;  // kCompact: [chunk][64] stage entry of (pose, window slot)
   double *prob = S.vm_prob + (size_t)inst * V;
   double *ixx = S.vm_info + ((size_t)inst * 3 + 0) * V, *ixy = S.vm_info + ((size_t)inst * 3 + 1) * V,
          *iyy = S.vm_info + ((size_t)inst * 3 + 2) * V;
@@ -215,7 +228,7 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
     for (int v = tid; v < V; v += kThreads) {  // (the first chunk's masks too, while the loads above are in flight)
       lmc[v] = 0;
       mask[v] = 0ull;
-      omask[v] = 0ull;
+      if (!kCompact) omask[v] = 0ull;
     }
     if (tid == 0) *pcount = 0;
     if (lo.have) {
@@ -307,7 +320,7 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
       if (c0 > 0) {  // (the first chunk's masks were cleared while the pose tables were loading)
         for (int v = tid; v < V; v += kThreads) {
           mask[v] = 0ull;
-          omask[v] = 0ull;
+          if (!kCompact) omask[v] = 0ull;
         }
         if (tid == 0) *pcount = 0;
         __syncthreads();
@@ -381,6 +394,10 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
       __syncthreads();
       if (c0 == 0) DRLGX_PROF(S, 43);
       const int npairs = *pcount;
+      if (kCompact && npairs > nc * kPairsPerPose) {  // (cannot happen for a disc-shaped footprint: flag it, leave the map alone)
+        if (tid == 0) atomicMin(S.status, DRLGX_E_CAPACITY);
+        return;
+      }
       for (int k = tid; k < npairs; k += kThreads) {
         const int e = plist[k];
         const int pl = e >> 6, widx = e & 63;
@@ -392,7 +409,14 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
         const bool in_bbox = !use_bbox || !(row < bbox[4 * p] || row > bbox[4 * p + 1] || col < bbox[4 * p + 2] || col > bbox[4 * p + 3]);
         if (in_bbox) atomicOr(&omask[row * cols + col], 1ull << pl);  // OccupancyMap::update visits this cell
         double a, b, d;
-        if (predict_cell<false>(S, ps, sl + 9 * p, pt, a, b, d)) {
+        const bool upd_ok = predict_cell<false>(S, ps, sl + 9 * p, pt, a, b, d);
+        if constexpr (kCompact) {
+          // entry k of the pair list; the cell pass finds it through sidx[(pose, window slot)].  A pair that is seen but does not
+          // update (inside min_range) keeps its bit - the one mask is the sees-me mask - and carries a negative sentinel
+          double *o = stage + (size_t)k * 3;
+          o[0] = upd_ok ? a : -1.0; o[1] = b; o[2] = d;
+          sidx[pl * 64 + (row & 7) * 8 + (col & 7)] = (unsigned short)k;
+        } else if (upd_ok) {
           // stage slot of (pose, cell): the window spans at most 8 consecutive rows / columns, so (row mod 8, col mod 8)
           // is unique within it - the cell pass finds the entry without the window origin
           double *o = stage + ((size_t)pl * 64 + (row & 7) * 8 + (col & 7)) * 3;
@@ -423,19 +447,19 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
       };
       int nrow = 0, ncol = 0;
       int nv = wave < ntiles ? cell_of(wave, nrow, ncol) : -1;
-      unsigned long long nm = nv >= 0 ? mask[nv] : 0ull, nom = nv >= 0 ? omask[nv] : 0ull;
+      unsigned long long nm = nv >= 0 ? mask[nv] : 0ull, nom = (!kCompact && nv >= 0) ? omask[nv] : 0ull;
       int nlmc = nv >= 0 ? lmc[nv] : 0;
       for (int t = wave; t < ntiles; t += kWaves) {
         const int row = nrow, col = ncol;
         const bool ok = nv >= 0;
         const int v = ok ? nv : 0;
         unsigned long long m = nm;
-        const unsigned long long om_cell = nom;
+        const unsigned long long om_cell = kCompact ? nm : nom;
         const int lmc_cell = nlmc;
         if (t + kWaves < ntiles) {
           nv = cell_of(t + kWaves, nrow, ncol);
           nm = nv >= 0 ? mask[nv] : 0ull;
-          nom = nv >= 0 ? omask[nv] : 0ull;
+          if (!kCompact) nom = nv >= 0 ? omask[nv] : 0ull;
           nlmc = nv >= 0 ? lmc[nv] : 0;
         }
         // a middle chunk of poses (trajectories beyond 128 poses) that neither updates nor sees any cell of the tile leaves
@@ -449,6 +473,34 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
         }
         const double *nx = stage + lane * 3;  // + 192 * (pose within the chunk): the slot is the lane
         const long long tc0 = wprof ? wall_clock64() : 0;
+        if constexpr (kCompact) {
+          // the same walk over the set bits in trajectory order; an entry is found through the index table and fetched one
+          // step ahead of its use, an entry with the sentinel is a pose that sees the cell without updating it
+          auto fetch = [&](unsigned long long &mm, double &xx, double &xy, double &yy) {
+            const int pl = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            const double *o = stage + (size_t)sidx[pl * 64 + lane] * 3;
+            xx = o[0]; xy = o[1]; yy = o[2];
+          };
+          if (m) {
+            double nxx, nxy, nyy;
+            fetch(m, nxx, nxy, nyy);
+            while (true) {
+              const double bxx = nxx, bxy = nxy, byy = nyy;
+              const bool more = m != 0ull;
+              if (more) fetch(m, nxx, nxy, nyy);
+              if (bxx >= 0.0) {
+                if (!u) {  // the first update of an untouched cell replaces the prior (VirtualMap.cpp:300-304)
+                  axx = bxx; axy = bxy; ayy = byy;
+                  u = 1;
+                } else {
+                  ci_fuse(axx, axy, ayy, bxx, bxy, byy);
+                }
+              }
+              if (!more) break;
+            }
+          }
+        } else {
         if (m && !u) {  // the first update of an untouched cell replaces the prior (VirtualMap.cpp:300-304)
           const double *o = nx + (__ffsll((long long)m) - 1) * 192;
           axx = o[0]; axy = o[1]; ayy = o[2];
@@ -472,6 +524,7 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
             ci_fuse(axx, axy, ayy, bxx, bxy, byy);
             if (!more) break;
           }
+        }
         }
         if (wprof) ci_clk += wall_clock64() - tc0;
         if (ok) {
@@ -605,14 +658,21 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
 }
 
 __global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, int rebuild, int chunk) {
-  map_body(S, sel, rebuild, chunk);
+  map_body<false>(S, sel, rebuild, chunk);
+}
+// The multi-resident form: <= 128 VGPRs (four waves per SIMD) and, with the compact carve, <= 80 KB of LDS - two workgroups
+// per CU, each covering the other's dependent chains and barriers.  Launched when there are more instances than CUs.
+__global__ __launch_bounds__(kThreads, KMAPC_WAVES) void k_map_c(DrlgxState S, LaunchSel sel, int rebuild, int chunk) {
+  map_body<true>(S, sel, rebuild, chunk);
 }
 
 }  // namespace kmap
 
-static size_t map_lds_bytes(const DrlgxState &S, int chunk, int pc) {
-  size_t d = (size_t)pc * 19 + (size_t)chunk * 64 * 3 + 2 * (size_t)S.V + kmap::kWaves + DRLGX_LO_TAB;  // + two u64 masks per cell
-  size_t i = (size_t)pc * 7 + (size_t)S.V + DRLGX_LO_TAB + 1 + (size_t)chunk * 32;  // (+ pair counter, pair list)
+static size_t map_lds_bytes(const DrlgxState &S, int chunk, int pc, bool compact = false) {
+  // pose tables, stage, the u64 mask(s) per cell, reduction scratch + ladder values
+  size_t d = (size_t)pc * 19 + (size_t)chunk * (compact ? kmap::kPairsPerPose : 64) * 3 + (compact ? 1 : 2) * (size_t)S.V + kmap::kWaves + DRLGX_LO_TAB;
+  // per-pose ints, landmark counts, ladder transitions, pair counter, pair list (+ the compact stage's index table)
+  size_t i = (size_t)pc * 7 + (size_t)S.V + DRLGX_LO_TAB + 1 + (size_t)chunk * 32 * (compact ? 2 : 1);
   return d * sizeof(double) + i * sizeof(int) + 16;
 }
 namespace kmap {
@@ -630,6 +690,17 @@ size_t drlgx_map_lds_bytes(const DrlgxState &S, int *chunk_out, int pcap) {
   return map_lds_bytes(S, chunk, pc);
 }
 
+// the compact carve for the launch's pose bound, if it lets two workgroups share a CU (<= 80 KB each): bytes, else 0
+static size_t map_lds_bytes_compact(const DrlgxState &S, int pcap, int *chunk_out) {
+  if (!S.bbox_noop) return 0;
+  const int pc = pcap > 0 && pcap < S.P_max ? pcap : S.P_max;
+  const int chunk = pc < 64 ? pc : 64;
+  const size_t b = map_lds_bytes(S, chunk, pc, true);
+  if (b > 80 * 1024) return 0;
+  *chunk_out = chunk;
+  return b;
+}
+
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
   // sel.act_idx == -2 encodes "reductions only" (used after reset)
   int rebuild = 1;
@@ -640,7 +711,21 @@ void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
   int chunk = 0;
   const size_t lds = drlgx_map_lds_bytes(S, &chunk, sel.pcap);
   static bool attr_set[32] = {false};
-  const void *fns[] = {reinterpret_cast<const void *>(&kmap::k_map)};
-  drlgx_ensure_lds_attr(attr_set, fns, 1, 160 * 1024);
-  hipLaunchKernelGGL(kmap::k_map, dim3(sel.n), dim3(kmap::kThreads), lds, st, S, sel, rebuild, chunk);
+  const void *fns[] = {reinterpret_cast<const void *>(&kmap::k_map), reinterpret_cast<const void *>(&kmap::k_map_c)};
+  drlgx_ensure_lds_attr(attr_set, fns, 2, 160 * 1024);
+  // more instances than CUs: the form of which two workgroups fit a CU (DRLGX_MAP_COMPACT=0 / 1 forces either, A/B runs)
+  static int n_cu = 0;
+  const char *fv = getenv("DRLGX_MAP_COMPACT");
+  const int force = fv ? atoi(fv) : -1;
+  if (n_cu == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  int cchunk = 0;
+  const size_t clds = rebuild ? map_lds_bytes_compact(S, sel.pcap, &cchunk) : 0;
+  if (clds && (force == 1 || (force != 0 && sel.n > n_cu)))
+    hipLaunchKernelGGL(kmap::k_map_c, dim3(sel.n), dim3(kmap::kThreads), clds, st, S, sel, rebuild, cchunk);
+  else
+    hipLaunchKernelGGL(kmap::k_map, dim3(sel.n), dim3(kmap::kThreads), lds, st, S, sel, rebuild, chunk);
 }

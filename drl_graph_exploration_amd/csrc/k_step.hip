@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
   }
   const unsigned char *map_masks = step_smem + kmap::masks_offset(pc, map_chunk);
   if (!handed || reinterpret_cast<const unsigned char *>(lm_lds + 2 * (size_t)S.L_max) > map_masks) lm_lds = nullptr;
-  kmap::map_body(S, sel, 1, map_chunk, handed, lm_lds, lo);
+  kmap::map_body<false>(S, sel, 1, map_chunk, handed, lm_lds, lo);
   if (S.prof && tid == 0 && bi < 448) S.prof[129 + 2 * bi] = wall_clock64();
 }
 
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step_arrow(DrlgxState S, La
   __syncthreads();
   kslam::arrow_body<0>(S, sel, lds_bytes);  // (or, between relinearisations, the incremental update: arrow_body's first lines)
   __syncthreads();
-  kmap::map_body(S, sel, 1, map_chunk);
+  kmap::map_body<false>(S, sel, 1, map_chunk);
 }
 
 }  // namespace kstep

@@ -685,3 +685,39 @@ def test_incremental_update_equals_the_full_solve_across_relinearisations(monkey
     assert inc >= n * (len(script) - 4) and full >= n
     eng.close()
     ref.close()
+
+
+def test_compact_map_kernel_equals_the_resident_one(monkeypatch):
+    """The stand-alone map kernel has a second form for launches with more instances than CUs (csrc/k_map.hip, k_map_c: <= 128
+    VGPRs, <= 80 KB of LDS - compact stage, one mask per cell - so that two workgroups share a CU).  Same arithmetic in the same
+    order: virtual map, traces and the utility sums must be bit-equal to the one-workgroup-per-CU kernel, step after step."""
+    n = 5
+    a, cfg = make_engine(n, num_landmarks=60)
+    b, _ = make_engine(n, num_landmarks=60)
+    for e in (a, b):
+        e.timing_enable(2)  # the three stage kernels, so that the stand-alone map kernel runs
+    starts = generic_starts(n)
+    for e in (a, b):
+        e.reset(np.arange(n), np.arange(n), starts=starts)
+    for s, act in enumerate(SCRIPT + [(2, 0, 0), (0, 0, 0.9), (2, 0, 0)] * 5):
+        odom = torch.tensor([act] * n, dtype=torch.float64, device=a.device)
+        monkeypatch.setenv("DRLGX_MAP_COMPACT", "0")
+        a.step(odom)
+        a.synchronize()
+        monkeypatch.setenv("DRLGX_MAP_COMPACT", "1")
+        b.step(odom)
+        b.synchronize()
+        assert a.status() == 0 and b.status() == 0
+        for i in range(n):
+            pa, ia, ta, ua = a.virtual_map(i)
+            pb, ib, tb, ub = b.virtual_map(i)
+            np.testing.assert_array_equal(ua, ub)
+            np.testing.assert_array_equal(pa, pb)
+            np.testing.assert_array_equal(ia, ib)
+            np.testing.assert_array_equal(ta, tb)
+        np.testing.assert_array_equal(a.utility().cpu().numpy(), b.utility().cpu().numpy())
+        np.testing.assert_array_equal(a.uncertainty_em(1).cpu().numpy(), b.uncertainty_em(1).cpu().numpy())
+        np.testing.assert_array_equal(a.explored().cpu().numpy(), b.explored().cpu().numpy())
+    monkeypatch.delenv("DRLGX_MAP_COMPACT")
+    a.close()
+    b.close()
