@@ -713,7 +713,7 @@ void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
   static bool attr_set[32] = {false};
   const void *fns[] = {reinterpret_cast<const void *>(&kmap::k_map), reinterpret_cast<const void *>(&kmap::k_map_c)};
   drlgx_ensure_lds_attr(attr_set, fns, 2, 160 * 1024);
-  // more instances than CUs: the form of which two workgroups fit a CU (DRLGX_MAP_COMPACT=0 / 1 forces either, A/B runs)
+  // the form of which two workgroups fit a CU, for launches with more instances than CUs (DRLGX_MAP_COMPACT=1)
   static int n_cu = 0;
   const char *fv = getenv("DRLGX_MAP_COMPACT");
   const int force = fv ? atoi(fv) : -1;
@@ -724,7 +724,8 @@ void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
   }
   int cchunk = 0;
   const size_t clds = rebuild ? map_lds_bytes_compact(S, sel.pcap, &cchunk) : 0;
-  if (clds && (force == 1 || (force != 0 && sel.n > n_cu)))
+  // (measured slower so far - its 128-VGPR cap spills, profiles/r04_ab_map_two_workgroups_per_cu.txt - so only on request)
+  if (clds && force == 1 && n_cu > 0)
     hipLaunchKernelGGL(kmap::k_map_c, dim3(sel.n), dim3(kmap::kThreads), clds, st, S, sel, rebuild, cchunk);
   else
     hipLaunchKernelGGL(kmap::k_map, dim3(sel.n), dim3(kmap::kThreads), lds, st, S, sel, rebuild, chunk);
