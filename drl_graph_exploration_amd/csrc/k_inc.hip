@@ -89,7 +89,8 @@ constexpr int INEW = 12;
 struct IncCtx {
   int inst, P, pn, pp, L0, M0, Lcap, n1, n1p, a0, ldw;
   int *fre, *fnew, *fslot, *ictl;
-  double *fq, *recs, *gs, *vvec, *wks, *thp, *thl, *dl, *Dl, *Y, *cwl;
+  double *fq, *recs, *gs, *vvec, *wks, *thp, *thl, *dl, *Dl, *Y, *Yh, *cwl;
+  bool wide;  // room for the second half of Y: batches of up to 16 re-observed landmarks
 };
 // false: the step cannot take this path (LDS).  lds_panel: the panel is staged in LDS for the step (else updated in place in
 // HBM / L2).  The decision is taken for the SAME LDS offset in every kernel (the fused step's: behind the simulator's region),
@@ -117,8 +118,8 @@ __device__ __forceinline__ bool inc_plan(const DrlgxState &S, int inst, int P, i
   x.fq = reinterpret_cast<double *>(take(32 * 8));            // F (9), c (3), theta of the new pose (4), measured odometry (4)
   x.recs = reinterpret_cast<double *>(take(INF * REC * 8));   // linearised new factors
   x.gs = reinterpret_cast<double *>(take(INEW * 12 * 8));     // per new landmark: G (6), c (2), Q (xx xy yy), pad
-  x.vvec = reinterpret_cast<double *>(take(16 * 8));
-  x.wks = reinterpret_cast<double *>(take(16 * IYS * 8));
+  x.vvec = reinterpret_cast<double *>(take(32 * 8));
+  x.wks = reinterpret_cast<double *>(take(5 * 16 * IYS * 8));  // W' as operand images: one tile, or four + a transposition scratch
   x.thp = reinterpret_cast<double *>(take((size_t)P * 4 * 8));
   x.thl = reinterpret_cast<double *>(take((size_t)x.Lcap * 2 * 8));
   x.dl = reinterpret_cast<double *>(take((size_t)ncap * 8));  // delta, logical row order
@@ -128,6 +129,10 @@ __device__ __forceinline__ bool inc_plan(const DrlgxState &S, int inst, int P, i
   const size_t fixed = ((plan_off + 15) & ~(size_t)15) + (off - off0);
   if (fixed > (size_t)lds_bytes) return false;
   lds_panel = fixed + (size_t)ncap * x.ldw * 8 <= (size_t)lds_bytes;
+  // the second half of Y (wide batches) sits behind the panel, if there is room left
+  const size_t pan = lds_panel ? (size_t)ncap * x.ldw * 8 : 0, yh = (size_t)(x.n1p + 1) * IYS * 8;
+  x.Yh = x.cwl + pan / 8;
+  x.wide = fixed + pan + yh <= (size_t)lds_bytes;
   return true;
 }
 
@@ -202,7 +207,10 @@ __device__ __forceinline__ void inc_pre(const DrlgxState &S, const IncCtx &x, in
         dst(q0, v0); dst(q1, v1); dst(q2, v2); dst(q3, v3);
       }
   }
-  for (int e = ft; e < (x.n1p + 1 - n1) * IYS; e += fn) x.Y[(size_t)n1 * IYS + e] = 0.0;  // pad rows + the zero row
+  for (int e = ft; e < (x.n1p + 1 - n1) * IYS; e += fn) {  // pad rows + the zero row
+    x.Y[(size_t)n1 * IYS + e] = 0.0;
+    if (x.wide) x.Yh[(size_t)n1 * IYS + e] = 0.0;
+  }
   bar();
   if (S.prof && blockIdx.x == S.prof_block && ft == 0) S.prof[1] = wall_clock64();
   // ---- A. the new pose: every row's covariance with the current pose moves through F; the new pose's own rows ----
@@ -288,11 +296,17 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
   // ---- B. the re-observed landmarks, <= 8 at a time (independent measurement noise: sequential batches are exact) ----
   const double Rb = S.cfg.bearing_noise * S.cfg.bearing_noise, Rr = S.cfg.range_noise * S.cfg.range_noise;
   const int ntr = n1p >> 4, ntc = (a0 + 15) >> 4;
-  for (int b0 = 0; b0 < n_re; b0 += 8) {
-    const int nb = min(8, n_re - b0), k = 2 * nb;
-    // B1. Y = Sigma A^T, row by row: a thread serves ONE factor of the batch (its Jacobians in registers) for every 64th row
+  // One batch of nb re-observed landmarks starting at list position b0.  kWide: up to 16 landmarks (k = 2 nb <= 32 columns, the
+  // k x k system inverted by 2 x 2 blocks of 16 x 16 tiles) instead of up to 8 - one walk over the panel instead of two for the
+  // steps that re-observe 9 .. 16 landmarks; needs the second half of Y (x.Yh) in LDS.
+  auto batch = [&](int b0, int nb, auto wide_tag) {
+    constexpr bool kWide = decltype(wide_tag)::value;
+    const int k = 2 * nb, kD = kWide ? k - 16 : 0;  // (kWide: the first 16 columns are all live, kD of the second 16)
+    double *Yh = x.Yh;
+    // B1. Y = Sigma A^T, row by row: a thread serves ONE factor of the batch (its Jacobians in registers) for every 64th (32nd) row
     {
-      const int f = tid & 7;
+      constexpr int FS = kWide ? 16 : 8, RS = kThreads / FS;
+      const int f = tid & (FS - 1);
       double j0 = 0, j1 = 0, j2 = 0, j3 = 0, j4 = 0, j5 = 0, l0c = 0, l1c = 0, l2c = 0, l3c = 0;
       int cl = 3;
       if (f < nb) {
@@ -302,21 +316,22 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
         l0c = rc[6]; l1c = rc[7]; l2c = rc[8]; l3c = rc[9];
         cl = 3 + 2 * fslot[t];
       }
-      const int k0 = ks16(2 * f), k1 = ks16(2 * f + 1);
+      double *Yf = (kWide && f >= 8) ? Yh : Y;
+      const int k0 = ks16(2 * (f & 7)), k1 = ks16(2 * (f & 7) + 1);
       // (four rows' loads in flight per thread: in the HBM / L2 form of the panel every load is a round trip)
-      for (int q0 = tid >> 3; q0 < n1; q0 += 4 * (kThreads >> 3)) {
+      for (int q0 = tid / FS; q0 < n1; q0 += 4 * RS) {
         double c0[4], c1[4], c2[4], l0[4], l1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const double *r = rowp(min(q0 + u * (kThreads >> 3), n1 - 1));
+          const double *r = rowp(min(q0 + u * RS, n1 - 1));
           c0[u] = r[0]; c1[u] = r[1]; c2[u] = r[2]; l0[u] = r[cl]; l1[u] = r[cl + 1];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int q = q0 + u * (kThreads >> 3);
+          const int q = q0 + u * RS;
           if (q < n1) {  // (factors beyond the batch: all-zero Jacobians, zero columns)
-            Y[(size_t)q * IYS + k0] = c0[u] * j0 + c1[u] * j1 + c2[u] * j2 + l0[u] * l0c + l1[u] * l1c;
-            Y[(size_t)q * IYS + k1] = c0[u] * j3 + c1[u] * j4 + c2[u] * j5 + l0[u] * l2c + l1[u] * l3c;
+            Yf[(size_t)q * IYS + k0] = c0[u] * j0 + c1[u] * j1 + c2[u] * j2 + l0[u] * l0c + l1[u] * l1c;
+            Yf[(size_t)q * IYS + k1] = c0[u] * j3 + c1[u] * j4 + c2[u] * j5 + l0[u] * l2c + l1[u] * l3c;
           }
         }
       }
@@ -325,21 +340,18 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
     if (b0 == 0) DRLGX_PROF(S, 36);
     // B2. T = R + A Y (symmetric by construction), v = -e - A delta, W' = -T^-1: one wave
     if (wave == 0) {
-      v4d d = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = lr + 4 * r, hi = max(i, lc), lo = min(i, lc);
-        if (hi < k) {
-          const int t = fre[b0 + (hi >> 1)], u = hi & 1;
-          const double *rc = recs + (size_t)REC * t;
-          const int col = ks16(lo);
-          const double *yp = Y + (size_t)(3 * pn) * IYS + col, *yl = Y + (size_t)(3 * P + 2 * fslot[t]) * IYS + col;
-          double s = rc[3 * u] * yp[0] + rc[3 * u + 1] * yp[IYS] + rc[3 * u + 2] * yp[2 * IYS] + rc[6 + 2 * u] * yl[0] + rc[7 + 2 * u] * yl[IYS];
-          if (hi == lo) s += u ? Rr : Rb;
-          d[r] = s;
-        }
-      }
-      if (lane < 16) {
+      // entry (i, j), i >= j, of T: row i = (factor i / 2, bearing or range), column j of Y (in the half j / 16)
+      auto tent = [&](int i, int j) -> double {
+        const int t = fre[b0 + (i >> 1)], u = i & 1;
+        const double *rc = recs + (size_t)REC * t;
+        const double *Yj = (kWide && j >= 16) ? Yh : Y;
+        const int col = ks16(j & 15);
+        const double *yp = Yj + (size_t)(3 * pn) * IYS + col, *yl = Yj + (size_t)(3 * P + 2 * fslot[t]) * IYS + col;
+        double sv = rc[3 * u] * yp[0] + rc[3 * u + 1] * yp[IYS] + rc[3 * u + 2] * yp[2 * IYS] + rc[6 + 2 * u] * yl[0] + rc[7 + 2 * u] * yl[IYS];
+        if (i == j) sv += u ? Rr : Rb;
+        return sv;
+      };
+      if (lane < (kWide ? 32 : 16)) {
         double v = 0.0;
         if (lane < k) {
           const int t = fre[b0 + (lane >> 1)], u = lane & 1;
@@ -347,33 +359,85 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
           const double *dp = dl + 3 * pn, *dq = dl + 3 * P + 2 * fslot[t];
           v = -rc[10 + u] - (rc[3 * u] * dp[0] + rc[3 * u + 1] * dp[1] + rc[3 * u + 2] * dp[2] + rc[6 + 2 * u] * dq[0] + rc[7 + 2 * u] * dq[1]);
         }
-        vvec[ks16(lane)] = v;  // (ks16 order, like the rows of Y)
+        vvec[(lane & 16) + ks16(lane & 15)] = v;  // (ks16 order per half, like the rows of Y)
       }
-      const SweepCtx sx{0, lane, lc, lr, k, 16, true, true, ictl + 1, nullptr};
-      inv16_blk<true>(sx, k, d);
-      // image of W' for the matrix cores: row lc, columns lr + 4 r at ks16 positions 4 lr + r (W' is symmetric)
-      double *o = wks + lc * IYS + 4 * lr;
+      const int kA = kWide ? 16 : k;
+      v4d d = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (lc < k && lr + 4 * r < k) ? d[r] : 0.0;
+      for (int r = 0; r < 4; ++r) {
+        const int i = lr + 4 * r, hi = max(i, lc), lo = min(i, lc);
+        if (hi < kA) d[r] = tent(hi, lo);
+      }
+      const SweepCtx sx{0, lane, lc, lr, kA, 16, true, true, ictl + 1, nullptr};
+      if constexpr (!kWide) {
+        inv16_blk<true>(sx, kA, d);
+        // image of W' for the matrix cores: row lc, columns lr + 4 r at ks16 positions 4 lr + r (W' is symmetric)
+        double *o = wks + lc * IYS + 4 * lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (lc < k && lr + 4 * r < k) ? d[r] : 0.0;
+      } else {
+        // T = [A B; B^T D] in 16 x 16 tiles (accumulator layout: lane (lr, lc), register r = element (lr + 4 r, lc)):
+        //   A' = -A^-1,  X' = A' B,  S = D + B^T X',  S' = -S^-1,   W' = -T^-1 = [A' + X' S' X'^T, X' S'; S' X'^T, S']
+        // Accumulator registers used as the A operand are the TRANSPOSE of the tile, as the B operand the tile itself; the one
+        // transposition that is not free (X'^T as a B operand) goes through LDS.
+        v4d tb = {0.0, 0.0, 0.0, 0.0}, td = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = lr + 4 * r, hi = max(i, lc), lo = min(i, lc);
+          if (lc < kD) tb[r] = tent(16 + lc, i);          // B[i][lc] = T[i][16 + lc]
+          if (hi < kD) td[r] = tent(16 + hi, 16 + lo);    // D
+        }
+        inv16_blk<false>(sx, 16, d);  // A'
+        double a4[4] = {d[0], d[1], d[2], d[3]}, b4[4] = {tb[0], tb[1], tb[2], tb[3]};
+        v4d xp = {0.0, 0.0, 0.0, 0.0};
+        xp = mfma4(a4, b4, xp);       // X' = A' B  (A' symmetric)
+        double x4[4] = {xp[0], xp[1], xp[2], xp[3]};
+        td = mfma4(b4, x4, td);       // S = D + B^T X'
+        const SweepCtx sd{0, lane, lc, lr, kD, 16, true, true, ictl + 1, nullptr};
+        inv16_blk<true>(sd, kD, td);  // S'
+        double *tsc = wks + 4 * 16 * IYS;  // X' row-major (ks16 columns): read back as the image whose B-operand use is X'^T
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tsc[(lr + 4 * r) * IYS + ks16(lc)] = xp[r];
+        wave_lds_sync();
+        double xt4[4], s4[4];
+        ld4(tsc + lc * IYS + 4 * lr, xt4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s4[r] = (lc < kD && lr + 4 * r < kD) ? td[r] : 0.0;  // (S' with its inactive part zeroed)
+        v4d w10 = {0.0, 0.0, 0.0, 0.0};
+        w10 = mfma4(s4, xt4, w10);    // W'[1][0] = S' X'^T   (rows: second half, columns: first half)
+        double w10a[4] = {w10[0], w10[1], w10[2], w10[3]};
+        d = mfma4(w10a, xt4, d);      // W'[0][0] = A' + (S' X'^T)^T X'^T = A' + X' S' X'^T
+        // operand images (row lc, ks16 columns): [0] W00, [1] W01 = W10^T, [2] W10, [3] W11
+        double *o0 = wks + lc * IYS + 4 * lr, *o1 = o0 + 16 * IYS, *o3 = o0 + 3 * 16 * IYS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o0[r] = d[r];      // (symmetric: the registers are the image)
+          o1[r] = w10[r];    // (the registers of a tile, stored as they are, are the image of its transpose)
+          o3[r] = s4[r];
+          wks[2 * 16 * IYS + (lr + 4 * r) * IYS + ks16(lc)] = w10[r];  // W10 itself: element (lr + 4 r, lc)
+        }
+      }
     }
     __syncthreads();
     if (b0 == 0) DRLGX_PROF(S, 37);
     // B3. U'^T = W' Y^T per 16-row tile; delta and the pose marginals; every column tile of the panel: C += U' Ya^T.
     // A wave owns the row tiles I = wave, wave + 8, ...; the columns are walked in PAIRS of 16-column tiles.  The wave's
-    // (row tile, pair) units form ONE software pipeline: the loads of the next unit are issued before the products of the current one (the
-    // panel may live in HBM / L2: a unit that loads only after the previous one's stores pays a full round trip each time).
-    // Loads and stores are unconditional: the rows up to the next multiple of 16 and the columns up to the next multiple of
-    // 32 exist (the future landmarks' rows / columns), their operands are zero rows of Y: they are written back unchanged.
+    // (row tile, pair) units form ONE software pipeline: the loads of the next unit are issued before the products of the
+    // current one (the panel may live in HBM / L2: a unit that loads only after the previous one's stores pays a full
+    // round trip each time).  Loads and stores are unconditional: the rows up to the next multiple of 16 and the columns up
+    // to the next multiple of 32 exist (the future landmarks' rows / columns), their operands are zero rows of Y: they are
+    // written back unchanged.
     if (wave < ntr) {
-      const int npr = (a0 + 31) >> 5;  // column pairs
-      const int nks = (k + 3) >> 2;    // K steps with live columns (k = 2 nb)
+      const int npr = (a0 + 31) >> 5;                  // column pairs
+      const int nks = kWide ? 4 : (k + 3) >> 2;        // K steps with live columns (k = 2 nb; kWide: of the first half)
+      const int nks1 = kWide ? (kD + 3) >> 2 : 0;      // ... of the second half
       const int nun = ((ntr - wave + kWaves - 1) / kWaves) * npr;
       // the two accumulator tiles of a unit, twice (current / next): element r = row 16 I + lr + 4 r, columns 32 p + lc and
       // 32 p + 16 + lc - loaded straight into the registers the matrix cores accumulate in (16-byte accesses of adjacent
       // column pairs were tried: the two halves belong to different accumulator tuples, the compiler copies them apart right
       // behind the load and waits for it there - no pipeline left)
       v4d aA0, aA1, aB0, aB1;
-      double ua[4] = {0.0, 0.0, 0.0, 0.0};
+      double ua[4] = {0.0, 0.0, 0.0, 0.0}, ub[4] = {0.0, 0.0, 0.0, 0.0};  // U' of the row tile: columns 0 .. 15 / 16 .. 31
       auto loads = [&](int e, v4d &c0, v4d &c1) {
         const int it = e / npr, pr = e - it * npr, I = wave + kWaves * it;
 #pragma unroll
@@ -392,28 +456,44 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
         const int it = e / npr, pr = e - it * npr, I = wave + kWaves * it;
         if (pr == 0) {
           // U' of this row tile: lane (lr, lc), register r: U'[16 I + lc][lr + 4 r]
-          double w4[4], yI[4];
+          double w4[4], yI[4], yH[4];
           ld4(wks + lc * IYS + 4 * lr, w4);
           ld4(Y + (size_t)(16 * I + lc) * IYS + 4 * lr, yI);
           v4d ut = {0.0, 0.0, 0.0, 0.0};
           ut = mfma4(w4, yI, ut);
+          if constexpr (kWide) {
+            ld4(Yh + (size_t)(16 * I + lc) * IYS + 4 * lr, yH);
+            ld4(wks + 16 * IYS + lc * IYS + 4 * lr, w4);
+            ut = mfma4(w4, yH, ut);
+            v4d u2 = {0.0, 0.0, 0.0, 0.0};
+            ld4(wks + 2 * 16 * IYS + lc * IYS + 4 * lr, w4);
+            u2 = mfma4(w4, yI, u2);
+            ld4(wks + 3 * 16 * IYS + lc * IYS + 4 * lr, w4);
+            u2 = mfma4(w4, yH, u2);
+            ub[0] = u2[0]; ub[1] = u2[1]; ub[2] = u2[2]; ub[3] = u2[3];
+          }
           ua[0] = ut[0]; ua[1] = ut[1]; ua[2] = ut[2]; ua[3] = ut[3];
           // this row's delta and - pose rows - its entries of the pose marginal, from the U' registers: a lane holds the columns
           // lr + 4 r of row q = 16 I + lc; the four lanes of a row (lc, lc + 16, lc + 32, lc + 48) are summed with the gfx950
           // permlane swaps (no trip through LDS):  delta' = delta - U' v  (U' = -Sigma A^T T^-1, v = -e - A delta),  D_i += U'_i Y_i^T
           const int q = 16 * I + lc;
-          auto rowdot = [&](const double *vec) -> double {
+          auto rowdot = [&](const double *vec, const double *vech) -> double {
             double y4[4];
             ld4(vec + 4 * lr, y4);
             double sdot = ua[0] * y4[0] + ua[1] * y4[1] + ua[2] * y4[2] + ua[3] * y4[3];
+            if constexpr (kWide) {
+              ld4(vech + 4 * lr, y4);
+              sdot += ub[0] * y4[0] + ub[1] * y4[1] + ub[2] * y4[2] + ub[3] * y4[3];
+            }
             sdot += rowgroup_xor<16>(sdot);
             sdot += rowgroup_xor<32>(sdot);
             return sdot;
           };
-          const double sv = rowdot(vvec);
+          const double sv = rowdot(vvec, vvec + 16);
           const bool prow = q < 3 * pn;
           const int qc = prow ? q : 0, pi = qc / 3, rp = qc - 3 * pi;
-          const double s0 = rowdot(Y + (size_t)(3 * pi) * IYS), s1 = rowdot(Y + (size_t)(3 * pi + 1) * IYS), s2 = rowdot(Y + (size_t)(3 * pi + 2) * IYS);
+          const size_t o3 = (size_t)(3 * pi) * IYS;
+          const double s0 = rowdot(Y + o3, Yh + o3), s1 = rowdot(Y + o3 + IYS, Yh + o3 + IYS), s2 = rowdot(Y + o3 + 2 * IYS, Yh + o3 + 2 * IYS);
           if (lr == 0 && q < n1) {
             dl[q] -= sv;
             if (prow) {
@@ -437,6 +517,16 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
               acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[ks], yJ0[ks], acc0, 0, 0, 0);
               acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[ks], yJ1[ks], acc1, 0, 0, 0);
             }
+          if constexpr (kWide) {
+            ld4(Yh + (size_t)y0 * IYS + 4 * lr, yJ0);
+            ld4(Yh + (size_t)y1 * IYS + 4 * lr, yJ1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+              if (ks < nks1) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ub[ks], yJ0[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ub[ks], yJ1[ks], acc1, 0, 0, 0);
+              }
+          }
         }
 #ifndef INC_EXP_NOSTORE
 #pragma unroll
@@ -459,6 +549,18 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
     }
     __syncthreads();
     if (b0 == 0) DRLGX_PROF(S, 38);
+  };
+  for (int b0 = 0; b0 < n_re;) {
+    const int left = n_re - b0;
+    if (left > 8 && x.wide) {
+      const int nb = min(16, left);
+      batch(b0, nb, std::true_type{});
+      b0 += nb;
+    } else {
+      const int nb = min(8, left);
+      batch(b0, nb, std::false_type{});
+      b0 += nb;
+    }
   }
   DRLGX_PROF(S, 3);
   // ---- C. landmarks seen for the first time ----

@@ -22,6 +22,7 @@
 // LDS: the packed system + per-factor records when they fit; the records fall back to an HBM/L2 workspace otherwise.
 // Trajectories beyond 42 poses: k_slam_arrow.hip (pose chain eliminated first).
 #include "drlgx_dev.h"
+#include <type_traits>
 #pragma clang fp contract(fast)  // (the unity build k_step.hip is compiled with -ffp-contract=off)
 
 namespace kslam {
