@@ -242,8 +242,11 @@ __device__ __forceinline__ void inc_pre(const DrlgxState &S, const IncCtx &x, in
 // the new factors is verified either way (the staged C ABI can append anything; the fused step's own simulator cannot, but
 // it runs the same code).  Returns false when the step does not fit this path after all: the caller runs the full solve
 // (the HBM panel, if inc_pre already moved it, is marked invalid); uniform over the workgroup.
+// hand (k_step; or null): LDS that receives what the map stage reads next - est_pose [P][4] and, at hand + 4 hand_cap,
+// pose_info [P][6] (as SlamCtx::back leaves them) - and the landmark estimates are left in x.thl for the same reason.
 template <bool kLds>
-__device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, int L, int M, const SimBox &box, int tid) {
+__device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, int L, int M, const SimBox &box, int tid,
+                                         double *hand = nullptr, int hand_cap = 0) {
   const int lane = tid & 63, wave = tid >> 6, lc = lane & 15, lr = lane >> 4;
   const int inst = x.inst, P = x.P, pn = x.pn, L0 = x.L0, M0 = x.M0, n1 = x.n1, n1p = x.n1p, a0 = x.a0;
   int *meta = inc_meta(S, inst);
@@ -628,7 +631,13 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
     double *go = jd + 6 * i;
     go[0] = c00; go[1] = c10; go[2] = c11; go[3] = c20; go[4] = c21; go[5] = c22;
     pose_tr[i] = c00 + c11 + c22;
-    inv3_sym_fast(c00, c10, c20, c11, c21, c22, pose_info + 6 * i);
+    double info[6];
+    inv3_sym_fast(c00, c10, c20, c11, c21, c22, info);
+    for (int k = 0; k < 6; ++k) pose_info[6 * i + k] = info[k];
+    if (hand) {
+      hand[4 * i] = e.x; hand[4 * i + 1] = e.y; hand[4 * i + 2] = e.c; hand[4 * i + 3] = e.s;
+      for (int k = 0; k < 6; ++k) hand[4 * hand_cap + 6 * i + k] = info[k];
+    }
   }
   {
     double *est_lm = S.est_lm + (size_t)inst * S.L_max * 2;
@@ -637,8 +646,13 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
     for (int j = kThreads - 1 - tid; j < L; j += kThreads) {
       const double dx = dl[3 * P + 2 * j], dy = dl[3 * P + 2 * j + 1];
       d_lm[2 * j] = dx; d_lm[2 * j + 1] = dy;
-      est_lm[2 * j] = thl[2 * j] + dx;
-      est_lm[2 * j + 1] = thl[2 * j + 1] + dy;
+      const double ex = thl[2 * j] + dx, ey = thl[2 * j + 1] + dy;
+      est_lm[2 * j] = ex;
+      est_lm[2 * j + 1] = ey;
+      if (hand) {  // (the linearisation points are dead by now: the map stage reads the estimates here)
+        thl[2 * j] = ex;
+        thl[2 * j + 1] = ey;
+      }
       const double *r0 = rowp(3 * P + 2 * j), *r1 = rowp(3 * P + 2 * j + 1);
       const double c00 = r0[3 + 2 * j], c11 = r1[3 + 2 * j + 1], cs = 0.5 * (r0[3 + 2 * j + 1] + r1[3 + 2 * j]);
       lm_tr[j] = c00 + c11;

@@ -116,8 +116,11 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
     kslam::IncCtx ix;
     bool inc_lds = false;
     if (kslam::inc_plan(S, sel.base + bi, P0 + 1, lds_bytes, sim_bytes, ix, inc_lds, pc)) {
-      inc_done = inc_lds ? kslam::inc_post<true>(S, ix, sub_cnt[2], sub_cnt[3], box, tid) : kslam::inc_post<false>(S, ix, sub_cnt[2], sub_cnt[3], box, tid);
-      if (!inc_done) __syncthreads();
+      double *hp = hand ? reinterpret_cast<double *>(step_smem) : nullptr;
+      inc_done = inc_lds ? kslam::inc_post<true>(S, ix, sub_cnt[2], sub_cnt[3], box, tid, hp, pc)
+                         : kslam::inc_post<false>(S, ix, sub_cnt[2], sub_cnt[3], box, tid, hp, pc);
+      if (inc_done) lm_lds = ix.thl;  // (the map stage's inputs are in LDS, as after slam_finish)
+      else __syncthreads();
     }
   }
   if (!inc_done)
