@@ -1840,7 +1840,7 @@ bool drlgx_slam_capacity_ok(int P_max, int L_max, int M_max) {
 // chain (6 + 9 + 9 per pose), the leaf -> right-separator rhs scratch, the square landmark system of the workspace variant, the factor records and the observation
 // table when they do not fit the LDS
 size_t drlgx_slam_ws_doubles(int P_max, int L_max, int M_max) {
-  const size_t ldx = (size_t)((2 * L_max + 1 + 3) & ~3);
+  const size_t ldx = (size_t)((2 * L_max + 1 + 3 + 3) & ~3);  // (+ the three unit columns of the newest pose: arrow_body)
   const size_t n = (size_t)3 * P_max * ldx + (size_t)24 * P_max + (size_t)(P_max / kslam::kSeg + 2) * 3 * ldx + (size_t)(2 * L_max + 17) * (2 * L_max + 17) + (size_t)32 * (2 * L_max + 17) +
                    (size_t)M_max * kslam::REC + ((size_t)L_max * P_max * 2 + 7) / 8 + 16;
   return (n + 31) & ~(size_t)31;  // instances stay 256-byte aligned: 32-byte row loads of X

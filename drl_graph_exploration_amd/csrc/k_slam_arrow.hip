@@ -102,7 +102,11 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   const int Tn = (ncol + 15) / 16, N = 16 * Tn;
   const int ntiles = Tn * (Tn + 1) / 2;
   const bool c_lds = Tn <= kFastTilesArrow;          // <= 63 landmarks: packed system + sweep panels in LDS
-  const int ldx = (ncol + 3) & ~3;                   // row stride of X
+  // With the incremental update on (S.jc), the chain solve carries three more right-hand sides - the unit columns of the
+  // newest pose - so that X also holds (T^-1)[., pn]: the covariance panel needs every pose's cross block with it.
+  const bool mk_panel = S.jc != nullptr && !refresh && full && P >= 1;
+  const int ncx = mk_panel ? ncol + 3 : ncol;        // columns of [B eta_p (E_pn)]
+  const int ldx = (ncol + 3 + 3) & ~3;               // row stride of X (room for those columns whether used or not)
   const bool c_reg = !c_lds && NTW > 0 && ntiles <= NTW * (kWaves - 1);  // lower tiles in registers, panels in LDS
   if (!c_lds && NTW == 0) {  // (this instantiation serves engines whose landmark capacity always fits the LDS)
     if (tid == 0) atomicMin(S.status, DRLGX_E_CAPACITY);
@@ -130,11 +134,11 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   unsigned long long *lmask = reinterpret_cast<unsigned long long *>(take((size_t)L * MW * 8));
   off = (off + 31) & ~(size_t)31;
   double *wsd = S.slam_ws + (size_t)inst * S.slam_ws_stride;
-  double *X = wsd; wsd += (size_t)3 * S.P_max * (size_t)((2 * S.L_max + 1 + 3) & ~3);
+  double *X = wsd; wsd += (size_t)3 * S.P_max * (size_t)((2 * S.L_max + 1 + 3 + 3) & ~3);
   double *Ti = wsd; wsd += (size_t)6 * S.P_max;    // (T^-1)_ii, symmetric
   double *Sl = wsd; wsd += (size_t)9 * S.P_max;    // (T^-1)_{i-s,i} at i's elimination level
   double *Sr = wsd; wsd += (size_t)9 * S.P_max;    // (T^-1)_{i+s,i}
-  double *sepR = wsd; wsd += (size_t)(S.P_max / kSeg + 2) * 3 * (size_t)((2 * S.L_max + 1 + 3) & ~3);  // leaf -> right separator rhs
+  double *sepR = wsd; wsd += (size_t)(S.P_max / kSeg + 2) * 3 * (size_t)((2 * S.L_max + 1 + 3 + 3) & ~3);  // leaf -> right separator rhs
   // the landmark x pose observation table: LDS when it fits
   unsigned short *obs;
   double *rec_ws = wsd; wsd += (size_t)S.M_max * REC;
@@ -375,14 +379,17 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   auto rhs_of = [&](int i, int c, double &b0, double &b1, double &b2) {  // column c of [B eta_p] at pose i
     if (c == np) {
       b0 = X[(size_t)(3 * i) * ldx + np]; b1 = X[(size_t)(3 * i + 1) * ldx + np]; b2 = X[(size_t)(3 * i + 2) * ldx + np];
+    } else if (c > np) {  // unit column c - np - 1 of the newest pose
+      const bool at = i == P - 1;
+      b0 = (at && c == np + 1) ? 1.0 : 0.0; b1 = (at && c == np + 2) ? 1.0 : 0.0; b2 = (at && c == np + 3) ? 1.0 : 0.0;
     } else {
       const int m1 = obs[(c >> 1) * P + i], a = c & 1;
       const double *bm = rec + (size_t)REC * (m1 ? m1 - 1 : 0);
       b0 = m1 ? bm[a] : 0.0; b1 = m1 ? bm[2 + a] : 0.0; b2 = m1 ? bm[4 + a] : 0.0;
     }
   };
-  for (int e = tid; e < nsep * ncol; e += kThreads) {
-    const int g = e / ncol, c = e - g * ncol;
+  for (int e = tid; e < nsep * ncx; e += kThreads) {
+    const int g = e / ncx, c = e - g * ncx;
     const int l = g << kSegLog, nk = min(kSeg - 1, P - 1 - l);
     double bk[kSeg][3];
 #pragma unroll
@@ -423,8 +430,8 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     }
   }
   __syncthreads();
-  for (int e = tid; e < (nsep - 1) * ncol; e += kThreads) {  // separator g + 1 += its left leaf's contribution
-    const int g = e / ncol, c = e - g * ncol;
+  for (int e = tid; e < (nsep - 1) * ncx; e += kThreads) {  // separator g + 1 += its left leaf's contribution
+    const int g = e / ncx, c = e - g * ncx;
     const double *pr = sepR + (size_t)g * 3 * ldx + c;
     double *sr = srow((g + 1) << kSegLog) + c;
     sr[0] += pr[0]; sr[ldx] += pr[ldx]; sr[2 * ldx] += pr[2 * ldx];
@@ -472,8 +479,8 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     // ... and their rhs rows: b_j -= GR_i1^T b_i1 + GL_i2^T b_i2
     {
       const int nsurv = (P - 1) / (2 * s) + 1;
-      for (int e = tid; e < nsurv * ncol; e += kThreads) {
-        const int k = e / ncol, c = e - k * ncol, j = 2 * k * s;
+      for (int e = tid; e < nsurv * ncx; e += kThreads) {
+        const int k = e / ncx, c = e - k * ncx, j = 2 * k * s;
         double *bj = srow(j) + c;
         double b0 = bj[0], b1 = bj[ldx], b2 = bj[2 * ldx];
         if (j >= s) {
@@ -505,7 +512,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     }
   }
   __syncthreads();
-  for (int c = tid; c < ncol; c += kThreads) {
+  for (int c = tid; c < ncx; c += kThreads) {
     double *b = srow(0) + c;
     const double v0 = b[0], v1 = b[ldx], v2 = b[2 * ldx];
     b[0] = Dd[0] * v0 + Dd[1] * v1 + Dd[2] * v2;
@@ -571,8 +578,8 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
         }
       }
       // solutions x_i = E_i b_i - GL_i x_l - GR_i x_r, one thread per (pose, column)
-      for (int e = tid; e < nel * ncol; e += kThreads) {
-        const int k = e / ncol, c = e - k * ncol, i = (2 * k + 1) * s;
+      for (int e = tid; e < nel * ncx; e += kThreads) {
+        const int k = e / ncx, c = e - k * ncx, i = (2 * k + 1) * s;
         double *bi = srow(i) + c;
         const double *ei = Dd + 6 * i, *gl = GL + 9 * i, *gr = GR + 9 * i;
         const double v0 = bi[0], v1 = bi[ldx], v2 = bi[2 * ldx];
@@ -620,8 +627,8 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
       }
     }
   }
-  for (int e = tid; e < nsep * ncol; e += kThreads) {
-    const int g = e / ncol, c = e - g * ncol;
+  for (int e = tid; e < nsep * ncx; e += kThreads) {
+    const int g = e / ncx, c = e - g * ncx;
     const int l = g << kSegLog, nk = min(kSeg - 1, P - 1 - l);
     double yk[kSeg][3];
 #pragma unroll
@@ -793,6 +800,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   double *est_pose = S.est_pose + (size_t)inst * S.P_max * 4;
   double *pose_info = S.pose_info + (size_t)inst * S.P_max * 6;
   double *pose_tr = S.pose_tr + (size_t)inst * S.P_max;
+  double *pan_pose = mk_panel ? S.jc + (size_t)inst * S.jc_stride : nullptr;  // the covariance panel's pose rows (k_inc.hip)
   double *Sc = Sl;  // [3P][3]: rows of X_i (-C^-1) X_i^T   (the Takahashi cross blocks are dead by now)
   double *dz = Sr;  // [3P]:    X_B delta_l
   if (!full) {
@@ -832,6 +840,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
 #pragma unroll
           for (int r = 0; r < 3; ++r) {
             sc[r][0] += z[r] * xr[0][c]; sc[r][1] += z[r] * xr[1][c]; sc[r][2] += z[r] * xr[2][c];
+            if (mk_panel) pan_pose[(size_t)(3 * i + r) * S.jc_ld + 3 + c] = z[r];  // Sigma[pose i][landmark column c]
           }
           const double dl = A[AT(np, c)];
           dzr[0] += xr[0][c] * dl; dzr[1] += xr[1][c] * dl; dzr[2] += xr[2][c] * dl;
@@ -898,6 +907,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
           sp[r][1] += acc[r] * xe[r][1];
           sp[r][2] += acc[r] * xe[r][2];
           if (row < nrows && c == np) dz[row] = acc[r];
+          if (mk_panel && row < nrows && c < np) pan_pose[(size_t)row * S.jc_ld + 3 + c] = acc[r];  // Sigma_pl = X_B (-C^-1)
         }
       };
       if (panel) {
@@ -998,8 +1008,40 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     const double c11 = ti[3] - sc[4], c21 = ti[4] - 0.5 * (sc[5] + sc[7]), c22 = ti[5] - sc[8];
     pose_tr[i] = c00 + c11 + c22;
     inv3_sym_fast(c00, c10, c20, c11, c21, c22, pose_info + 6 * i);  // information = inverse(covariance) (SLAM2D.cpp:395-408)
+    if (mk_panel) {
+      double *go = S.jd + ((size_t)inst * S.P_max + i) * 6;
+      go[0] = c00; go[1] = c10; go[2] = c11; go[3] = c20; go[4] = c21; go[5] = c22;
+    }
   }
   DRLGX_PROF(S, 9);
+  if (mk_panel) {
+    // The covariance panel the incremental updates continue from (k_inc.hip): every variable against the active set
+    // (newest pose pn, landmarks).  Sigma_pl = X_B (-C^-1) was stored by the pose outputs above, Sigma_ll = C^-1; the
+    // cross blocks with the newest pose are  Sigma[i][pn] = (T^-1)[i][pn] + X_i C^-1 X_pn^T = X[., np+1..np+3] - Sigma_pl[i] X_pn^T.
+    __syncthreads();
+    const int pn = P - 1, ldg = S.jc_ld;
+    double *pan_lm = pan_pose + (size_t)3 * S.P_max * ldg;
+    for (int e = tid; e < 3 * P * 3; e += kThreads) {
+      const int row = e / 3, b = e - 3 * row;
+      const double *zr = pan_pose + (size_t)row * ldg + 3, *xp = X + (size_t)(3 * pn + b) * ldx;
+      double v = X[(size_t)row * ldx + np + 1 + b];
+      for (int c = 0; c < np; ++c) v -= zr[c] * xp[c];
+      pan_pose[(size_t)row * ldg + b] = v;
+    }
+    for (int e = tid; e < np * np; e += kThreads) {
+      const int r = e / np, c = e - r * np;
+      pan_lm[(size_t)r * ldg + 3 + c] = -A[c_lds ? AT(max(r, c), min(r, c)) : (size_t)max(r, c) * N + min(r, c)];
+    }
+    for (int e = tid; e < np * 3; e += kThreads) {
+      const int r = e / 3, b = e - 3 * r;
+      pan_lm[(size_t)r * ldg + b] = pan_pose[(size_t)(3 * pn + b) * ldg + 3 + r];  // Sigma[l][pn] = Sigma[pn][l]^T
+    }
+    if (tid == 0) {
+      int *meta = inc_meta(S, inst);
+      meta[0] = 1; meta[1] = P; meta[2] = L; meta[3] = M;
+      if (S.inc_stats) atomicAdd(S.inc_stats + 1, 1ull);
+    }
+  }
   if (tid == 0) {
     if (!refresh) {
       cnt[C_ISAM] = count;
@@ -1008,7 +1050,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     }
     if (bad[0]) atomicMin(S.status, DRLGX_E_NUMERIC);
   }
-  if (!refresh) panel_invalidate(S, inst, tid);  // (this solver leaves no covariance panel: full solves from here on)
+  if (!refresh && !mk_panel) panel_invalidate(S, inst, tid);  // (a solve for the estimates only leaves no covariance panel)
 }
 
 template <int NTW>
