@@ -1,7 +1,10 @@
 // Virtual-map kernel: occupancy rebuild + covariance propagation (EKF push-through of every core
 // pose onto the virtual-landmark grid, fused by covariance intersection) + utility reductions.
-// One 512-thread workgroup per instance (8 waves: 2 per SIMD is what the ~160 VGPRs of the propagation code allow
-// without spilling; the kernel is bound by fp64 instruction issue, not by latency, so more waves do not help).
+// One 512-thread workgroup per instance: 201 VGPRs and ~100 KB of LDS at the bench state, i.e. ONE workgroup per CU (2 waves
+// per SIMD).  By the SQ counters (profiles/r04_ab_map_two_workgroups_per_cu.txt) the VALU is busy 37 % of the time and 57 % of the
+// wave-cycles are spent parked on waitcnt / barriers: the waves wait for each other at the phase barriers and along the
+// dependent fusion chains, the kernel is neither HBM- nor issue-bound.  k_map_c below is the two-workgroups-per-CU form
+// (compact carve, 128 VGPRs); it spills and is slower so far.
 //
 // Reference: src/em_exploration/OccupancyMap.cpp:55-138 (log-odds ladder, bbox sector sweep),
 // src/em_exploration/VirtualMap.cpp:47-84 (explored, updateProbability), :213-229
@@ -17,8 +20,8 @@
 //            ladder over the "sees me" bits as a host-built state machine (DrlgxState::lo_tr); probability, trace,
 //            and the five utility sums.  Every cell is written once per belief update and never read back.
 //   phase R: block reduction of the sums (wave shuffles + LDS).
-// The kernel is issue-bound on fp64, so (1) only (cell, pose) pairs that interact are visited, (2) divisions and square
-// roots whose results are only compared against a tolerance use v_rcp/v_rsq + Newton (rcp_n / rsqrt_n), never the
+// fp64 instruction count is what every phase pays, so (1) only (cell, pose) pairs that interact are visited, (2) divisions and
+// square roots whose results are only compared against a tolerance use v_rcp/v_rsq + Newton (rcp_n / rsqrt_n), never the
 // ones that feed a decision, and
 // (3) two exact shortcuts avoid fp64 transcendentals:
 //   * the field-of-view test needs atan2 only inside a thin wedge around the sensor's blind ray; cells
