@@ -440,6 +440,17 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
       // kernel slower: ranking costs more than it saves, and with the queue the barrier after the pass completed 1.9 us
       // after the last wave instead of 0.2 us.)
       const int tiles_c = (cols + 7) >> 3, ntiles = ((rows + 7) >> 3) * tiles_c;
+      // the untouched cell (prior information I / sigma0^2, ladder state 0), as the general path computes it
+      double pv_prior = 0.0;
+      if (S.lo_ntab > 0) {
+        pv_prior = lpv[0];
+      } else {
+        const double pv1 = logodds2prob(0.0);
+        for (int s2 = 0; s2 < cfg.num_samples; ++s2) pv_prior += pv1 / cfg.num_samples;
+      }
+      const double rdet_prior = rcp_n1(i0 * i0 - 0.0 * 0.0), tr_prior = (i0 + i0) * rdet_prior;
+      const double wgt_prior = pv_prior > 0.49 ? 1.0 : 0.0;
+      const bool expl_prior = pv_prior < 0.49 || pv_prior > 0.6;
       // the three per-cell LDS words of a tile (update mask, sees-me mask, landmark count) are fetched one tile ahead: each
       // is the head of a dependent chain and a wave has nothing else to cover the LDS latency with
       auto cell_of = [&](int t, int &row, int &col) -> int {
@@ -468,6 +479,26 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
         // a middle chunk of poses (trajectories beyond 128 poses) that neither updates nor sees any cell of the tile leaves
         // it as it is: no read-modify-write of its planes
         if (c0 > 0 && !last && __ballot((m | om_cell) != 0ull) == 0ull) continue;
+        // a tile that no pose sees and no landmark lies in (most of the map: ~15 of 25 tiles at the bench state), whole
+        // trajectory in one chunk: every cell is the untouched prior - the same values the general path below computes for
+        // such a cell (same expressions, same order of the utility sums), without its ladder walk and per-cell algebra
+        if (c0 == 0 && last && __ballot((m | om_cell) != 0ull || lmc_cell != 0) == 0ull) {
+          if (ok) {
+            ixx[v] = i0; ixy[v] = 0.0; iyy[v] = i0;
+            upd[v] = (uint8_t)0;
+            prob[v] = pv_prior;
+            vtr[v] = tr_prior;
+            utr += 1.0 * tr_prior;
+            if (pv_prior < cfg.occupancy_threshold) known += 1.0;
+            udet += wgt_prior * rdet_prior;
+            uwtr += wgt_prior * tr_prior;
+            if (expl_prior) {
+              const double x = (col + 0.5) * cfg.resolution + cfg.map_min_x, y = (row + 0.5) * cfg.resolution + cfg.map_min_y;
+              if (cfg.map_min_x + extg <= x && x <= cfg.map_max_x - extg && cfg.map_min_y + extg <= y && y <= cfg.map_max_y - extg) expl += 1.0;
+            }
+          }
+          continue;
+        }
         double axx = i0, axy = 0.0, ayy = i0;
         int u = 0;
         if (c0 > 0) {
