@@ -41,6 +41,9 @@ def pinned_plan(env, acts, ks, choice):
     return env._sim.line_plan((choice[0], choice[1]))
 
 
+exact_rows = {}  # seed -> rows whose entropy was asserted at 1e-9 (test_entropy_is_exact_away_from_decision_boundaries)
+
+
 # every seed the oracle follows for >= 10 rows; 4 runs the reference's whole episode (179 actions, 184 poses),
 # 5 / 30 / 38 / 48 follow it for 95-136 rows
 LONG = [4, 5, 30, 38, 48]
@@ -53,7 +56,7 @@ def test_oracle_tracks_reference_csv(pins, dqn_weights, lo):
     assert len(rows_ref) >= 19
     env = O.OracleEnv(40, lo)
     st = 0
-    agree = n_frontier_choices = 0
+    agree = n_frontier_choices = n_exact = 0
     for d, (choice, gcn_choice) in enumerate(zip(pin["choices"], pin["gcn_choices"])):
         A, X, _, fro = env.graph_matrix()
         acts = env.actions_all_goals()
@@ -76,11 +79,26 @@ def test_oracle_tracks_reference_csv(pins, dqn_weights, lo):
             # landmark error and max pose-covariance trace: 1e-4 relative (observed <= 1e-5, often 1e-9..1e-16)
             assert got[0] == pytest.approx(ref[0], rel=1e-4)
             assert got[2] == pytest.approx(ref[2], rel=1e-4)
-            # map entropy: boundary cells flip (DESIGN.md "oracle pin") and the flips accumulate along an episode
-            assert got[1] == pytest.approx(ref[1], rel=2e-2)
+            # map entropy: a cell whose range / bearing test is decided by less than the reference's own truncation of the
+            # back-substitution (iSAM2 wildfire threshold 1e-3, not restated) can fall on the other side there, and such flips
+            # accumulate along an episode: 2 % for those maps.  A map in which NO cell of NO pose is that close to a boundary
+            # must reproduce the reference's entropy to round-off (observed: 2e-16 on all 201 such rows of the fixture).
+            if env._sim.knife_edge_cells(1e-3).any():
+                assert got[1] == pytest.approx(ref[1], rel=2e-2)
+            else:
+                assert got[1] == pytest.approx(ref[1], rel=1e-9)
+                n_exact += 1
             st += 1
     assert st == len(rows_ref)
+    exact_rows[lo] = n_exact
     assert agree >= 0.85 * n_frontier_choices  # (the oracle's map drifts from the reference's through knife-edge cells)
+
+
+def test_entropy_is_exact_away_from_decision_boundaries():
+    """Runs after the parametrised replay: the tight entropy assertion was not vacuous."""
+    if len(exact_rows) < 10:
+        pytest.skip("the replay tests were deselected")
+    assert sum(exact_rows.values()) >= 60
 
 
 def test_pin_covers_long_trajectories(pins):
