@@ -118,6 +118,16 @@ def lib():
     return L
 
 
+def stream_ptr(device):
+    """Raw hipStream_t (int) of torch's current stream on `device`: what `torch.cuda.current_stream(device).cuda_stream`
+    returns without building the Stream object (the update loop asks ~7 times per mini-batch)."""
+    import torch
+    idx = device.index if isinstance(device, torch.device) else device
+    if idx is None:
+        idx = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
+
+
 def check(rc, handle=None):
     if rc != 0:
         L = lib()

@@ -25,6 +25,7 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // graph normalisation + CSR
@@ -770,6 +771,209 @@ __global__ __launch_bounds__(256) void k_gemm(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tall-tile GEMM for the hidden x hidden products of a batch (M or K = the batch's node count).  The 64x64 kernels above
+// ask the CU's vector L1 for 16 B per clock and workgroup - 68-80 B/clk at the 4-5 workgroups a CU holds, against the
+// 64 B/clk it delivers: 64-75 % of the fp32 MFMA rate is their ceiling.  Here a workgroup of 8 waves owns (16 RT) x 128
+// of C (RT = 6 .. 10 row sub-tiles, picked per launch so that the tile count fills whole rounds of 256 CUs):
+//  * wave w owns the 16 columns 16 w .. 16 w + 15 of the tile and all its rows: RT accumulators of v_mfma_f32_16x16x4_f32,
+//    issued with the operands swapped (D = B^T A^T) so that a lane holds four consecutive columns of one row of C and the
+//    epilogue is one 16-byte store (bias / mask one 16-byte load) per sub-tile;
+//  * operand tiles global -> LDS directly as in k_gemm_dl (four stages, 16 k per stage), (16 RT + 128) * 64 B per stage:
+//    7-8 B per clock and workgroup from the L1;
+//  * MFMA step s multiplies k = 4 q + s in lane group q = lane >> 4, so that a k-contiguous operand's fragment is one
+//    ds_read_b128 ([x][16 k] rows, quads XOR-swizzled by (x >> 1) & 3: the four 16-lane groups of the read are
+//    conflict-free) and an x-contiguous one's four ds_read_b32 ([16 k][W x], 16-float groups of row k XOR-swizzled by
+//    (k >> 2) & 1: lane groups q and q + 1 read different bank halves);
+//  * a DMA instruction brings 1 KB = 16 rows of a k-contiguous tile (or 256 / W rows of an x-contiguous one); the RT + 8
+//    instructions of a stage are dealt round-robin to the 8 waves, and a wave without a real one in a round issues it
+//    into a scratch KB (every wave's vmcnt then counts the same number per stage).
+// Contract (host): vec_ok() operands and C, x-contiguous A only with 16 RT % 32 == 0.
+// ------------------------------------------------------------------------------------------------
+constexpr int WD_ST = 4;
+constexpr int WD_N = 128;
+template <int RT>
+struct WideTile {
+  static constexpr int AI = (RT + 7) / 8;                     // A instructions per wave and stage
+  static constexpr int stage_floats = (RT + 8) * 256;         // A tile, then B tile
+  static constexpr int lds_floats = WD_ST * stage_floats + 256;  // + the scratch KB
+};
+
+// source address of DMA instruction j (1 KB = quads 64 j .. 64 j + 63 of the tile) for this lane
+template <bool KC>
+__device__ __forceinline__ const float *wd_src(const float *P, int ld, int x0, int X, int W, int j, int lane) {
+  const int q = 64 * j + lane;
+  if (KC) {
+    const int x = q >> 2;
+    return P + (size_t)min(x0 + x, X - 1) * ld + 4 * ((q & 3) ^ ((x >> 1) & 3));  // (+ k0)
+  }
+  const int wq = W >> 2, k = q / wq, xq = (q - k * wq) ^ (4 * ((k >> 2) & 1));
+  return P + (size_t)k * ld + min(x0 + 4 * xq, X - 4);  // (+ k0 * ld)
+}
+// the four values lane (i = lane & 15, q = lane >> 4) feeds to MFMA steps 0..3 for tile row / column xb + i: k = 4 q + s
+template <bool KC>
+__device__ __forceinline__ float4 wd_frag(const float *T, int W, int xb, int lane) {
+  const int x = xb + (lane & 15), q = lane >> 4;
+  if (KC) return *reinterpret_cast<const float4 *>(T + x * 16 + 4 * (q ^ ((x >> 1) & 3)));
+  const float *p = T + (4 * q) * W + (x ^ (16 * (q & 1)));
+  return make_float4(p[0], p[W], p[2 * W], p[3 * W]);
+}
+// the partial last K-tile goes through registers with zero fill
+template <bool KC>
+__device__ __forceinline__ void wd_tail(float *T, const float *P, int ld, int x0, int X, int W, int k0, int kend, int tid) {
+  for (int q = tid; q < 4 * W; q += 512) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {
+      const int x = q >> 2, c = q & 3;
+      if (k0 + 4 * c < kend) v = *reinterpret_cast<const float4 *>(P + (size_t)min(x0 + x, X - 1) * ld + k0 + 4 * c);
+      *reinterpret_cast<float4 *>(T + x * 16 + 4 * (c ^ ((x >> 1) & 3))) = v;
+    } else {
+      const int wq = W >> 2, k = q / wq, xq = q - k * wq;
+      if (k0 + k < kend) v = *reinterpret_cast<const float4 *>(P + (size_t)(k0 + k) * ld + min(x0 + 4 * xq, X - 4));
+      *reinterpret_cast<float4 *>(T + k * W + 4 * (xq ^ (4 * ((k >> 2) & 1)))) = v;
+    }
+  }
+}
+
+template <bool AKC, bool BKC, int EPI, int RT>
+__global__ __launch_bounds__(512) void k_gemm_wide(int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                                   int ldb, float *__restrict__ C, int ldc, const float *__restrict__ bias,
+                                                   const float *__restrict__ mask, int k_per_split, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) float wd_smem[];
+  using WT = WideTile<RT>;
+  constexpr int TM = 16 * RT;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tn = slot % tiles_n, tm = (slot / tiles_n) * 8 + xcd;
+  if (tm >= tiles_m) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = tm * TM, n0 = tn * WD_N;
+  const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+  floatx4 acc[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int nfull = (kend - kbeg) / 16, tail = (kend - kbeg) - 16 * nfull;
+  const unsigned lds0 =
+      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) const void *)wd_smem);
+  constexpr unsigned stage_bytes = WT::stage_floats * sizeof(float);
+  auto dma16 = [](const float *g, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(g) : "memory");
+  };
+  // this wave's instructions of a stage: A instruction j = wave + 8 i (the scratch KB when j >= RT), B instruction j = wave
+  const float *ga[WT::AI];
+  unsigned la[WT::AI], la_step[WT::AI];
+#pragma unroll
+  for (int i = 0; i < WT::AI; ++i) {
+    const int j = wave + 8 * i;
+    const bool real = j < RT;
+    ga[i] = wd_src<AKC>(A, lda, m0, M, TM, real ? j : 0, lane) + (AKC ? (size_t)kbeg : (size_t)kbeg * lda);
+    la[i] = real ? lds0 + j * 1024u : lds0 + WD_ST * stage_bytes;
+    la_step[i] = real ? stage_bytes : 0u;
+  }
+  const float *gb = wd_src<BKC>(B, ldb, n0, N, WD_N, wave, lane) + (BKC ? (size_t)kbeg : (size_t)kbeg * ldb);
+  const unsigned lb = lds0 + (RT + wave) * 1024u;
+  const size_t sa = AKC ? 16 : (size_t)16 * lda, sb = BKC ? 16 : (size_t)16 * ldb;  // source step per K-tile
+  constexpr int PER = WT::AI + 1;  // DMA instructions of this wave per stage
+  const unsigned scratch = lds0 + WD_ST * stage_bytes;
+  // DMA instruction n (0 .. PER - 1) of K-tile t; past the last full tile it re-reads that tile into the scratch KB, so that
+  // every step issues PER instructions and one vmcnt value is right throughout
+  auto dma = [&](int n, int t) {
+    const bool live = t < nfull;
+    const int ts = live ? t : nfull - 1;
+    const unsigned st = (unsigned)(t & (WD_ST - 1));
+    if (n < WT::AI) dma16(ga[n] + sa * ts, live ? la[n] + st * la_step[n] : scratch);
+    else dma16(gb + sb * ts, live ? lb + st * stage_bytes : scratch);
+  };
+  // K-tile t is multiplied from registers; between its MFMAs (one filler behind each of the first few, in the shadow of the
+  // MFMA pipe) the wave issues its DMA instructions of tile t + 4 into the stage tile t just left and reads the fragments
+  // of tile t + 1.  The barrier at the top (tile t + 1 complete in LDS, every wave has tile t in registers) is followed by
+  // MFMAs that wait for nothing.
+  float4 fa0[RT], fa1[RT], fb0, fb1;
+  auto step = [&](int t, const float4 (&fa)[RT], const float4 &fb, float4 (&na)[RT], float4 &nb) {
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * PER));  // tiles t + 2 and t + 3 may still be in flight
+    __builtin_amdgcn_s_barrier();
+    const float *As = wd_smem + ((t + 1) & (WD_ST - 1)) * WT::stage_floats, *Bs = As + RT * 256;
+    const float bs[4] = {fb.x, fb.y, fb.z, fb.w};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const float as[4] = {fa[i].x, fa[i].y, fa[i].z, fa[i].w};
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bs[s], as[s], acc[i], 0, 0, 0);
+        const int n = s * RT + i;
+        __builtin_amdgcn_sched_barrier(0);
+        if (n < PER) dma(n, t + 4);
+        else if (n == PER) nb = wd_frag<BKC>(Bs, WD_N, 16 * wave, lane);
+        else if (n <= PER + RT) na[n - PER - 1] = wd_frag<AKC>(As, TM, 16 * (n - PER - 1), lane);
+        if (n <= PER + RT) __builtin_amdgcn_sched_barrier(0);
+      }
+  };
+  if (nfull > 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int n = 0; n < PER; ++n) dma(n, t);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * PER));
+    __builtin_amdgcn_s_barrier();
+    fb0 = wd_frag<BKC>(wd_smem + RT * 256, WD_N, 16 * wave, lane);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) fa0[i] = wd_frag<AKC>(wd_smem, TM, 16 * i, lane);
+  }
+  for (int t = 0; t < nfull; t += 2) {
+    step(t, fa0, fb0, fa1, fb1);
+    if (t + 1 >= nfull) break;
+    step(t + 1, fa1, fb1, fa0, fb0);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // the scratch re-reads of the last steps (LDS must not be written after the workgroup ends)
+  auto read = [&](float4 (&fa)[RT], float4 &fb, int st) {
+    const float *As = wd_smem + st * WT::stage_floats, *Bs = As + RT * 256;
+    fb = wd_frag<BKC>(Bs, WD_N, 16 * wave, lane);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) fa[i] = wd_frag<AKC>(As, TM, 16 * i, lane);
+  };
+  auto multiply = [&](const float4 (&fa)[RT], const float4 &fb) {
+    const float bs[4] = {fb.x, fb.y, fb.z, fb.w};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const float as[4] = {fa[i].x, fa[i].y, fa[i].z, fa[i].w};
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bs[s], as[s], acc[i], 0, 0, 0);
+      }
+  };
+  if (tail > 0) {
+    __syncthreads();
+    const int st = nfull & (WD_ST - 1), k0 = kbeg + 16 * nfull;
+    float *As = wd_smem + st * WT::stage_floats;
+    wd_tail<AKC>(As, A, lda, m0, M, TM, k0, kend, tid);
+    wd_tail<BKC>(As + RT * 256, B, ldb, n0, N, WD_N, k0, kend, tid);
+    __syncthreads();
+    read(fa0, fb0, st);
+    multiply(fa0, fb0);
+  }
+  // D = (B^T A^T) sub-tile: lane holds C[m0 + 16 i + (lane & 15)][n .. n + 3], n = n0 + 16 wave + 4 (lane >> 4)
+  float *Cz = C + (EPI == 0 ? (size_t)blockIdx.z * M * ldc : 0);
+  const int n = n0 + 16 * wave + 4 * (lane >> 4);
+  if (n < N) {
+    float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == 1) bj = *reinterpret_cast<const float4 *>(bias + n);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int m = m0 + 16 * i + (lane & 15);
+      if (m >= M) continue;
+      const size_t at = (size_t)m * ldc + n;
+      float4 v = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+      if (EPI == 1) {
+        v = make_float4(fmaxf(v.x + bj.x, 0.f), fmaxf(v.y + bj.y, 0.f), fmaxf(v.z + bj.z, 0.f), fmaxf(v.w + bj.w, 0.f));
+        if (mask) {
+          const float4 mk = *reinterpret_cast<const float4 *>(mask + at);
+          v = make_float4(v.x * mk.x, v.y * mk.y, v.z * mk.z, v.w * mk.w);
+        }
+      }
+      *reinterpret_cast<float4 *>(Cz + at) = v;
+    }
+  }
+}
+
 // thin-M products  out[m][n] = sum_k A[k][m] B[k][n]  (m < M <= 8; A stored [K x lda]) plus, as row M, the column sums
 // of B: one pass over B (HBM-bound).  A workgroup owns 256 adjacent columns (a lane 4 of them; N % 4 == 0) of the K-slice
 // blockIdx.y; its four waves take every fourth row of the slice and are summed in a fixed order through LDS (one wave per
@@ -1012,10 +1216,73 @@ void gemm_tile(hipStream_t st, int M, int N, int K, const float *A, int lda, con
 #undef DRLGX_GEMM
 }
 
+// DRLGX_GEMM_WIDE=0 keeps the 64x64 kernels everywhere (A/B runs); DRLGX_GEMM_WIDE=6..10 pins the tile height
+int gemm_wide_mode() {
+  static const int v = [] {
+    const char *e = std::getenv("DRLGX_GEMM_WIDE");
+    return e ? atoi(e) : -1;
+  }();
+  return v;
+}
+
+template <bool TA, bool TB, int EPI, int RT>
+void gemm_wide_launch(hipStream_t st, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                      const float *bias, const float *mask, int kps) {
+  const int tiles_m = (M + 16 * RT - 1) / (16 * RT), tiles_n = (N + WD_N - 1) / WD_N;
+  dim3 grid(tiles_n * ((tiles_m + 7) / 8) * 8, 1, (K + kps - 1) / kps);
+  constexpr int lds = WideTile<RT>::lds_floats * (int)sizeof(float);
+  static bool attr_set[32] = {false};
+  const void *fns[] = {reinterpret_cast<const void *>(&k_gemm_wide<!TA, TB, EPI, RT>)};
+  drlgx_ensure_lds_attr(attr_set, fns, 1, lds);
+  hipLaunchKernelGGL((k_gemm_wide<!TA, TB, EPI, RT>), grid, dim3(512), lds, st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps, tiles_m,
+                     tiles_n);
+}
+
+// the tall-tile kernel where the product is large enough to fill the chip with its tiles: the tile height (16 RT rows) is
+// the one whose tile count wastes least of the last round of 256 CUs
+template <bool TA, bool TB, int EPI>
+bool gemm_wide(hipStream_t st, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias,
+               const float *mask, int kps) {
+  const int mode = gemm_wide_mode();
+  if (mode == 0 || !vec_ok(A, lda, TA ? M : K) || !vec_ok(B, ldb, TB ? K : N) || !vec_ok(C, ldc, N)) return false;
+  if ((EPI == 1 && (!vec_ok(bias, 4, 4) || (mask && !vec_ok(mask, ldc, N)))) || (TA ? M : K) < 4 || (TB ? K : N) < 4) return false;
+  const int S = (K + kps - 1) / kps, tiles_n = (N + WD_N - 1) / WD_N;
+  if ((long)((M + 127) / 128) * tiles_n * S < 192) return false;  // too few tiles: the 64x64 kernels spread further
+  int best = 0;
+  long best_cost = 0;
+  for (int rt = 6; rt <= 10; ++rt) {
+    if (TA && (rt & 1)) continue;  // x-contiguous A: whole 32-float swizzle blocks
+    if (mode >= 6 && mode <= 10 && rt != mode && !(TA && (mode & 1))) continue;
+    const long tiles = (long)((M + 16 * rt - 1) / (16 * rt)) * tiles_n * S;
+    const long cost = ((tiles + 255) / 256) * rt;
+    if (!best || cost <= best_cost) best = rt, best_cost = cost;
+  }
+#define DRLGX_WIDE(RT)                                                                          \
+  case RT:                                                                                      \
+    gemm_wide_launch<TA, TB, EPI, RT>(st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps); \
+    return true
+  switch (best) {
+    DRLGX_WIDE(6);
+    DRLGX_WIDE(8);
+    DRLGX_WIDE(10);
+    default: break;
+  }
+  if constexpr (!TA) {
+    switch (best) {
+      DRLGX_WIDE(7);
+      DRLGX_WIDE(9);
+      default: break;
+    }
+  }
+#undef DRLGX_WIDE
+  return false;
+}
+
 template <bool TA, bool TB, int EPI>
 void gemm(hipStream_t st, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias,
           const float *mask, int splits) {
   const int kps = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+  if (gemm_wide<TA, TB, EPI>(st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps)) return;
   if (pick_tile() == 1) gemm_tile<TA, TB, EPI, 1, 2>(st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps);
   else gemm_tile<TA, TB, EPI, 1, 1>(st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps);
 }

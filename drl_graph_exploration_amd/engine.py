@@ -52,7 +52,7 @@ class Engine(object):
         """Enqueue engine kernels on torch's current stream of the engine's device, so that tensors can be shared
         without syncs.  Called before every call that enqueues work (cheap when the stream has not changed), so the
         engine follows `with torch.cuda.stream(...)` blocks."""
-        s = torch.cuda.current_stream(self.device).cuda_stream
+        s = _lib.stream_ptr(self.device)
         if s != getattr(self, "_bound_stream", None):
             self._chk(self.L.drlgx_set_stream(self.h, C.c_void_p(s)))
             self._bound_stream = s

@@ -43,7 +43,7 @@ class _GCNTrunk(torch.autograd.Function):
         out = torch.empty(N, out_dim, dtype=torch.float32, device=x.device)
         if mask is not None:
             mask = mask.contiguous().float()
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stream = _lib.stream_ptr(x.device)
         _lib.check(_forward_call(L, stream, N, E, in_dim, hidden, out_dim, x, edge_index, edge_attr, (W1c, b1c, W2c, b2c, Wfc, bfc), mask, out,
                                  ws, segs))
         ctx.save_for_backward(x, edge_index, edge_attr, W1c, W2c, Wfc, mask if mask is not None else torch.empty(0, device=x.device), ws)
@@ -64,7 +64,7 @@ class _GCNTrunk(torch.autograd.Function):
         db2 = torch.empty(hidden, dtype=torch.float32, device=dev)
         dWf = torch.empty(out_dim, hidden, dtype=torch.float32, device=dev)
         dbf = torch.empty(out_dim, dtype=torch.float32, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         rc = L.drlgx_gcn_backward(C.c_void_p(stream), N, E, in_dim, hidden, out_dim, _p(x), _p(edge_index), _p(edge_attr), _p(W1),
                                   _p(W2), _p(Wf), _p(mask) if ctx.has_mask else None, _p(d_out), _p(dW1), _p(db1), _p(dW2), _p(db2),
                                   _p(dWf), _p(dbf), _p(ws))
@@ -103,7 +103,7 @@ def gcn_forward_raw(x, edge_index, edge_attr, params, mask=None, segs=None):
     hidden, out_dim = W1.shape[1], Wf.shape[0]
     ws = torch.empty(L.drlgx_gcn_workspace_bytes(N, E, hidden, out_dim), dtype=torch.uint8, device=x.device)
     out = torch.empty(N, out_dim, dtype=torch.float32, device=x.device)
-    stream = torch.cuda.current_stream(x.device).cuda_stream
+    stream = _lib.stream_ptr(x.device)
     _lib.check(_forward_call(L, stream, N, E, in_dim, hidden, out_dim, x, edge_index, edge_attr, (W1, b1, W2, b2, Wf, bf), mask, out, ws, segs))
     return out, (x, edge_index, edge_attr, W1, W2, Wf, mask, ws, (N, E, in_dim, hidden, out_dim))
 
@@ -112,7 +112,7 @@ def gcn_backward_raw(saved, d_out, grads):
     """Gradients of the six parameter tensors written (not accumulated) into `grads` = (dW1, db1, dW2, db2, dWf, dbf)."""
     L = _lib.lib()
     x, edge_index, edge_attr, W1, W2, Wf, mask, ws, (N, E, in_dim, hidden, out_dim) = saved
-    stream = torch.cuda.current_stream(x.device).cuda_stream
+    stream = _lib.stream_ptr(x.device)
     _lib.check(L.drlgx_gcn_backward(C.c_void_p(stream), N, E, in_dim, hidden, out_dim, _p(x), _p(edge_index), _p(edge_attr), _p(W1), _p(W2),
                                     _p(Wf), _p(mask), _p(d_out), *(_p(g) for g in grads), _p(ws)))
 
@@ -172,7 +172,7 @@ class _SegmentSoftmax(torch.autograd.Function):
         q = q.contiguous().float()
         mask = mask.contiguous()
         p = torch.empty(n_selected, dtype=torch.float32, device=q.device)
-        stream = torch.cuda.current_stream(q.device).cuda_stream
+        stream = _lib.stream_ptr(q.device)
         _lib.check(L.drlgx_segment_softmax(C.c_void_p(stream), node_off.numel() - 1, _p(node_off), _p(q), _p(mask), _p(p)))
         ctx.save_for_backward(p, mask, node_off)
         ctx.n = q.numel()
@@ -183,7 +183,7 @@ class _SegmentSoftmax(torch.autograd.Function):
         L = _lib.lib()
         p, mask, node_off = ctx.saved_tensors
         dq = torch.empty(ctx.n, dtype=torch.float32, device=p.device)
-        stream = torch.cuda.current_stream(p.device).cuda_stream
+        stream = _lib.stream_ptr(p.device)
         _lib.check(L.drlgx_segment_softmax_backward(C.c_void_p(stream), node_off.numel() - 1, _p(node_off), _p(p), _p(dp.contiguous().float()),
                                                     _p(mask), _p(dq)))
         return dq, None, None, None
@@ -198,7 +198,7 @@ class _MeanPool(torch.autograd.Function):
         h = h.contiguous().float()
         G = node_off.numel() - 1
         v = torch.empty(G, dtype=torch.float32, device=h.device)
-        stream = torch.cuda.current_stream(h.device).cuda_stream
+        stream = _lib.stream_ptr(h.device)
         _lib.check(L.drlgx_mean_pool(C.c_void_p(stream), G, _p(node_off), _p(h), h.shape[1], _p(v)))
         ctx.save_for_backward(node_off)
         ctx.shape = tuple(h.shape)
@@ -209,7 +209,7 @@ class _MeanPool(torch.autograd.Function):
         L = _lib.lib()
         (node_off,) = ctx.saved_tensors
         dh = torch.empty(ctx.shape, dtype=torch.float32, device=dv.device)
-        stream = torch.cuda.current_stream(dv.device).cuda_stream
+        stream = _lib.stream_ptr(dv.device)
         _lib.check(L.drlgx_mean_pool_backward(C.c_void_p(stream), node_off.numel() - 1, _p(node_off), _p(dv.contiguous().float()), ctx.shape[1],
                                               _p(dh)))
         return dh, None
@@ -363,6 +363,7 @@ class ReplayPool(object):
         self.EA = torch.empty(n_slots * cap_edges, dtype=torch.float32, device=device)
         self.node_off = [None] * n_slots  # host int64 [n_graphs + 1] per slot
         self.edge_off = [None] * n_slots
+        self.desc = [None] * n_slots      # host int64 [n_graphs, 5] per slot
         self.ref = [0] * n_slots
         self._next = 0
         # one cached float per pooled node (the DQN trainer keeps the target network's read-out here), with the version of
@@ -385,8 +386,10 @@ class ReplayPool(object):
         self.X[slot * self.cap_nodes:slot * self.cap_nodes + N] = g["x"]
         self.EI[:, slot * self.cap_edges:slot * self.cap_edges + E] = g["edge_index"]
         self.EA[slot * self.cap_edges:slot * self.cap_edges + E] = g["edge_attr"]
-        self.node_off[slot] = np.asarray(g["node_off_h"], dtype=np.int64)
-        self.edge_off[slot] = np.asarray(g["edge_off_h"], dtype=np.int64)
+        no = self.node_off[slot] = np.asarray(g["node_off_h"], dtype=np.int64)
+        eo = self.edge_off[slot] = np.asarray(g["edge_off_h"], dtype=np.int64)
+        # drlgx_replay_collate's descriptor of every graph of the export (PoolRef.d5 is a row of this)
+        self.desc[slot] = np.stack([slot * self.cap_nodes + no[:-1], np.diff(no), slot * self.cap_edges + eo[:-1], np.diff(eo), no[:-1]], axis=1)
         self.q_version[slot] = None
         return slot
 
@@ -403,7 +406,7 @@ class ReplayPool(object):
     def descriptors(refs):
         """Host side of a collation: int64 [5, k] = node start in the pool, node count, edge start in the pool, edge count,
         first node id inside the export (drlgx_replay_collate's `desc`), plus the node / edge totals."""
-        d = np.array([(r.n0, r.nn, r.e0, r.ne, r.loc) for r in refs], dtype=np.int64).T.copy()
+        d = np.concatenate([r.d5 for r in refs]).reshape(len(refs), 5).T.copy()
         return d, int(d[1].sum()), int(d[3].sum())
 
     def collate_from(self, desc_dev, k, n_nodes, n_edges, max_graph_edges=None, with_q=False):
@@ -416,7 +419,7 @@ class ReplayPool(object):
         bt = torch.empty(n_nodes, dtype=torch.int64, device=dev)
         offs = torch.empty(2, k + 1, dtype=torch.int32, device=dev)
         q = torch.empty(n_nodes, dtype=torch.float32, device=dev) if with_q else None
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         _lib.check(_lib.lib().drlgx_replay_collate(C.c_void_p(stream), k, _p(desc_dev), _p(self.X), self.X.shape[1], _p(self.EI),
                                                    self.EI.shape[1], _p(self.EA), _p(x), _p(ei), n_edges, _p(ea), _p(bt), _p(offs[0]),
                                                    _p(offs[1]), _p(self.Q) if with_q else None, _p(q)))
@@ -427,7 +430,7 @@ class ReplayPool(object):
     def gather_q(self, desc_dev, k, n_nodes):
         """The per-node cache of `k` pooled graphs, concatenated in collation order."""
         q = torch.empty(n_nodes, dtype=torch.float32, device=self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        stream = _lib.stream_ptr(self.device)
         _lib.check(_lib.lib().drlgx_replay_collate(C.c_void_p(stream), k, _p(desc_dev), _p(self.X), self.X.shape[1], _p(self.EI),
                                                    self.EI.shape[1], _p(self.EA), None, None, 0, None, None, None, None, _p(self.Q), _p(q)))
         return q
@@ -441,16 +444,12 @@ class PoolRef(object):
     """One graph of a `ReplayPool` (what a replay transition holds); same duck type as GraphData.  The graph's ranges in
     the pooled tensors are resolved once, at construction."""
 
-    __slots__ = ("pool", "slot", "env", "batch", "n0", "nn", "e0", "ne", "loc")
+    __slots__ = ("pool", "slot", "env", "batch", "n0", "nn", "e0", "ne", "loc", "d5")
 
     def __init__(self, pool, slot, env):
         self.pool, self.slot, self.env, self.batch = pool, int(slot), int(env), None
-        no, eo = pool.node_off[self.slot], pool.edge_off[self.slot]
-        self.loc = int(no[self.env])
-        self.n0 = self.slot * pool.cap_nodes + self.loc
-        self.nn = int(no[self.env + 1]) - self.loc
-        self.e0 = self.slot * pool.cap_edges + int(eo[self.env])
-        self.ne = int(eo[self.env + 1] - eo[self.env])
+        self.d5 = pool.desc[self.slot][self.env]  # (n0, nn, e0, ne, loc) as the collation kernel reads them
+        self.n0, self.nn, self.e0, self.ne, self.loc = self.d5.tolist()
 
     @property
     def num_nodes(self):

@@ -34,18 +34,20 @@ class GradientBucket(object):
             self._offsets.append(n)
             n += -(-p.numel() // self._align) * self._align
         self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
+        self._views = [self.flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self._offsets)]
         self.attach()
         self._work = None
 
     def attach(self):
-        """(Re-)bind every parameter's .grad to its slice of the flat tensor (after a zero_grad(set_to_none=True))."""
-        for p, off in zip(self.params, self._offsets):
-            k = p.numel()
-            view = self.flat[off:off + k].view_as(p)
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                if p.grad is not None:
-                    view.copy_(p.grad)
-                p.grad = view
+        """(Re-)bind every parameter's .grad to its slice of the flat tensor (after a zero_grad(set_to_none=True)).  The
+        slices are built once; a parameter that still holds its own is left alone (two calls per update on the fused path)."""
+        for p, view in zip(self.params, self._views):
+            g = p.grad
+            if g is view:
+                continue
+            if g is not None and g.data_ptr() != view.data_ptr():
+                view.copy_(g)
+            p.grad = view
 
     @staticmethod
     def world(group=None):
@@ -107,7 +109,7 @@ class FusedAdam(object):
         grads = self.grads()
         sizes = (C.c_int64 * n)(*[p.numel() for p in self.params])
         dev = self.params[0].device
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         _lib.check(_lib.lib().drlgx_adam_step_scaled(vp(stream), n, arr([p.data for p in self.params]), arr(grads), arr(self.exp_avg),
                                                      arr(self.exp_avg_sq), sizes, self.param_groups[0]["lr"], self.betas[0],
                                                      self.betas[1], self.eps, self.step_count, self.grad_clamp, float(grad_scale)))

@@ -244,7 +244,7 @@ class DeepQ(object):
         loss = torch.empty(1, dtype=torch.float64, device=x.device)
         d_out = torch.empty(n, 1, dtype=torch.float32, device=x.device)
         vp = C.c_void_p
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stream = _lib.stream_ptr(x.device)
         _lib.check(_lib.lib().drlgx_dqn_loss_grad(vp(stream), n, vp(out.data_ptr()), vp(action.data_ptr()), vp(y.data_ptr()),
                                                   float(self.BATCH), vp(loss.data_ptr()), vp(d_out.data_ptr())))
         self._loss_t = loss
@@ -282,14 +282,15 @@ class DeepQ(object):
         return self._td_apply(q1, torch.from_numpy(meta).to(device), torch.from_numpy(r).to(device), len(minibatch), n_tot,
                               meta if not q1.is_cuda else None, r)
 
-    def _td_meta(self, minibatch, n1_tot):
+    def _td_meta(self, minibatch, n1_tot, n_j=None):
         """Host part of `td_targets`: int64 [4, B] = lo, hi (the read-out window of every sample in the collated next-state
         read-out), pos (the sample's action node among the collated current-state nodes), terminal; float64 rewards [B];
         the current-state node total.  Raises like numpy would on an empty window."""
-        n_j = np.array([d[0].num_nodes for d in minibatch], dtype=np.int64)
-        fro1 = np.array([d[5] for d in minibatch], dtype=np.int64)
-        a_loc = np.array([d[1] for d in minibatch], dtype=np.int64)
-        term = np.array([bool(d[4]) for d in minibatch])
+        s_j, a_loc, rew, _, term, fro1 = zip(*minibatch)
+        n_j = np.array([g.num_nodes for g in s_j], dtype=np.int64) if n_j is None else n_j
+        fro1 = np.array(fro1, dtype=np.int64)
+        a_loc = np.array(a_loc, dtype=np.int64)
+        term = np.array(term, dtype=bool)
         off_j = np.cumsum(n_j) - n_j
         if self.target_window == "reference":
             lo = np.minimum(off_j, n1_tot)               # python slicing clips to the array
@@ -302,7 +303,7 @@ class DeepQ(object):
         if bool(((hi <= lo) & ~term).any()):
             raise ValueError("zero-size array to reduction operation maximum which has no identity")  # as numpy would
         meta = np.stack([lo, hi, off_j + a_loc, term.astype(np.int64)])
-        return meta, np.array([d[2] for d in minibatch], dtype=np.float64), int(n_j.sum())
+        return meta, np.array(rew, dtype=np.float64), int(n_j.sum())
 
     def _td_apply(self, q1, meta_dev, r_dev, B, n_tot, meta_host=None, r_host=None):
         """(a_batch, y_batch) from the read-out and the windows: drlgx_dqn_targets on the device; plain tensor ops for
@@ -311,7 +312,7 @@ class DeepQ(object):
             a_batch = torch.empty(n_tot, dtype=torch.float64, device=q1.device)
             y_batch = torch.empty(n_tot, dtype=torch.float64, device=q1.device)
             vp = C.c_void_p
-            stream = torch.cuda.current_stream(q1.device).cuda_stream
+            stream = _lib.stream_ptr(q1.device)
             q1 = q1.contiguous()
             _lib.check(_lib.lib().drlgx_dqn_targets(vp(stream), B, vp(q1.data_ptr()), vp(meta_dev.data_ptr()), vp(r_dev.data_ptr()),
                                                     float(self.GAMMA), n_tot, vp(a_batch.data_ptr()), vp(y_batch.data_ptr())))
@@ -365,7 +366,8 @@ class DeepQ(object):
                 self._train_end(pending)
                 pending = None
             if fused and s_j.x.is_cuda:
-                policy_net.train()
+                if not policy_net.training:
+                    policy_net.train()
                 pending = self._train_begin(s_j.to(device), a_batch, y_batch, device, policy_net, optimizer)
             else:
                 self.train(s_j, a_batch, y_batch, device, policy_net, optimizer)
@@ -399,11 +401,13 @@ class DeepQ(object):
         R = np.empty((n_upd, B), dtype=np.float64)
         tot = []
         for u, mb in enumerate(batches):
-            if not all(isinstance(d[0], PoolRef) and isinstance(d[3], PoolRef) and d[0].pool is pool and d[3].pool is pool for d in mb):
+            refs, refs1 = [d[0] for d in mb], [d[3] for d in mb]
+            # every state of the sample must live in this pool (a buffer resumed from a pickle may hold plain graphs)
+            if {type(r) for r in refs + refs1} != {PoolRef} or {id(r.pool) for r in refs + refs1} != {id(pool)}:
                 return None, batches
-            I[u, 0:5], n, e = ReplayPool.descriptors([d[0] for d in mb])
-            I[u, 5:10], n1, e1 = ReplayPool.descriptors([d[3] for d in mb])
-            I[u, 10:14], R[u], _ = self._td_meta(mb, n1)
+            I[u, 0:5], n, e = ReplayPool.descriptors(refs)
+            I[u, 5:10], n1, e1 = ReplayPool.descriptors(refs1)
+            I[u, 10:14], R[u], _ = self._td_meta(mb, n1, I[u, 1])
             tot.append((n, e, n1, e1, int(I[u, 3].max()), int(I[u, 8].max())))
         self._refresh_target_readout(pool, sorted({d[3].slot for mb in batches for d in mb}), device, target_net)
         I_dev, R_dev = torch.from_numpy(I).to(device), torch.from_numpy(R).to(device)

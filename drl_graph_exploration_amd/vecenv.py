@@ -39,7 +39,7 @@ def normalise_rewards(raw, cand_env, cand_first, n_envs, n_frontier=None):
         out = torch.empty_like(raw)
         loop = torch.empty(n_envs, dtype=torch.uint8, device=raw.device)
         vp = C.c_void_p
-        _lib.check(_lib.lib().drlgx_normalise_rewards(vp(torch.cuda.current_stream(raw.device).cuda_stream), n_envs, vp(raw.data_ptr()),
+        _lib.check(_lib.lib().drlgx_normalise_rewards(vp(_lib.stream_ptr(raw.device)), n_envs, vp(raw.data_ptr()),
                                                       vp(cand_first.contiguous().data_ptr()), vp(n_frontier.contiguous().data_ptr()),
                                                       vp(out.data_ptr()), vp(loop.data_ptr())))
         return out, loop.bool()

@@ -40,13 +40,26 @@ with tempfile.TemporaryDirectory() as tmp:
                         ("step", "env.step (plan execution)"), ("reset", "env.reset")):
         timed(env, name, label)
     timed(dq, "test", "policy forward (acting)")
-    timed(dq, "_train_minibatch", "train minibatches")
+    prof = None
+    if len(sys.argv) > 3 and sys.argv[3] == "cprofile":  # host-side cost of the updates: no synchronising timer around them
+        import cProfile, pstats
+        prof = cProfile.Profile()
+    else:
+        timed(dq, "_train_minibatches", "train minibatches")
     dq.epoch = n_envs * iters
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if prof:
+        prof.enable()
     dq.running(pol, tgt, test=True, env=env)
+    if prof:
+        prof.disable()
+    t1 = time.perf_counter()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if prof:
+        print("host returned after %.1f ms per vector step, device drained after %.1f ms" % ((t1 - t0) / iters * 1e3, dt / iters * 1e3))
+        pstats.Stats(prof).sort_stats("tottime").print_stats(45)
     c = env.engine.counts_dev().cpu().numpy()
     print("poses at the end: mean %.1f max %d; landmarks mean %.1f" % (c[:, 0].mean(), c[:, 0].max(), c[:, 1].mean()))
     env.close()
