@@ -304,18 +304,30 @@ __global__ __launch_bounds__(256) void k_ax(int N, int in_dim, const float *x, c
   AX[(size_t)n * 8 + t] = s;
 }
 
-// H1[m][4c .. 4c+3] from AX[m] (8 floats), this thread's four W1 columns (w[k]) and biases
+// H1[m][4c .. 4c+3] from AX[m] (8 floats), this thread's four W1 columns (w[k]) and biases: one FMA chain over k per column,
+// written on two-float vectors so that it compiles to v_pk_fma_f32 (two columns per instruction, a[k] broadcast).  Left to
+// itself the compiler packs along k instead - v_pk_mul_f32 + two v_add_f32 per pair of products, 28 VALU instructions per
+// (row, four columns) where 10 + 4 (ReLU) + 2 (weighted sum) do.
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+template <int IN>
+__device__ __forceinline__ void h1_core(floatx2 &lo, floatx2 &hi, const float (&a)[8], int in_dim, const float4 (&w)[8], const float4 &bias) {
+  lo = floatx2{bias.x, bias.y};
+  hi = floatx2{bias.z, bias.w};
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (IN > 0 ? k < IN : k < in_dim) {
+      const floatx2 ak = {a[k], a[k]};
+      lo = __builtin_elementwise_fma(ak, floatx2{w[k].x, w[k].y}, lo);
+      hi = __builtin_elementwise_fma(ak, floatx2{w[k].z, w[k].w}, hi);
+    }
+}
 template <int IN = 0>  // IN > 0: the number of input features at compile time (the reference's 5): straight-line code
 __device__ __forceinline__ float4 h1_row(const float *AX, int m, int in_dim, const float4 (&w)[8], const float4 &bias) {
   const float4 a0 = reinterpret_cast<const float4 *>(AX + (size_t)m * 8)[0], a1 = reinterpret_cast<const float4 *>(AX + (size_t)m * 8)[1];
   const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-  float4 s = bias;
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    if (IN > 0 ? k < IN : k < in_dim) {
-      s.x += a[k] * w[k].x; s.y += a[k] * w[k].y; s.z += a[k] * w[k].z; s.w += a[k] * w[k].w;
-    }
-  return s;  // pre-activation
+  floatx2 lo, hi;
+  h1_core<IN>(lo, hi, a, in_dim, w, bias);
+  return make_float4(lo.x, lo.y, hi.x, hi.y);  // pre-activation
 }
 
 // H1 row from 8 staged AX values
@@ -323,59 +335,82 @@ template <int IN = 0>
 __device__ __forceinline__ float4 h1_row_lds(const float *ax, int in_dim, const float4 (&w)[8], const float4 &bias) {
   const float4 a0 = reinterpret_cast<const float4 *>(ax)[0], a1 = reinterpret_cast<const float4 *>(ax)[1];
   const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-  float4 s = bias;
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    if (IN > 0 ? k < IN : k < in_dim) {
-      s.x += a[k] * w[k].x; s.y += a[k] * w[k].y; s.z += a[k] * w[k].z; s.w += a[k] * w[k].w;
-    }
-  return s;
+  floatx2 lo, hi;
+  h1_core<IN>(lo, hi, a, in_dim, w, bias);
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+// acc += wi * relu(u)
+__device__ __forceinline__ void relu_axpy(floatx2 &alo, floatx2 &ahi, float wi, const float4 &u) {
+  const floatx2 w2 = {wi, wi};
+  alo = __builtin_elementwise_fma(w2, floatx2{fmaxf(u.x, 0.f), fmaxf(u.y, 0.f)}, alo);
+  ahi = __builtin_elementwise_fma(w2, floatx2{fmaxf(u.z, 0.f), fmaxf(u.w, 0.f)}, ahi);
 }
 
 constexpr int kAggStage = 64;  // neighbour rows of AX (and their weights) staged in LDS; longer rows read the rest from memory
 constexpr int kAggNodes = 4;   // nodes per workgroup: the thread's W1 columns and biases are loaded once for all of them, and
                                // the neighbour lists of all of them are staged together (one round of memory latency)
+static_assert(kAggNodes * kAggStage == 256, "one staging thread per (node, neighbour slot)");
+// Every memory access of the kernel sits in ONE dependent chain of three loads (row bounds -> neighbour id -> its AX row),
+// walked once by every thread for its own (node, slot) with the W1 columns requested in front of it; the multiply loop
+// reads LDS only.  (The first version staged 8 elements per thread in a loop - 24 dependent round trips - and loaded W1
+// and the row bounds behind one wait each: 57 us for the 17 288-node batch, a fifth of the VALU rate.)
 template <int IN>
 __global__ __launch_bounds__(256) void k_aggregate_l1(int N, int in_dim, int hidden, const float *AX, const float *W1, const float *b1,
                                                       const float *deg, const float *selfw, const int *ptr, const int *pend, const int *nbr,
                                                       const float *wn, float *out) {
-  __shared__ __attribute__((aligned(16))) float s_ax[kAggNodes][kAggStage * 8];
-  __shared__ float s_wn[kAggNodes][kAggStage];
+  __shared__ __attribute__((aligned(16))) float s_ax[kAggNodes][(kAggStage + 1) * 8];  // slot kAggStage: the node's own row
+  __shared__ float s_wn[kAggNodes][kAggStage + 1];                                       // slot kAggStage: its self weight
+  __shared__ int s_ab[kAggNodes][2];
   const int tid = threadIdx.x;
   const int h4 = hidden >> 2;
   const int nb0 = blockIdx.x * kAggNodes, nn = min(kAggNodes, N - nb0);
-  for (int e = tid; e < nn * kAggStage * 8; e += 256) {
-    const int q = e / (kAggStage * 8), r = e - q * (kAggStage * 8);
-    const int n = nb0 + q, a = ptr[n], j = r >> 3;
-    if (a + j < pend[n]) {
-      s_ax[q][r] = AX[(size_t)nbr[a + j] * 8 + (r & 7)];
-      if ((r & 7) == 0) s_wn[q][j] = wn[a + j];
+  auto load_w = [&](float4 (&w)[8], float4 &bias, int c) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      w[k] = (IN > 0 ? k < IN : k < in_dim) ? reinterpret_cast<const float4 *>(W1 + (size_t)k * hidden)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    bias = reinterpret_cast<const float4 *>(b1)[c];
+  };
+  float4 w[8], bias;
+  load_w(w, bias, min(tid, h4 - 1));  // (unconditional: under a branch the compiler waits for the loads before leaving it)
+  {
+    // every load unconditional (clamped to a valid element), only the LDS stores are predicated: under branches the loads
+    // of the own row / self weight / neighbour row would each be waited for in turn
+    const int q = tid >> 6, j = tid & (kAggStage - 1), n = min(nb0 + q, N - 1);
+    const float4 *AX4 = reinterpret_cast<const float4 *>(AX);
+    const int a = ptr[n], b = pend[n];
+    const float4 own = AX4[(size_t)n * 2 + (j & 1)];
+    const float sw = selfw[n], dg = deg[n];
+    const int e = max(min(a + j, b - 1), 0);
+    const int m = a + j < b ? nbr[e] : n;  // (outside the row nbr[e] may be a never-written gap of the batched CSR: not an address)
+    const float wv = wn[e];
+    const float4 r0 = AX4[(size_t)m * 2], r1 = AX4[(size_t)m * 2 + 1];
+    if (q < nn) {
+      if (j < 2) reinterpret_cast<float4 *>(s_ax[q] + 8 * kAggStage)[j] = own;
+      if (j == 2) {
+        s_wn[q][kAggStage] = sw / dg;
+        s_ab[q][0] = a;
+        s_ab[q][1] = b;
+      }
+      if (a + j < b) {
+        s_wn[q][j] = wv;
+        reinterpret_cast<float4 *>(s_ax[q] + 8 * j)[0] = r0;
+        reinterpret_cast<float4 *>(s_ax[q] + 8 * j)[1] = r1;
+      }
     }
   }
   __syncthreads();
   for (int c = tid; c < h4; c += 256) {
-    float4 w[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = k < in_dim ? reinterpret_cast<const float4 *>(W1 + (size_t)k * hidden)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 bias = reinterpret_cast<const float4 *>(b1)[c];
+    if (c != tid) load_w(w, bias, c);
     for (int q = 0; q < nn; ++q) {
       const int n = nb0 + q;
-      const int a = ptr[n], b = pend[n];
+      const int a = s_ab[q][0], b = s_ab[q][1];
       const int ns = min(b - a, kAggStage);
-      const float self = selfw[n] / deg[n];
-      const float4 v = h1_row<IN>(AX, n, in_dim, w, bias);
-      float4 acc = make_float4(self * fmaxf(v.x, 0.f), self * fmaxf(v.y, 0.f), self * fmaxf(v.z, 0.f), self * fmaxf(v.w, 0.f));
-      for (int j = 0; j < ns; ++j) {
-        const float wi = s_wn[q][j];
-        const float4 u = h1_row_lds<IN>(s_ax[q] + 8 * j, in_dim, w, bias);
-        acc.x += wi * fmaxf(u.x, 0.f); acc.y += wi * fmaxf(u.y, 0.f); acc.z += wi * fmaxf(u.z, 0.f); acc.w += wi * fmaxf(u.w, 0.f);
-      }
-      for (int i = a + ns; i < b; ++i) {
-        const float wi = wn[i];
-        const float4 u = h1_row<IN>(AX, nbr[i], in_dim, w, bias);
-        acc.x += wi * fmaxf(u.x, 0.f); acc.y += wi * fmaxf(u.y, 0.f); acc.z += wi * fmaxf(u.z, 0.f); acc.w += wi * fmaxf(u.w, 0.f);
-      }
-      reinterpret_cast<float4 *>(out + (size_t)n * hidden)[c] = acc;
+      const float self = s_wn[q][kAggStage];
+      const float4 v = h1_row_lds<IN>(s_ax[q] + 8 * kAggStage, in_dim, w, bias);
+      floatx2 alo = {self * fmaxf(v.x, 0.f), self * fmaxf(v.y, 0.f)}, ahi = {self * fmaxf(v.z, 0.f), self * fmaxf(v.w, 0.f)};
+      for (int j = 0; j < ns; ++j) relu_axpy(alo, ahi, s_wn[q][j], h1_row_lds<IN>(s_ax[q] + 8 * j, in_dim, w, bias));
+      for (int i = a + ns; i < b; ++i) relu_axpy(alo, ahi, wn[i], h1_row<IN>(AX, nbr[i], in_dim, w, bias));
+      reinterpret_cast<float4 *>(out + (size_t)n * hidden)[c] = make_float4(alo.x, alo.y, ahi.x, ahi.y);
     }
   }
 }
