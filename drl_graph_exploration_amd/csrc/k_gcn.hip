@@ -1273,25 +1273,31 @@ void gemm_wide_launch(hipStream_t st, int M, int N, int K, const float *A, int l
                      tiles_n);
 }
 
-// the tall-tile kernel where the product is large enough to fill the chip with its tiles: the tile height (16 RT rows) is
-// the one whose tile count wastes least of the last round of 256 CUs
-template <bool TA, bool TB, int EPI>
-bool gemm_wide(hipStream_t st, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias,
-               const float *mask, int kps) {
+// tile height (in 16-row sub-tiles) of the tall-tile kernel for an M x N product in S K-slices, 0 = the 64x64 kernels: the
+// product must be large enough to fill the chip with tall tiles, and the height is the one whose tile count wastes least
+// of the last round of 256 CUs (measured order at 4 340 and 17 288 rows: profiles/r04_ab_gemm_tall_tiles.txt)
+int wide_tile_subrows(int M, int N, int S, bool ta) {
   const int mode = gemm_wide_mode();
-  if (mode == 0 || !vec_ok(A, lda, TA ? M : K) || !vec_ok(B, ldb, TB ? K : N) || !vec_ok(C, ldc, N)) return false;
-  if ((EPI == 1 && (!vec_ok(bias, 4, 4) || (mask && !vec_ok(mask, ldc, N)))) || (TA ? M : K) < 4 || (TB ? K : N) < 4) return false;
-  const int S = (K + kps - 1) / kps, tiles_n = (N + WD_N - 1) / WD_N;
-  if ((long)((M + 127) / 128) * tiles_n * S < 192) return false;  // too few tiles: the 64x64 kernels spread further
+  const int tiles_n = (N + WD_N - 1) / WD_N;
+  if (mode == 0 || (long)((M + 127) / 128) * tiles_n * S < 192) return 0;
   int best = 0;
   long best_cost = 0;
   for (int rt = 6; rt <= 10; ++rt) {
-    if (TA && (rt & 1)) continue;  // x-contiguous A: whole 32-float swizzle blocks
-    if (mode >= 6 && mode <= 10 && rt != mode && !(TA && (mode & 1))) continue;
+    if (ta && (rt & 1)) continue;  // x-contiguous A: whole 32-float swizzle blocks
+    if (mode >= 6 && mode <= 10 && !(ta && (mode & 1)) && rt != mode) continue;
     const long tiles = (long)((M + 16 * rt - 1) / (16 * rt)) * tiles_n * S;
     const long cost = ((tiles + 255) / 256) * rt;
     if (!best || cost <= best_cost) best = rt, best_cost = cost;
   }
+  return best;
+}
+
+template <bool TA, bool TB, int EPI>
+bool gemm_wide(hipStream_t st, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias,
+               const float *mask, int kps) {
+  if (!vec_ok(A, lda, TA ? M : K) || !vec_ok(B, ldb, TB ? K : N) || !vec_ok(C, ldc, N)) return false;
+  if ((EPI == 1 && (!vec_ok(bias, 4, 4) || (mask && !vec_ok(mask, ldc, N)))) || (TA ? M : K) < 4 || (TB ? K : N) < 4 || kps < 16) return false;
+  const int best = wide_tile_subrows(M, N, (K + kps - 1) / kps, TA);
 #define DRLGX_WIDE(RT)                                                                          \
   case RT:                                                                                      \
     gemm_wide_launch<TA, TB, EPI, RT>(st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps); \
@@ -1394,6 +1400,11 @@ bool build_graph_batched(hipStream_t st, const GcnWs &w, int N, int E, const int
 }  // namespace
 
 extern "C" {
+
+int drlgx_debug_gemm_tile_rows(int m, int n, int k_slices, int transpose_a) {
+  const int rt = wide_tile_subrows(m, n, k_slices, transpose_a != 0);
+  return rt ? 16 * rt : 64;
+}
 
 size_t drlgx_gcn_workspace_bytes(int n_nodes, int n_edges, int hidden, int out_dim) {
   if (n_nodes <= 0 || n_edges < 0 || hidden <= 0 || out_dim <= 0) return 0;

@@ -45,16 +45,61 @@ def make_params(dev, out_dim=1, seed=0):
     return {k: v.to(dev).requires_grad_(True) for k, v in p.items()}
 
 
+def batch_of_about(n_nodes, seed, dev):
+    """A random batch whose node count is n_nodes (graphs of 20..69 nodes; the last one trimmed to fit by regenerating)."""
+    g = torch.Generator().manual_seed(seed)
+    sizes = []
+    while sum(sizes) < n_nodes:
+        sizes.append(int(torch.randint(20, 70, (1,), generator=g)))
+    sizes[-1] -= sum(sizes) - n_nodes
+    if sizes[-1] < 2:
+        sizes[-2] += sizes.pop()
+    xs, eis, eas = [], [], []
+    off = 0
+    for n in sizes:
+        m = int(torch.randint(n, 3 * n, (1,), generator=g))
+        src, dst = torch.randint(0, n, (m,), generator=g), torch.randint(0, n, (m,), generator=g)
+        keep = src != dst
+        src, dst = src[keep], dst[keep]
+        w = torch.rand(src.shape[0], generator=g) * 5.9 + 0.1
+        eis.append(torch.stack([torch.cat([src, dst]), torch.cat([dst, src])]) + off)
+        eas.append(torch.cat([w, w]))
+        x = torch.randn(n, 5, generator=g)
+        x[:, 4] = torch.randint(-1, 2, (n,), generator=g).float()
+        xs.append(x)
+        off += n
+    return torch.cat(xs).to(dev), torch.cat(eis, 1).to(dev), torch.cat(eas).to(dev)
+
+
 def rel_err(a, b):
     a, b = a.detach(), b.detach()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize("n_graphs,out_dim,with_mask", [(1, 1, False), (7, 1, True), (64, 1, False), (5, 100, True)])
+def test_tall_tile_gemm_heights_are_all_exercised():
+    """The batches of the parametrised test below that are large enough for the tall-tile GEMM (k_gemm_wide) make the
+    dispatcher pick every compiled tile height for the forward / dZ2 W2^T products, and the 128-row one for the split-K
+    weight gradient (asked of the library itself, so the test cannot drift from the dispatch rule)."""
+    from drl_graph_exploration_amd import _lib
+    L = _lib.lib()
+    picked = {L.drlgx_debug_gemm_tile_rows(n, 1000, 1, 0) for n in TALL_TILE_NODES}
+    assert picked == {96, 112, 128, 144, 160}, picked
+    assert {L.drlgx_debug_gemm_tile_rows(1000, 1000, 4, 1) for n in TALL_TILE_NODES} == {128}
+    assert L.drlgx_debug_gemm_tile_rows(2880, 1000, 1, 0) == 64  # (the 64-graph case below stays on the 64x64 kernels)
+
+
+TALL_TILE_NODES = (3050, 3301, 3803, 4342, 4799)  # node counts (odd ones too: ragged last row tile) per tile height 96 .. 160
+
+
+@pytest.mark.parametrize("n_graphs,out_dim,with_mask", [(1, 1, False), (7, 1, True), (64, 1, False), (5, 100, True)] +
+                         [(-n, 1, n % 2 == 0) for n in TALL_TILE_NODES])
 def test_gcn_forward_backward_matches_torch_reference(n_graphs, out_dim, with_mask):
     from drl_graph_exploration_amd.networks import gcn_trunk
     dev = torch.device("cuda", 0)
-    x, ei, ea, batch = random_batch(n_graphs, 123 + n_graphs, dev)
+    if n_graphs > 0:
+        x, ei, ea, batch = random_batch(n_graphs, 123 + n_graphs, dev)
+    else:  # a batch of exactly -n_graphs nodes (the tall-tile GEMM path)
+        x, ei, ea = batch_of_about(-n_graphs, 77 - n_graphs, dev)
     P = make_params(dev, out_dim)
     N = x.shape[0]
     mask = None
