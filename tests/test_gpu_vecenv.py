@@ -206,6 +206,25 @@ def test_deepq_running_smoke(tmp_path):
     assert (tmp_path / "training_object_data" / "smoke" / "Model_Policy.pt").exists()
 
 
+def test_deepq_running_at_256_envs(tmp_path):
+    """BASELINE configs[2] at its own size: `DeepQ.running` over 256 lock-step environments with the reference's mini-batch of
+    64 graphs and one update per environment step (3 vector steps: one to fill the replay, two with 256 updates each)."""
+    from drl_graph_exploration_amd.networks import GCN
+    from drl_graph_exploration_amd.policy import DeepQ
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    dq = DeepQ("smoke256/", "GCN", data_root=str(tmp_path))
+    dq.OBSERVE, dq.epoch = 256, 768
+    assert dq.BATCH == 64
+    pol, tgt = GCN().to(dev), GCN().to(dev)
+    tgt.load_state_dict(pol.state_dict())
+    w0 = pol.conv2.weight.detach().clone()
+    dq.running(pol, tgt, test=True, n_envs=256)
+    assert dq.step_t == 768 and len(dq.buffer) == 768
+    assert dq.temp_loss > 0 and math.isfinite(dq.temp_loss)
+    assert torch.isfinite(pol.conv2.weight).all() and not torch.equal(w0, pol.conv2.weight.detach())
+
+
 def test_deepq_reload_repools_the_replay_buffer(tmp_path):
     """run_training.py re-loads saved_training.pkl between epochs (train.py:85-94): the pickled replay buffer carries its
     graphs as host tensors.  The next epoch puts them back into the device pool (DeepQ._repool), so that its updates take
