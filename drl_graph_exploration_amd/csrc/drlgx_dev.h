@@ -624,11 +624,9 @@ void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel);  // sel.act_idx == -2: reductions only
 void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
                        const int32_t *dst, int src_off, int dst_off, int skip_mask,  // skip fields with cls & mask
-                       const int *cnt = nullptr);  // S.cnt: copy the live part of per-pose / -landmark / -factor fields only
+                       const int *cnt = nullptr,  // S.cnt: copy the live part of per-pose / -landmark / -factor fields only
+                       const DrlgxState *panel = nullptr);  // &S: the same launch copies the instances' covariance panels too
 void drlgx_launch_rebase(const DrlgxState &S, hipStream_t st, int base0, int n);
-// the incremental update's covariance panel of instance src[i] -> dst[i] (live rows / columns only; k_inc.hip)
-void drlgx_launch_copy_panel(const DrlgxState &S, hipStream_t st, int n, const int32_t *src, const int32_t *dst, int src_off,
-                             int dst_off);
 void drlgx_launch_fix_rollouts(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0);
 void drlgx_launch_rewards(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0,
                           double *rewards);

@@ -745,8 +745,8 @@ int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env
     const int32_t *na = n_actions_dev + c0;
     {
       ScopedTimer t(e, 3);
-      drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, nc, ce, nullptr, base0, roll0, 3, e->S.cnt);
-      drlgx_launch_copy_panel(S, e->stream, nc, ce, nullptr, base0, roll0);  // (the base solve's covariance panel)
+      drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, nc, ce, nullptr, base0, roll0, 3, e->S.cnt,
+                        &S);  // (with the base solve's covariance panel)
       drlgx_launch_fix_rollouts(S, e->stream, nc, ce, roll0);
     }
     for (int a = 0; a < max_n_actions; ++a) {
@@ -1049,8 +1049,7 @@ int drlgx_snapshot(drlgx_engine *e, int slot) {
   const DrlgxState &S = e->S;
   ScopedTimer t(e, 3);
   drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr, 0,
-                    2 * S.n_envs + S.n_roll + slot * S.n_envs, 0, e->S.cnt);
-  drlgx_launch_copy_panel(S, e->stream, S.n_envs, nullptr, nullptr, 0, 2 * S.n_envs + S.n_roll + slot * S.n_envs);
+                    2 * S.n_envs + S.n_roll + slot * S.n_envs, 0, e->S.cnt, &S);
   e->snap_pbound[slot] = e->pbound;
   return check_launch(e);
 }
@@ -1061,8 +1060,7 @@ int drlgx_restore(drlgx_engine *e, int slot) {
   const DrlgxState &S = e->S;
   ScopedTimer t(e, 3);
   drlgx_launch_copy(e->fields_dev, (int)e->fields.size(), e->stream, S.n_envs, nullptr, nullptr,
-                    2 * S.n_envs + S.n_roll + slot * S.n_envs, 0, 0, e->S.cnt);
-  drlgx_launch_copy_panel(S, e->stream, S.n_envs, nullptr, nullptr, 2 * S.n_envs + S.n_roll + slot * S.n_envs, 0);
+                    2 * S.n_envs + S.n_roll + slot * S.n_envs, 0, 0, e->S.cnt, &S);
   e->pbound = e->snap_pbound[slot];
   return check_launch(e);
 }

@@ -767,36 +767,4 @@ __device__ __forceinline__ void panel_invalidate(const DrlgxState &S, int inst, 
   }
 }
 
-// panel of instance src -> dst: the live rows / columns only.  grid (instances, kCopySplit): a block copies every
-// kCopySplit-th group of 8 rows, 32 threads x 16 bytes per row, four rows' loads in flight per thread
-constexpr int kCopySplit = 4;
-__global__ __launch_bounds__(256) void k_copy_panel(DrlgxState S, const int32_t *src, const int32_t *dst, int src_off, int dst_off) {
-  const int i = blockIdx.x, part = blockIdx.y;
-  const int s = (src ? src[i] : i) + src_off, d = (dst ? dst[i] : i) + dst_off;
-  const int *ms = S.jc_meta + (size_t)s * 4;
-  int *md = S.jc_meta + (size_t)d * 4;
-  const int valid = ms[0], P = ms[1], L = ms[2], M = ms[3];
-  if (threadIdx.x == 0 && part == 0) {
-    md[0] = valid; md[1] = P; md[2] = L; md[3] = M;
-  }
-  if (valid != 1) return;
-  const double *ps = S.jc + (size_t)s * S.jc_stride;
-  double *pd = S.jc + (size_t)d * S.jc_stride;
-  const int npair = (3 + 2 * L + 1) >> 1, rows = 3 * P + 2 * L;
-  const int cp0 = threadIdx.x & 31, r0 = (threadIdx.x >> 5) + 8 * part, rs = 8 * kCopySplit;
-  auto roff = [&](int q) -> size_t { return (size_t)(q < 3 * P ? q : q - 3 * P + 3 * S.P_max) * S.jc_ld; };
-  for (int cp = cp0; cp < npair; cp += 32)
-    for (int q = r0; q < rows; q += 4 * rs) {
-      const int q1 = q + rs, q2 = q + 2 * rs, q3 = q + 3 * rs;
-      const size_t o0 = roff(q), o1 = roff(min(q1, rows - 1)), o2 = roff(min(q2, rows - 1)), o3 = roff(min(q3, rows - 1));
-      const double2 v0 = reinterpret_cast<const double2 *>(ps + o0)[cp], v1 = reinterpret_cast<const double2 *>(ps + o1)[cp];
-      const double2 v2 = reinterpret_cast<const double2 *>(ps + o2)[cp], v3 = reinterpret_cast<const double2 *>(ps + o3)[cp];
-      reinterpret_cast<double2 *>(pd + o0)[cp] = v0;
-      if (q1 < rows) reinterpret_cast<double2 *>(pd + o1)[cp] = v1;
-      if (q2 < rows) reinterpret_cast<double2 *>(pd + o2)[cp] = v2;
-      if (q3 < rows) reinterpret_cast<double2 *>(pd + o3)[cp] = v3;
-    }
-  if (part == 0)
-    for (int e = threadIdx.x; e < 6 * P; e += 256) S.jd[(size_t)d * S.P_max * 6 + e] = S.jd[(size_t)s * S.P_max * 6 + e];
-}
 #pragma clang fp contract(fast)

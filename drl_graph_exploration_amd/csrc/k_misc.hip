@@ -7,14 +7,52 @@
 
 namespace {
 
-// copy every non-virtual-map field of instance src[i] to dst[i]
+// the incremental update's covariance panel (csrc/k_inc.hip) of instance s -> d: the live rows / columns only.  Block
+// `part` of kCopySplit copies every kCopySplit-th group of 8 rows, 32 threads x 16 bytes per row, four rows' loads in
+// flight per thread
+constexpr int kCopySplit = 4;
+__device__ __forceinline__ void copy_panel_part(const DrlgxState &S, int s, int d, int part) {
+  const int *ms = S.jc_meta + (size_t)s * 4;
+  int *md = S.jc_meta + (size_t)d * 4;
+  const int valid = ms[0], P = ms[1], L = ms[2], M = ms[3];
+  if (threadIdx.x == 0 && part == 0) {
+    md[0] = valid; md[1] = P; md[2] = L; md[3] = M;
+  }
+  if (valid != 1) return;
+  const double *ps = S.jc + (size_t)s * S.jc_stride;
+  double *pd = S.jc + (size_t)d * S.jc_stride;
+  const int npair = (3 + 2 * L + 1) >> 1, rows = 3 * P + 2 * L;
+  const int cp0 = threadIdx.x & 31, r0 = (threadIdx.x >> 5) + 8 * part, rs = 8 * kCopySplit;
+  auto roff = [&](int q) -> size_t { return (size_t)(q < 3 * P ? q : q - 3 * P + 3 * S.P_max) * S.jc_ld; };
+  for (int cp = cp0; cp < npair; cp += 32)
+    for (int q = r0; q < rows; q += 4 * rs) {
+      const int q1 = q + rs, q2 = q + 2 * rs, q3 = q + 3 * rs;
+      const size_t o0 = roff(q), o1 = roff(min(q1, rows - 1)), o2 = roff(min(q2, rows - 1)), o3 = roff(min(q3, rows - 1));
+      const double2 v0 = reinterpret_cast<const double2 *>(ps + o0)[cp], v1 = reinterpret_cast<const double2 *>(ps + o1)[cp];
+      const double2 v2 = reinterpret_cast<const double2 *>(ps + o2)[cp], v3 = reinterpret_cast<const double2 *>(ps + o3)[cp];
+      reinterpret_cast<double2 *>(pd + o0)[cp] = v0;
+      if (q1 < rows) reinterpret_cast<double2 *>(pd + o1)[cp] = v1;
+      if (q2 < rows) reinterpret_cast<double2 *>(pd + o2)[cp] = v2;
+      if (q3 < rows) reinterpret_cast<double2 *>(pd + o3)[cp] = v3;
+    }
+  if (part == 0)
+    for (int e = threadIdx.x; e < 6 * P; e += 256) S.jd[(size_t)d * S.P_max * 6 + e] = S.jd[(size_t)s * S.P_max * 6 + e];
+}
+
+// copy every field of instance src[i] to dst[i] whose class is not in skip_mask and - panel != 0 - its covariance panel:
+// one launch for everything an instance copy (snapshot / restore, env -> base -> rollout) moves
 __global__ __launch_bounds__(256) void k_copy_instances(const DrlgxField *fields, int n_fields, const int32_t *src,
-                                                        const int32_t *dst, int src_off, int dst_off, int skip_mask, const int *cnt) {
-  // grid = (instances, fields): every (instance, field) slice is streamed by its own workgroup with
+                                                        const int32_t *dst, int src_off, int dst_off, int skip_mask, const int *cnt,
+                                                        DrlgxState S, int panel) {
+  // grid = (instances, fields [+ kCopySplit]): every (instance, field) slice is streamed by its own workgroup with
   // 16-byte accesses when the slice is 16-byte aligned (all large fields are)
   const int i = blockIdx.x, f = blockIdx.y;
-  if (f >= n_fields || (fields[f].cls & skip_mask)) return;
   const int s = (src ? src[i] : i) + src_off, d = (dst ? dst[i] : i) + dst_off;
+  if (f >= n_fields) {
+    if (panel) copy_panel_part(S, s, d, f - n_fields);
+    return;
+  }
+  if (fields[f].cls & skip_mask) return;
   const size_t stride = fields[f].stride;
   const char *sb = fields[f].base + (size_t)s * stride;
   char *db = fields[f].base + (size_t)d * stride;
@@ -237,9 +275,11 @@ void drlgx_launch_cov_array(const DrlgxState &S, hipStream_t st, double *length,
   hipLaunchKernelGGL(k_cov_array, dim3((S.V + 255) / 256, S.n_envs), dim3(256), 0, st, S, length, angle);
 }
 void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
-                       const int32_t *dst, int src_off, int dst_off, int skip_mask, const int *cnt) {
-  hipLaunchKernelGGL(k_copy_instances, dim3(n, n_fields), dim3(256), 0, st, fields_dev, n_fields, src, dst, src_off,
-                     dst_off, skip_mask, cnt);
+                       const int32_t *dst, int src_off, int dst_off, int skip_mask, const int *cnt, const DrlgxState *panel) {
+  if (n <= 0) return;
+  const bool with_panel = panel && panel->jc;
+  hipLaunchKernelGGL(k_copy_instances, dim3(n, n_fields + (with_panel ? kCopySplit : 0)), dim3(256), 0, st, fields_dev, n_fields, src, dst,
+                     src_off, dst_off, skip_mask, cnt, with_panel ? *panel : DrlgxState{}, with_panel ? 1 : 0);
 }
 void drlgx_launch_rebase(const DrlgxState &S, hipStream_t st, int base0, int n) {
   hipLaunchKernelGGL(k_rebase, dim3(n), dim3(64), 0, st, S, base0, n);

@@ -1863,9 +1863,4 @@ void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p
   else
     hipLaunchKernelGGL((kslam::k_slam_arrow<kslam::kArrowRegTiles>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
 }
-void drlgx_launch_copy_panel(const DrlgxState &S, hipStream_t st, int n, const int32_t *src, const int32_t *dst, int src_off,
-                             int dst_off) {
-  if (!S.jc || n <= 0) return;
-  hipLaunchKernelGGL(kslam::k_copy_panel, dim3(n, kslam::kCopySplit), dim3(256), 0, st, S, src, dst, src_off, dst_off);
-}
 #pragma clang fp contract(off)
