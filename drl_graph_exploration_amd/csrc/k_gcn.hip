@@ -357,7 +357,7 @@ static_assert(kAggNodes * kAggStage == 256, "one staging thread per (node, neigh
 template <int IN>
 __global__ __launch_bounds__(256) void k_aggregate_l1(int N, int in_dim, int hidden, const float *AX, const float *W1, const float *b1,
                                                       const float *deg, const float *selfw, const int *ptr, const int *pend, const int *nbr,
-                                                      const float *wn, float *out) {
+                                                      const float *wn, float *out, float *b1_keep) {
   __shared__ __attribute__((aligned(16))) float s_ax[kAggNodes][(kAggStage + 1) * 8];  // slot kAggStage: the node's own row
   __shared__ float s_wn[kAggNodes][kAggStage + 1];                                       // slot kAggStage: its self weight
   __shared__ int s_ab[kAggNodes][2];
@@ -401,6 +401,7 @@ __global__ __launch_bounds__(256) void k_aggregate_l1(int N, int in_dim, int hid
   __syncthreads();
   for (int c = tid; c < h4; c += 256) {
     if (c != tid) load_w(w, bias, c);
+    if (blockIdx.x == 0) reinterpret_cast<float4 *>(b1_keep)[c] = bias;  // the backward pass's copy of b1 (the ReLU gate of layer 1)
     for (int q = 0; q < nn; ++q) {
       const int n = nb0 + q;
       const int a = s_ab[q][0], b = s_ab[q][1];
@@ -1062,9 +1063,27 @@ __global__ __launch_bounds__(256) void k_thin_tn_part(int K, int N, int M, const
 
 // second stage (deterministic): rows < rows_w of the [M x N] product -> outW, the column-sum row -> outB (either may
 // be null). 64 outputs per workgroup, the S partials of each summed by 16 threads in a fixed order.
+// With outA, one more workgroup (the last) writes the column sums of A itself, outA[m] = sum_k A[k][m] (m < M; the bias
+// gradient of the read-out layer, A = dOut), in a fixed order too.
 __global__ __launch_bounds__(1024) void k_thin_tn_reduce(int N, int M, int S, const float *part, float *outW, int rows_w,
-                                                         float *outB) {
+                                                         float *outB, const float *A, int lda, int K, float *outA) {
   __shared__ float red[16][64];
+  if (outA && blockIdx.x == gridDim.x - 1) {
+    float *r1 = &red[0][0];
+    for (int m = 0; m < M; ++m) {
+      float s = 0.f;
+      for (int k = threadIdx.x; k < K; k += 1024) s += A[(size_t)k * lda + m];
+      r1[threadIdx.x] = s;
+      __syncthreads();
+      for (int h = 512; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) r1[threadIdx.x] += r1[threadIdx.x + h];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) outA[m] = r1[0];
+      __syncthreads();
+    }
+    return;
+  }
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + c;
   const int total = (M + 1) * N;
@@ -1346,13 +1365,14 @@ void gemm_tn_splitk(hipStream_t st, const GcnWs &w, int M, int N, int K, const f
 // outW[rows_w x N] = (A^T B)[:rows_w], outB[N] = column sums of B, for M <= 8 columns of A (M = 0: column sums
 // only): one pass over B. N % 4 == 0 and 16-byte aligned B rows (hidden-sized operands).
 void thin_tn(hipStream_t st, const GcnWs &w, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *outW,
-             int rows_w, float *outB) {
+             int rows_w, float *outB, float *outA = nullptr) {
   int nb = std::min(128, (K + 7) / 8);
   nb = (int)std::max<size_t>(1, std::min<size_t>(nb, w.part_floats / ((size_t)(M + 1) * N)));
   const int rpb = (K + nb - 1) / nb;
   nb = (K + rpb - 1) / rpb;
   hipLaunchKernelGGL(k_thin_tn_part, dim3((N / 4 + 63) / 64, nb), dim3(256), 0, st, K, N, M, A, lda, B, ldb, w.part, rpb);
-  hipLaunchKernelGGL(k_thin_tn_reduce, dim3(((M + 1) * N + 63) / 64), dim3(1024), 0, st, N, M, nb, w.part, outW, rows_w, outB);
+  hipLaunchKernelGGL(k_thin_tn_reduce, dim3(((M + 1) * N + 63) / 64 + (outA ? 1 : 0)), dim3(1024), 0, st, N, M, nb, w.part, outW, rows_w, outB,
+                     A, lda, K, outA);
 }
 
 void colsum(hipStream_t st, const GcnWs &w, int N, int C, const float *X, float *out) {
@@ -1429,12 +1449,11 @@ static int gcn_forward_impl(void *hip_stream, int n_nodes, int n_edges, int in_d
     const dim3 ga((n_nodes + kAggNodes - 1) / kAggNodes), ba(256);
     if (in_dim == 5)  // the reference's feature count: compiled straight-line
       hipLaunchKernelGGL(k_aggregate_l1<5>, ga, ba, 0, st, n_nodes, in_dim, hidden, w.AX, W1, b1, w.deg, w.selfw, w.ptr_dst, w.end_dst, w.nbr_dst,
-                         w.wn_dst, w.AH1);
+                         w.wn_dst, w.AH1, w.b1s);
     else
       hipLaunchKernelGGL(k_aggregate_l1<0>, ga, ba, 0, st, n_nodes, in_dim, hidden, w.AX, W1, b1, w.deg, w.selfw, w.ptr_dst, w.end_dst, w.nbr_dst,
-                         w.wn_dst, w.AH1);
+                         w.wn_dst, w.AH1, w.b1s);
   }
-  if (hipMemcpyAsync(w.b1s, b1, (size_t)hidden * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return DRLGX_E_HIP;
   // H2 = relu(AH1 W2 + b2) * mask   (fp32 MFMA, fused epilogue)
   gemm<false, false, 1>(st, n_nodes, hidden, hidden, w.AH1, hidden, W2, hidden, w.H2, hidden, b2, dropout_mask, 1);
   hipLaunchKernelGGL(k_linear_out, dim3((n_nodes + 3) / 4), dim3(256), 0, st, n_nodes, hidden, out_dim, w.H2, Wf, bf, out);
@@ -1470,11 +1489,11 @@ int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, i
   carve(&w, reinterpret_cast<char *>(ws_dev), n_nodes, std::max(n_edges, 1), hidden, out_dim);
   // output layer
   if (out_dim <= 8) {
-    thin_tn(st, w, out_dim, hidden, n_nodes, d_out, out_dim, w.H2, hidden, dWf, out_dim, nullptr);  // dWf = dOut^T H2m
+    thin_tn(st, w, out_dim, hidden, n_nodes, d_out, out_dim, w.H2, hidden, dWf, out_dim, nullptr, dbf);  // dWf = dOut^T H2m, dbf = colsum(dOut)
   } else {
     gemm_tn_splitk(st, w, out_dim, hidden, n_nodes, d_out, out_dim, w.H2, hidden, dWf);
+    colsum(st, w, n_nodes, out_dim, d_out, dbf);
   }
-  colsum(st, w, n_nodes, out_dim, d_out, dbf);
   hipLaunchKernelGGL(k_dz2, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, out_dim, d_out, Wf, dropout_mask, w.H2, w.T0);  // T0 = dZ2
   // layer 2
   gemm_tn_splitk(st, w, hidden, hidden, n_nodes, w.AH1, hidden, w.T0, hidden, dW2);  // dW2 = AH1^T dZ2
