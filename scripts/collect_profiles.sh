@@ -11,22 +11,22 @@ mkdir -p $out
 export TMPDIR=/tmp
 BENCH="python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-policy --no-train"
 db() { find "$1" -name '*_results.db' | head -1; }
-rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -- $BENCH > $out/bench_under_rocprof.json 2> $out/rocprof_stats.err
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -- $BENCH > $out/bench_under_rocprof.json 2> $out/rocprof_stats.err
 python scripts/rocpd_summary.py "$(db /tmp/prof_stats)" > $out/kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_fetch -- $BENCH > /dev/null 2> $out/rocprof_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_write -- $BENCH > /dev/null 2> $out/rocprof_write.err
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_fetch -- $BENCH > /dev/null 2> $out/rocprof_fetch.err
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_write -- $BENCH > /dev/null 2> $out/rocprof_write.err
 python scripts/rocpd_pmc.py "$(db /tmp/prof_fetch)" "$(db /tmp/prof_write)" > $out/pmc_traffic.json
-rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
+timeout 400 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
   --kernel-trace -d /tmp/prof_sq -- $BENCH > /dev/null 2> $out/rocprof_sq.err
-rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES \
+timeout 400 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES \
   --kernel-trace -d /tmp/prof_sq2 -- $BENCH > /dev/null 2> $out/rocprof_sq2.err
 python scripts/pmc_sq_summary.py "$(db /tmp/prof_sq)" "$(db /tmp/prof_sq2)" --json $out/sq_counters.json > $out/sq_counters.txt
 ls -la $out
 # the bench line itself, the 2-rank control flow on one device (gloo), and the step-vs-trajectory-length tables
-python bench.py > $out/bench.json 2> $out/bench.err
+timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
 DRLGX_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 50 --warmup 5 > $out/bench_2ranks_gloo.json 2> $out/bench_2ranks_gloo.err
-python scripts/bench_vs_poses.py 206 100 phases > $out/vs_poses_100lm.txt 2>&1
-python scripts/bench_vs_poses.py 206 8 phases > $out/vs_poses_8lm.txt 2>&1
-(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_gcn -- python $OLDPWD/scripts/profile_gcn.py > /dev/null 2>&1)
+timeout 300 python scripts/bench_vs_poses.py 206 100 phases > $out/vs_poses_100lm.txt 2>&1
+timeout 300 python scripts/bench_vs_poses.py 206 8 phases > $out/vs_poses_8lm.txt 2>&1
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_gcn -- python $OLDPWD/scripts/profile_gcn.py > /dev/null 2>&1)
 python scripts/rocpd_summary.py "$(db /tmp/prof_gcn)" --by-grid k_ > $out/gcn_kernels_by_grid.csv 2>/dev/null
 ls -la $out
