@@ -1,0 +1,14 @@
+#!/bin/bash
+# Copy the summaries of a scripts/collect_profiles.sh run (gpurun_out/<tag>/) into profiles/ as <tag>_*, and make them the
+# current digest-checked counter files (profiles/pmc_traffic.json, profiles/sq_counters.json) that bench.py reads.
+set -eu
+tag=$1
+src=gpurun_out/$tag
+for f in kernel_stats.csv pmc_traffic.json sq_counters.txt sq_counters.json bench.json bench_2ranks_gloo.json gcn_kernels_by_grid.csv; do
+  cp $src/$f profiles/${tag}_$f
+done
+cp $src/vs_poses_100lm.txt profiles/${tag}_step_vs_poses_100lm.txt
+cp $src/vs_poses_8lm.txt profiles/${tag}_step_vs_poses_8lm.txt
+cp $src/pmc_traffic.json profiles/pmc_traffic.json
+cp $src/sq_counters.json profiles/sq_counters.json
+ls -la profiles | grep $tag
