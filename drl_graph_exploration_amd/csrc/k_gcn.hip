@@ -11,9 +11,10 @@
 //   * layer 1 (K = 5) is never materialised: AX = Â X is 8 floats per node (k_ax), and the aggregation of layer 2
 //     recomputes the rows of H1 = relu(AX W1 + b1) it gathers (k_aggregate_l1; the backward pass recomputes the ReLU gate);
 //   * aggregation (Â H): float4 lanes across the 1000 features, neighbour rows gathered with coalesced 4 KB reads;
-//   * the dense 1000x1000 contractions run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
-//     157 TFLOP/s peak): 64x64 block tile, 4 waves of one 32x32 MFMA tile, three LDS stages,
-//     fused bias+ReLU(+mask) epilogue; the weight-gradient products (K = #nodes) use split-K with a
+//   * the dense 1000x1000 contractions run on the fp32 matrix cores (exact fp32, 157 TFLOP/s peak) with a fused
+//     bias+ReLU(+mask) epilogue: batches large enough to fill the chip with (96..160) x 128 tiles on k_gemm_wide (8 waves,
+//     v_mfma_f32_16x16x4_f32, tile height picked per launch), smaller ones on the 64x64 kernels (4 waves of one 32x32 MFMA
+//     tile); operand tiles global -> LDS directly in both; the weight-gradient products (K = #nodes) use split-K with a
 //     deterministic second-stage reduction.
 // fp32 throughout (the reference trains in fp32); (Â X) W1 is used instead of Â (X W1) — same value up to fp32
 // rounding (tests: <= 2e-5 relative against the plain-torch reference).
@@ -1233,8 +1234,8 @@ bool vec_ok(const float *p, int ld, int contiguous_dim) {
   return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0 && (contiguous_dim & 3) == 0;
 }
 
-// workgroup tile: 64x64 (four waves of 32x32) measured best or equal on every GCN shape (4k .. 33k nodes x 1000 x 1000:
-// 81 .. 118 TFLOP/s); DRLGX_GEMM_TILE=1 selects the 64x128 variant for experiments
+// workgroup tile of the small-product kernels: 64x64 (four waves of 32x32), best or equal among the register-staged tilings
+// on every GCN shape; DRLGX_GEMM_TILE=1 selects the 64x128 variant for experiments.  (Large products: gemm_wide below.)
 int pick_tile() {
   static const int v = [] {
     const char *e = getenv("DRLGX_GEMM_TILE");
