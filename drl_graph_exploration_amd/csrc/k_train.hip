@@ -21,9 +21,18 @@ namespace {
 __global__ __launch_bounds__(256) void k_replay_collate(int G, const int64_t *desc, const float *pool_x, int in_dim, const int64_t *pool_ei,
                                                         int64_t pool_edges, const float *pool_ea, float *x_out, int64_t *ei_out,
                                                         int64_t E_total, float *ea_out, int64_t *batch_out, int *node_off_out,
-                                                        int *edge_off_out, const float *pool_q, float *q_out) {
+                                                        int *edge_off_out, const float *pool_q, float *q_out, const int64_t *desc2,
+                                                        float *q2_out) {
   __shared__ long long red[2][4];
-  const int g = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
+  int g = blockIdx.x;
+  if (g >= G) {  // the second list (drlgx_replay_collate_pair): only the per-node value of its graphs is gathered
+    g -= G;
+    desc = desc2;
+    x_out = nullptr;
+    node_off_out = edge_off_out = nullptr;
+    q_out = q2_out;
+  }
   long long sn = 0, se = 0;
   for (int j = tid; j < g; j += 256) {
     sn += desc[(size_t)G + j];
@@ -335,7 +344,20 @@ int drlgx_replay_collate(void *hip_stream, int n_graphs, const int64_t *desc_dev
     return DRLGX_E_INVALID;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   hipLaunchKernelGGL(k_replay_collate, dim3(n_graphs), dim3(256), 0, st, n_graphs, desc_dev, pool_x, in_dim, pool_ei, pool_edges, pool_ea,
-                     x_out, ei_out, n_edges_total, ea_out, batch_out, node_off_out, edge_off_out, pool_q, q_out);
+                     x_out, ei_out, n_edges_total, ea_out, batch_out, node_off_out, edge_off_out, pool_q, q_out, nullptr, nullptr);
+  return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
+}
+
+int drlgx_replay_collate_pair(void *hip_stream, int n_graphs, const int64_t *desc_dev, const float *pool_x, int in_dim, const int64_t *pool_ei,
+                              int64_t pool_edges, const float *pool_ea, float *x_out, int64_t *ei_out, int64_t n_edges_total, float *ea_out,
+                              int64_t *batch_out, int32_t *node_off_out, int32_t *edge_off_out, const int64_t *desc2_dev, const float *pool_q,
+                              float *q2_out) {
+  if (n_graphs <= 0 || !desc_dev || !pool_x || in_dim <= 0 || !pool_ei || !pool_ea || n_edges_total < 0 || pool_edges < 0 || !x_out ||
+      !ei_out || !ea_out || !batch_out || !desc2_dev || !pool_q || !q2_out)
+    return DRLGX_E_INVALID;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  hipLaunchKernelGGL(k_replay_collate, dim3(2 * n_graphs), dim3(256), 0, st, n_graphs, desc_dev, pool_x, in_dim, pool_ei, pool_edges, pool_ea,
+                     x_out, ei_out, n_edges_total, ea_out, batch_out, node_off_out, edge_off_out, pool_q, nullptr, desc2_dev, q2_out);
   return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
 }
 

@@ -134,12 +134,26 @@ class GCNConvParams(torch.nn.Module):
             self.weight.uniform_(-stdv, stdv)
 
 
+_ONES = {}  # device -> a [rows, hidden] tensor of ones (the input of the mask draw below)
+_ONES_MAX_ELEMS = 1 << 26  # 256 MB of float32: larger masks take the two-kernel path
+
+
 def _dropout_mask(n, hidden, p, device):
-    """F.dropout(x, p) is the FUNCTIONAL form in the reference => always active."""
+    """F.dropout(x, p) is the FUNCTIONAL form in the reference => always active.  The mask (0 or
+    1 / (1 - p)) is drawn by F.dropout itself on a tensor of ones of the activations' shape: one kernel, and the same
+    Philox draw as the reference's F.dropout(x) on its [n, hidden] activations."""
     if p <= 0.0:
         return None
     if p >= 1.0:
         return torch.zeros(n, hidden, device=device)
+    if n * hidden <= _ONES_MAX_ELEMS:
+        key = (str(device), hidden)
+        ones = _ONES.get(key)
+        if ones is None or ones.shape[0] < n:
+            rows = max(n, 2 * (ones.shape[0] if ones is not None else 0))
+            rows = min(rows, _ONES_MAX_ELEMS // hidden)
+            ones = _ONES[key] = torch.ones(rows, hidden, device=device)
+        return torch.nn.functional.dropout(ones[:n], p, True)
     return torch.empty(n, hidden, device=device).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
 
 
@@ -409,20 +423,27 @@ class ReplayPool(object):
         d = np.concatenate([r.d5 for r in refs]).reshape(len(refs), 5).T.copy()
         return d, int(d[1].sum()), int(d[3].sum())
 
-    def collate_from(self, desc_dev, k, n_nodes, n_edges, max_graph_edges=None, with_q=False):
+    def collate_from(self, desc_dev, k, n_nodes, n_edges, max_graph_edges=None, with_q=False, q_desc=None, q_nodes=0):
         """The PyG batch of `k` pooled graphs from their device descriptors: one kernel, no host synchronisation.
-        with_q: also gather the pool's per-node cache (`.q` of the result)."""
+        with_q: also gather the pool's per-node cache (`.q` of the result).  q_desc / q_nodes: gather the cache of a SECOND
+        list of `k` graphs (their descriptors, their node total) in the same launch instead - `.q` is then theirs."""
         dev = self.device
         x = torch.empty(n_nodes, self.X.shape[1], dtype=torch.float32, device=dev)
         ei = torch.empty(2, n_edges, dtype=torch.int64, device=dev)
         ea = torch.empty(n_edges, dtype=torch.float32, device=dev)
         bt = torch.empty(n_nodes, dtype=torch.int64, device=dev)
         offs = torch.empty(2, k + 1, dtype=torch.int32, device=dev)
-        q = torch.empty(n_nodes, dtype=torch.float32, device=dev) if with_q else None
         stream = _lib.stream_ptr(dev)
-        _lib.check(_lib.lib().drlgx_replay_collate(C.c_void_p(stream), k, _p(desc_dev), _p(self.X), self.X.shape[1], _p(self.EI),
-                                                   self.EI.shape[1], _p(self.EA), _p(x), _p(ei), n_edges, _p(ea), _p(bt), _p(offs[0]),
-                                                   _p(offs[1]), _p(self.Q) if with_q else None, _p(q)))
+        if q_desc is not None:
+            q = torch.empty(q_nodes, dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().drlgx_replay_collate_pair(C.c_void_p(stream), k, _p(desc_dev), _p(self.X), self.X.shape[1], _p(self.EI),
+                                                            self.EI.shape[1], _p(self.EA), _p(x), _p(ei), n_edges, _p(ea), _p(bt), _p(offs[0]),
+                                                            _p(offs[1]), _p(q_desc), _p(self.Q), _p(q)))
+        else:
+            q = torch.empty(n_nodes, dtype=torch.float32, device=dev) if with_q else None
+            _lib.check(_lib.lib().drlgx_replay_collate(C.c_void_p(stream), k, _p(desc_dev), _p(self.X), self.X.shape[1], _p(self.EI),
+                                                       self.EI.shape[1], _p(self.EA), _p(x), _p(ei), n_edges, _p(ea), _p(bt), _p(offs[0]),
+                                                       _p(offs[1]), _p(self.Q) if with_q else None, _p(q)))
         d = GraphData(x, ei, ea, bt, offs[0], offs[1], max_graph_edges)
         d.q = q
         return d

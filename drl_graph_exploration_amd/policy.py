@@ -341,11 +341,12 @@ class DeepQ(object):
             a_batch, y_batch = self.td_targets(minibatch, q1, device)
         else:  # everything the host contributes was uploaded in one piece by _prepare_updates
             pool, B = prepared["pool"], self.BATCH
-            s_j = pool.collate_from(prepared["desc_j"], B, prepared["N"], prepared["E"], prepared["ME"])
             # the target network's read-out over the next states (`self.test(s_j1_batch, 0.0, device, target_net)`): a
             # function of the graph and the frozen target weights only, evaluated once per stored export and target refresh
-            # (_refresh_target_readout) and gathered here
-            q1 = pool.gather_q(prepared["desc_j1"], B, prepared["N1"])
+            # (_refresh_target_readout) and gathered here, in the launch that collates the current states
+            s_j = pool.collate_from(prepared["desc_j"], B, prepared["N"], prepared["E"], prepared["ME"], q_desc=prepared["desc_j1"],
+                                    q_nodes=prepared["N1"])
+            q1 = s_j.q
             a_batch, y_batch = self._td_apply(q1, prepared["meta"], prepared["r"], B, prepared["N"])
         return s_j, a_batch, y_batch
 

@@ -324,6 +324,13 @@ int drlgx_replay_collate(void *hip_stream, int n_graphs, const int64_t *desc_dev
                          int64_t n_edges_total, float *ea_out, int64_t *batch_out,
                          int32_t *node_off_out /* [n_graphs + 1] or NULL */, int32_t *edge_off_out /* [n_graphs + 1] or NULL */,
                          const float *pool_q /* [rows] or NULL */, float *q_out /* [N] or NULL */);
+/* The two collations of one DQN mini-batch in one launch (scripts/policy.py:146-156): the current states s_j as
+ * drlgx_replay_collate emits them, and - for the next states s_j1, desc2_dev int64 [5][n_graphs] - only the cached per-node
+ * value pool_q gathered into q2_out [sum of their node counts] (the target network's read-out over the collated s_j1). */
+int drlgx_replay_collate_pair(void *hip_stream, int n_graphs, const int64_t *desc_dev, const float *pool_x, int in_dim,
+                              const int64_t *pool_ei, int64_t pool_edges, const float *pool_ea, float *x_out, int64_t *ei_out,
+                              int64_t n_edges_total, float *ea_out, int64_t *batch_out, int32_t *node_off_out, int32_t *edge_off_out,
+                              const int64_t *desc2_dev, const float *pool_q, float *q2_out);
 /* TD targets, scripts/policy.py:154-175: sample i takes max(q1[lo_i:hi_i]) (float32, the target network's read-out over
  * the collated next states; the caller resolves the reference's slicing into [lo, hi)), and
  * a_batch[pos_i] = 1, y_batch[pos_i] = r_i + gamma max  (r_i alone when terminal_i) in float64; both vectors
