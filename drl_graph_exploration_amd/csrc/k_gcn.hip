@@ -1105,6 +1105,67 @@ __global__ __launch_bounds__(1024) void k_thin_tn_reduce(int N, int M, int S, co
   }
 }
 
+// The read-out layer's backward in one pass over H2 (out_dim <= 8): dZ2 as k_dz2 writes it, and - from the same registers -
+// the partials of dWf = dOut^T H2m (rows m < M of the thin product: H2 already holds relu(Z2) * mask) and of db2 = the
+// column sums of dZ2 (row M), in k_thin_tn_part's layout and summation order: k_thin_tn_reduce finishes both.  Replaces
+// thin product + k_dz2 + column sums (five launches) by two.
+__global__ __launch_bounds__(256) void k_dz2_sums(int K, int N, int M, const float *__restrict__ dOut, const float *__restrict__ Wf,
+                                                  const float *__restrict__ mask, const float *__restrict__ H2, float *__restrict__ dZ2,
+                                                  float *__restrict__ part, int rows_per_block) {
+  __shared__ float4 red[3][9][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = (blockIdx.x * 64 + lane) * 4;
+  const bool col_ok = n < N;
+  const int k0 = blockIdx.y * rows_per_block, k1 = min(K, k0 + rows_per_block);
+  float4 acc[9], wf[8];
+#pragma unroll
+  for (int m = 0; m < 9; ++m) acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) wf[m] = (m < M && col_ok) ? *reinterpret_cast<const float4 *>(Wf + (size_t)m * N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col_ok)
+    for (int k = k0 + wave; k < k1; k += 4) {
+      const float4 h = *reinterpret_cast<const float4 *>(H2 + (size_t)k * N + n);
+      const float *a = dOut + (size_t)k * M;  // wave-uniform: scalar loads
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        if (m < M) {
+          const float am = a[m];
+          s.x += am * wf[m].x; s.y += am * wf[m].y; s.z += am * wf[m].z; s.w += am * wf[m].w;
+          acc[m].x += am * h.x; acc[m].y += am * h.y; acc[m].z += am * h.z; acc[m].w += am * h.w;
+        }
+      float4 g = make_float4(h.x > 0.f ? 1.f : 0.f, h.y > 0.f ? 1.f : 0.f, h.z > 0.f ? 1.f : 0.f, h.w > 0.f ? 1.f : 0.f);
+      if (mask) {
+        const float4 mk = *reinterpret_cast<const float4 *>(mask + (size_t)k * N + n);
+        g.x *= mk.x; g.y *= mk.y; g.z *= mk.z; g.w *= mk.w;
+      }
+      const float4 dz = make_float4(s.x * g.x, s.y * g.y, s.z * g.z, s.w * g.w);
+      *reinterpret_cast<float4 *>(dZ2 + (size_t)k * N + n) = dz;
+      acc[8].x += dz.x; acc[8].y += dz.y; acc[8].z += dz.z; acc[8].w += dz.w;
+    }
+  if (wave > 0) {
+#pragma unroll
+    for (int m = 0; m < 9; ++m)
+      if (m < M || m == 8) red[wave - 1][m][lane] = acc[m];
+  }
+  __syncthreads();
+  if (wave > 0 || !col_ok) return;
+#pragma unroll
+  for (int m = 0; m < 9; ++m)
+    if (m < M || m == 8) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        const float4 o = red[w][m][lane];
+        acc[m].x += o.x; acc[m].y += o.y; acc[m].z += o.z; acc[m].w += o.w;
+      }
+    }
+  float *o = part + (size_t)blockIdx.y * (M + 1) * N + n;
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    if (m < M) *reinterpret_cast<float4 *>(o + (size_t)m * N) = acc[m];
+  *reinterpret_cast<float4 *>(o + (size_t)M * N) = acc[8];
+}
+
 // deterministic second stage of split-K: out = sum_z part[z]
 __global__ void k_splitk_reduce(int n, int S, const float *part, float *out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1489,16 +1550,30 @@ int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, i
   GcnWs w;
   carve(&w, reinterpret_cast<char *>(ws_dev), n_nodes, std::max(n_edges, 1), hidden, out_dim);
   // output layer
-  if (out_dim <= 8) {
-    thin_tn(st, w, out_dim, hidden, n_nodes, d_out, out_dim, w.H2, hidden, dWf, out_dim, nullptr, dbf);  // dWf = dOut^T H2m, dbf = colsum(dOut)
+  const uintptr_t al16 = reinterpret_cast<uintptr_t>(Wf) | reinterpret_cast<uintptr_t>(dropout_mask) | reinterpret_cast<uintptr_t>(w.H2) |
+                         reinterpret_cast<uintptr_t>(w.T0);
+  if (out_dim <= 8 && (al16 & 15) == 0) {
+    // dWf = dOut^T H2m, dbf = colsum(dOut), T0 = dZ2, db2 = colsum(dZ2): one pass over H2 and one reduce
+    int nb = std::min(128, (n_nodes + 7) / 8);
+    nb = (int)std::max<size_t>(1, std::min<size_t>(nb, w.part_floats / ((size_t)(out_dim + 1) * hidden)));
+    const int rpb = (n_nodes + nb - 1) / nb;
+    nb = (n_nodes + rpb - 1) / rpb;
+    hipLaunchKernelGGL(k_dz2_sums, dim3((hidden / 4 + 63) / 64, nb), dim3(256), 0, st, n_nodes, hidden, out_dim, d_out, Wf, dropout_mask, w.H2, w.T0,
+                       w.part, rpb);
+    hipLaunchKernelGGL(k_thin_tn_reduce, dim3(((out_dim + 1) * hidden + 63) / 64 + 1), dim3(1024), 0, st, hidden, out_dim, nb, w.part, dWf, out_dim,
+                       db2, d_out, out_dim, n_nodes, dbf);
   } else {
-    gemm_tn_splitk(st, w, out_dim, hidden, n_nodes, d_out, out_dim, w.H2, hidden, dWf);
-    colsum(st, w, n_nodes, out_dim, d_out, dbf);
+    if (out_dim <= 8) {
+      thin_tn(st, w, out_dim, hidden, n_nodes, d_out, out_dim, w.H2, hidden, dWf, out_dim, nullptr, dbf);  // dWf = dOut^T H2m, dbf = colsum(dOut)
+    } else {
+      gemm_tn_splitk(st, w, out_dim, hidden, n_nodes, d_out, out_dim, w.H2, hidden, dWf);
+      colsum(st, w, n_nodes, out_dim, d_out, dbf);
+    }
+    hipLaunchKernelGGL(k_dz2, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, out_dim, d_out, Wf, dropout_mask, w.H2, w.T0);  // T0 = dZ2
+    colsum(st, w, n_nodes, hidden, w.T0, db2);
   }
-  hipLaunchKernelGGL(k_dz2, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, out_dim, d_out, Wf, dropout_mask, w.H2, w.T0);  // T0 = dZ2
   // layer 2
   gemm_tn_splitk(st, w, hidden, hidden, n_nodes, w.AH1, hidden, w.T0, hidden, dW2);  // dW2 = AH1^T dZ2
-  colsum(st, w, n_nodes, hidden, w.T0, db2);
   gemm<false, true, 0>(st, n_nodes, hidden, hidden, w.T0, hidden, W2, hidden, w.T1, hidden, nullptr, nullptr, 1);  // T1 = dZ2 W2^T
   // dZ1 = (Â^T dAH1) * (H1 > 0)   -> T0
   hipLaunchKernelGGL(k_aggregate<true>, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, w.T1, w.deg, w.selfw, w.ptr_src, w.end_src, w.nbr_src,
