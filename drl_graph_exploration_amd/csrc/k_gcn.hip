@@ -177,7 +177,8 @@ constexpr uint32_t kCsrNoKey = 0xffffffffu;
 
 __global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, int extra, const int64_t *ei, const float *ew, const int *node_off,
                                                     const int *edge_off, float *deg, float *selfw_out, int *ptr_dst, int *end_dst,
-                                                    int *nbr_dst, float *wn_dst, int *ptr_src, int *end_src, int *nbr_src, float *wn_src) {
+                                                    int *nbr_dst, float *wn_dst, int *ptr_src, int *end_src, int *nbr_src, float *wn_src,
+                                                    const float *x, int in_dim, float *AX) {
   extern __shared__ uint32_t s_keys[];  // [2][P2]: by source, by destination; then (extra) the weights and packed endpoints
   uint32_t *ks = s_keys, *kd = s_keys + P2;
   float *s_w = reinterpret_cast<float *>(s_keys + 2 * (size_t)P2);
@@ -281,6 +282,19 @@ __global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, int ex
       nbr_dst[e0 + i] = r;
       wn_dst[e0 + i] = dr * (ext ? s_w[j] : ew[e0 + j]) * dc;
     }
+  }
+  if (!AX) return;
+  // AX = Â X of the graph's own nodes (k_ax's expression and order), from the rows this workgroup has just written
+  __threadfence_block();
+  __syncthreads();
+  for (int e = tid; e < ng * 8; e += 256) {
+    const int n = n0 + (e >> 3), t = e & 7;
+    float s = 0.f;
+    if (t < in_dim) {
+      s = (selfw_out[n] / deg[n]) * x[(size_t)n * in_dim + t];
+      for (int i = ptr_dst[n]; i < end_dst[n]; ++i) s += wn_dst[i] * x[(size_t)nbr_dst[i] * in_dim + t];
+    }
+    AX[(size_t)n * 8 + t] = s;
   }
 }
 
@@ -1464,8 +1478,9 @@ void build_graph(hipStream_t st, const GcnWs &w, int N, int E, const int64_t *ei
 }
 
 // false: a graph of the batch may have more edges than the per-graph kernel sorts in LDS (the caller falls back to build_graph)
+// x / in_dim: the node features - AX = Â X comes out of the same launch (k_ax otherwise)
 bool build_graph_batched(hipStream_t st, const GcnWs &w, int N, int E, const int64_t *ei, const float *ew, int G, const int *node_off,
-                         const int *edge_off, int max_edges_per_graph) {
+                         const int *edge_off, int max_edges_per_graph, const float *x, int in_dim) {
   if (max_edges_per_graph > kCsrMaxEdges) return false;
   int P2 = 64;
   while (P2 < max_edges_per_graph) P2 <<= 1;
@@ -1475,7 +1490,7 @@ bool build_graph_batched(hipStream_t st, const GcnWs &w, int N, int E, const int
   const void *fns[] = {reinterpret_cast<const void *>(&k_csr_graphs)};
   drlgx_ensure_lds_attr(attr_set, fns, 1, 160 * 1024);
   hipLaunchKernelGGL(k_csr_graphs, dim3(G), dim3(256), lds, st, N, E, P2, extra, ei, ew, node_off, edge_off, w.deg, w.selfw, w.ptr_dst, w.end_dst,
-                     w.nbr_dst, w.wn_dst, w.ptr_src, w.end_src, w.nbr_src, w.wn_src);
+                     w.nbr_dst, w.wn_dst, w.ptr_src, w.end_src, w.nbr_src, w.wn_src, x, in_dim, w.AX);
   return true;
 }
 
@@ -1503,10 +1518,12 @@ static int gcn_forward_impl(void *hip_stream, int n_nodes, int n_edges, int in_d
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   GcnWs w;
   carve(&w, reinterpret_cast<char *>(ws_dev), n_nodes, std::max(n_edges, 1), hidden, out_dim);
-  if (n_graphs <= 0 || !build_graph_batched(st, w, n_nodes, n_edges, edge_index, edge_attr, n_graphs, node_off, edge_off, max_edges_per_graph))
+  if (n_graphs <= 0 ||
+      !build_graph_batched(st, w, n_nodes, n_edges, edge_index, edge_attr, n_graphs, node_off, edge_off, max_edges_per_graph, x, in_dim)) {
     build_graph(st, w, n_nodes, n_edges, edge_index, edge_attr);
-  hipLaunchKernelGGL(k_ax, dim3((n_nodes * 8 + 255) / 256), dim3(256), 0, st, n_nodes, in_dim, x, w.deg, w.selfw, w.ptr_dst, w.end_dst, w.nbr_dst,
-                     w.wn_dst, w.AX);
+    hipLaunchKernelGGL(k_ax, dim3((n_nodes * 8 + 255) / 256), dim3(256), 0, st, n_nodes, in_dim, x, w.deg, w.selfw, w.ptr_dst, w.end_dst,
+                       w.nbr_dst, w.wn_dst, w.AX);
+  }
   {
     const dim3 ga((n_nodes + kAggNodes - 1) / kAggNodes), ba(256);
     if (in_dim == 5)  // the reference's feature count: compiled straight-line
