@@ -90,8 +90,11 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   if (inc_stage(S, sel, lds_bytes, 0)) return;  // between relinearisations: the rank-k covariance update (k_inc.hip)
   const int inst = sel.base + bi;
   int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
-  // (`full` / `refresh`: see slam_body - intermediate look-ahead steps solve for the estimates only)
-  const bool full = sel.map_on(bi);
+  // (`full` / `refresh`: see slam_body - intermediate look-ahead steps solve for the estimates only.  Not with the
+  // incremental update on: a full solve is what leaves the covariance panel, and the rollout's remaining actions then cost
+  // a rank-k update each instead of another solve - at the bench state the relinearising 10th update is action 9 of up to
+  // 11, and the two actions behind it were 1.3 of the look-ahead's 5.2 ms)
+  const bool full = sel.map_on(bi) || S.jc != nullptr;
   const bool refresh = cnt[C_FLAG] != 0;
   if (refresh && !(sel.map_last_only && sel.n_act && full)) return;
   const drlgx_config &cfg = S.cfg;

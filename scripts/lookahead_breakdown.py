@@ -38,3 +38,21 @@ for _ in range(5):
     eng.lookahead(cand_env, acts, nact)
 tm = eng.timing_read()
 print({k: (round(v[0] / 5, 3), v[1] // 5) for k, v in tm.items() if v[1]}); eng.check_status()
+# one bounded look-ahead by span, and its cost per action index: bounded calls of increasing depth (the difference of two
+# consecutive depths is what one action index's launches cost)
+mx = int(na.max())
+eng.timing_read()
+eng.lookahead(cand_env, acts, nact, mx)
+print("spans of one bounded look-ahead (ms, launches):", {k: (round(v[0], 3), v[1]) for k, v in eng.timing_read().items() if v[1]})
+eng.timing_enable(False)
+prev = 0.0
+for a in range(1, mx + 1):
+    eng.lookahead(cand_env, acts, nact, a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.lookahead(cand_env, acts, nact, a)
+    torch.cuda.synchronize()
+    ms_a = (time.perf_counter() - t0) / 3 * 1e3
+    print("  action indices < %2d: %.3f ms (+%.3f); rollouts running at the last one: %d" % (a, ms_a, ms_a - prev, int((na >= a).sum())))
+    prev = ms_a
