@@ -1,5 +1,5 @@
 """Dev tool: belief-step stage times as the trajectories grow (256 envs, 40 m map).
-usage: bench_vs_poses.py [pose capacity = 206] [landmarks in the world = 100] [phases]
+usage: bench_vs_poses.py [pose capacity = 206] [landmarks in the world = 100] [phases]     (PP_SAMPLE=49,59: sample these pose counts too)
 With `phases`, the in-kernel phase stamps of block 0 of the SLAM kernel are printed too (k_slam_arrow beyond 42 poses)."""
 import ctypes as C, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,11 +24,12 @@ odoms = [torch.tensor([a] * n, dtype=torch.float64, device=eng.device) for a in 
 names = ["tables+linearise", "blocks", "leaf factor", "leaf rhs down", "separator CR", "leaf up + selinv", "landmark system", "sweep", "lm out", "pose out"]
 order = [0, 1, 2, 3, 4, 5, 10, 6, 7, 8, 9]  # stamp slots in program order
 out = (C.c_int64 * 64)()
+extra_samples = [int(v) for v in os.environ.get("PP_SAMPLE", "").split(",") if v]  # more pose counts to sample (e.g. one whose update relinearises)
 print("# %d envs, %d landmarks in the world, capacity %d poses" % (n, num_lm, cap))
 for s in range(cap - 3):
     eng.step(odoms[s % len(loop)])
     p = s + 2
-    if (p < 48 and p % 8 == 0) or p in (41, 42, 43) or (p >= 48 and p % 16 == 0) or p == cap - 2:
+    if (p < 48 and p % 8 == 0) or p in (41, 42, 43) or (p >= 48 and p % 16 == 0) or p == cap - 2 or p in extra_samples:
         assert eng.status() == 0 or os.environ.get("DRLGX_LIB_DEV")  # (kernel-variant timing experiments compute nonsense on purpose)
         eng.snapshot(0)
         eng.timing_enable(2)
