@@ -94,9 +94,9 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   // incremental update on: a full solve is what leaves the covariance panel, and the rollout's remaining actions then cost
   // a rank-k update each instead of another solve - at the bench state the relinearising 10th update is action 9 of up to
   // 11, and the two actions behind it were 1.3 of the look-ahead's 5.2 ms)
-  const bool full = sel.map_on(bi) || S.jc != nullptr;
+  const bool want = sel.map_on(bi), full = want || S.jc != nullptr;
   const bool refresh = cnt[C_FLAG] != 0;
-  if (refresh && !(sel.map_last_only && sel.n_act && full)) return;
+  if (refresh && !(sel.map_last_only && sel.n_act && want)) return;
   const drlgx_config &cfg = S.cfg;
   const int P = cnt[C_P], L = cnt[C_L], M = cnt[C_M];
   const int n_old_p = cnt[C_NEWP], n_old_l = cnt[C_NEWL];
