@@ -28,3 +28,7 @@ d = dur.mean(axis=0)
 print("corr(duration, landmarks) %.2f, corr(duration, factors) %.2f; landmarks min/mean/max %d/%.1f/%d; factors %d/%.1f/%d" % (np.corrcoef(d, L)[0, 1], np.corrcoef(d, M)[0, 1], L.min(), L.mean(), L.max(), M.min(), M.mean(), M.max()))
 order = np.argsort(d)
 print("slowest 5 workgroups:", [(int(i), round(float(d[i]), 1), int(L[i]), int(M[i])) for i in order[-5:]])
+for lo_, hi_ in ((0, 18), (19, 26), (27, 100)):
+    sel_ = (L >= lo_) & (L <= hi_)
+    if sel_.any():
+        print("landmarks %2d..%3d: %3d workgroups, mean duration %.1f us (factors mean %.0f)" % (lo_, hi_, sel_.sum(), d[sel_].mean(), M[sel_].mean()))

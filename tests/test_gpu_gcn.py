@@ -91,7 +91,7 @@ def test_tall_tile_gemm_heights_are_all_exercised():
 TALL_TILE_NODES = (3050, 3301, 3803, 4342, 4799)  # node counts (odd ones too: ragged last row tile) per tile height 96 .. 160
 
 
-@pytest.mark.parametrize("n_graphs,out_dim,with_mask", [(1, 1, False), (7, 1, True), (64, 1, False), (5, 100, True)] +
+@pytest.mark.parametrize("n_graphs,out_dim,with_mask", [(1, 1, False), (7, 1, True), (64, 1, False), (5, 100, True), (9, 3, True), (6, 8, False)] +
                          [(-n, 1, n % 2 == 0) for n in TALL_TILE_NODES])
 def test_gcn_forward_backward_matches_torch_reference(n_graphs, out_dim, with_mask):
     from drl_graph_exploration_amd.networks import gcn_trunk
