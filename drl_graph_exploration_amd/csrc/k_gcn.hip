@@ -842,11 +842,10 @@ __global__ __launch_bounds__(256) void k_gemm(
 // Contract (host): vec_ok() operands and C, x-contiguous A only with 16 RT % 32 == 0.
 // ------------------------------------------------------------------------------------------------
 constexpr int WD_ST = 4;
-constexpr int WD_N = 128;
-template <int RT>
+template <int RT, int NW>  // RT 16-row sub-tiles x NW waves of 16 columns each
 struct WideTile {
-  static constexpr int AI = (RT + 7) / 8;                     // A instructions per wave and stage
-  static constexpr int stage_floats = (RT + 8) * 256;         // A tile, then B tile
+  static constexpr int AI = (RT + NW - 1) / NW;                  // A instructions per wave and stage
+  static constexpr int stage_floats = (RT + NW) * 256;           // A tile, then B tile
   static constexpr int lds_floats = WD_ST * stage_floats + 256;  // + the scratch KB
 };
 
@@ -870,9 +869,9 @@ __device__ __forceinline__ float4 wd_frag(const float *T, int W, int xb, int lan
   return make_float4(p[0], p[W], p[2 * W], p[3 * W]);
 }
 // the partial last K-tile goes through registers with zero fill
-template <bool KC>
+template <bool KC, int NT>
 __device__ __forceinline__ void wd_tail(float *T, const float *P, int ld, int x0, int X, int W, int k0, int kend, int tid) {
-  for (int q = tid; q < 4 * W; q += 512) {
+  for (int q = tid; q < 4 * W; q += NT) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KC) {
       const int x = q >> 2, c = q & 3;
@@ -886,13 +885,13 @@ __device__ __forceinline__ void wd_tail(float *T, const float *P, int ld, int x0
   }
 }
 
-template <bool AKC, bool BKC, int EPI, int RT>
-__global__ __launch_bounds__(512) void k_gemm_wide(int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B,
+template <bool AKC, bool BKC, int EPI, int RT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gemm_wide(int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B,
                                                    int ldb, float *__restrict__ C, int ldc, const float *__restrict__ bias,
                                                    const float *__restrict__ mask, int k_per_split, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float wd_smem[];
-  using WT = WideTile<RT>;
-  constexpr int TM = 16 * RT;
+  using WT = WideTile<RT, NW>;
+  constexpr int TM = 16 * RT, WD_N = 16 * NW;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int tn = slot % tiles_n, tm = (slot / tiles_n) * 8 + xcd;
   if (tm >= tiles_m) return;
@@ -909,12 +908,12 @@ __global__ __launch_bounds__(512) void k_gemm_wide(int M, int N, int K, const fl
   auto dma16 = [](const float *g, unsigned lds) {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(g) : "memory");
   };
-  // this wave's instructions of a stage: A instruction j = wave + 8 i (the scratch KB when j >= RT), B instruction j = wave
+  // this wave's instructions of a stage: A instruction j = wave + NW i (the scratch KB when j >= RT), B instruction j = wave
   const float *ga[WT::AI];
   unsigned la[WT::AI], la_step[WT::AI];
 #pragma unroll
   for (int i = 0; i < WT::AI; ++i) {
-    const int j = wave + 8 * i;
+    const int j = wave + NW * i;
     const bool real = j < RT;
     ga[i] = wd_src<AKC>(A, lda, m0, M, TM, real ? j : 0, lane) + (AKC ? (size_t)kbeg : (size_t)kbeg * lda);
     la[i] = real ? lds0 + j * 1024u : lds0 + WD_ST * stage_bytes;
@@ -995,8 +994,8 @@ __global__ __launch_bounds__(512) void k_gemm_wide(int M, int N, int K, const fl
     __syncthreads();
     const int st = nfull & (WD_ST - 1), k0 = kbeg + 16 * nfull;
     float *As = wd_smem + st * WT::stage_floats;
-    wd_tail<AKC>(As, A, lda, m0, M, TM, k0, kend, tid);
-    wd_tail<BKC>(As + RT * 256, B, ldb, n0, N, WD_N, k0, kend, tid);
+    wd_tail<AKC, 64 * NW>(As, A, lda, m0, M, TM, k0, kend, tid);
+    wd_tail<BKC, 64 * NW>(As + RT * 256, B, ldb, n0, N, WD_N, k0, kend, tid);
     __syncthreads();
     read(fa0, fb0, st);
     multiply(fa0, fb0);
@@ -1355,36 +1354,46 @@ int gemm_wide_mode() {
   return v;
 }
 
-template <bool TA, bool TB, int EPI, int RT>
+template <bool TA, bool TB, int EPI, int RT, int NW = 8>
 void gemm_wide_launch(hipStream_t st, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                       const float *bias, const float *mask, int kps) {
-  const int tiles_m = (M + 16 * RT - 1) / (16 * RT), tiles_n = (N + WD_N - 1) / WD_N;
+  const int tiles_m = (M + 16 * RT - 1) / (16 * RT), tiles_n = (N + 16 * NW - 1) / (16 * NW);
   dim3 grid(tiles_n * ((tiles_m + 7) / 8) * 8, 1, (K + kps - 1) / kps);
-  constexpr int lds = WideTile<RT>::lds_floats * (int)sizeof(float);
+  constexpr int lds = WideTile<RT, NW>::lds_floats * (int)sizeof(float);
   static bool attr_set[32] = {false};
-  const void *fns[] = {reinterpret_cast<const void *>(&k_gemm_wide<!TA, TB, EPI, RT>)};
+  const void *fns[] = {reinterpret_cast<const void *>(&k_gemm_wide<!TA, TB, EPI, RT, NW>)};
   drlgx_ensure_lds_attr(attr_set, fns, 1, lds);
-  hipLaunchKernelGGL((k_gemm_wide<!TA, TB, EPI, RT>), grid, dim3(512), lds, st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps, tiles_m,
-                     tiles_n);
+  hipLaunchKernelGGL((k_gemm_wide<!TA, TB, EPI, RT, NW>), grid, dim3(64 * NW), lds, st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps,
+                     tiles_m, tiles_n);
 }
 
-// tile height (in 16-row sub-tiles) of the tall-tile kernel for an M x N product in S K-slices, 0 = the 64x64 kernels: the
-// product must be large enough to fill the chip with tall tiles, and the height is the one whose tile count wastes least
-// of the last round of 256 CUs (measured order at 4 340 and 17 288 rows: profiles/r04_ab_gemm_tall_tiles.txt)
-int wide_tile_subrows(int M, int N, int S, bool ta) {
+// Tile of an M x N product in S K-slices: rt 16-row sub-tiles x nw waves of 16 columns, or rt = 0 for the 64x64 kernels.
+//  * enough 128-row x 128-column tiles to occupy half the chip: 8 waves, the height whose tile count wastes least of the last
+//    round of 256 CUs (measured order at 4 340 and 17 288 rows: profiles/r04_ab_gemm_tall_tiles.txt);
+//  * else, if the 64x64 tiles would not fit one round of 256 CUs: 4 waves x 64 columns, same rule (the 1 000 - 2 000-node
+//    mini-batches of the DQN loop: 96 x 64 tiles fill the chip once where 64 x 64 ones need a second, thin round);
+//  * else the 64x64 kernels.
+struct WidePick {
+  int rt, nw;
+};
+WidePick wide_pick(int M, int N, int S, bool ta) {
   const int mode = gemm_wide_mode();
-  const int tiles_n = (N + WD_N - 1) / WD_N;
-  if (mode == 0 || (long)((M + 127) / 128) * tiles_n * S < 192) return 0;
-  int best = 0;
-  long best_cost = 0;
-  for (int rt = 6; rt <= 10; ++rt) {
-    if (ta && (rt & 1)) continue;  // x-contiguous A: whole 32-float swizzle blocks
-    if (mode >= 6 && mode <= 10 && !(ta && (mode & 1)) && rt != mode) continue;
-    const long tiles = (long)((M + 16 * rt - 1) / (16 * rt)) * tiles_n * S;
-    const long cost = ((tiles + 255) / 256) * rt;
-    if (!best || cost <= best_cost) best = rt, best_cost = cost;
-  }
-  return best;
+  if (mode == 0) return {0, 0};
+  auto best_rt = [&](int nw) {
+    int best = 0;
+    long best_cost = 0;
+    for (int rt = 6; rt <= (nw == 8 ? 10 : 8); ++rt) {  // (4 waves: one round of 96 / 112 / 128-row tiles covers every size that gets here)
+      if (ta && (rt & 1)) continue;  // x-contiguous A: whole 32-float swizzle blocks
+      if (mode >= 6 && mode <= 10 && !(ta && (mode & 1)) && rt != mode) continue;
+      const long tiles = (long)((M + 16 * rt - 1) / (16 * rt)) * ((N + 16 * nw - 1) / (16 * nw)) * S;
+      const long cost = ((tiles + 255) / 256) * rt;
+      if (!best || cost <= best_cost) best = rt, best_cost = cost;
+    }
+    return best;
+  };
+  if ((long)((M + 127) / 128) * ((N + 127) / 128) * S >= 128) return {best_rt(8), 8};
+  if (!ta && (long)((M + 63) / 64) * ((N + 63) / 64) * S > 256 && (long)((M + 95) / 96) * ((N + 63) / 64) * S >= 128) return {best_rt(4), 4};
+  return {0, 0};
 }
 
 template <bool TA, bool TB, int EPI>
@@ -1392,22 +1401,34 @@ bool gemm_wide(hipStream_t st, int M, int N, int K, const float *A, int lda, con
                const float *mask, int kps) {
   if (!vec_ok(A, lda, TA ? M : K) || !vec_ok(B, ldb, TB ? K : N) || !vec_ok(C, ldc, N)) return false;
   if ((EPI == 1 && (!vec_ok(bias, 4, 4) || (mask && !vec_ok(mask, ldc, N)))) || (TA ? M : K) < 4 || (TB ? K : N) < 4 || kps < 16) return false;
-  const int best = wide_tile_subrows(M, N, (K + kps - 1) / kps, TA);
-#define DRLGX_WIDE(RT)                                                                          \
-  case RT:                                                                                      \
-    gemm_wide_launch<TA, TB, EPI, RT>(st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps); \
+  const WidePick pick = wide_pick(M, N, (K + kps - 1) / kps, TA);
+#define DRLGX_WIDE(RT, NW)                                                                          \
+  case RT:                                                                                          \
+    gemm_wide_launch<TA, TB, EPI, RT, NW>(st, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps); \
     return true
-  switch (best) {
-    DRLGX_WIDE(6);
-    DRLGX_WIDE(8);
-    DRLGX_WIDE(10);
-    default: break;
+  if (pick.nw == 8) {
+    switch (pick.rt) {
+      DRLGX_WIDE(6, 8);
+      DRLGX_WIDE(8, 8);
+      DRLGX_WIDE(10, 8);
+      default: break;
+    }
+    if constexpr (!TA) {
+      switch (pick.rt) {
+        DRLGX_WIDE(7, 8);
+        DRLGX_WIDE(9, 8);
+        default: break;
+      }
+    }
   }
   if constexpr (!TA) {
-    switch (best) {
-      DRLGX_WIDE(7);
-      DRLGX_WIDE(9);
-      default: break;
+    if (pick.nw == 4) {
+      switch (pick.rt) {
+        DRLGX_WIDE(6, 4);
+        DRLGX_WIDE(7, 4);
+        DRLGX_WIDE(8, 4);
+        default: break;
+      }
     }
   }
 #undef DRLGX_WIDE
@@ -1499,8 +1520,8 @@ bool build_graph_batched(hipStream_t st, const GcnWs &w, int N, int E, const int
 extern "C" {
 
 int drlgx_debug_gemm_tile_rows(int m, int n, int k_slices, int transpose_a) {
-  const int rt = wide_tile_subrows(m, n, k_slices, transpose_a != 0);
-  return rt ? 16 * rt : 64;
+  const WidePick p = wide_pick(m, n, k_slices, transpose_a != 0);
+  return p.rt ? 1000 * (16 * p.nw) + 16 * p.rt : 64064;
 }
 
 size_t drlgx_gcn_workspace_bytes(int n_nodes, int n_edges, int hidden, int out_dim) {

@@ -264,9 +264,10 @@ int drlgx_timing_read_host(drlgx_engine *e, double ms[DRLGX_N_TIMERS], int64_t l
  * of every workgroup of the last k_step launch (scripts/phase_profile*.py). */
 int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t *out /* 64 values; 1024 with arm & 4 (read from the buffer's start) */);
 
-/* Development aid: the tile height (rows of C per workgroup) the GCN's fp32 GEMM dispatcher picks for an m x n product computed
- * in k_slices K-slices (transpose_a: A is stored [K x M], the weight-gradient products): 64 = the 64x64 kernels, 96..160 = the
- * tall-tile kernel k_gemm_wide (csrc/k_gcn.hip).  The numerics tests use it to prove that they cover every compiled height. */
+/* Development aid: the tile of C per workgroup the GCN's fp32 GEMM dispatcher picks for an m x n product computed in k_slices
+ * K-slices (transpose_a: A is stored [K x M], the weight-gradient products), as 1000 * columns + rows: 64064 = the 64x64
+ * kernels, 128096..128160 / 64096..64160 = the tall-tile kernel k_gemm_wide with 8 / 4 waves (csrc/k_gcn.hip).  The numerics
+ * tests use it to prove that they cover every compiled tile. */
 int drlgx_debug_gemm_tile_rows(int m, int n, int k_slices, int transpose_a);
 
 /* The incremental belief update (csrc/k_inc.hip): between relinearisations of the iSAM2 policy (SLAM2D.cpp:10-12: every

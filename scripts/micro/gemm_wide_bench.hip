@@ -7,19 +7,27 @@
 #include <vector>
 
 namespace {
+// rt: 0 = the 64x64 kernel, 6..10 = 8-wave tall tiles (rt x 16 rows x 128 columns), 106..110 = 4-wave ones (x 64 columns)
 template <bool TA, bool TB, int EPI>
 void run_rt(int rt, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias, const float *mask, int kps) {
+#define ARGS 0, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps
   switch (rt) {
-    case 0: gemm_tile<TA, TB, EPI, 1, 1>(0, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps); break;
-    case 6: gemm_wide_launch<TA, TB, EPI, 6>(0, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps); break;
-    case 8: gemm_wide_launch<TA, TB, EPI, 8>(0, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps); break;
-    case 10: gemm_wide_launch<TA, TB, EPI, 10>(0, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps); break;
+    case 0: gemm_tile<TA, TB, EPI, 1, 1>(ARGS); break;
+    case 6: gemm_wide_launch<TA, TB, EPI, 6, 8>(ARGS); break;
+    case 8: gemm_wide_launch<TA, TB, EPI, 8, 8>(ARGS); break;
+    case 10: gemm_wide_launch<TA, TB, EPI, 10, 8>(ARGS); break;
+    case 106: gemm_wide_launch<TA, TB, EPI, 6, 4>(ARGS); break;
+    case 108: gemm_wide_launch<TA, TB, EPI, 8, 4>(ARGS); break;
+    case 110: gemm_wide_launch<TA, TB, EPI, 10, 4>(ARGS); break;
     default:
       if constexpr (!TA) {
-        if (rt == 7) gemm_wide_launch<TA, TB, EPI, 7>(0, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps);
-        if (rt == 9) gemm_wide_launch<TA, TB, EPI, 9>(0, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, kps);
+        if (rt == 7) gemm_wide_launch<TA, TB, EPI, 7, 8>(ARGS);
+        if (rt == 9) gemm_wide_launch<TA, TB, EPI, 9, 8>(ARGS);
+        if (rt == 107) gemm_wide_launch<TA, TB, EPI, 7, 4>(ARGS);
+        if (rt == 109) gemm_wide_launch<TA, TB, EPI, 9, 4>(ARGS);
       }
   }
+#undef ARGS
 }
 }  // namespace
 
@@ -43,14 +51,14 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float *part;
   hipMalloc(&part, (size_t)8 * hidden * hidden * 4);
-  for (int M : {4340, 4213, 17288}) {
+  for (int M : {1300, 2100, 2880, 4340, 17288}) {
     for (int shape = 0; shape < 3; ++shape) {  // 0: NN + epilogue (forward), 1: NT (T1 = dZ2 W2^T), 2: TN split-K (dW2 = AH1^T dZ2)
       const int gk = shape == 2 ? M : hidden;
       const int splits = shape == 2 ? 4 : 1;
       const int kps = ((gk + splits - 1) / splits + 15) / 16 * 16, S = (gk + kps - 1) / kps;
       const size_t n = (size_t)(shape == 2 ? hidden : M) * hidden;
       std::vector<float> c0(n), c1(n);
-      for (int rt : {0, 6, 7, 8, 9, 10}) {
+      for (int rt : {0, 6, 7, 8, 9, 10, 106, 107, 108, 109, 110}) {
         if (shape == 2 && (rt & 1)) continue;
         float *Cx = rt == 0 ? C0 : C1;
         hipMemset(Cx, 0xff, n * 4);
@@ -72,8 +80,8 @@ int main() {
           hipMemcpy(c1.data(), C1, n * 4, hipMemcpyDeviceToHost);
           for (size_t i = 0; i < n; ++i) { md = std::max(md, fabs((double)c0[i] - c1[i])); mx = std::max(mx, fabs((double)c0[i])); }
         }
-        printf("shape %d M=%6d rows/tile %3d (splits %d): %8.1f us  %6.1f TFLOP/s   max |diff to 64x64| %.3e (max |value| %.3e)  %s\n", shape, M,
-               rt ? 16 * rt : 64, S, ms * 1e3, 2.0 * M * hidden * hidden / ms * 1e-9, md, mx, hipGetErrorString(hipGetLastError()));
+        printf("shape %d M=%6d tile %3d x %3d (splits %d): %8.1f us  %6.1f TFLOP/s   max |diff to 64x64| %.3e (max |value| %.3e)  %s\n", shape, M,
+               rt ? 16 * (rt % 100) : 64, rt == 0 ? 64 : rt > 100 ? 64 : 128, S, ms * 1e3, 2.0 * M * hidden * hidden / ms * 1e-9, md, mx, hipGetErrorString(hipGetLastError()));
       }
     }
   }

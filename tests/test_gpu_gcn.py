@@ -77,18 +77,20 @@ def rel_err(a, b):
 
 
 def test_tall_tile_gemm_heights_are_all_exercised():
-    """The batches of the parametrised test below that are large enough for the tall-tile GEMM (k_gemm_wide) make the
-    dispatcher pick every compiled tile height for the forward / dZ2 W2^T products, and the 128-row one for the split-K
-    weight gradient (asked of the library itself, so the test cannot drift from the dispatch rule)."""
+    """The batches of the parametrised test below make the dispatcher pick every compiled tile of the tall-tile GEMM
+    (k_gemm_wide) for the forward / dZ2 W2^T products - five heights of the 8-wave kernel (128 columns), three of the 4-wave
+    one (64 columns) - and the 128 x 128 one for the split-K weight gradient (asked of the library itself, as 1000 * columns +
+    rows, so the test cannot drift from the dispatch rule)."""
     from drl_graph_exploration_amd import _lib
     L = _lib.lib()
     picked = {L.drlgx_debug_gemm_tile_rows(n, 1000, 1, 0) for n in TALL_TILE_NODES}
-    assert picked == {96, 112, 128, 144, 160}, picked
-    assert {L.drlgx_debug_gemm_tile_rows(1000, 1000, 4, 1) for n in TALL_TILE_NODES} == {128}
-    assert L.drlgx_debug_gemm_tile_rows(2880, 1000, 1, 0) == 64  # (the 64-graph case below stays on the 64x64 kernels)
+    assert picked == {128096, 128112, 128128, 128144, 128160, 64096, 64112, 64128}, picked
+    assert L.drlgx_debug_gemm_tile_rows(1000, 1000, 4, 1) == 128128
+    assert L.drlgx_debug_gemm_tile_rows(900, 1000, 1, 0) == 64064  # (small batches stay on the 64x64 kernels)
 
 
-TALL_TILE_NODES = (3050, 3301, 3803, 4342, 4799)  # node counts (odd ones too: ragged last row tile) per tile height 96 .. 160
+# node counts (odd ones too: ragged last row tile) per tile: 96 .. 128 x 64 (4 waves), 96 .. 160 x 128 (8 waves)
+TALL_TILE_NODES = (1101, 1700, 1903, 3050, 3301, 3803, 4342, 4799)
 
 
 @pytest.mark.parametrize("n_graphs,out_dim,with_mask", [(1, 1, False), (7, 1, True), (64, 1, False), (5, 100, True), (9, 3, True), (6, 8, False)] +
