@@ -285,6 +285,32 @@ def _bucket_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_gradient_bucket_rebinds_gradients_to_its_slices():
+    """GradientBucket.attach keeps every parameter's .grad bound to ITS slice of the flat tensor (the slices are built once):
+    untouched when it still is, re-bound after zero_grad(set_to_none=True), and a gradient tensor someone else assigned is
+    copied into the slice first; slices start on 256-byte boundaries."""
+    sys.path.insert(0, ROOT)
+    from drl_graph_exploration_amd.optim import GradientBucket
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    params = list(m.parameters())
+    bucket = GradientBucket(params)
+    views = [p.grad for p in params]
+    assert all((v.data_ptr() - bucket.flat.data_ptr()) % 256 == 0 for v in views)  # (the device allocation itself is 256-byte aligned)
+    bucket.attach()
+    assert all(p.grad is v for p, v in zip(params, views))  # nothing rebuilt, nothing rebound
+    params[0].grad = None
+    foreign = torch.full_like(params[1], 3.5)
+    params[1].grad = foreign
+    bucket.attach()
+    assert all(p.grad is v for p, v in zip(params, views))
+    assert torch.equal(views[1], foreign)  # the foreign gradient's values moved into the bucket
+    m(torch.randn(4, 5)).sum().backward()  # autograd accumulates into the slices
+    off = bucket._offsets
+    for p, o in zip(params, off):
+        assert torch.equal(bucket.flat[o:o + p.numel()].view_as(p), p.grad)
+
+
 def test_gradient_bucket_three_updates_gloo_world_size_2():
     """The trainer's exchange (optim.GradientBucket: gradients as views of ONE flat tensor, asynchronous in-place all-reduce,
     1 / world folded into the update) over three updates on two ranks: the replicas stay bit-identical, and equal a single
