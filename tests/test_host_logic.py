@@ -285,6 +285,33 @@ def _bucket_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_dropout_mask_and_pool_descriptors_host_side():
+    """networks._dropout_mask: None at p = 0, zeros at p = 1, else 0 or 1 / (1 - p) drawn by F.dropout on a cached tensor of
+    ones that grows with the request.  ReplayPool.put / PoolRef / descriptors: the collation descriptor of a pooled graph =
+    (node start in the pool, node count, edge start in the pool, edge count, first node id inside its export)."""
+    sys.path.insert(0, ROOT)
+    import drl_graph_exploration_amd.networks as NW
+    dev = torch.device("cpu")
+    assert NW._dropout_mask(10, 8, 0.0, dev) is None
+    assert float(NW._dropout_mask(10, 8, 1.0, dev).abs().sum()) == 0.0
+    torch.manual_seed(1)
+    m = NW._dropout_mask(2000, 8, 0.5, dev)
+    assert m.shape == (2000, 8) and set(m.unique().tolist()) == {0.0, 2.0} and abs(float(m.mean()) - 1.0) < 0.05
+    assert NW._dropout_mask(5000, 8, 0.5, dev).shape == (5000, 8) and NW._ONES[(str(dev), 8)].shape[0] >= 5000
+    pool = NW.ReplayPool(dev, 3, 100, 400)
+    node_off, edge_off = np.array([0, 4, 9, 15]), np.array([0, 6, 14, 30])
+    g = {"x": torch.randn(15, 5), "edge_index": torch.randint(0, 15, (2, 30)), "edge_attr": torch.rand(30), "node_off_h": node_off,
+         "edge_off_h": edge_off}
+    pool.put(g)
+    slot = pool.put(g)  # the second slot: pool offsets are not zero
+    refs = [NW.PoolRef(pool, slot, e) for e in (2, 0)]
+    d, n_nodes, n_edges = NW.ReplayPool.descriptors(refs)
+    want = np.array([[slot * 100 + 9, 6, slot * 400 + 14, 16, 9], [slot * 100 + 0, 4, slot * 400 + 0, 6, 0]]).T
+    assert d.dtype == np.int64 and np.array_equal(d, want) and (n_nodes, n_edges) == (10, 22)
+    assert (refs[0].n0, refs[0].nn, refs[0].e0, refs[0].ne, refs[0].loc) == (slot * 100 + 9, 6, slot * 400 + 14, 16, 9)
+    assert torch.equal(refs[0].x, g["x"][9:15]) and refs[0].num_nodes == 6
+
+
 def test_gradient_bucket_rebinds_gradients_to_its_slices():
     """GradientBucket.attach keeps every parameter's .grad bound to ITS slice of the flat tensor (the slices are built once):
     untouched when it still is, re-bound after zero_grad(set_to_none=True), and a gradient tensor someone else assigned is
