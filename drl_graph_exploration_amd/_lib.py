@@ -30,7 +30,7 @@ SYMBOLS = [
     "drlgx_get_poses_host", "drlgx_get_landmarks_host", "drlgx_get_cov_traces_host", "drlgx_vm_shape",
     "drlgx_get_virtual_map_host", "drlgx_get_ground_truth_host", "drlgx_get_adjacency_host", "drlgx_get_factors_host",
     "drlgx_get_landmark_order_host", "drlgx_snapshot", "drlgx_restore", "drlgx_timing_enable",
-    "drlgx_timing_read_host", "drlgx_debug_phase_clocks_host", "drlgx_debug_gemm_tile_rows", "drlgx_inc_stats_host", "drlgx_gcn_workspace_bytes", "drlgx_gcn_forward", "drlgx_gcn_forward_batched", "drlgx_gcn_backward",
+    "drlgx_timing_read_host", "drlgx_debug_phase_clocks_host", "drlgx_debug_gemm_tile_rows", "drlgx_debug_map_form", "drlgx_inc_stats_host", "drlgx_gcn_workspace_bytes", "drlgx_gcn_forward", "drlgx_gcn_forward_batched", "drlgx_gcn_backward",
     "drlgx_replay_collate", "drlgx_replay_collate_pair", "drlgx_dqn_targets", "drlgx_dqn_loss_grad", "drlgx_adam_step", "drlgx_adam_step_scaled", "drlgx_normalise_rewards",
     "drlgx_segment_softmax", "drlgx_segment_softmax_backward", "drlgx_mean_pool", "drlgx_mean_pool_backward",
 ]
@@ -97,6 +97,7 @@ def lib():
     L.drlgx_timing_read_host.argtypes = [vp, dp, C.POINTER(C.c_int64)]
     L.drlgx_debug_phase_clocks_host.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     L.drlgx_debug_gemm_tile_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.drlgx_debug_map_form.argtypes = [C.c_int]
     L.drlgx_inc_stats_host.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
     L.drlgx_gcn_workspace_bytes.restype = C.c_size_t
     L.drlgx_gcn_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]

@@ -386,19 +386,38 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
     TRY(dev_alloc(e, &S.slam_iws, S.slam_iws_stride * (size_t)S.n_inst));
   }
   // Covariance panel of the incremental belief update (k_inc.hip): on unless DRLGX_INCREMENTAL=0 or the panels of all
-  // instances would not fit the budget (DRLGX_INC_MAX_GB, 32 GB by default) - then every update is a full solve.
+  // instances would not fit the budget (DRLGX_INC_MAX_GB; default: 60 % of the memory that is free on the device now) or the
+  // allocation fails - then every update is a full solve (the engine works either way; said once on stderr).
   {
     const char *v = getenv("DRLGX_INCREMENTAL");
     const char *g = getenv("DRLGX_INC_MAX_GB");
-    const double max_gb = g ? atof(g) : 32.0;
+    size_t free_b = 0, total_b = 0;
+    double max_gb = 32.0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) max_gb = 0.6 * (double)free_b / 1073741824.0;
+    if (g) max_gb = atof(g);
     S.jc_ld = (3 + 2 * S.L_max + 31) & ~31;  // whole pairs of 16-column tiles, rows on 256-byte boundaries (k_inc.hip, B3)
     S.jc_stride = (size_t)(3 * S.P_max + 2 * S.L_max + 16) * (size_t)S.jc_ld;  // (+ 16: the row tiles are written whole)
     const double gb = (double)S.jc_stride * 8.0 * (double)S.n_inst / 1073741824.0;
-    if (!(v && v[0] == '0') && gb <= max_gb) {
-      TRY(dev_alloc(e, &S.jc, S.jc_stride * (size_t)S.n_inst));
-      TRY(dev_alloc(e, &S.jd, (size_t)S.P_max * 6 * (size_t)S.n_inst));
-      TRY(dev_alloc(e, &S.jc_meta, (size_t)4 * (size_t)S.n_inst));
-      TRY(dev_alloc(e, &S.inc_stats, 2));
+    if (!(v && v[0] == '0')) {
+      const size_t n_before = e->allocs.size();
+      bool ok = gb <= max_gb;
+      if (ok) {
+        ok = dev_alloc(e, &S.jc, S.jc_stride * (size_t)S.n_inst) == DRLGX_OK && dev_alloc(e, &S.jd, (size_t)S.P_max * 6 * (size_t)S.n_inst) == DRLGX_OK &&
+             dev_alloc(e, &S.jc_meta, (size_t)4 * (size_t)S.n_inst) == DRLGX_OK && dev_alloc(e, &S.inc_stats, 2) == DRLGX_OK;
+      }
+      if (!ok) {
+        (void)hipGetLastError();  // a failed hipMalloc is not this engine's error
+        while (e->allocs.size() > n_before) {
+          hipFree(e->allocs.back());
+          e->allocs.pop_back();
+        }
+        S.jc = nullptr;
+        S.jd = nullptr;
+        S.jc_meta = nullptr;
+        S.inc_stats = nullptr;
+        e->last_error.clear();
+        fprintf(stderr, "drlgx: covariance panels (%.1f GB) not allocated (budget %.1f GB): every belief update is a full solve\n", gb, max_gb);
+      }
     }
   }
   TRY(dev_alloc(e, &S.status, 1));

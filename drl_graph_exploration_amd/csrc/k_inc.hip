@@ -26,7 +26,8 @@
 // Who may take this path is decided per instance and per update (inc_precheck / inc_body's own checks): a valid panel, exactly
 // one new pose since it was left, every new factor on that pose, no landmark twice, and no relinearisation due (update count
 // % 10 == 0 with some |delta| >= 0.1).  Everything else - and every update that relinearises - runs the full solve, which
-// leaves a fresh panel behind (panel_from_dense); the pose-chain solver for long trajectories invalidates it.
+// leaves a fresh panel behind: panel_from_dense after the dense solver (<= 42 poses), the pose-chain solver of longer
+// trajectories through its own three extra right-hand sides (k_slam_arrow.hip: mk_panel).  k_reset and k_rebase invalidate it.
 
 // Contraction is decided in the front end here (a * b + c written in one expression becomes an fma, nothing else does): with
 // contract(fast) the back end fuses differently in the fused step kernel and in the stage kernel, and the two must agree bit
@@ -759,7 +760,7 @@ __device__ __forceinline__ void panel_from_dense(const DrlgxState &S, const Slam
   }
 }
 
-// an update by a solver that leaves no panel (the pose-chain solver of long trajectories)
+// an update by a solver call that leaves no panel (estimates-only solves; the pose-chain solver builds one when S.jc is set)
 __device__ __forceinline__ void panel_invalidate(const DrlgxState &S, int inst, int tid) {
   if (S.jc && tid == 0) {
     inc_meta(S, inst)[0] = 0;

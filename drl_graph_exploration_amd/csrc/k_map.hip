@@ -735,6 +735,22 @@ static size_t map_lds_bytes_compact(const DrlgxState &S, int pcap, int *chunk_ou
   return b;
 }
 
+// Which form of the stand-alone map kernel runs: DRLGX_MAP_COMPACT read ONCE (this is the host side of every map launch),
+// overridden by drlgx_debug_map_form (the A/B of the parity test).
+static int g_map_form = -2;
+static int map_form() {
+  if (g_map_form == -2) {
+    const char *fv = getenv("DRLGX_MAP_COMPACT");
+    g_map_form = fv ? atoi(fv) : -1;
+  }
+  return g_map_form;
+}
+extern "C" int drlgx_debug_map_form(int form) {
+  const int was = map_form();
+  g_map_form = form;
+  return was;
+}
+
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
   // sel.act_idx == -2 encodes "reductions only" (used after reset)
   int rebuild = 1;
@@ -749,8 +765,7 @@ void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
   drlgx_ensure_lds_attr(attr_set, fns, 2, 160 * 1024);
   // the form of which two workgroups fit a CU, for launches with more instances than CUs (DRLGX_MAP_COMPACT=1)
   static int n_cu = 0;
-  const char *fv = getenv("DRLGX_MAP_COMPACT");
-  const int force = fv ? atoi(fv) : -1;
+  const int force = map_form();
   if (n_cu == 0) {
     hipDeviceProp_t prop;
     int dev = 0;

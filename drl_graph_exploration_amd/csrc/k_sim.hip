@@ -251,6 +251,9 @@ __global__ __launch_bounds__(64) void k_reset(DrlgxState S, int first_measure, c
     cnt[C_NEWP] = 0;
     cnt[C_NEWL] = 0;
     cnt[C_FLAG] = 0;
+    // a new episode never continues the previous one's covariance panel (k_inc.hip): the staged reset runs no solve that
+    // would overwrite it, and (valid, P = 1) of an old episode would pass inc_precheck at this episode's second pose
+    if (S.jc_meta) S.jc_meta[(size_t)inst * 4] = 0;
     // SLAM2D::addPrior (SLAM2D.cpp:44-57)
     double *pr = S.prior + (size_t)inst * DRLGX_PRIOR_STRIDE;
     pr[0] = c.veh.x; pr[1] = c.veh.y; pr[2] = c.veh.c; pr[3] = c.veh.s;

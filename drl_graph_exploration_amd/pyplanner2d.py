@@ -98,6 +98,11 @@ class _Map(object):
     def get_trajectory_size(self):
         return self._o.engine.counts(0)["poses"]
 
+    @property
+    def distance(self):
+        """Environment::getDistance (Simulator2D.cpp:244-250)."""
+        return ss2d.trajectory_distance([v.pose for v in self.iter_trajectory()])
+
     def iter_landmarks(self):
         if self._truth:
             _, lms = self._o.engine.ground_truth(0)
@@ -241,7 +246,8 @@ class SS2D(object):
 
     @property
     def distance(self):
-        return None
+        """pyss2d.py:216-218: the travelled distance of the estimated trajectory."""
+        return self._slam.map.distance
 
 
 class EMExplorer(SS2D):

@@ -11,9 +11,12 @@ ONE one-environment engine: every call of the reference's call sequence maps ont
     slam.add_measurement(key, m) ... slam.optimize()      -> drlgx_stage_add_measurements + drlgx_stage_optimize
     vm.update_probability(slam, sensor) / update_information(map, sensor) -> drlgx_stage_update_map
 
-The objects of one simulation find each other the way the reference's script wires them: a `Simulator2D` opens a session,
-the `SLAM2D` / `VirtualMap` constructed next join it, and the engine is created at `SLAM2D.add_prior` (the first call that
-needs every parameter).  The batched product path does not go through these classes (`VecExplorationEnv`); they exist so
+The objects of one simulation find each other through the values the reference's script passes between them: the
+`Pose2` of `Simulator2D.vehicle` carries its simulation into `SLAM2D.add_prior`, the `ControlState` of `Simulator2D.move`
+into `add_odometry`, `slam` / `sensor_model` into `VirtualMap.update_*`; every such call checks that both sides belong to
+ONE simulation and raises otherwise.  A `SLAM2D` / `VirtualMap` constructed without `simulator=` joins the most recently
+constructed `Simulator2D` that still lacks one (the construction order of pyss2d.py:105-108); a second one for the same
+simulator raises.  The engine is created at `SLAM2D.add_prior` (the first call that needs every parameter).  The batched product path does not go through these classes (`VecExplorationEnv`); they exist so
 that code written against the reference's module keeps working, one environment at a time.  No CPU path: creating the
 engine without a HIP device raises.
 """
@@ -154,17 +157,39 @@ class Measurement(object):
         return Point2(origin._c * q.x - origin._s * q.y + origin.x, origin._s * q.x + origin._c * q.y + origin.y)
 
 
+def trajectory_distance(poses, angle_weight=0.5):
+    d = 0.0
+    for a, b in zip(poses[:-1], poses[1:]):
+        dx, dy = b.x - a.x, b.y - a.y
+        bearing = math.atan2(-a._s * dx + a._c * dy, a._c * dx + a._s * dy)  # Pose2::bearing(Pose2).theta()
+        d += math.sqrt(math.hypot(dx, dy) ** 2 + (bearing * angle_weight) ** 2)
+    return d
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # classes with behaviour (engine-backed)
 # ------------------------------------------------------------------------------------------------------------------
 class _Session(object):
     """The objects of one simulation + their engine (created lazily at SLAM2D.add_prior)."""
-    current = None
+    _latest = None  # the most recently constructed Simulator2D's session: only a DEFAULT for `simulator=None`
 
     def __init__(self):
         self.sim = self.slam = self.vm = self.engine = None
         self.planner_params = None
         self.max_poses = 256
+
+    @staticmethod
+    def join(role, obj, simulator):
+        """Attach `obj` as the `role` ('slam' / 'vm') of `simulator`'s session (default: the latest simulator).  One object
+        per role: a second one raises instead of silently re-wiring another simulation's parts."""
+        ses = simulator._ses if simulator is not None else _Session._latest
+        if ses is None:
+            raise RuntimeError("construct a Simulator2D first (or pass simulator=...)")
+        if getattr(ses, role) is not None:
+            raise RuntimeError("this Simulator2D already has its %s: simulations constructed interleaved must be wired "
+                               "explicitly, %s(..., simulator=sim)" % (role, type(obj).__name__))
+        setattr(ses, role, obj)
+        return ses
 
     def require_engine(self):
         if self.engine is None:
@@ -240,7 +265,9 @@ class Environment(object):
 
     @property
     def distance(self):
-        return None
+        """Environment::getDistance (Simulator2D.cpp:244-250): path length of the trajectory with the heading term of
+        `sqDistanceBetweenPoses(a, b, 0.5)` (Distance.cpp:5-9: range^2 + (0.5 * bearing of b seen from a)^2)."""
+        return trajectory_distance([v.pose for v in self.iter_trajectory()])
 
     def get_landmark_size(self):
         e = self._ses.require_engine()
@@ -291,7 +318,7 @@ class Simulator2D(object):
     """src/SS2D.cpp:173-187.  `Simulator2D(sensor_params, control_params[, seed])`; opens a new simulation session."""
 
     def __init__(self, sensor_params, control_params, seed=0, device=0):
-        self._ses = _Session.current = _Session()
+        self._ses = _Session._latest = _Session()
         self._ses.sim = self
         self._sensor_params, self._control_params, self._seed, self._device = sensor_params, control_params, int(seed), device
         self._start, self._env_params, self._num_landmarks = Pose2(), None, 0
@@ -314,20 +341,23 @@ class Simulator2D(object):
 
     @property
     def vehicle(self):
-        if self._ses.engine is None:
-            return self._start
-        return Pose2(*self._ses.engine.ground_truth(0)[0])
+        p = self._start if self._ses.engine is None else Pose2(*self._ses.engine.ground_truth(0)[0])
+        p._session = self._ses  # (carries the simulation into SLAM2D.add_prior)
+        return p
 
-    def move(self, odom, core=True):
-        """Simulator2D::move (Simulator2D.cpp:491-503) -> (collision flag, ControlState).  The SLAM side of the same step
+    def move(self, odom, ignore_safety=True):
+        """Simulator2D::move(odom, ignore_safety) (Simulator2D.cpp:491-503) -> (True = the move was applied, ControlState);
+        the reference returns False only when `checkSafety` rejects the new pose, which needs obstacles (none on this
+        path: SURVEY.md section 8, `safe_distance` inert).  The SLAM side of the same step
         (`SLAM2D.add_odometry(control_state)`) is part of the same staged call."""
         import torch
         e = self._ses.require_engine()
         e.stage_move(torch.tensor([[odom.x, odom.y, odom.theta]], dtype=torch.float64, device=e.device))
         cp = self._control_params
         cs = SimpleControlModelState(self.vehicle, odom, (cp.translation_noise, cp.translation_noise, cp.rotation_noise))
+        cs._session = self._ses
         self._ses.slam._pending_odometry = cs
-        return False, cs
+        return True, cs
 
     def measure(self):
         """Simulator2D::measure (Simulator2D.cpp:505-527): [(key, Measurement)] of the landmarks that pass the gates."""
@@ -346,11 +376,8 @@ class Simulator2D(object):
 class SLAM2D(object):
     """src/SS2D.cpp:189-208 over the engine's factor lists and k_slam."""
 
-    def __init__(self, map_params):
-        self._ses = _Session.current
-        if self._ses is None or self._ses.slam is not None:
-            raise RuntimeError("construct a Simulator2D first: SLAM2D joins the simulation it opened")
-        self._ses.slam = self
+    def __init__(self, map_params, simulator=None):
+        self._ses = _Session.join("slam", self, simulator)
         self._map_params = map_params
         self._pending, self._pending_odometry = [], None
         self.map = Environment(self._ses, False, map_params)
@@ -359,10 +386,14 @@ class SLAM2D(object):
         """SLAM2D::addPrior(VehicleBeliefState) (SLAM2D.cpp:44-57); creates the engine (every parameter is known now)."""
         if self._ses.engine is not None:
             raise RuntimeError("add_prior: the prior is added once, at step 0")
+        if getattr(state.pose, "_session", self._ses) is not self._ses:
+            raise RuntimeError("add_prior: the prior pose comes from another simulation's Simulator2D.vehicle")
         self._ses.materialise(state)
 
     def add_odometry(self, control_state):
         """SLAM2D::addOdometry (SLAM2D.cpp:70-89): appended by the staged move that produced `control_state`."""
+        if getattr(control_state, "_session", self._ses) is not self._ses:
+            raise RuntimeError("add_odometry: the ControlState comes from another simulation's Simulator2D.move")
         if control_state is not self._pending_odometry:
             raise ValueError("add_odometry takes the ControlState of the Simulator2D.move that preceded it")
         self._pending_odometry = None
@@ -435,12 +466,15 @@ class VirtualLandmark(object):
 class VirtualMap(object):
     """src/SS2D.cpp:217-239 over the engine's virtual-map planes and k_map."""
 
-    def __init__(self, parameter, seed=0):
-        self._ses = _Session.current
-        if self._ses is None or self._ses.vm is not None:
-            raise RuntimeError("construct a Simulator2D first: VirtualMap joins the simulation it opened")
-        self._ses.vm = self
+    def __init__(self, parameter, seed=0, simulator=None):
+        self._ses = _Session.join("vm", self, simulator)
         self._params, self._fresh = parameter, False
+
+    def _same_simulation(self, *others):
+        for o in others:
+            ses = getattr(o, "_ses", None) or getattr(o, "_session", None)
+            if ses is not None and ses is not self._ses:
+                raise RuntimeError("VirtualMap.update_*: the argument belongs to another simulation")
 
     def _rebuild(self):
         if not self._fresh:
@@ -451,10 +485,12 @@ class VirtualMap(object):
         """VirtualMap::updateProbability(slam, sensor) (VirtualMap.cpp:61-84).  The device rebuilds occupancy and
         information together (both are functions of the SLAM state only): the rebuild runs at the first of the two
         update calls after an optimise, the second one finds its result in place."""
+        self._same_simulation(slam, sensor_model)
         self._rebuild()
 
     def update_information(self, map_, sensor_model):
         """VirtualMap::updateInformation(map, sensor) (VirtualMap.cpp:256-271)."""
+        self._same_simulation(map_, sensor_model)
         self._rebuild()
 
     def get_parameter(self):

@@ -687,7 +687,7 @@ def test_incremental_update_equals_the_full_solve_across_relinearisations(monkey
     ref.close()
 
 
-def test_compact_map_kernel_equals_the_resident_one(monkeypatch):
+def test_compact_map_kernel_equals_the_resident_one():
     """The stand-alone map kernel has a second form for launches with more instances than CUs (csrc/k_map.hip, k_map_c: <= 128
     VGPRs, <= 80 KB of LDS - compact stage, one mask per cell - so that two workgroups share a CU).  Same arithmetic in the same
     order: virtual map, traces and the utility sums must be bit-equal to the one-workgroup-per-CU kernel, step after step."""
@@ -701,12 +701,13 @@ def test_compact_map_kernel_equals_the_resident_one(monkeypatch):
         e.reset(np.arange(n), np.arange(n), starts=starts)
     for s, act in enumerate(SCRIPT + [(2, 0, 0), (0, 0, 0.9), (2, 0, 0)] * 5):
         odom = torch.tensor([act] * n, dtype=torch.float64, device=a.device)
-        monkeypatch.setenv("DRLGX_MAP_COMPACT", "0")
+        was = a.L.drlgx_debug_map_form(0)
         a.step(odom)
         a.synchronize()
-        monkeypatch.setenv("DRLGX_MAP_COMPACT", "1")
+        a.L.drlgx_debug_map_form(1)
         b.step(odom)
         b.synchronize()
+        a.L.drlgx_debug_map_form(was)
         assert a.status() == 0 and b.status() == 0
         for i in range(n):
             pa, ia, ta, ua = a.virtual_map(i)
@@ -718,6 +719,100 @@ def test_compact_map_kernel_equals_the_resident_one(monkeypatch):
         np.testing.assert_array_equal(a.utility().cpu().numpy(), b.utility().cpu().numpy())
         np.testing.assert_array_equal(a.uncertainty_em(1).cpu().numpy(), b.uncertainty_em(1).cpu().numpy())
         np.testing.assert_array_equal(a.explored().cpu().numpy(), b.explored().cpu().numpy())
-    monkeypatch.delenv("DRLGX_MAP_COMPACT")
     a.close()
     b.close()
+
+
+def _staged_episode(e, seed, start, n_moves):
+    """reset; measure + add at pose 0 WITHOUT an optimise there; then moves, each followed by the step's two measure calls,
+    add and optimise (the staged C ABI, include/drlgx.h drlgx_stage_*)."""
+    e.stage_reset([0], [seed], np.array([start]))
+    k, br, c = e.stage_measure()
+    e.stage_add_measurements(k, br, c)
+    for _ in range(n_moves):
+        e.stage_move(torch.tensor([[1.0, 1.0, math.pi / 2]], dtype=torch.float64, device=e.device))
+        e.stage_measure()
+        k, br, c = e.stage_measure()
+        e.stage_add_measurements(k, br, c)
+        e.stage_optimize()
+    e.check_status()
+
+
+def test_staged_reset_never_continues_the_previous_episodes_covariance_panel():
+    """k_reset invalidates the incremental path's covariance panel (csrc/k_sim.hip): a staged reset runs no solve, so an
+    episode whose last panel was left at one pose must not pass `inc_precheck` at the next episode's second pose.  The
+    re-used engine must give, bit for bit, what a fresh engine gives for the second episode, by a FULL solve."""
+    from drl_graph_exploration_amd import default_config
+    from drl_graph_exploration_amd.engine import Engine
+    cfg = default_config(MAP, num_landmarks=100, max_poses=41, max_landmarks=100)
+    used, fresh = Engine(cfg, 1, 0), Engine(cfg, 1, 0)
+    starts = generic_starts(4)
+    # episode 1 on `used`: fused reset = prior + measure + optimise at ONE pose -> panel (valid, P = 1, L, M) left behind
+    used.reset([0], [3], starts=starts[3:4])
+    used.synchronize()
+    used.inc_stats(reset=True)
+    for e in (used, fresh):
+        _staged_episode(e, 1, starts[1], 1)
+    assert used.inc_stats() == (0, 1), "the first optimise after a staged reset must be a full solve"
+    for a, b in zip(used.poses(0) + used.landmarks(0) + used.factors(0), fresh.poses(0) + fresh.landmarks(0) + fresh.factors(0)):
+        np.testing.assert_array_equal(a, b)
+    # ... and twice in a row without any optimise at one pose in between
+    for e in (used, fresh):
+        e.stage_reset([0], [2], np.array([starts[2]]))
+        _staged_episode(e, 1, starts[1], 3)
+    for a, b in zip(used.poses(0) + used.landmarks(0), fresh.poses(0) + fresh.landmarks(0)):
+        np.testing.assert_array_equal(a, b)
+    for e in (used, fresh):
+        e.close()
+
+
+@pytest.mark.parametrize("num_landmarks, max_poses, steps", [(100, 64, 52), (8, 64, 48), (8, 41, 30)])
+def test_incremental_update_equals_the_full_solve_beyond_the_dense_solver_and_with_the_panel_in_lds(monkeypatch, num_landmarks, max_poses, steps):
+    """The incremental path against DRLGX_INCREMENTAL=0 where the explicit 31-step test does not reach: trajectories beyond
+    42 poses (the pose-chain solver builds the panel itself: k_slam_arrow.hip, mk_panel) and few-landmark worlds whose panel
+    is LDS-resident for the step (k_inc.hip, kLds = true).  Estimates 1e-9, information 1e-7 relative between the engines
+    and against the oracle at the end; `inc_stats` proves which path served the updates."""
+    from drl_graph_exploration_amd import default_config
+    from drl_graph_exploration_amd.engine import Engine
+    n = 4
+    cfg = default_config(MAP, num_landmarks=num_landmarks, max_poses=max_poses, max_landmarks=num_landmarks)
+    eng = Engine(cfg, n, 0)
+    monkeypatch.setenv("DRLGX_INCREMENTAL", "0")
+    ref = Engine(cfg, n, 0)
+    monkeypatch.delenv("DRLGX_INCREMENTAL")
+    assert ref.inc_stats() == (-1, -1)
+    starts = generic_starts(n)
+    ocfg = O.default_config(MAP, num_landmarks=num_landmarks)
+    sims = [O.OracleSim(ocfg, lo, lo, start=tuple(starts[lo])) for lo in range(n)]
+    for e in (eng, ref):
+        e.reset(np.arange(n), np.arange(n), starts=starts)
+    script = ([(1, 1, math.pi / 2)] * 4 + [(2, 0, 0), (1.5, 0, 0), (0, 0, 0.7), (2, 0, 0), (0, 0, 0.9)] * 12)[:steps]
+    for s, act in enumerate(script):
+        odom = torch.tensor([act] * n, dtype=torch.float64, device=eng.device)
+        eng.step(odom)
+        ref.step(odom)
+        for sim in sims:
+            sim.simulate(act)
+        if s % 6 != 5 and s != len(script) - 1:
+            continue
+        assert eng.status() == 0 and ref.status() == 0
+        for i in range(n):
+            name = "step %d env %d" % (s, i)
+            xyt, info = eng.poses(i)
+            rxyt, rinfo = ref.poses(i)
+            np.testing.assert_allclose(xyt, rxyt, atol=1e-9, err_msg=name)
+            np.testing.assert_allclose(info, rinfo, rtol=1e-7, atol=1e-6, err_msg=name)
+            k, xy, linfo = eng.landmarks(i)
+            rk, rxy, rlinfo = ref.landmarks(i)
+            np.testing.assert_array_equal(k, rk)
+            np.testing.assert_allclose(xy, rxy, atol=1e-9, err_msg=name)
+            np.testing.assert_allclose(linfo, rlinfo, rtol=1e-7, atol=1e-6, err_msg=name)
+            np.testing.assert_array_equal(eng.virtual_map(i)[3], ref.virtual_map(i)[3])
+            np.testing.assert_allclose(eng.virtual_map(i)[1], ref.virtual_map(i)[1], rtol=1e-6, atol=1e-9, err_msg=name)
+    for i in range(n):
+        compare_state(eng, i, sims[i], "final env %d" % i, check_vm=False)
+    inc, full = eng.inc_stats()
+    assert inc + full == n * (len(script) + 1)
+    assert inc >= n * (len(script) - len(script) // 10 - 4), (inc, full)  # all but the reset and the 10th updates
+    eng.close()
+    ref.close()

@@ -60,9 +60,9 @@ def test_module_classes_follow_the_reference_call_sequence():
     script = [(1, 1, math.pi / 2)] * 4 + [(2.0, 0.0, 0.0), (0.0, 0.0, 0.8), (2.0, 0.0, 0.0), (1.1, 0.0, 0.0)]
     for odom in script:
         # ---- the reference's SS2D.simulate (pyss2d.py:171-206)
-        collided, control_state = sim.move(ss2d.Pose2(*odom), True)
+        moved, control_state = sim.move(ss2d.Pose2(*odom), True)
         slam.add_odometry(control_state)
-        assert collided is False and control_state.odom.x == odom[0]
+        assert moved is True and control_state.odom.x == odom[0]  # Simulator2D.cpp:491-503: true = applied
         discarded = sim.measure()  # obstacle logic: only consumes sensor noise at safe_distance = 0
         measurements = sim.measure()
         assert [k for k, _ in discarded] == [k for k, _ in measurements]
@@ -86,6 +86,13 @@ def test_module_classes_follow_the_reference_call_sequence():
     assert sim.environment.get_landmark_size() == 8 and slam.map.get_trajectory_size() == len(script) + 1
     cur = slam.map.get_current_vehicle()
     np.testing.assert_allclose(np.linalg.inv(cur.information), cur.covariance)
+    # Environment.distance (Simulator2D.cpp:244-250, Distance.cpp:5-9) of the estimated trajectory
+    est, want = ref.poses()[0], 0.0
+    for a, b in zip(est[:-1], est[1:]):
+        dx, dy = b[0] - a[0], b[1] - a[1]
+        bear = math.atan2(-math.sin(a[2]) * dx + math.cos(a[2]) * dy, math.cos(a[2]) * dx + math.sin(a[2]) * dy)
+        want += math.sqrt(dx * dx + dy * dy + (0.5 * bear) ** 2)
+    assert slam.map.distance == pytest.approx(want, abs=1e-8) and fused.distance == pytest.approx(want, abs=1e-8)
     # planner calls (pyplanner2d.py:64-81)
     goal = (cur.pose.x + 3.0, cur.pose.y - 2.0)
     plan = planner.line_planner(slam, virtual_map, slam.key_size(), goal[0], goal[1])
@@ -157,3 +164,72 @@ def test_exploration_env_member_accesses_through_the_facade():
         for a in acts[ks + decision % fro]:
             assert ex.simulate([a[0], a[1], a[2]]) is False
             ref.step(a)
+
+
+def test_two_simulations_driven_alternately_and_constructed_interleaved():
+    """The reference's objects are independent values: two simulations may be constructed interleaved (with explicit
+    wiring) and driven alternately; implicit wiring that would cross two simulations raises instead of mis-wiring."""
+    from drl_graph_exploration_amd import ss2d
+    from drl_graph_exploration_amd.pyplanner2d import EMExplorer, config_from_ini
+    from staged_facade import StagedEMExplorer
+    los = (2, 5)
+    starts = [tuple(np.array(O.start_pose(lo, MAP / 2 + 20)) + np.array([0.21, -0.13, 0.05])) for lo in los]
+    # (1) two staged facades + two fused facades, stepped alternately
+    st = [StagedEMExplorer(ini(lo), start=s) for lo, s in zip(los, starts)]
+    fu = [EMExplorer(ini(lo), start=s) for lo, s in zip(los, starts)]
+    ref = [O.OracleSim(O.default_config(MAP), lo, lo, start=s) for lo, s in zip(los, starts)]
+    script = [(1, 1, math.pi / 2)] * 3 + [(2.0, 0.0, 0.0), (0.0, 0.0, -0.6), (1.5, 0.0, 0.0)]
+    for k, odom in enumerate(script):
+        order = (0, 1) if k % 2 == 0 else (1, 0)
+        for i in order:
+            st[i].simulate(odom)
+        for i in reversed(order):
+            fu[i].simulate(odom)
+            ref[i].simulate(odom)
+    for i in range(2):
+        np.testing.assert_array_equal(st[i].engine.poses(0)[0], fu[i].engine.poses(0)[0])
+        np.testing.assert_array_equal(st[i].engine.virtual_map(0)[1], fu[i].engine.virtual_map(0)[1])
+        np.testing.assert_allclose(st[i].engine.poses(0)[0], ref[i].poses()[0], atol=1e-9)
+    assert not np.array_equal(st[0].engine.poses(0)[0], st[1].engine.poses(0)[0])
+    # (2) interleaved construction, wired explicitly
+    prm = [config_from_ini(ini(lo))[1] for lo in los]
+    sims = [ss2d.Simulator2D(p["sensor"], p["control"], lo) for p, lo in zip(prm, los)]
+    slams = [ss2d.SLAM2D(p["map"], simulator=s) for p, s in zip(prm, sims)]
+    vms = [ss2d.VirtualMap(p["virtual_map"], lo, simulator=s) for p, lo, s in zip(prm, los, sims)]
+    for i in (1, 0):
+        sims[i].initialize_vehicle(ss2d.Pose2(*starts[i]))
+        sims[i].random_landmarks([], 8, prm[i]["environment"])
+    prior = np.diag([1.0 / 0.05 ** 2, 1.0 / 0.05 ** 2, 1.0 / math.radians(0.01) ** 2])
+    with pytest.raises(RuntimeError):  # simulation 0's SLAM2D given simulation 1's vehicle
+        slams[0].add_prior(ss2d.VehicleBeliefState(sims[1].vehicle, prior))
+    for i in (0, 1):
+        slams[i].add_prior(ss2d.VehicleBeliefState(sims[i].vehicle, prior))
+    for i in (1, 0):
+        for key, m in sims[i].measure():
+            slams[i].add_measurement(key, m)
+        slams[i].optimize(update_covariance=True)
+    for odom in script:
+        cs = [sims[i].move(ss2d.Pose2(*odom), True)[1] for i in (0, 1)]
+        with pytest.raises(RuntimeError):
+            slams[0].add_odometry(cs[1])
+        for i in (1, 0):
+            slams[i].add_odometry(cs[i])
+            sims[i].measure()
+            for key, m in sims[i].measure():
+                slams[i].add_measurement(key, m)
+            slams[i].optimize(update_covariance=True)
+        with pytest.raises(RuntimeError):
+            vms[0].update_probability(slams[1], sims[1].sensor_model)
+        for i in (0, 1):
+            vms[i].update_probability(slams[i], sims[i].sensor_model)
+            vms[i].update_information(slams[i].map, sims[i].sensor_model)
+    for i in range(2):
+        np.testing.assert_array_equal(slams[i]._ses.engine.poses(0)[0], fu[i].engine.poses(0)[0])
+        np.testing.assert_array_equal(vms[i].to_cov_trace(), fu[i].engine.virtual_map(0)[2])
+    # (3) implicit wiring never crosses simulations: a second SLAM2D / VirtualMap for the latest simulator raises
+    a = ss2d.Simulator2D(prm[0]["sensor"], prm[0]["control"], 1)
+    b = ss2d.Simulator2D(prm[1]["sensor"], prm[1]["control"], 2)
+    ss2d.SLAM2D(prm[0]["map"])  # joins b (the latest)
+    with pytest.raises(RuntimeError):
+        ss2d.SLAM2D(prm[1]["map"])
+    ss2d.SLAM2D(prm[0]["map"], simulator=a)

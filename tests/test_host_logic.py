@@ -434,3 +434,35 @@ def test_bench_launch_contract():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr
+
+
+def test_build_alias_resolves_the_reference_import_lines():
+    """`import build.ss2d as ss2d` / `import build.planner2d as planner2d` (scripts/envs/pyss2d.py:7, pyplanner2d.py:6)."""
+    import build.planner2d as planner2d_alias
+    import build.ss2d as ss2d_alias
+    from build import planner2d as p2, ss2d as s2
+    from drl_graph_exploration_amd import planner2d, ss2d
+    assert ss2d_alias is ss2d is s2 and planner2d_alias is planner2d is p2
+    assert hasattr(ss2d_alias, "Simulator2D") and hasattr(planner2d_alias, "EMPlanner2D")
+
+
+def test_module_objects_never_join_across_simulations():
+    """`ss2d.SLAM2D` / `VirtualMap` without `simulator=` join the latest Simulator2D once; a second one raises (no engine
+    is created here: that happens at `add_prior`)."""
+    from drl_graph_exploration_amd import ss2d
+    sp, cp, ep = ss2d.BearingRangeSensorModelParameter(), ss2d.SimpleControlModelParameter(), ss2d.EnvironmentParameter()
+    a = ss2d.Simulator2D(sp, cp, 1)
+    b = ss2d.Simulator2D(sp, cp, 2)
+    sb = ss2d.SLAM2D(ep)
+    assert sb._ses is b._ses
+    with pytest.raises(RuntimeError):
+        ss2d.SLAM2D(ep)
+    sa = ss2d.SLAM2D(ep, simulator=a)
+    va = ss2d.VirtualMap(ss2d.VirtualMapParameter(ep), 0, simulator=a)
+    assert sa._ses is a._ses is va._ses and b._ses.vm is None
+    with pytest.raises(RuntimeError):  # b's vehicle handed to a's SLAM2D
+        sa.add_prior(ss2d.VehicleBeliefState(b.vehicle, np.eye(3)))
+    with pytest.raises(RuntimeError):
+        va.update_probability(sb, b.sensor_model)
+    assert ss2d.trajectory_distance([ss2d.Pose2(0, 0, 0), ss2d.Pose2(3, 4, 1.0)]) == pytest.approx(
+        math.sqrt(25.0 + (0.5 * math.atan2(4, 3)) ** 2))
