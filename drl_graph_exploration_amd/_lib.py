@@ -31,7 +31,7 @@ SYMBOLS = [
     "drlgx_get_virtual_map_host", "drlgx_get_ground_truth_host", "drlgx_get_adjacency_host", "drlgx_get_factors_host",
     "drlgx_get_landmark_order_host", "drlgx_snapshot", "drlgx_restore", "drlgx_timing_enable",
     "drlgx_timing_read_host", "drlgx_debug_phase_clocks_host", "drlgx_debug_gemm_tile_rows", "drlgx_debug_map_form", "drlgx_inc_stats_host", "drlgx_gcn_workspace_bytes", "drlgx_gcn_forward", "drlgx_gcn_forward_batched", "drlgx_gcn_backward",
-    "drlgx_replay_collate", "drlgx_replay_collate_pair", "drlgx_dqn_targets", "drlgx_dqn_loss_grad", "drlgx_adam_step", "drlgx_adam_step_scaled", "drlgx_normalise_rewards",
+    "drlgx_replay_collate", "drlgx_replay_collate_pair", "drlgx_dqn_targets", "drlgx_dqn_loss_grad", "drlgx_dqn_arena_bytes", "drlgx_dqn_arena_views", "drlgx_dqn_prepare", "drlgx_dqn_forward_backward", "drlgx_adam_step", "drlgx_adam_step_scaled", "drlgx_normalise_rewards",
     "drlgx_segment_softmax", "drlgx_segment_softmax_backward", "drlgx_mean_pool", "drlgx_mean_pool_backward",
 ]
 
@@ -108,6 +108,14 @@ def lib():
     L.drlgx_gcn_forward_batched.argtypes = [vp] + [C.c_int] * 5 + [vp] * 12 + [C.c_int, vp, vp, C.c_int]
     L.drlgx_dqn_targets.argtypes = [vp, C.c_int, vp, vp, vp, C.c_double, C.c_int64, vp, vp]
     L.drlgx_dqn_loss_grad.argtypes = [vp, C.c_int, vp, vp, vp, C.c_double, vp, vp]
+    i64 = C.c_int64
+    L.drlgx_dqn_arena_bytes.restype = C.c_size_t
+    L.drlgx_dqn_arena_bytes.argtypes = [C.c_int, i64, i64, i64, C.c_int, C.c_int, C.c_int]
+    L.drlgx_dqn_arena_views.argtypes = [vp, C.c_int, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.drlgx_dqn_prepare.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, i64, vp, vp, i64, i64, i64, vp, vp, C.c_double, vp, i64, i64, i64,
+                                    C.c_int, C.c_int]
+    L.drlgx_dqn_forward_backward.argtypes = [vp, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp), vp, C.c_double,
+                                             C.POINTER(vp), vp, i64, i64, i64]
     L.drlgx_normalise_rewards.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.drlgx_segment_softmax.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.drlgx_segment_softmax_backward.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]

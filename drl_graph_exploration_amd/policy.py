@@ -89,10 +89,92 @@ def broadcast_parameters(model, src=0, group=None):
 
 class ReplayList(list):
     """The replay buffer: a list with the two deque methods the reference's trainer uses (O(1) random access for
-    `random.sample`; `popleft` moves 10^4 pointers, microseconds)."""
+    `random.sample`; `popleft` moves 10^4 pointers, microseconds).
+
+    Beside the tuples it keeps a NUMERIC side table of the transitions whose graphs live in one `ReplayPool` (int64
+    [rows][14] = the collation descriptor of s_j (5) and of s_j1 (5), action node, next-state frontier count, terminal,
+    slot of s_j1; float64 reward), so that sampling n mini-batches is one fancy-indexing gather instead of n x BATCH
+    attribute reads (`DeepQ._prepare_updates`).  `append` / `extend` / `popleft` keep it aligned; any other mutation, or a
+    transition that is not pool-backed, switches it off (`table()` returns None and the trainer takes the generic path)."""
+    _COLS = 14
+
+    def __init__(self, items=()):
+        super().__init__()
+        self._reset_side()
+        for t in items:
+            self.append(t)
+
+    def _reset_side(self):
+        self._rows, self._rew, self._head, self._n, self._pool, self._ok = None, None, 0, 0, None, True
+
+    def _side_push(self, t):
+        a, b = t[0], t[3]
+        if not (isinstance(a, PoolRef) and isinstance(b, PoolRef)) or a.pool is not b.pool or (self._pool is not None and a.pool is not self._pool):
+            self._ok = False
+            self._rows = self._rew = None
+            return
+        if self._rows is None:
+            self._pool = a.pool
+            self._rows = np.empty((4096, self._COLS), dtype=np.int64)
+            self._rew = np.empty(4096, dtype=np.float64)
+            self._head = self._n = 0
+        end = self._head + self._n
+        if end == self._rows.shape[0]:
+            if self._head >= self._rows.shape[0] // 2:  # compact: the live rows move to the front
+                self._rows[:self._n] = self._rows[self._head:end]
+                self._rew[:self._n] = self._rew[self._head:end]
+            else:                                        # grow
+                rows, rew = np.empty((2 * self._rows.shape[0], self._COLS), dtype=np.int64), np.empty(2 * self._rows.shape[0])
+                rows[:self._n], rew[:self._n] = self._rows[self._head:end], self._rew[self._head:end]
+                self._rows, self._rew = rows, rew
+            self._head, end = 0, self._n
+        r = self._rows[end]
+        r[0:5], r[5:10] = a.d5, b.d5
+        r[10], r[11], r[12], r[13] = t[1], t[5], 1 if t[4] else 0, b.slot
+        self._rew[end] = t[2]
+        self._n += 1
+
+    def append(self, t):
+        if "_ok" not in self.__dict__:  # (unpickling appends the items before it restores the attributes)
+            self._reset_side()
+        list.append(self, t)
+        if self._ok:
+            self._side_push(t)
+
+    def extend(self, items):
+        for t in items:
+            self.append(t)
 
     def popleft(self):
-        return self.pop(0)
+        t = list.pop(self, 0)
+        if self._ok and self._n:
+            self._head += 1
+            self._n -= 1
+        return t
+
+    def table(self):
+        """(pool, rows int64 [len][14], rewards float64 [len]) aligned with the list, or None."""
+        if not self.__dict__.get("_ok") or self._rows is None or self._n != len(self) or self._n == 0:
+            return None
+        a, z = self[0], self[-1]
+        h = self._head
+        if self._rows[h, 0] != a[0].n0 or self._rows[h + self._n - 1, 5] != z[3].n0:  # (someone reordered the list behind our back)
+            self._ok = False
+            return None
+        return self._pool, self._rows[h:h + self._n], self._rew[h:h + self._n]
+
+    def __reduce_ex__(self, protocol):  # pickled as its items (the side table is rebuilt, or stays off for host graphs)
+        return (ReplayList, (list(self),))
+
+
+class _Prepared(dict):
+    """What `_prepare_updates` hands to one update: scalars + raw device addresses; the tensor views (`desc_j`, `desc_j1`,
+    `meta`, `r`) of the generic path are made on first use."""
+
+    def __missing__(self, key):
+        I, R, u = self["_I"], self["_R"], self["_u"]
+        self["desc_j"], self["desc_j1"], self["meta"], self["r"] = I[u, 0:5], I[u, 5:10], I[u, 10:14], R[u]
+        return dict.__getitem__(self, key)
 
 
 class DeepQ(object):
@@ -143,6 +225,7 @@ class DeepQ(object):
         st["_loss_v"], st["_loss_t"] = self.temp_loss, None
         st["buffer"] = ReplayList((_graph_to_host(t[0]), t[1], t[2], _graph_to_host(t[3]), t[4], t[5]) for t in self.buffer)
         st.pop("_pool", None)  # device storage: the pickled transitions carry their graphs themselves
+        st.pop("_arena", None)
         return st
 
     def __setstate__(self, st):
@@ -262,6 +345,70 @@ class DeepQ(object):
             scale = 1.0
         optimizer.step(grad_scale=scale)
 
+    # ------------------------------------------------------------------ the fused update of pooled mini-batches
+    class _Arena(object):
+        """ONE device buffer for every intermediate of an update (include/drlgx.h: drlgx_dqn_arena_bytes), grown in steps; the
+        views the Python side reads (loss, out, a_batch, y_batch) are slices of it."""
+
+        def __init__(self, device, k, cap_n, cap_e, cap_n1, dims):
+            L = _lib.lib()
+            self.k, self.cap = k, (int(cap_n), int(cap_e), int(cap_n1))
+            self.dims = dims  # (in_dim, hidden, out_dim)
+            nbytes = L.drlgx_dqn_arena_bytes(k, *self.cap, *dims)
+            if nbytes == 0:
+                raise _lib.DrlgxError("drlgx_dqn_arena_bytes: invalid capacities %r" % (self.cap,))
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self.ptr = C.c_void_p(self.buf.data_ptr())
+            v = (C.c_void_p * 12)()
+            _lib.check(L.drlgx_dqn_arena_views(self.ptr, k, *self.cap, *dims, v))
+            off = [int(a) - self.buf.data_ptr() for a in v]
+            self.off = dict(zip(("x", "ei", "ea", "bt", "node_off", "edge_off", "q1", "a", "y", "out", "d_out", "loss"), off))
+            self.loss = self.buf[off[11]:off[11] + 8].view(torch.float64)
+
+        def fits(self, k, n, e, n1, dims):
+            return k == self.k and dims == self.dims and n <= self.cap[0] and e <= self.cap[1] and n1 <= self.cap[2]
+
+        def view(self, name, count, dtype):
+            o = self.off[name]
+            return self.buf[o:o + count * torch.empty(0, dtype=dtype).element_size()].view(dtype)
+
+    def _arena_for(self, device, k, n, e, n1, dims):
+        a = self.__dict__.get("_arena")
+        if a is None or a.buf.device != torch.device(device) or not a.fits(k, n, e, n1, dims):
+            grow = lambda v, old: max(int(v * 1.25) + 64, old)  # noqa: E731
+            old = a.cap if a is not None and a.k == k and a.dims == dims else (0, 0, 0)
+            # (the previous arena may still be read by launches in flight: stream-ordered free of the caching allocator)
+            a = self.__dict__["_arena"] = DeepQ._Arena(device, k, grow(n, old[0]), grow(e, old[1]), grow(n1, old[2]), dims)
+        return a
+
+    def _fused_prepare(self, pr, device, dims):
+        """Collation of s_j, the cached target read-out of s_j1 and the TD targets of one prepared mini-batch: one host call
+        (drlgx_dqn_prepare), results in the arena."""
+        pool, B = pr["pool"], self.BATCH
+        a = self._arena_for(device, B, pr["N"], pr["E"], pr["N1"], dims)
+        vp = C.c_void_p
+        _lib.check(_lib.lib().drlgx_dqn_prepare(vp(_lib.stream_ptr(device)), B, vp(pr["p_desc_j"]), vp(pr["p_desc_j1"]), vp(pool.X.data_ptr()),
+                                                pool.X.shape[1], vp(pool.EI.data_ptr()), pool.EI.shape[1], vp(pool.EA.data_ptr()),
+                                                vp(pool.Q.data_ptr()), pr["N"], pr["E"], pr["N1"], vp(pr["p_meta"]), vp(pr["p_r"]),
+                                                float(self.GAMMA), a.ptr, *a.cap, dims[1], dims[2]))
+        return a
+
+    def _fused_forward_backward(self, pr, arena, device, model, optimizer):
+        """Trunk forward, cost + its gradient, trunk backward into the optimiser's flat gradient buffer: one host call
+        (drlgx_dqn_forward_backward); then the gradient exchange is issued (several ranks).  Handle for `_train_end`."""
+        n = pr["N"]
+        in_dim, hidden, out_dim = arena.dims
+        mask = NW._dropout_mask(n, hidden, 0.5, arena.buf.device)
+        vp = C.c_void_p
+        params = (vp * 6)(*[t.data_ptr() for t in model.trunk_parameters()])
+        grads = (vp * 6)(*[g.data_ptr() for g in optimizer.grads()])
+        _lib.check(_lib.lib().drlgx_dqn_forward_backward(vp(_lib.stream_ptr(device)), self.BATCH, n, pr["E"], pr["ME"], in_dim, hidden, out_dim,
+                                                         params, vp(mask.data_ptr()) if mask is not None else None, float(self.BATCH), grads,
+                                                         arena.ptr, *arena.cap))
+        self._loss_t = arena.loss
+        optimizer.bucket.start()
+        return model, optimizer
+
     def test(self, data, prob, device, model):
         model.eval()
         data = data.to(device)
@@ -357,9 +504,24 @@ class DeepQ(object):
     def _train_minibatches(self, device, policy_net, target_net, optimizer, prepared, batches, n_upd):
         """`n_upd` updates.  On the fused path the next mini-batch is collated (and its targets gathered) between an update's
         backward pass and its Adam step, i.e. while that update's gradient all-reduce travels: the collective is hidden
-        behind work that does not depend on it."""
+        behind work that does not depend on it.  Pool-backed mini-batches (`prepared`) take two host calls per update
+        (`_fused_prepare`, `_fused_forward_backward`) plus the Adam launch; the generic path issues the same launches one by one."""
         fused = type(policy_net) is GCN and isinstance(optimizer, FusedAdam)
         pending = None
+        if fused and prepared is not None and self.target_window in ("reference", "aligned"):
+            if not policy_net.training:
+                policy_net.train()
+            W1, _, _, _, Wf, _ = policy_net.trunk_parameters()
+            dims = (int(W1.shape[0]), int(W1.shape[1]), int(Wf.shape[0]))
+            if dims[2] == 1:
+                for u in range(n_upd):
+                    arena = self._fused_prepare(prepared[u], device, dims)
+                    if pending is not None:
+                        self._train_end(pending)
+                    pending = self._fused_forward_backward(prepared[u], arena, device, policy_net, optimizer)
+                if pending is not None:
+                    self._train_end(pending)
+                return
         for u in range(n_upd):
             s_j, a_batch, y_batch = self._collate_minibatch(device, target_net, None if prepared is None else prepared[u],
                                                             None if prepared is not None else batches[u])
@@ -392,28 +554,44 @@ class DeepQ(object):
         """Sample `n_upd` mini-batches (the buffer does not change between them, so sampling them up front draws the same
         transitions as sampling before every update) and upload everything the host contributes to the updates - the
         collation descriptors of s_j / s_j1, the TD-target windows, the rewards - as ONE int64 and ONE float64 tensor.
-        Returns a list of `prepared` dicts for `_train_minibatch`, or None when the buffer is not pool-backed."""
-        batches = [random.sample(self.buffer, self.BATCH) for _ in range(n_upd)]
-        first = batches[0][0][0]
-        if not isinstance(first, PoolRef):
-            return None, batches
-        pool, B = first.pool, self.BATCH
+        Returns a list of `prepared` dicts for `_train_minibatch`, or None when the buffer is not pool-backed.
+
+        `random.sample(range(len(buffer)), BATCH)` makes the draws of `random.sample(buffer, BATCH)` (the population's length
+        is all the sampler looks at), so the indices ARE the reference's sample (policy.py:141); everything per transition
+        then comes out of the buffer's numeric side table with a few array operations for all updates at once."""
+        B = self.BATCH
+        tab = self.buffer.table() if isinstance(self.buffer, ReplayList) else None
+        if tab is None:
+            return None, [random.sample(self.buffer, B) for _ in range(n_upd)]
+        pool, rows, rew = tab
+        idx = np.array([random.sample(range(len(self.buffer)), B) for _ in range(n_upd)], dtype=np.int64)  # [n_upd, B]
+        T = rows[idx]                                                                                       # [n_upd, B, 14]
         I = np.empty((n_upd, 14, B), dtype=np.int64)
-        R = np.empty((n_upd, B), dtype=np.float64)
-        tot = []
-        for u, mb in enumerate(batches):
-            refs, refs1 = [d[0] for d in mb], [d[3] for d in mb]
-            # every state of the sample must live in this pool (a buffer resumed from a pickle may hold plain graphs)
-            if {type(r) for r in refs + refs1} != {PoolRef} or {id(r.pool) for r in refs + refs1} != {id(pool)}:
-                return None, batches
-            I[u, 0:5], n, e = ReplayPool.descriptors(refs)
-            I[u, 5:10], n1, e1 = ReplayPool.descriptors(refs1)
-            I[u, 10:14], R[u], _ = self._td_meta(mb, n1, I[u, 1])
-            tot.append((n, e, n1, e1, int(I[u, 3].max()), int(I[u, 8].max())))
-        self._refresh_target_readout(pool, sorted({d[3].slot for mb in batches for d in mb}), device, target_net)
+        I[:, 0:10] = T[:, :, 0:10].transpose(0, 2, 1)
+        n_j, n_j1 = T[:, :, 1], T[:, :, 6]
+        N, E, N1, E1 = n_j.sum(1), T[:, :, 3].sum(1), n_j1.sum(1), T[:, :, 8].sum(1)
+        ME, ME1 = T[:, :, 3].max(1), T[:, :, 8].max(1)
+        # the TD-target windows (`_td_meta`, for every update at once)
+        off_j = np.cumsum(n_j, axis=1) - n_j
+        term = T[:, :, 12] != 0
+        if self.target_window == "reference":
+            lo, hi = np.minimum(off_j, N1[:, None]), np.minimum(off_j + n_j, N1[:, None])
+        else:
+            hi = np.cumsum(n_j1, axis=1)
+            lo = hi - n_j1
+        lo = np.maximum(lo, hi - T[:, :, 11])
+        if bool(((hi <= lo) & ~term).any()):
+            raise ValueError("zero-size array to reduction operation maximum which has no identity")  # as numpy would
+        I[:, 10], I[:, 11], I[:, 12], I[:, 13] = lo, hi, off_j + T[:, :, 10], T[:, :, 12]
+        R = rew[idx]
+        self._refresh_target_readout(pool, np.unique(T[:, :, 13]).tolist(), device, target_net)
         I_dev, R_dev = torch.from_numpy(I).to(device), torch.from_numpy(R).to(device)
-        return [dict(pool=pool, desc_j=I_dev[u, 0:5], desc_j1=I_dev[u, 5:10], meta=I_dev[u, 10:14], r=R_dev[u], N=tot[u][0],
-                     E=tot[u][1], N1=tot[u][2], E1=tot[u][3], ME=tot[u][4], ME1=tot[u][5]) for u in range(n_upd)], batches
+        pI, pR, sI, sR = I_dev.data_ptr(), R_dev.data_ptr(), 14 * B * 8, B * 8
+        N, E, N1, E1, ME, ME1 = (v.tolist() for v in (N, E, N1, E1, ME, ME1))
+        prepared = [_Prepared(pool=pool, _I=I_dev, _R=R_dev, _u=u, N=N[u], E=E[u], N1=N1[u], E1=E1[u], ME=ME[u], ME1=ME1[u],
+                              p_desc_j=pI + u * sI, p_desc_j1=pI + u * sI + 5 * B * 8, p_meta=pI + u * sI + 10 * B * 8, p_r=pR + u * sR)
+                    for u in range(n_upd)]
+        return prepared, idx
 
     # ------------------------------------------------------------------ main loop (policy.py:60-208)
     def running(self, model, modelTarget, test=False, n_envs=64, env=None, log_every=0):

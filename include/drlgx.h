@@ -360,6 +360,28 @@ int drlgx_adam_step_scaled(void *hip_stream, int n_tensors, float *const *params
                     float *const *exp_avg, float *const *exp_avg_sq, const int64_t *sizes, double lr, double beta1,
                     double beta2, double eps, int64_t step, double grad_clamp, double grad_scale);
 
+/* One DQN update as TWO host calls (scripts/policy.py:139-178 and :234-249).  Nothing new runs on the device - the launches of
+ * drlgx_replay_collate_pair + drlgx_dqn_targets (prepare), and of drlgx_gcn_forward_batched + drlgx_dqn_loss_grad +
+ * drlgx_gcn_backward (forward_backward), are issued back to back on the caller's stream with every intermediate in ONE
+ * caller-owned DEVICE arena of drlgx_dqn_arena_bytes(): the 256-env trainer was bound by the host work of those launches.
+ * The arena's layout is a function of the capacities (cap_nodes / cap_edges of the collated current states, cap_nodes1 of the
+ * next states' read-out) only; both calls of an update - and drlgx_dqn_arena_views, for read-backs - must pass the same ones.
+ * views[12] = x, edge_index [2][n_edges], edge_attr, batch, node_off, edge_off, q1, a_batch, y_batch, out, d_out, loss.
+ * params / grads: HOST arrays of six DEVICE pointers (W1 b1 W2 b2 Wf bf and their gradients, written not accumulated). */
+size_t drlgx_dqn_arena_bytes(int n_graphs, int64_t cap_nodes, int64_t cap_edges, int64_t cap_nodes1, int in_dim, int hidden,
+                             int out_dim);
+int drlgx_dqn_arena_views(void *arena_dev, int n_graphs, int64_t cap_nodes, int64_t cap_edges, int64_t cap_nodes1, int in_dim,
+                          int hidden, int out_dim, void **views);
+int drlgx_dqn_prepare(void *hip_stream, int n_graphs, const int64_t *desc_dev, const int64_t *desc1_dev, const float *pool_x,
+                      int in_dim, const int64_t *pool_ei, int64_t pool_edges, const float *pool_ea, const float *pool_q,
+                      int64_t n_nodes, int64_t n_edges, int64_t n_nodes1, const int64_t *meta_dev, const double *r_dev,
+                      double gamma, void *arena_dev, int64_t cap_nodes, int64_t cap_edges, int64_t cap_nodes1, int hidden,
+                      int out_dim);
+int drlgx_dqn_forward_backward(void *hip_stream, int n_graphs, int64_t n_nodes, int64_t n_edges, int max_edges_per_graph,
+                               int in_dim, int hidden, int out_dim, const float *const *params, const float *dropout_mask,
+                               double batch, float *const *grads, void *arena_dev, int64_t cap_nodes, int64_t cap_edges,
+                               int64_t cap_nodes1);
+
 /* ---- env wrapper / actor-critic heads ------------------------------------------------------------------------- */
 
 /* The normalisation of ExplorationEnv.rewards_all_goals (scripts/envs/exploration_env.py:151-161) for every env: raw

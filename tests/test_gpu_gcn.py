@@ -358,6 +358,7 @@ def test_fused_dqn_update_equals_the_framework_path(monkeypatch, tmp_path):
         for b_ in (pol_a.conv1.bias, pol_a.conv2.bias, pol_a.fully_con1.bias):
             b_.normal_(0, 0.05)
     pol_b, tgt = copy.deepcopy(pol_a), copy.deepcopy(pol_a)
+    pol_c = copy.deepcopy(pol_a)
     masks = {}
 
     def fixed_mask(n, hidden, p, device):  # the same Bernoulli(0.5) mask for both paths (keyed by the batch size)
@@ -402,6 +403,24 @@ def test_fused_dqn_update_equals_the_framework_path(monkeypatch, tmp_path):
             # one Adam step moves a parameter by at most ~lr: the two paths must agree to a small fraction of that
             assert float((va - vb).abs().max()) < 2e-2 * 1e-3 * (u + 1), (u, k)
     assert opt_a.step_count == 3
+    # the same three updates through the trainer's loop: two host calls per update (drlgx_dqn_prepare,
+    # drlgx_dqn_forward_backward) over one arena - the same launches in the same order, so bit-equal parameters and loss
+    dq_c = DeepQ("c/", "GCN", data_root=str(tmp_path))
+    dq_c.BATCH = B
+    dq_c.buffer.extend(pooled)
+    opt_c = FusedAdam(pol_c.parameters(), lr=1e-3, grad_clamp=dq_c.max_grad_norm)
+    it = iter(order)
+    prepared_c, _ = dq_c._prepare_updates(3, dev, tgt)
+    calls = []
+    orig_fb = dq_c._fused_forward_backward
+    dq_c._fused_forward_backward = lambda *a, **k: (calls.append(1), orig_fb(*a, **k))[1]
+    dq_c._train_minibatches(dev, pol_c, tgt, opt_c, prepared_c, None, 3)
+    assert len(calls) == 3 and opt_c.step_count == 3
+    for (k, va), vc in zip(pol_a.state_dict().items(), pol_c.state_dict().values()):
+        assert torch.equal(va, vc), k
+    assert dq_c.temp_loss == dq_a.temp_loss
+    a_c = dq_c._arena.view("a", prepared_c[2]["N"], torch.float64)
+    assert torch.equal(a_c, spy["aa"]) and torch.equal(dq_c._arena.view("y", prepared_c[2]["N"], torch.float64), spy["ya"])
 
 
 def test_batched_graph_build_equals_the_generic_one():

@@ -466,3 +466,79 @@ def test_module_objects_never_join_across_simulations():
         va.update_probability(sb, b.sensor_model)
     assert ss2d.trajectory_distance([ss2d.Pose2(0, 0, 0), ss2d.Pose2(3, 4, 1.0)]) == pytest.approx(
         math.sqrt(25.0 + (0.5 * math.atan2(4, 3)) ** 2))
+
+
+def test_replay_list_side_table_and_vectorised_minibatch_preparation(tmp_path, monkeypatch):
+    """ReplayList's numeric side table stays aligned with the list through append / extend / popleft (compaction and growth
+    included) and switches off for transitions that are not pool-backed; `DeepQ._prepare_updates` built from it equals the
+    per-update formulation (`ReplayPool.descriptors` + `_td_meta` on `random.sample(buffer, BATCH)`) for both window modes."""
+    import random
+    sys.path.insert(0, ROOT)
+    import drl_graph_exploration_amd.networks as NW
+    from drl_graph_exploration_amd.policy import DeepQ, ReplayList
+    dev = torch.device("cpu")
+    rng = np.random.RandomState(0)
+    n_env = 12
+    pool = NW.ReplayPool(dev, 6, 2400, 2400)
+    slots = []
+    for s in range(5):
+        nn = rng.randint(4, 30, n_env) + 30 * s  # (next states larger than current ones: no empty reference-mode window)
+        ne = rng.randint(3, 40, n_env) * 2
+        no, eo = np.concatenate([[0], np.cumsum(nn)]), np.concatenate([[0], np.cumsum(ne)])
+        slots.append(pool.put({"x": torch.randn(int(no[-1]), 5), "edge_index": torch.zeros(2, int(eo[-1]), dtype=torch.int64),
+                               "edge_attr": torch.rand(int(eo[-1])), "node_off_h": no, "edge_off_h": eo}))
+
+    def transition(i):
+        a, b = NW.PoolRef(pool, slots[i % 4], i % n_env), NW.PoolRef(pool, slots[i % 4 + 1], (i * 5) % n_env)
+        return (a, int(a.num_nodes - 1 - i % 3), float(rng.randn()), b, i % 7 == 0, 1 + i % 3)
+    buf = ReplayList()
+    kept = []
+    for i in range(9000):  # beyond the first 4096 rows: growth; with popleft: compaction
+        t = transition(i)
+        buf.append(t)
+        kept.append(t)
+        if len(buf) > 3000:
+            assert buf.popleft() is kept.pop(0)
+    p, rows, rew = buf.table()
+    assert p is pool and rows.shape == (3000, 14) and len(buf) == 3000
+    for k in (0, 1, 1499, 2999):
+        t = kept[k]
+        assert rows[k, 0:5].tolist() == t[0].d5.tolist() and rows[k, 5:10].tolist() == t[3].d5.tolist()
+        assert rows[k, 10:14].tolist() == [t[1], t[5], int(t[4]), t[3].slot] and rew[k] == t[2]
+    assert buf[5] is kept[5] and pickle_roundtrip_len(buf) == 3000
+    # ---- _prepare_updates from the table == the per-update formulation
+    dq = DeepQ("side/", "GCN", data_root=str(tmp_path))
+    dq.BATCH = 16
+    dq.buffer = buf
+    monkeypatch.setattr(DeepQ, "_refresh_target_readout", lambda self, pool, slots, device, net: setattr(self, "_seen_slots", slots))
+    for mode in ("reference", "aligned"):
+        dq.target_window = mode
+        random.seed(11)
+        prepared, idx = dq._prepare_updates(5, dev, None)
+        random.seed(11)
+        for u in range(5):
+            mb = random.sample(dq.buffer, dq.BATCH)
+            assert [kept.index(t) for t in mb] == idx[u].tolist()  # the same draws as sampling the buffer itself
+            d, n, e = NW.ReplayPool.descriptors([t[0] for t in mb])
+            d1, n1, e1 = NW.ReplayPool.descriptors([t[3] for t in mb])
+            meta, r, n_tot = dq._td_meta(mb, n1)
+            pr = prepared[u]
+            assert (pr["N"], pr["E"], pr["N1"], pr["E1"], pr["ME"], pr["ME1"]) == (n, e, n1, e1, int(d[3].max()), int(d1[3].max()))
+            assert np.array_equal(pr["desc_j"].numpy(), d) and np.array_equal(pr["desc_j1"].numpy(), d1)
+            assert np.array_equal(pr["meta"].numpy(), meta) and np.array_equal(pr["r"].numpy(), r) and n_tot == n
+            assert pr["p_meta"] == pr["meta"].data_ptr() and pr["p_r"] == pr["r"].data_ptr() and pr["p_desc_j1"] == pr["desc_j1"].data_ptr()
+        assert dq._seen_slots == sorted({t[3].slot for u in range(5) for t in [kept[i] for i in idx[u]]})
+    # ---- a transition that is not pool-backed switches the table off (generic path)
+    buf.append((object(), 0, 0.0, object(), False, 1))
+    assert buf.table() is None
+    prepared, batches = dq._prepare_updates(2, dev, None)
+    assert prepared is None and len(batches) == 2 and len(batches[0]) == dq.BATCH
+
+
+def pickle_roundtrip_len(buf):
+    import pickle
+    class _P(object):  # PoolRefs are not picklable as such (they hold the pool): only the container protocol is checked here
+        pass
+    b2 = pickle.loads(pickle.dumps(type(buf)([(1, 0, 0.0, 2, False, 1)] * len(buf))))
+    assert type(b2) is type(buf) and b2.table() is None
+    return len(b2)
