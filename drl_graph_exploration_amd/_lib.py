@@ -16,6 +16,14 @@ class DrlgxError(RuntimeError):
     pass
 
 
+class CsrCache(C.Structure):
+    """struct drlgx_csr_cache (include/drlgx.h): device addresses of the per-graph normalisation / CSR / AX cache."""
+    _fields_ = [(n, C.c_void_p) for n in ("deg", "selfw", "ax", "ptr_dst", "end_dst", "ptr_src", "end_src", "nbr_dst", "nbr_src", "wn_dst",
+                                          "wn_src")]
+    NODE_WORDS = dict(deg=1, selfw=1, ax=8, ptr_dst=1, end_dst=1, ptr_src=1, end_src=1)  # 4-byte words per node
+    EDGE_WORDS = dict(nbr_dst=1, nbr_src=1, wn_dst=1, wn_src=1)                          # ... per edge
+
+
 def lib_path():
     return _PATH
 
@@ -31,7 +39,7 @@ SYMBOLS = [
     "drlgx_get_virtual_map_host", "drlgx_get_ground_truth_host", "drlgx_get_adjacency_host", "drlgx_get_factors_host",
     "drlgx_get_landmark_order_host", "drlgx_snapshot", "drlgx_restore", "drlgx_timing_enable",
     "drlgx_timing_read_host", "drlgx_debug_phase_clocks_host", "drlgx_debug_gemm_tile_rows", "drlgx_debug_map_form", "drlgx_inc_stats_host", "drlgx_gcn_workspace_bytes", "drlgx_gcn_forward", "drlgx_gcn_forward_batched", "drlgx_gcn_backward",
-    "drlgx_replay_collate", "drlgx_replay_collate_pair", "drlgx_dqn_targets", "drlgx_dqn_loss_grad", "drlgx_dqn_arena_bytes", "drlgx_dqn_arena_views", "drlgx_dqn_prepare", "drlgx_dqn_forward_backward", "drlgx_adam_step", "drlgx_adam_step_scaled", "drlgx_normalise_rewards",
+    "drlgx_replay_collate", "drlgx_replay_collate_pair", "drlgx_dqn_targets", "drlgx_dqn_loss_grad", "drlgx_dqn_arena_bytes", "drlgx_dqn_arena_views", "drlgx_dqn_prepare", "drlgx_dqn_forward_backward", "drlgx_replay_cache_csr", "drlgx_gcn_collate_csr", "drlgx_gcn_forward_prebuilt", "drlgx_adam_step", "drlgx_adam_step_scaled", "drlgx_normalise_rewards",
     "drlgx_segment_softmax", "drlgx_segment_softmax_backward", "drlgx_mean_pool", "drlgx_mean_pool_backward",
 ]
 
@@ -113,9 +121,12 @@ def lib():
     L.drlgx_dqn_arena_bytes.argtypes = [C.c_int, i64, i64, i64, C.c_int, C.c_int, C.c_int]
     L.drlgx_dqn_arena_views.argtypes = [vp, C.c_int, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.drlgx_dqn_prepare.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, i64, vp, vp, i64, i64, i64, vp, vp, C.c_double, vp, i64, i64, i64,
-                                    C.c_int, C.c_int]
+                                    C.c_int, C.c_int, C.POINTER(CsrCache)]
     L.drlgx_dqn_forward_backward.argtypes = [vp, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp), vp, C.c_double,
-                                             C.POINTER(vp), vp, i64, i64, i64]
+                                             C.POINTER(vp), vp, i64, i64, i64, C.c_int]
+    L.drlgx_replay_cache_csr.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, i64, vp, C.POINTER(CsrCache)]
+    L.drlgx_gcn_collate_csr.argtypes = [vp, C.c_int, vp, C.POINTER(CsrCache), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.drlgx_gcn_forward_prebuilt.argtypes = [vp] + [C.c_int] * 5 + [vp] * 9
     L.drlgx_normalise_rewards.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.drlgx_segment_softmax.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.drlgx_segment_softmax_backward.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]

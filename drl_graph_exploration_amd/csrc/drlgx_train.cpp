@@ -74,14 +74,18 @@ int drlgx_dqn_arena_views(void *arena_dev, int n_graphs, int64_t cap_nodes, int6
 int drlgx_dqn_prepare(void *hip_stream, int n_graphs, const int64_t *desc_dev, const int64_t *desc1_dev, const float *pool_x, int in_dim,
                       const int64_t *pool_ei, int64_t pool_edges, const float *pool_ea, const float *pool_q, int64_t n_nodes,
                       int64_t n_edges, int64_t n_nodes1, const int64_t *meta_dev, const double *r_dev, double gamma, void *arena_dev,
-                      int64_t cap_nodes, int64_t cap_edges, int64_t cap_nodes1, int hidden, int out_dim) {
-  if (!arena_dev || !desc_dev || !desc1_dev || !pool_x || !pool_q || !meta_dev || !r_dev ||
+                      int64_t cap_nodes, int64_t cap_edges, int64_t cap_nodes1, int hidden, int out_dim, const drlgx_csr_cache *cache) {
+  if (!arena_dev || !desc_dev || !desc1_dev || (!pool_x && !cache) || !pool_q || !meta_dev || !r_dev ||
       !caps_ok(n_graphs, cap_nodes, cap_edges, cap_nodes1, in_dim, hidden, out_dim) || n_nodes <= 0 || n_nodes > cap_nodes || n_edges < 0 ||
       n_edges > cap_edges || n_nodes1 < 0 || n_nodes1 > cap_nodes1)
     return DRLGX_E_INVALID;
   const Arena a = carve(static_cast<char *>(arena_dev), n_graphs, cap_nodes, std::max<int64_t>(cap_edges, 1), cap_nodes1, in_dim, hidden, out_dim);
-  int rc = drlgx_replay_collate_pair(hip_stream, n_graphs, desc_dev, pool_x, in_dim, pool_ei, pool_edges, pool_ea, a.x, a.ei, n_edges, a.ea, a.bt,
-                                     a.node_off, a.edge_off, desc1_dev, pool_q, a.q1);
+  // with the pool's per-graph cache the collation fills the graph part of the GCN workspace (the forward then builds nothing
+  // and never reads x / edge_index / edge_attr); the workspace is carved for the ACTUAL counts, as the forward / backward do
+  int rc = cache ? drlgx_gcn_collate_csr(hip_stream, n_graphs, desc_dev, cache, (int)n_nodes, (int)n_edges, hidden, out_dim, a.gcn_ws, a.node_off,
+                                         a.edge_off, desc1_dev, pool_q, a.q1)
+                 : drlgx_replay_collate_pair(hip_stream, n_graphs, desc_dev, pool_x, in_dim, pool_ei, pool_edges, pool_ea, a.x, a.ei, n_edges, a.ea,
+                                             a.bt, a.node_off, a.edge_off, desc1_dev, pool_q, a.q1);
   if (rc) return rc;
   return drlgx_dqn_targets(hip_stream, n_graphs, a.q1, meta_dev, r_dev, gamma, n_nodes, a.a_batch, a.y_batch);
 }
@@ -89,7 +93,7 @@ int drlgx_dqn_prepare(void *hip_stream, int n_graphs, const int64_t *desc_dev, c
 int drlgx_dqn_forward_backward(void *hip_stream, int n_graphs, int64_t n_nodes, int64_t n_edges, int max_edges_per_graph, int in_dim,
                                int hidden, int out_dim, const float *const *params /* W1 b1 W2 b2 Wf bf */, const float *dropout_mask,
                                double batch, float *const *grads /* dW1 db1 dW2 db2 dWf dbf */, void *arena_dev, int64_t cap_nodes,
-                               int64_t cap_edges, int64_t cap_nodes1) {
+                               int64_t cap_edges, int64_t cap_nodes1, int graph_prebuilt) {
   if (!arena_dev || !params || !grads || !caps_ok(n_graphs, cap_nodes, cap_edges, cap_nodes1, in_dim, hidden, out_dim) || n_nodes <= 0 ||
       n_nodes > cap_nodes || n_edges < 0 || n_edges > cap_edges || out_dim != 1)
     return DRLGX_E_INVALID;
@@ -97,8 +101,12 @@ int drlgx_dqn_forward_backward(void *hip_stream, int n_graphs, int64_t n_nodes, 
     if (!params[i] || !grads[i]) return DRLGX_E_INVALID;
   const Arena a = carve(static_cast<char *>(arena_dev), n_graphs, cap_nodes, std::max<int64_t>(cap_edges, 1), cap_nodes1, in_dim, hidden, out_dim);
   const int N = (int)n_nodes, E = (int)n_edges;
-  int rc = drlgx_gcn_forward_batched(hip_stream, N, E, in_dim, hidden, out_dim, a.x, a.ei, a.ea, params[0], params[1], params[2], params[3],
-                                     params[4], params[5], dropout_mask, a.out, a.gcn_ws, n_graphs, a.node_off, a.edge_off, max_edges_per_graph);
+  int rc = graph_prebuilt
+               ? drlgx_gcn_forward_prebuilt(hip_stream, N, E, in_dim, hidden, out_dim, params[0], params[1], params[2], params[3], params[4],
+                                            params[5], dropout_mask, a.out, a.gcn_ws)
+               : drlgx_gcn_forward_batched(hip_stream, N, E, in_dim, hidden, out_dim, a.x, a.ei, a.ea, params[0], params[1], params[2], params[3],
+                                           params[4], params[5], dropout_mask, a.out, a.gcn_ws, n_graphs, a.node_off, a.edge_off,
+                                           max_edges_per_graph);
   if (rc) return rc;
   rc = drlgx_dqn_loss_grad(hip_stream, N, a.out, a.a_batch, a.y_batch, batch, a.loss, a.d_out);
   if (rc) return rc;

@@ -178,7 +178,9 @@ constexpr uint32_t kCsrNoKey = 0xffffffffu;
 __global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, int extra, const int64_t *ei, const float *ew, const int *node_off,
                                                     const int *edge_off, float *deg, float *selfw_out, int *ptr_dst, int *end_dst,
                                                     int *nbr_dst, float *wn_dst, int *ptr_src, int *end_src, int *nbr_src, float *wn_src,
-                                                    const float *x, int in_dim, float *AX) {
+                                                    const float *x, int in_dim, float *AX, int local) {
+  // local (the replay pool's per-graph cache, drlgx_replay_cache_csr): row starts / ends and neighbour ids are stored relative
+  // to the graph's first edge / node, so that a later collation only adds the graph's offsets in the mini-batch
   extern __shared__ uint32_t s_keys[];  // [2][P2]: by source, by destination; then (extra) the weights and packed endpoints
   uint32_t *ks = s_keys, *kd = s_keys + P2;
   float *s_w = reinterpret_cast<float *>(s_keys + 2 * (size_t)P2);
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, int ex
   const int g = blockIdx.x, tid = threadIdx.x;
   const int n0 = node_off[g], n1 = node_off[g + 1], e0 = edge_off[g];
   const int ng = n1 - n0, eg = min(edge_off[g + 1] - e0, P2);  // (the caller promised eg <= P2)
+  const int eb = local ? 0 : e0, nb = local ? 0 : n0;  // what stored positions / ids are relative to
   const bool ext = extra && ng <= 65535;  // the edges' weights and local endpoints stay in LDS: the later passes read no edge from memory
   for (int m = tid; m < ng; m += 256) selfw_out[n0 + m] = 2.0f;  // add_remaining_self_loops(fill_value = 2)
   __syncthreads();
@@ -252,10 +255,10 @@ __global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, int ex
     const uint32_t v0 = (uint32_t)m << kCsrKeyShift, v1 = (uint32_t)(m + 1) << kCsrKeyShift;
     const int s0 = lower(ks, v0), s1 = lower(ks, v1), d0 = lower(kd, v0), d1 = lower(kd, v1);
     const int n = n0 + m;
-    ptr_src[n] = e0 + s0;
-    end_src[n] = e0 + s1;
-    ptr_dst[n] = e0 + d0;
-    end_dst[n] = e0 + d1;
+    ptr_src[n] = eb + s0;
+    end_src[n] = eb + s1;
+    ptr_dst[n] = eb + d0;
+    end_dst[n] = eb + d1;
     float dsum = 0.f;
     for (int i = s0; i < s1; ++i) {
       const int j = (int)(ks[i] & (kCsrMaxEdges - 1));
@@ -272,14 +275,14 @@ __global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, int ex
       const int j = (int)(a & (kCsrMaxEdges - 1));
       const int r = n0 + (int)(a >> kCsrKeyShift), c = ext ? n0 + (int)(s_pk[j] >> 16) : (int)ei[(size_t)E + e0 + j];
       const float dr = deg[r] > 0 ? 1.0f / sqrtf(deg[r]) : 0.0f, dc = deg[c] > 0 ? 1.0f / sqrtf(deg[c]) : 0.0f;
-      nbr_src[e0 + i] = c;
+      nbr_src[e0 + i] = c - n0 + nb;
       wn_src[e0 + i] = dr * (ext ? s_w[j] : ew[e0 + j]) * dc;
     }
     if (b != kCsrNoKey) {
       const int j = (int)(b & (kCsrMaxEdges - 1));
       const int c = n0 + (int)(b >> kCsrKeyShift), r = ext ? n0 + (int)(s_pk[j] & 0xffffu) : (int)ei[e0 + j];
       const float dr = deg[r] > 0 ? 1.0f / sqrtf(deg[r]) : 0.0f, dc = deg[c] > 0 ? 1.0f / sqrtf(deg[c]) : 0.0f;
-      nbr_dst[e0 + i] = r;
+      nbr_dst[e0 + i] = r - n0 + nb;
       wn_dst[e0 + i] = dr * (ext ? s_w[j] : ew[e0 + j]) * dc;
     }
   }
@@ -292,9 +295,81 @@ __global__ __launch_bounds__(256) void k_csr_graphs(int N, int E, int P2, int ex
     float s = 0.f;
     if (t < in_dim) {
       s = (selfw_out[n] / deg[n]) * x[(size_t)n * in_dim + t];
-      for (int i = ptr_dst[n]; i < end_dst[n]; ++i) s += wn_dst[i] * x[(size_t)nbr_dst[i] * in_dim + t];
+      for (int i = ptr_dst[n] + (e0 - eb); i < end_dst[n] + (e0 - eb); ++i) s += wn_dst[i] * x[(size_t)(nbr_dst[i] + (n0 - nb)) * in_dim + t];
     }
     AX[(size_t)n * 8 + t] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mini-batch collation of replay graphs whose normalisation, CSRs and ÂX were cached per graph when their export entered the
+// pool (k_csr_graphs in `local` mode): graph g of the mini-batch (desc int64 [5][G] = node_start, node_cnt, edge_start,
+// edge_cnt, loc, as k_replay_collate) is copied into the GCN workspace's arrays at its cumulative node / edge offsets, row
+// starts / ends shifted by the edge offset, neighbour ids by the node offset - what build_graph_batched + the ÂX pass would
+// have produced for the collated batch, bit for bit (the per-graph sort order does not depend on where the graph sits).
+// Blocks [G, 2G): the second list's cached per-node value only (the target read-out over the next states), as
+// k_replay_collate's pair form.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_csr_collate(int G, const int64_t *desc, drlgx_csr_cache c, float *deg, float *selfw, float *AX,
+                                                     int *ptr_dst, int *end_dst, int *ptr_src, int *end_src, int *nbr_dst, int *nbr_src,
+                                                     float *wn_dst, float *wn_src, int *node_off_out, int *edge_off_out,
+                                                     const int64_t *desc2, const float *pool_q, float *q2_out) {
+  __shared__ long long red[2][4];
+  const int tid = threadIdx.x;
+  int g = blockIdx.x;
+  const bool second = g >= G;
+  if (second) {
+    g -= G;
+    desc = desc2;
+  }
+  long long sn = 0, se = 0;
+  for (int j = tid; j < g; j += 256) {
+    sn += desc[(size_t)G + j];
+    se += desc[3 * (size_t)G + j];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sn += __shfl_down(sn, o);
+    se += __shfl_down(se, o);
+  }
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = sn;
+    red[1][tid >> 6] = se;
+  }
+  __syncthreads();
+  const long long node_off = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  const long long edge_off = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const long long n0 = desc[g], nn = desc[(size_t)G + g], e0 = desc[2 * (size_t)G + g], ne = desc[3 * (size_t)G + g];
+  if (second) {
+    for (long long i = tid; i < nn; i += 256) q2_out[node_off + i] = pool_q[n0 + i];
+    return;
+  }
+  if (tid == 0) {
+    node_off_out[g] = (int)node_off;
+    edge_off_out[g] = (int)edge_off;
+    if (g == G - 1) {
+      node_off_out[G] = (int)(node_off + nn);
+      edge_off_out[G] = (int)(edge_off + ne);
+    }
+  }
+  const int eo = (int)edge_off, no = (int)node_off;
+  for (long long i = tid; i < nn; i += 256) {
+    deg[node_off + i] = c.deg[n0 + i];
+    selfw[node_off + i] = c.selfw[n0 + i];
+    ptr_dst[node_off + i] = c.ptr_dst[n0 + i] + eo;
+    end_dst[node_off + i] = c.end_dst[n0 + i] + eo;
+    ptr_src[node_off + i] = c.ptr_src[n0 + i] + eo;
+    end_src[node_off + i] = c.end_src[n0 + i] + eo;
+  }
+  {
+    const float4 *s4 = reinterpret_cast<const float4 *>(c.ax + n0 * 8);
+    float4 *d4 = reinterpret_cast<float4 *>(AX + node_off * 8);
+    for (long long i = tid; i < nn * 2; i += 256) d4[i] = s4[i];
+  }
+  for (long long j = tid; j < ne; j += 256) {
+    nbr_dst[edge_off + j] = c.nbr_dst[e0 + j] + no;
+    nbr_src[edge_off + j] = c.nbr_src[e0 + j] + no;
+    wn_dst[edge_off + j] = c.wn_dst[e0 + j];
+    wn_src[edge_off + j] = c.wn_src[e0 + j];
   }
 }
 
@@ -1511,7 +1586,7 @@ bool build_graph_batched(hipStream_t st, const GcnWs &w, int N, int E, const int
   const void *fns[] = {reinterpret_cast<const void *>(&k_csr_graphs)};
   drlgx_ensure_lds_attr(attr_set, fns, 1, 160 * 1024);
   hipLaunchKernelGGL(k_csr_graphs, dim3(G), dim3(256), lds, st, N, E, P2, extra, ei, ew, node_off, edge_off, w.deg, w.selfw, w.ptr_dst, w.end_dst,
-                     w.nbr_dst, w.wn_dst, w.ptr_src, w.end_src, w.nbr_src, w.wn_src, x, in_dim, w.AX);
+                     w.nbr_dst, w.wn_dst, w.ptr_src, w.end_src, w.nbr_src, w.wn_src, x, in_dim, w.AX, 0);
   return true;
 }
 
@@ -1529,17 +1604,21 @@ size_t drlgx_gcn_workspace_bytes(int n_nodes, int n_edges, int hidden, int out_d
   return carve(nullptr, nullptr, n_nodes, std::max(n_edges, 1), hidden, out_dim) + 256;
 }
 
+constexpr int kPrebuilt = -7;  // gcn_forward_impl's n_graphs: the graph part of the workspace is already built
 static int gcn_forward_impl(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim, const float *x,
                             const int64_t *edge_index, const float *edge_attr, const float *W1, const float *b1, const float *W2,
                             const float *b2, const float *Wf, const float *bf, const float *dropout_mask, float *out, void *ws_dev,
                             int n_graphs, const int32_t *node_off, const int32_t *edge_off, int max_edges_per_graph) {
-  if (n_nodes <= 0 || n_edges < 0 || in_dim <= 0 || in_dim > 8 || hidden <= 0 || (hidden & 3) || out_dim <= 0 || !x || !W1 || !b1 ||
-      !W2 || !b2 || !Wf || !bf || !out || !ws_dev || (n_edges > 0 && (!edge_index || !edge_attr)))
+  const bool prebuilt = n_graphs == kPrebuilt;
+  if (n_nodes <= 0 || n_edges < 0 || in_dim <= 0 || in_dim > 8 || hidden <= 0 || (hidden & 3) || out_dim <= 0 || (!x && !prebuilt) || !W1 ||
+      !b1 || !W2 || !b2 || !Wf || !bf || !out || !ws_dev || (n_edges > 0 && !prebuilt && (!edge_index || !edge_attr)))
     return DRLGX_E_INVALID;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   GcnWs w;
   carve(&w, reinterpret_cast<char *>(ws_dev), n_nodes, std::max(n_edges, 1), hidden, out_dim);
-  if (n_graphs <= 0 ||
+  if (n_graphs == kPrebuilt) {
+    // normalisation, both CSRs and AX already are in the workspace (drlgx_gcn_collate_csr)
+  } else if (n_graphs <= 0 ||
       !build_graph_batched(st, w, n_nodes, n_edges, edge_index, edge_attr, n_graphs, node_off, edge_off, max_edges_per_graph, x, in_dim)) {
     build_graph(st, w, n_nodes, n_edges, edge_index, edge_attr);
     hipLaunchKernelGGL(k_ax, dim3((n_nodes * 8 + 255) / 256), dim3(256), 0, st, n_nodes, in_dim, x, w.deg, w.selfw, w.ptr_dst, w.end_dst,
@@ -1574,6 +1653,55 @@ int drlgx_gcn_forward_batched(void *hip_stream, int n_nodes, int n_edges, int in
   if (n_graphs <= 0 || !node_off || !edge_off || max_edges_per_graph < 0) return DRLGX_E_INVALID;
   return gcn_forward_impl(hip_stream, n_nodes, n_edges, in_dim, hidden, out_dim, x, edge_index, edge_attr, W1, b1, W2, b2, Wf, bf,
                           dropout_mask, out, ws_dev, n_graphs, node_off, edge_off, max_edges_per_graph);
+}
+
+int drlgx_gcn_forward_prebuilt(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim, const float *W1, const float *b1,
+                               const float *W2, const float *b2, const float *Wf, const float *bf, const float *dropout_mask, float *out,
+                               void *ws_dev) {
+  return gcn_forward_impl(hip_stream, n_nodes, n_edges, in_dim, hidden, out_dim, nullptr, nullptr, nullptr, W1, b1, W2, b2, Wf, bf, dropout_mask,
+                          out, ws_dev, kPrebuilt, nullptr, nullptr, 0);
+}
+
+static bool cache_ok(const drlgx_csr_cache *c) {
+  return c && c->deg && c->selfw && c->ax && c->ptr_dst && c->end_dst && c->ptr_src && c->end_src && c->nbr_dst && c->nbr_src && c->wn_dst &&
+         c->wn_src;
+}
+
+int drlgx_replay_cache_csr(void *hip_stream, int n_graphs, const int32_t *node_off, const int32_t *edge_off, int max_edges_per_graph,
+                           const float *x, int in_dim, const int64_t *edge_index, int64_t edge_row_stride, const float *edge_attr,
+                           const drlgx_csr_cache *cache) {
+  if (n_graphs <= 0 || !node_off || !edge_off || max_edges_per_graph < 0 || !x || in_dim <= 0 || in_dim > 8 || !edge_index || !edge_attr ||
+      edge_row_stride <= 0 || edge_row_stride >= (1ll << 31) || !cache_ok(cache))
+    return DRLGX_E_INVALID;
+  if (max_edges_per_graph > kCsrMaxEdges) return DRLGX_E_CAPACITY;  // (the caller keeps such an export uncached)
+  int P2 = 64;
+  while (P2 < max_edges_per_graph) P2 <<= 1;
+  const int extra = P2 <= 4096 ? 1 : 0;
+  const size_t lds = (size_t)(extra ? 4 : 2) * P2 * sizeof(uint32_t);
+  static bool attr_set[32] = {false};
+  const void *fns[] = {reinterpret_cast<const void *>(&k_csr_graphs)};
+  drlgx_ensure_lds_attr(attr_set, fns, 1, 160 * 1024);
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  // (E = the row stride of edge_index: the kernel reads the second row at ei[E + e])
+  hipLaunchKernelGGL(k_csr_graphs, dim3(n_graphs), dim3(256), lds, st, 0, (int)edge_row_stride, P2, extra, edge_index, edge_attr, node_off, edge_off,
+                     cache->deg, cache->selfw, cache->ptr_dst, cache->end_dst, cache->nbr_dst, cache->wn_dst, cache->ptr_src, cache->end_src,
+                     cache->nbr_src, cache->wn_src, x, in_dim, cache->ax, 1);
+  return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
+}
+
+int drlgx_gcn_collate_csr(void *hip_stream, int n_graphs, const int64_t *desc_dev, const drlgx_csr_cache *cache, int n_nodes, int n_edges, int hidden,
+                          int out_dim, void *ws_dev, int32_t *node_off_out, int32_t *edge_off_out, const int64_t *desc2_dev, const float *pool_q,
+                          float *q2_out) {
+  if (n_graphs <= 0 || !desc_dev || !cache_ok(cache) || n_nodes <= 0 || n_edges < 0 || hidden <= 0 || out_dim <= 0 || !ws_dev || !node_off_out ||
+      !edge_off_out || (desc2_dev && (!pool_q || !q2_out)))
+    return DRLGX_E_INVALID;
+  GcnWs w;
+  carve(&w, reinterpret_cast<char *>(ws_dev), n_nodes, std::max(n_edges, 1), hidden, out_dim);
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  hipLaunchKernelGGL(k_csr_collate, dim3(desc2_dev ? 2 * n_graphs : n_graphs), dim3(256), 0, st, n_graphs, desc_dev, *cache, w.deg, w.selfw, w.AX,
+                     w.ptr_dst, w.end_dst, w.ptr_src, w.end_src, w.nbr_dst, w.nbr_src, w.wn_dst, w.wn_src, node_off_out, edge_off_out, desc2_dev,
+                     pool_q, q2_out);
+  return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
 }
 
 int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim, const float *x,

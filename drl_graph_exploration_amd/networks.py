@@ -370,8 +370,23 @@ class ReplayPool(object):
     collated with ONE gather per tensor from host-built index arrays (the per-graph torch ops of a Python-side collate
     cost more than the train step they feed).  Slots are recycled when no transition refers to them any more."""
 
-    def __init__(self, device, n_slots, cap_nodes, cap_edges, in_dim=5):
+    def __init__(self, device, n_slots, cap_nodes, cap_edges, in_dim=5, cache_csr=False):
         self.device, self.n_slots, self.cap_nodes, self.cap_edges = device, n_slots, cap_nodes, cap_edges
+        # cache_csr: what the GCN derives from a stored graph (degrees, self weights, both CSRs with the normalised weights,
+        # AX) is computed once per export, at `put`, and a mini-batch is collated from THAT (include/drlgx.h: drlgx_csr_cache)
+        self.csr, self.csr_ok = None, np.zeros(n_slots, dtype=bool)
+        if cache_csr and torch.device(device).type == "cuda":
+            nodes, edges = n_slots * cap_nodes, n_slots * cap_edges
+            nw, ew = sum(_lib.CsrCache.NODE_WORDS.values()), sum(_lib.CsrCache.EDGE_WORDS.values())
+            self._csr_buf = torch.empty(nw * nodes + ew * edges + 64, dtype=torch.int32, device=device)
+            self.csr = _lib.CsrCache()
+            off = (-self._csr_buf.data_ptr() // 4) % 4  # (AX rows are moved as 16-byte pairs)
+            self._csr_off = {}
+            for name, _ in _lib.CsrCache._fields_:
+                words = _lib.CsrCache.NODE_WORDS.get(name, 0) * nodes + _lib.CsrCache.EDGE_WORDS.get(name, 0) * edges
+                self._csr_off[name] = off
+                setattr(self.csr, name, self._csr_buf.data_ptr() + 4 * off)
+                off += (words + 3) & ~3
         self.X = torch.empty(n_slots * cap_nodes, in_dim, dtype=torch.float32, device=device)
         self.EI = torch.empty(2, n_slots * cap_edges, dtype=torch.int64, device=device)
         self.EA = torch.empty(n_slots * cap_edges, dtype=torch.float32, device=device)
@@ -405,7 +420,29 @@ class ReplayPool(object):
         # drlgx_replay_collate's descriptor of every graph of the export (PoolRef.d5 is a row of this)
         self.desc[slot] = np.stack([slot * self.cap_nodes + no[:-1], np.diff(no), slot * self.cap_edges + eo[:-1], np.diff(eo), no[:-1]], axis=1)
         self.q_version[slot] = None
+        if self.csr is not None:
+            self._cache_csr(slot, g, no, eo)
         return slot
+
+    def _cache_csr(self, slot, g, no, eo):
+        """drlgx_replay_cache_csr over the export just stored in `slot` (one launch, one workgroup per graph)."""
+        n_graphs = len(no) - 1
+        nod, eod = g.get("node_off"), g.get("edge_off")
+        if nod is None or eod is None or nod.dtype != torch.int32 or not nod.is_cuda:
+            offs = torch.from_numpy(np.stack([no, eo]).astype(np.int32)).to(self.device)
+            nod, eod = offs[0], offs[1]
+        at = _lib.CsrCache()
+        n0, e0 = slot * self.cap_nodes, slot * self.cap_edges
+        for name, _ in _lib.CsrCache._fields_:
+            per = _lib.CsrCache.NODE_WORDS.get(name)
+            setattr(at, name, getattr(self.csr, name) + 4 * (per * n0 if per else e0))
+        rc = _lib.lib().drlgx_replay_cache_csr(C.c_void_p(_lib.stream_ptr(self.device)), n_graphs, _p(nod), _p(eod),
+                                               int(np.diff(eo).max()) if n_graphs else 0, C.c_void_p(self.X.data_ptr() + 4 * n0 * self.X.shape[1]),
+                                               self.X.shape[1], C.c_void_p(self.EI.data_ptr() + 8 * e0), self.EI.shape[1],
+                                               C.c_void_p(self.EA.data_ptr() + 4 * e0), C.byref(at))
+        self.csr_ok[slot] = rc == 0
+        if rc not in (0, -3):  # (DRLGX_E_CAPACITY: a graph beyond the per-graph sort - that export is collated the generic way)
+            _lib.check(rc)
 
     def export(self, slot):
         """The batched export stored in `slot` as one GraphData (views into the pool, with its graph boundaries)."""

@@ -390,7 +390,7 @@ class DeepQ(object):
         _lib.check(_lib.lib().drlgx_dqn_prepare(vp(_lib.stream_ptr(device)), B, vp(pr["p_desc_j"]), vp(pr["p_desc_j1"]), vp(pool.X.data_ptr()),
                                                 pool.X.shape[1], vp(pool.EI.data_ptr()), pool.EI.shape[1], vp(pool.EA.data_ptr()),
                                                 vp(pool.Q.data_ptr()), pr["N"], pr["E"], pr["N1"], vp(pr["p_meta"]), vp(pr["p_r"]),
-                                                float(self.GAMMA), a.ptr, *a.cap, dims[1], dims[2]))
+                                                float(self.GAMMA), a.ptr, *a.cap, dims[1], dims[2], C.byref(pool.csr) if pr["csr"] else None))
         return a
 
     def _fused_forward_backward(self, pr, arena, device, model, optimizer):
@@ -404,7 +404,7 @@ class DeepQ(object):
         grads = (vp * 6)(*[g.data_ptr() for g in optimizer.grads()])
         _lib.check(_lib.lib().drlgx_dqn_forward_backward(vp(_lib.stream_ptr(device)), self.BATCH, n, pr["E"], pr["ME"], in_dim, hidden, out_dim,
                                                          params, vp(mask.data_ptr()) if mask is not None else None, float(self.BATCH), grads,
-                                                         arena.ptr, *arena.cap))
+                                                         arena.ptr, *arena.cap, 1 if pr["csr"] else 0))
         self._loss_t = arena.loss
         optimizer.bucket.start()
         return model, optimizer
@@ -584,11 +584,13 @@ class DeepQ(object):
             raise ValueError("zero-size array to reduction operation maximum which has no identity")  # as numpy would
         I[:, 10], I[:, 11], I[:, 12], I[:, 13] = lo, hi, off_j + T[:, :, 10], T[:, :, 12]
         R = rew[idx]
+        # the pool's per-graph CSR cache serves a mini-batch when every export it draws its current states from is cached
+        csr = pool.csr is not None and bool(pool.csr_ok[np.unique(T[:, :, 0] // pool.cap_nodes)].all())
         self._refresh_target_readout(pool, np.unique(T[:, :, 13]).tolist(), device, target_net)
         I_dev, R_dev = torch.from_numpy(I).to(device), torch.from_numpy(R).to(device)
         pI, pR, sI, sR = I_dev.data_ptr(), R_dev.data_ptr(), 14 * B * 8, B * 8
         N, E, N1, E1, ME, ME1 = (v.tolist() for v in (N, E, N1, E1, ME, ME1))
-        prepared = [_Prepared(pool=pool, _I=I_dev, _R=R_dev, _u=u, N=N[u], E=E[u], N1=N1[u], E1=E1[u], ME=ME[u], ME1=ME1[u],
+        prepared = [_Prepared(pool=pool, csr=csr, _I=I_dev, _R=R_dev, _u=u, N=N[u], E=E[u], N1=N1[u], E1=E1[u], ME=ME[u], ME1=ME1[u],
                               p_desc_j=pI + u * sI, p_desc_j1=pI + u * sI + 5 * B * 8, p_meta=pI + u * sI + 10 * B * 8, p_r=pR + u * sR)
                     for u in range(n_upd)]
         return prepared, idx
@@ -611,7 +613,7 @@ class DeepQ(object):
         n_slots = 2 * (int(math.ceil(self.REPLAY_MEMORY / n_envs)) + 2)
         pool = getattr(self, "_pool", None)
         if pool is None or pool.device != device or pool.cap_nodes < mn or pool.cap_edges < me or pool.n_slots < n_slots:
-            pool = self._pool = ReplayPool(device, n_slots, mn, me)
+            pool = self._pool = ReplayPool(device, n_slots, mn, me, cache_csr=True)
         # a replay buffer re-loaded from saved_training.pkl holds host graphs: they go into the pool too (packed into
         # slot-sized synthetic exports, a few large copies), so that the updates after a reload take the same one-gather
         # collation and cached target read-out as before it; what does not fit stays a device GraphData (generic path)

@@ -360,6 +360,35 @@ int drlgx_adam_step_scaled(void *hip_stream, int n_tensors, float *const *params
                     float *const *exp_avg, float *const *exp_avg_sq, const int64_t *sizes, double lr, double beta1,
                     double beta2, double eps, int64_t step, double grad_clamp, double grad_scale);
 
+/* Replay graphs never change once stored, so what drlgx_gcn_forward_batched derives from a graph - weighted degrees, self
+ * weights, both CSRs with the normalised weights D^-1/2 (A_w + 2I) D^-1/2 (GCNConv(improved=True), scripts/Networks.py:15-16)
+ * and Â X - is computed ONCE per stored export and kept beside the pooled graphs, graph-local (row starts / ends relative to
+ * the graph's first edge, neighbour ids to its first node).  DEVICE arrays over the pool's node rows / edge columns. */
+typedef struct drlgx_csr_cache {
+  float *deg, *selfw, *ax;                         /* [nodes], [nodes], [nodes][8] */
+  int32_t *ptr_dst, *end_dst, *ptr_src, *end_src;  /* [nodes] */
+  int32_t *nbr_dst, *nbr_src;                      /* [edges] */
+  float *wn_dst, *wn_src;                          /* [edges] */
+} drlgx_csr_cache;
+/* Fill the cache for one export of n_graphs graphs (boundaries node_off / edge_off, DEVICE int32 [n_graphs + 1], relative to
+ * the export's first node / edge).  x, edge_index (second row at + edge_row_stride), edge_attr and every array of `cache`
+ * point AT the export's first node / edge.  DRLGX_E_CAPACITY: a graph has more edges than the per-graph kernel sorts
+ * (16 384) - the caller keeps that export uncached and collates it the generic way. */
+int drlgx_replay_cache_csr(void *hip_stream, int n_graphs, const int32_t *node_off, const int32_t *edge_off, int max_edges_per_graph,
+                           const float *x, int in_dim, const int64_t *edge_index, int64_t edge_row_stride, const float *edge_attr,
+                           const drlgx_csr_cache *cache);
+/* Mini-batch collation straight into the graph part of a GCN workspace (ws_dev of drlgx_gcn_workspace_bytes(n_nodes,
+ * n_edges, ...)): the cached arrays of graph g (desc_dev as drlgx_replay_collate; `cache` points at the POOL's first node /
+ * edge) land at its cumulative offsets with row bounds / neighbour ids shifted - bit for bit what
+ * drlgx_gcn_forward_batched builds for the collated batch.  desc2_dev / pool_q / q2_out: as drlgx_replay_collate_pair
+ * (or all NULL).  Then drlgx_gcn_forward_prebuilt runs the forward without touching x / edge_index / edge_attr. */
+int drlgx_gcn_collate_csr(void *hip_stream, int n_graphs, const int64_t *desc_dev, const drlgx_csr_cache *cache, int n_nodes,
+                          int n_edges, int hidden, int out_dim, void *ws_dev, int32_t *node_off_out, int32_t *edge_off_out,
+                          const int64_t *desc2_dev, const float *pool_q, float *q2_out);
+int drlgx_gcn_forward_prebuilt(void *hip_stream, int n_nodes, int n_edges, int in_dim, int hidden, int out_dim, const float *W1,
+                               const float *b1, const float *W2, const float *b2, const float *Wf, const float *bf,
+                               const float *dropout_mask, float *out, void *ws_dev);
+
 /* One DQN update as TWO host calls (scripts/policy.py:139-178 and :234-249).  Nothing new runs on the device - the launches of
  * drlgx_replay_collate_pair + drlgx_dqn_targets (prepare), and of drlgx_gcn_forward_batched + drlgx_dqn_loss_grad +
  * drlgx_gcn_backward (forward_backward), are issued back to back on the caller's stream with every intermediate in ONE
@@ -367,7 +396,9 @@ int drlgx_adam_step_scaled(void *hip_stream, int n_tensors, float *const *params
  * The arena's layout is a function of the capacities (cap_nodes / cap_edges of the collated current states, cap_nodes1 of the
  * next states' read-out) only; both calls of an update - and drlgx_dqn_arena_views, for read-backs - must pass the same ones.
  * views[12] = x, edge_index [2][n_edges], edge_attr, batch, node_off, edge_off, q1, a_batch, y_batch, out, d_out, loss.
- * params / grads: HOST arrays of six DEVICE pointers (W1 b1 W2 b2 Wf bf and their gradients, written not accumulated). */
+ * params / grads: HOST arrays of six DEVICE pointers (W1 b1 W2 b2 Wf bf and their gradients, written not accumulated).
+ * cache (or NULL): the pool's drlgx_csr_cache - prepare then collates the cached graph data straight into the GCN workspace
+ * (drlgx_gcn_collate_csr) instead of x / edge_index / edge_attr, and forward_backward (same `cache`-ness) skips the build. */
 size_t drlgx_dqn_arena_bytes(int n_graphs, int64_t cap_nodes, int64_t cap_edges, int64_t cap_nodes1, int in_dim, int hidden,
                              int out_dim);
 int drlgx_dqn_arena_views(void *arena_dev, int n_graphs, int64_t cap_nodes, int64_t cap_edges, int64_t cap_nodes1, int in_dim,
@@ -376,11 +407,11 @@ int drlgx_dqn_prepare(void *hip_stream, int n_graphs, const int64_t *desc_dev, c
                       int in_dim, const int64_t *pool_ei, int64_t pool_edges, const float *pool_ea, const float *pool_q,
                       int64_t n_nodes, int64_t n_edges, int64_t n_nodes1, const int64_t *meta_dev, const double *r_dev,
                       double gamma, void *arena_dev, int64_t cap_nodes, int64_t cap_edges, int64_t cap_nodes1, int hidden,
-                      int out_dim);
+                      int out_dim, const drlgx_csr_cache *cache);
 int drlgx_dqn_forward_backward(void *hip_stream, int n_graphs, int64_t n_nodes, int64_t n_edges, int max_edges_per_graph,
                                int in_dim, int hidden, int out_dim, const float *const *params, const float *dropout_mask,
                                double batch, float *const *grads, void *arena_dev, int64_t cap_nodes, int64_t cap_edges,
-                               int64_t cap_nodes1);
+                               int64_t cap_nodes1, int graph_prebuilt);
 
 /* ---- env wrapper / actor-critic heads ------------------------------------------------------------------------- */
 

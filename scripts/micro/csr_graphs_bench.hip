@@ -29,10 +29,10 @@ int main() {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int G : {1, 8, 32, 64, 128, 256, 512}) {
     for (int it = 0; it < 3; ++it)
-      hipLaunchKernelGGL(k_csr_graphs, dim3(G), dim3(256), 4 * 512 * 4, 0, N, (int)E, 512, 1, d_ei, d_ew, d_no, d_eo, deg, sw, pd, ed, nd, wd, ps, es, ns, ws_, nullptr, 0, nullptr);
+      hipLaunchKernelGGL(k_csr_graphs, dim3(G), dim3(256), 4 * 512 * 4, 0, N, (int)E, 512, 1, d_ei, d_ew, d_no, d_eo, deg, sw, pd, ed, nd, wd, ps, es, ns, ws_, nullptr, 0, nullptr, 0);
     hipEventRecord(a, 0);
     for (int it = 0; it < 20; ++it)
-      hipLaunchKernelGGL(k_csr_graphs, dim3(G), dim3(256), 4 * 512 * 4, 0, N, (int)E, 512, 1, d_ei, d_ew, d_no, d_eo, deg, sw, pd, ed, nd, wd, ps, es, ns, ws_, nullptr, 0, nullptr);
+      hipLaunchKernelGGL(k_csr_graphs, dim3(G), dim3(256), 4 * 512 * 4, 0, N, (int)E, 512, 1, d_ei, d_ew, d_no, d_eo, deg, sw, pd, ed, nd, wd, ps, es, ns, ws_, nullptr, 0, nullptr, 0);
     hipEventRecord(b, 0); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     printf("G %4d: %.1f us per launch\n", G, ms / 20 * 1e3);

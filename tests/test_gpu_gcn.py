@@ -328,6 +328,7 @@ def test_fused_dqn_update_equals_the_framework_path(monkeypatch, tmp_path):
     B, n_exports, n_env = 8, 3, 6
     gen = torch.Generator().manual_seed(3)
     pool = ReplayPool(dev, n_exports + 1, 512, 4096)
+    pool_cached = ReplayPool(dev, n_exports + 1, 512, 4096, cache_csr=True)  # the same exports with the per-graph CSR cache
     exports = []
     for k in range(n_exports):  # batched exports like Engine.graph: n_env graphs each, host offsets beside
         x, ei, ea, bt = random_batch(n_env, 300 + k, dev, nmin=10 if k == 0 else 18, nmax=18 if k == 0 else 28)  # graphs grow
@@ -337,6 +338,7 @@ def test_fused_dqn_update_equals_the_framework_path(monkeypatch, tmp_path):
         edge_off = np.concatenate([[0], np.cumsum(ecnt)])
         g = {"x": x, "edge_index": ei, "edge_attr": ea, "node_off_h": node_off, "edge_off_h": edge_off}
         exports.append((pool.put(g), g))
+        assert pool_cached.put(g) == exports[-1][0] and pool_cached.csr_ok[exports[-1][0]]
     plain, pooled = [], []
     for i in range(2 * B):
         (s0, g0), (s1, g1) = exports[0], exports[1 + i % 2]
@@ -421,6 +423,21 @@ def test_fused_dqn_update_equals_the_framework_path(monkeypatch, tmp_path):
     assert dq_c.temp_loss == dq_a.temp_loss
     a_c = dq_c._arena.view("a", prepared_c[2]["N"], torch.float64)
     assert torch.equal(a_c, spy["aa"]) and torch.equal(dq_c._arena.view("y", prepared_c[2]["N"], torch.float64), spy["ya"])
+    assert not prepared_c[0]["csr"]
+    # ... and from a pool that cached every graph's normalisation / CSRs / AX when its export was stored
+    # (drlgx_replay_cache_csr, drlgx_gcn_collate_csr, drlgx_gcn_forward_prebuilt): the same rows in the same order, bit-equal
+    pol_d = copy.deepcopy(tgt)
+    dq_d = DeepQ("d/", "GCN", data_root=str(tmp_path))
+    dq_d.BATCH = B
+    dq_d.buffer.extend([(PoolRef(pool_cached, t[0].slot, t[0].env), t[1], t[2], PoolRef(pool_cached, t[3].slot, t[3].env), t[4], t[5]) for t in pooled])
+    opt_d = FusedAdam(pol_d.parameters(), lr=1e-3, grad_clamp=dq_d.max_grad_norm)
+    it = iter(order)
+    prepared_d, _ = dq_d._prepare_updates(3, dev, tgt)
+    assert prepared_d[0]["csr"]
+    dq_d._train_minibatches(dev, pol_d, tgt, opt_d, prepared_d, None, 3)
+    for (k, va), vd in zip(pol_a.state_dict().items(), pol_d.state_dict().values()):
+        assert torch.equal(va, vd), k
+    assert dq_d.temp_loss == dq_a.temp_loss
 
 
 def test_batched_graph_build_equals_the_generic_one():
