@@ -452,24 +452,45 @@ def spawn_command(args_list, n):
 
 
 def make_train_step(model, d64, dev, split=False):
-    """The reference's DQN update on one collated mini-batch as the product issues it (`DeepQ.train` with the fused
-    optimiser: trunk forward with dropout, float64 cost + gradient, trunk backward, [gradient all-reduce over the ranks,]
-    clamp + Adam): synthetic targets, one action node per graph."""
+    """The reference's DQN update on one 64-graph mini-batch as the product's trainer issues it (`DeepQ._train_minibatches`):
+    the graphs live in a device replay pool whose per-graph normalisation / CSRs / AX were cached when they were stored; per
+    update ONE collation from that cache + the TD targets (drlgx_dqn_prepare), trunk forward with dropout + float64 cost +
+    gradient + trunk backward (drlgx_dqn_forward_backward), [gradient all-reduce over the ranks,] clamp + Adam.  Synthetic
+    rewards, one action node per graph, next state = the same graph (its cached target read-out is gathered and used)."""
+    import random
     import tempfile
+    from drl_graph_exploration_amd.networks import PoolRef, ReplayPool
     from drl_graph_exploration_amd.optim import FusedAdam
     from drl_graph_exploration_amd.policy import DeepQ
     dq = DeepQ("bench_train/", "GCN", data_root=tempfile.mkdtemp(prefix="drlgx_bench_"))
     opt = FusedAdam(model.parameters(), lr=1e-5, grad_clamp=dq.max_grad_norm)
-    n = d64.x.shape[0]
-    last = torch.cat([torch.nonzero(d64.batch[1:] != d64.batch[:-1]).view(-1), torch.tensor([n - 1], device=dev)])  # last node of every graph
-    action = torch.zeros(n, dtype=torch.float64, device=dev)
-    action[last] = 1.0
-    y = torch.zeros(n, dtype=torch.float64, device=dev)
-    y[last] = torch.randn(last.numel(), dtype=torch.float64, device=dev)
-    if split:  # (begin: forward / cost / backward + the gradient exchange issued; end: wait for it, clamp + Adam)
-        model.train()
-        return (lambda: dq._train_begin(d64, action, y, dev, model, opt)), dq._train_end
-    return lambda: dq.train(d64, action, y, dev, model, opt)
+    no, eo = d64.node_off.cpu().numpy().astype(np.int64), d64.edge_off.cpu().numpy().astype(np.int64)
+    B = len(no) - 1
+    pool = ReplayPool(dev, 2, int(no[-1]), max(int(eo[-1]), 1), cache_csr=True)
+    slot = pool.put({"x": d64.x, "edge_index": d64.edge_index, "edge_attr": d64.edge_attr, "node_off_h": no, "edge_off_h": eo,
+                     "node_off": d64.node_off, "edge_off": d64.edge_off})
+    assert pool.csr_ok[slot]
+    rng = np.random.RandomState(0)
+    for i in range(B):
+        ref = PoolRef(pool, slot, i)
+        dq.buffer.append((ref, ref.num_nodes - 1, float(rng.randn()), ref, False, 1))
+    dq.BATCH = B
+    sample, random.sample = random.sample, (lambda pop, k: list(range(k)))  # the mini-batch = the 64 graphs in order
+    try:
+        prepared, _ = dq._prepare_updates(1, dev, model)  # (evaluates the target read-out of the stored export once: not timed)
+    finally:
+        random.sample = sample
+    pr = prepared[0]
+    assert pr["csr"] and pr["N"] == int(no[-1])
+    W1, _, _, _, Wf, _ = model.trunk_parameters()
+    dims = (int(W1.shape[0]), int(W1.shape[1]), int(Wf.shape[0]))
+    model.train()
+
+    def begin():
+        return dq._fused_forward_backward(pr, dq._fused_prepare(pr, dev, dims), dev, model, opt)
+    if split:  # (begin: collation / targets / forward / cost / backward + the gradient exchange issued; end: wait, clamp + Adam)
+        return begin, dq._train_end
+    return lambda: dq._train_end(begin())
 
 
 def train_allreduce_bench(eng, dev, dist, world, iters=20, env_steps_per_iter=8):
