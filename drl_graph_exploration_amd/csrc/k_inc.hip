@@ -687,6 +687,9 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
 //     Sigma_pl = -Sigma_pp G          (column block of landmark j: the sum over its factor list)
 //     Sigma_ll = Lambda_ll^-1 + G^T Sigma_pp G = Lambda_ll^-1 - G^T Sigma_pl
 // written to the HBM panel (the second stage reads the first one's rows back through L2).
+struct __attribute__((aligned(8))) PanelPair {  // two adjacent panel entries (the landmark columns start at column 3: 8-byte aligned only)
+  double x, y;
+};
 __device__ __forceinline__ void panel_from_dense(const DrlgxState &S, const SlamCtx &c, int tid) {
   if (!S.jc) return;
   const int inst = c.inst, P = c.P, L = c.L, pn = P - 1;
@@ -696,6 +699,8 @@ __device__ __forceinline__ void panel_from_dense(const DrlgxState &S, const Slam
   auto lrow = [&](int q) -> double * { return gpan + (size_t)(3 * S.P_max + q) * ldg; };           // landmark rows
   auto asym = [&](int i, int j) -> double { return c.A[c.AT(max(i, j), min(i, j))]; };
   double *jd = S.jd + (size_t)inst * S.P_max * 6;
+  DRLGX_PROF(S, 44);
+  if (tid == 0) c.bad[1] = 0;  // work counter of the two item loops below
   // pose rows: columns of the current pose, the marginal, the landmark blocks
   for (int e = tid; e < 3 * P * 3; e += kThreads) {
     const int q = e / 3, cc = e - 3 * q;
@@ -706,53 +711,100 @@ __device__ __forceinline__ void panel_from_dense(const DrlgxState &S, const Slam
     const int r = t < 1 ? 0 : (t < 3 ? 1 : 2), cc = t - (r * (r + 1)) / 2;
     jd[e] = -c.A[c.AT(3 * i + r, 3 * i + cc)];
   }
-  for (int e = tid; e < P * L; e += kThreads) {
-    const int i = e / L, j = e - i * L;
-    double b[6] = {0, 0, 0, 0, 0, 0};
-    for (int t = c.lstart[j]; t < c.lstart[j + 1]; ++t) {
-      const int m = c.lfac[t], p = c.mp[m];
-      const double *g = c.rec + (size_t)REC * m;
-      const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4], g5 = g[5];
+  __syncthreads();
+  // Sigma_pl: one work item = (landmark j, pose i); the lanes of a wave share j and take consecutive poses, so that the walk over
+  // j's factor list is uniform (one trip count, the G block and the observing pose are wave-uniform loads: no divergence - with
+  // consecutive LANDMARKS per lane every wave paid for the longest list, ~40 entries against ~13 on average, and this stage plus
+  // the next cost more than the whole dense solve: 74 us at 40 poses).  Same sums in the same order per output as before.
+  // The items are handed out through an LDS counter (c.bad[1], free after the sweep): list lengths are very uneven - landmarks
+  // near the start are seen from most poses - and a static deal left some waves with twice the work of others.
+  {
+    const int lane = tid & 63, ib = (P + 63) >> 6;  // pose blocks of 64 per landmark
+    while (true) {
+      int w = 0;
+      if (lane == 0) w = atomicAdd(c.bad + 1, 1);
+      w = __builtin_amdgcn_readfirstlane(w);
+      if (w >= L * ib) break;
+      const int j = w / ib, i = (w - j * ib) * 64 + lane;
+      if (i >= P) continue;
+      int rb[3];  // packed row starts of this pose's three rows
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const double a0 = asym(3 * i + r, 3 * p), a1 = asym(3 * i + r, 3 * p + 1), a2 = asym(3 * i + r, 3 * p + 2);
-        b[2 * r] += a0 * g0 + a1 * g2 + a2 * g4;
-        b[2 * r + 1] += a0 * g1 + a1 * g3 + a2 * g5;
+      for (int r = 0; r < 3; ++r) rb[r] = ((3 * i + r) * (3 * i + r + 1)) >> 1;
+      double b[6] = {0, 0, 0, 0, 0, 0};
+      const int t1 = c.lstart[j + 1];
+      for (int t = c.lstart[j]; t < t1; ++t) {
+        const int m = c.lfac[t], p = c.mp[m];
+        const double *g = c.rec + (size_t)REC * m;
+        const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4], g5 = g[5];
+        const int c0 = 3 * p, cb0 = (c0 * (c0 + 1)) >> 1, cb1 = cb0 + c0 + 1, cb2 = cb1 + c0 + 2;  // (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int q = 3 * i + r;
+          // asym(q, c) = A[max (max + 1) / 2 + min]
+          const double a0 = c.A[q >= c0 ? rb[r] + c0 : cb0 + q], a1 = c.A[q >= c0 + 1 ? rb[r] + c0 + 1 : cb1 + q],
+                       a2 = c.A[q >= c0 + 2 ? rb[r] + c0 + 2 : cb2 + q];
+          b[2 * r] += a0 * g0 + a1 * g2 + a2 * g4;
+          b[2 * r + 1] += a0 * g1 + a1 * g3 + a2 * g5;
+        }
       }
-    }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      prow(3 * i + r)[3 + 2 * j] = b[2 * r];
-      prow(3 * i + r)[3 + 2 * j + 1] = b[2 * r + 1];
+      for (int r = 0; r < 3; ++r) *reinterpret_cast<PanelPair *>(prow(3 * i + r) + 3 + 2 * j) = PanelPair{b[2 * r], b[2 * r + 1]};
     }
   }
   __syncthreads();
+  DRLGX_PROF(S, 45);
+  if (tid == 0) c.bad[1] = 0;
   // landmark rows
   for (int e = tid; e < 2 * L * 3; e += kThreads) {
     const int q = e / 3, cc = e - 3 * q;
     lrow(q)[cc] = prow(3 * pn + cc)[3 + q];
   }
-  for (int e = tid; e < L * L; e += kThreads) {
-    const int j = e / L, j2 = e - j * L;
-    double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-    if (j == j2) {
-      const double *lb = c.lamb + 8 * j;
-      s00 = lb[3]; s01 = lb[4]; s10 = lb[4]; s11 = lb[5];
-    }
-    for (int t = c.lstart[j]; t < c.lstart[j + 1]; ++t) {
-      const int m = c.lfac[t], p = c.mp[m];
-      const double *g = c.rec + (size_t)REC * m;
-#pragma unroll
-      for (int kk = 0; kk < 3; ++kk) {
-        const double *pr = prow(3 * p + kk) + 3 + 2 * j2;
-        const double x0 = pr[0], x1 = pr[1];
-        s00 -= g[2 * kk] * x0; s01 -= g[2 * kk] * x1;
-        s10 -= g[2 * kk + 1] * x0; s11 -= g[2 * kk + 1] * x1;
+  __syncthreads();
+  // Sigma_ll: one work item = (landmark j, landmark j2), the lanes of a wave share j (uniform list walk, uniform G) and take
+  // consecutive j2: the rows of Sigma_pl come back from L2 as contiguous 16-byte pieces
+  {
+    const int lane = tid & 63, jb = (L + 63) >> 6;
+    while (true) {
+      int w = 0;
+      if (lane == 0) w = atomicAdd(c.bad + 1, 1);
+      w = __builtin_amdgcn_readfirstlane(w);
+      if (w >= L * jb) break;
+      const int j = w / jb, j2 = (w - j * jb) * 64 + lane;
+      if (j2 >= L) continue;
+      double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+      if (j == j2) {
+        const double *lb = c.lamb + 8 * j;
+        s00 = lb[3]; s01 = lb[4]; s10 = lb[4]; s11 = lb[5];
       }
+      // (the rows come back through L2, ~1 us per dependent round trip: four list entries' loads are in flight together - the
+      // longest list, ~40 entries, used to set this stage's time at one round trip per entry)
+      const int t1 = c.lstart[j + 1];
+      for (int t = c.lstart[j]; t < t1; t += 4) {
+        const double *g[4];
+        PanelPair x[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int m = c.lfac[min(t + u, t1 - 1)], p = c.mp[m];
+          g[u] = c.rec + (size_t)REC * m;
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) x[u][kk] = *reinterpret_cast<const PanelPair *>(prow(3 * p + kk) + 3 + 2 * j2);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (t + u >= t1) break;
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            const double x0 = x[u][kk].x, x1 = x[u][kk].y;
+            s00 -= g[u][2 * kk] * x0; s01 -= g[u][2 * kk] * x1;
+            s10 -= g[u][2 * kk + 1] * x0; s11 -= g[u][2 * kk + 1] * x1;
+          }
+        }
+      }
+      *reinterpret_cast<PanelPair *>(lrow(2 * j) + 3 + 2 * j2) = PanelPair{s00, s01};
+      *reinterpret_cast<PanelPair *>(lrow(2 * j + 1) + 3 + 2 * j2) = PanelPair{s10, s11};
     }
-    lrow(2 * j)[3 + 2 * j2] = s00; lrow(2 * j)[3 + 2 * j2 + 1] = s01;
-    lrow(2 * j + 1)[3 + 2 * j2] = s10; lrow(2 * j + 1)[3 + 2 * j2 + 1] = s11;
   }
+  DRLGX_PROF(S, 46);
   if (tid == 0) {
     int *meta = inc_meta(S, inst);
     meta[0] = 1; meta[1] = P; meta[2] = L; meta[3] = c.M;

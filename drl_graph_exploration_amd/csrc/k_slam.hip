@@ -90,11 +90,17 @@ __device__ __forceinline__ double fast_rcp(double x) {
 typedef double v4d __attribute__((ext_vector_type(4)));
 // doubles of the LDS region of a packed N x N system swept by sweep_packed_fast: the packed lower triangle, or the sweep's
 // panels (two pivot-column panels, two W panels, two E tiles, two diagonal-tile dumps) that alias it
+// (+ 6 N + 64 behind the triangle: SlamCtx::front parks 18 doubles per pose there - up to N = 128 the panels' size covers it)
 __host__ __device__ inline size_t sweep_region_doubles(size_t N) {
-  const size_t a = N * (N + 1) / 2, b = 64 * N + 1024;
+  const size_t a = N * (N + 1) / 2 + 6 * N + 64, b = 64 * N + 1024;
   return a > b ? a : b;
 }
 constexpr int kWaves = kThreads / 64;
+// The landmark-first dense solve serves systems of up to kDenseTiles tile rows (N = 160: 53 poses).  Up to eight the sweep gives
+// every wave ONE tile row (sweep_packed_fast); nine and ten rows (43 .. 53 poses) are swept by sweep_regtiles - the lower tiles
+// dealt over seven waves, eight accumulator tiles each - which is slower per block step but keeps such updates off the
+// pose-chain solver (k_slam_arrow.hip: ~230 us at 46 poses against ~65 us for the dense solve at 41).
+constexpr int kDenseTiles = 10;
 
 struct SweepCtx {
   int I, lane, lc, lr, np, N;
@@ -1534,8 +1540,9 @@ struct SlamCtx {
     }
     __syncthreads();
     DRLGX_PROF(S, 4);
-    // ---- 5. sweep: one tile row per wave (sweep_packed_fast) ----
-    sweep_packed_fast<FT>(S, A, np, N, Tn, bad, tid, pre_e0, e0);
+    // ---- 5. sweep: one tile row per wave (sweep_packed_fast); 9 - 10 tile rows: the tiles dealt over seven waves ----
+    if (Tn <= FT) sweep_packed_fast<FT>(S, A, np, N, Tn, bad, tid, pre_e0, e0);
+    else sweep_regtiles<true, 8>(A, A, np, N, Tn, Tn * (Tn + 1) / 2, bad, tid);
     __syncthreads();
     DRLGX_PROF(S, 5);
     for (int k = tid; k < np; k += kThreads) d_pose[k] = A[AT(np, k)];
@@ -1761,7 +1768,7 @@ __device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel
   const bool refresh = mailed ? false : cnt[C_FLAG] != 0;
   if (refresh && !(sel.map_last_only && sel.n_act && full)) return;
   const int P = mailed ? mail[0] : cnt[C_P], L = mailed ? mail[1] : cnt[C_L], M = mailed ? mail[2] : cnt[C_M];
-  if ((3 * P + 1 + 15) / 16 > FT) {
+  if ((3 * P + 1 + 15) / 16 > kDenseTiles) {
     // more poses than this kernel was launched for (the host's bound was wrong): flag it, touch nothing
     if (tid == 0) atomicMin(S.status, DRLGX_E_CAPACITY);
     return;
@@ -1827,8 +1834,8 @@ size_t arrow_lds_bytes(int P_max, int L_max, int M_max) {
 
 // true when the fused LDS-resident kernel applies to trajectories of up to P_max poses
 bool drlgx_slam_in_lds(int P_max, int L_max, int M_max) {
-  const size_t nf = 16 * kslam::kFastTiles;
-  return kslam::slam_dim(P_max) <= nf &&
+  const size_t n = kslam::slam_dim(P_max), nf = std::max<size_t>(n, 16 * kslam::kFastTiles);
+  return n <= (size_t)16 * kslam::kDenseTiles &&
          kslam::slam_small_bytes(P_max, L_max, M_max) + kslam::sweep_region_doubles(nf) * 8 <= (size_t)kslam::kLdsBudget;
 }
 // capacities the SLAM kernels can serve at all (checked by drlgx_create)

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
     // room for the landmarks / factors a step may add (more: slam_finish starts over); the front end only runs ahead when
     // the factor records fit the LDS (else slam_finish takes the workspace variant after the simulator)
     const int Lb = min(S.L_max, L0 + 48), Mb = min(S.M_max, M0 + 48);
-    pre = accepted && !inc_try && (3 * (P0 + 1) + 1 + 15) / 16 <= FT && kslam::SlamCtx::big_fits(sim_bytes, lds_bytes, P0 + 1, Lb, Mb);
+    pre = accepted && !inc_try && (3 * (P0 + 1) + 1 + 15) / 16 <= kslam::kDenseTiles && kslam::SlamCtx::big_fits(sim_bytes, lds_bytes, P0 + 1, Lb, Mb);
     if (pre) ctx.setup<true>(S, step_smem, sim_bytes, lds_bytes, inst, P0 + 1, Lb, Mb);
   }
   if (tid == 0) {
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step_arrow(DrlgxState S, La
 bool drlgx_step_fusable(const DrlgxState &S, int p_bound) {
   int chunk = 0;
   const int Pb = p_bound < S.P_max ? p_bound : S.P_max;
-  const size_t nf = 16 * kslam::kFastTiles;
+  const size_t nf = std::max<size_t>(kslam::slam_dim(Pb), 16 * kslam::kFastTiles);
   // (the SLAM stage sits behind the simulator's LDS: its front end runs beside the simulator wave)
   return drlgx_slam_in_lds(Pb, S.L_max, S.M_max) &&
          kstep::sim_lds_bytes(S.LG, Pb) + kslam::slam_small_bytes(Pb, S.L_max, S.M_max) + kslam::sweep_region_doubles(nf) * 8 <= (size_t)kslam::kLdsBudget &&
