@@ -111,6 +111,23 @@ struct DrlgxState {
     if ((S).prof && threadIdx.x == 0 && blockIdx.x == (S).prof_block) (S).prof[slot] = wall_clock64(); \
   } while (0)
 
+// The workgroup's index as a value the optimiser cannot look through.  The stage bodies derive every per-instance address from
+// it; inside k_step_loop (one workgroup runs a whole action list) a plain blockIdx.x let loop-invariant code motion hoist those
+// addresses - dozens of 64-bit pointers per thread - out of the action loop, and the body spilled 2 KB per thread.
+__device__ __forceinline__ int drlgx_bid() {
+  int b = blockIdx.x;
+  asm volatile("" : "+v"(b));                 // (opaque, and not movable: volatile)
+  return __builtin_amdgcn_readfirstlane(b);  // ... and uniform again: a scalar register for the selectors and the scalar loads
+}
+
+// ... and the thread index likewise (the stage bodies keep dozens of values derived from it - lane constants, tile offsets -
+// which the same motion would otherwise carry across the whole action loop)
+__device__ __forceinline__ int drlgx_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 struct LaunchSel {
   int base;                // first instance
   int n;                   // number of instances (= grid size)
@@ -621,6 +638,8 @@ bool drlgx_step_fusable(const DrlgxState &S, int p_bound);
 bool drlgx_step_arrow_fusable(const DrlgxState &S);
 void drlgx_launch_step_arrow(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure);
 void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure);  // requires drlgx_step_fusable
+// every instance's actions [sel.act_idx, min(a_end, n_act[i])) in ONE launch (requires drlgx_step_fusable for the bound of the LAST action)
+void drlgx_launch_step_loop(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end);
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel);  // sel.act_idx == -2: reductions only
 void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
                        const int32_t *dst, int src_off, int dst_off, int skip_mask,  // skip fields with cls & mask

@@ -59,6 +59,7 @@ struct drlgx_engine {
   double t_ms[DRLGX_N_TIMERS] = {0};
   int64_t t_n[DRLGX_N_TIMERS] = {0};
   std::string last_error;
+  bool la_loop = true;  // look-ahead rollouts: one launch for a candidate's whole action list (k_step_loop)
   // FastMarginals2 workspaces (allocated on first use): dense prior covariances, per-candidate scratch
   double *fm2_sig = nullptr, *fm2_scratch = nullptr;
   int *fm2_iscratch = nullptr;
@@ -186,6 +187,8 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   {
     const char *v = getenv("DRLGX_VARIANT_BY_CAPACITY");
     e->by_capacity = v && v[0] == '1';
+    const char *ll = getenv("DRLGX_LOOKAHEAD_LOOP");  // 0: one launch per action index (the A/B of the look-ahead tests)
+    e->la_loop = !(ll && ll[0] == '0');
   }
   e->snap_pbound.assign(cfg->max_snapshots > 0 ? cfg->max_snapshots : 0, std::vector<int>(n_envs, cfg->max_poses));
   S.P_max = cfg->max_poses;
@@ -768,6 +771,15 @@ int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env
                         &S);  // (with the base solve's covariance panel)
       drlgx_launch_fix_rollouts(S, e->stream, nc, ce, roll0);
     }
+    const int pb_last = std::min(pbe + max_n_actions, S.P_max);
+    if (e->la_loop && !e->per_stage && drlgx_step_fusable(S, pb_last)) {
+      // every candidate's whole action list in ONE launch (k_step_loop): no per-action tails, candidates dealt to the CUs as they finish
+      LaunchSel sel{roll0, nc, nullptr, na, 0};
+      sel.map_last_only = 1;
+      sel.pcap = pb_last;
+      ScopedTimer t(e, 5);
+      drlgx_launch_step_loop(S, e->stream, sel, act, S.A_max * 3, 1, max_n_actions);
+    } else
     for (int a = 0; a < max_n_actions; ++a) {
       LaunchSel sel{roll0, nc, nullptr, na, a};
       sel.map_last_only = 1;

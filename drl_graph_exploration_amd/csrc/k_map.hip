@@ -1,10 +1,11 @@
 // Virtual-map kernel: occupancy rebuild + covariance propagation (EKF push-through of every core
 // pose onto the virtual-landmark grid, fused by covariance intersection) + utility reductions.
-// One 512-thread workgroup per instance: 201 VGPRs and ~100 KB of LDS at the bench state, i.e. ONE workgroup per CU (2 waves
-// per SIMD).  By the SQ counters (profiles/r04_ab_map_two_workgroups_per_cu.txt) the VALU is busy 37 % of the time and 57 % of the
-// wave-cycles are spent parked on waitcnt / barriers: the waves wait for each other at the phase barriers and along the
-// dependent fusion chains, the kernel is neither HBM- nor issue-bound.  k_map_c below is the two-workgroups-per-CU form
-// (compact carve, 128 VGPRs); it spills and is slower so far.
+// One 512-thread workgroup per instance: ~100 KB of LDS at the bench state, i.e. ONE workgroup per CU (2 waves per SIMD).  By
+// the SQ counters (profiles/r04_ab_map_two_workgroups_per_cu.txt) the VALU is busy 37 % of the time and 57 % of the wave-cycles
+// are spent parked on waitcnt / barriers: the waves wait for each other at the phase barriers and along the dependent fusion
+// chains, the kernel is neither HBM- nor issue-bound.  k_map_c below is the two-workgroups-per-CU form (compact carve, <= 128
+// VGPRs): launched when there are more instances than CUs.  (Compiled without machine-level loop-invariant code motion - see the
+// Makefile - both forms need ~125 VGPRs; with it this one took 211 and k_map_c spilled.)
 //
 // Reference: src/em_exploration/OccupancyMap.cpp:55-138 (log-odds ladder, bbox sector sweep),
 // src/em_exploration/VirtualMap.cpp:47-84 (explored, updateProbability), :213-229
@@ -180,8 +181,8 @@ template <bool kCompact = false>
 __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &sel, int rebuild, int chunk, bool handed = false,
                                          const double *lm_lds = nullptr, LadderEntry lo = LadderEntry{false, 0.0, 0u, -1, 0, 0}) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bi = blockIdx.x;
+  const int tid = drlgx_tid(), lane = tid & 63, wave = tid >> 6;
+  const int bi = drlgx_bid();
   if (!sel.on(bi) || !sel.map_on(bi)) return;
   const int inst = sel.base + bi;
   const int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
@@ -773,8 +774,9 @@ void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
   }
   int cchunk = 0;
   const size_t clds = rebuild ? map_lds_bytes_compact(S, sel.pcap, &cchunk) : 0;
-  // (measured slower so far - its 128-VGPR cap spills, profiles/r04_ab_map_two_workgroups_per_cu.txt - so only on request)
-  if (clds && force == 1 && n_cu > 0)
+  // more instances than CUs: the form of which two workgroups share a CU (each covers the other's barriers and dependent chains:
+  // 97 against 136 us at 2 048 instances, profiles/r05_ab_machine_licm.txt); up to one instance per CU the resident form
+  if (clds && (force == 1 || (force != 0 && sel.n > n_cu)))
     hipLaunchKernelGGL(kmap::k_map_c, dim3(sel.n), dim3(kmap::kThreads), clds, st, S, sel, rebuild, cchunk);
   else
     hipLaunchKernelGGL(kmap::k_map, dim3(sel.n), dim3(kmap::kThreads), lds, st, S, sel, rebuild, chunk);

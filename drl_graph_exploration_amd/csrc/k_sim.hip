@@ -308,7 +308,7 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
   uint32_t *lds[2] = {lds0, lds1};
   double *nrm = dyn;
   int *inr = reinterpret_cast<int *>(dyn + 2 * S.LG + 2);
-  const int i = blockIdx.x;
+  const int i = drlgx_bid();
   if (!sel.on(i)) return;
   const int inst = sel.base + i;
   const drlgx_config &cfg = S.cfg;

@@ -1721,7 +1721,7 @@ struct SlamCtx {
 // The incremental update as a stage (k_slam / k_slam_arrow / k_step_arrow, after the simulator): true when it served the
 // instance - the caller then skips its solver.  Every thread of the workgroup calls it.
 __device__ __forceinline__ bool inc_stage(const DrlgxState &S, const LaunchSel &sel, int lds_bytes, size_t smem_off) {
-  const int tid = threadIdx.x, bi = blockIdx.x;
+  const int tid = drlgx_tid(), bi = drlgx_bid();
   if (!S.jc || !sel.on(bi)) return false;
   const int inst = sel.base + bi;
   const int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
@@ -1754,8 +1754,8 @@ __device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel
                                             const int *mail = nullptr, double *hand = nullptr, const double **lm_out = nullptr,
                                             SimBox box = SimBox{nullptr, nullptr, nullptr}, int hand_cap = 0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int tid = threadIdx.x;
-  const int bi = blockIdx.x;
+  const int tid = drlgx_tid();
+  const int bi = drlgx_bid();
   if (!sel.on(bi)) return;
   const int inst = sel.base + bi;
   int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;

@@ -27,12 +27,12 @@ namespace kstep {
 __host__ __device__ inline size_t sim_lds_bytes(int LG, int P_max) { return drlgx_sim_lds_bytes(LG, P_max); }
 
 template <int FT>
-__global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
-                                                          int n_measure, int lds_bytes, int map_chunk) {
+__device__ __forceinline__ void step_once(const DrlgxState &S, const LaunchSel &sel, const double *odom, int odom_stride, int n_measure,
+                                          int lds_bytes, int map_chunk) {
   static_assert(kslam::kThreads == kmap::kThreads, "the fused kernel runs both stages with one workgroup size");
   extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
-  const int tid = threadIdx.x;
-  const int bi = blockIdx.x;
+  const int tid = drlgx_tid();
+  const int bi = drlgx_bid();
   if (S.prof && tid == 0 && bi < 448) S.prof[128 + 2 * bi] = wall_clock64();  // (dev aid: per-workgroup start / end)
   // ---- what the SLAM front end needs is read before the simulator wave starts to change it ----
   const int pc = sel.cap(S.P_max);  // the launch's pose bound sizes the per-pose LDS tables (LaunchSel::pcap)
@@ -139,6 +139,32 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
   if (S.prof && tid == 0 && bi < 448) S.prof[129 + 2 * bi] = wall_clock64();
 }
 
+template <int FT>
+__global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
+                                                          int n_measure, int lds_bytes, int map_chunk) {
+  step_once<FT>(S, sel, odom, odom_stride, n_measure, lds_bytes, map_chunk);
+}
+
+// A whole action LIST per workgroup (the look-ahead's rollouts, EMPlanner2D::simulations_reward's loop, Planner2D.cpp:1432-1460):
+// instance bi runs its actions [sel.act_idx, min(a_end, n_act[bi])) back to back - the fused step above once per action, the
+// state of one action handed to the next through HBM / L2 exactly as between launches (a workgroup barrier orders them).
+// Against one launch per action index this removes the per-launch tails (every launch lasted as long as its slowest
+// instance) and lets the hardware deal the candidates to the CUs as they finish: a candidate with few actions makes room
+// for the next one instead of idling through the other candidates' later actions.
+template <int FT>
+__global__ __launch_bounds__(kslam::kThreads) void k_step_loop(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
+                                                               int n_measure, int lds_bytes, int map_chunk, int a_end) {
+  const int bi = blockIdx.x;
+  const int n_mine = sel.n_act ? min(a_end, sel.n_act[bi]) : a_end;
+  if (sel.active && !sel.active[bi]) return;
+  for (int a = sel.act_idx; a < n_mine; ++a) {
+    LaunchSel one = sel;
+    one.act_idx = a;
+    step_once<FT>(S, one, odom, odom_stride, n_measure, lds_bytes, map_chunk);
+    __syncthreads();  // (also a workgroup-scope fence: the next action reads what this one wrote)
+  }
+}
+
 // The same fusion around the pose-chain solver (trajectories beyond the LDS-resident dense solve): simulate -> k_slam_arrow's
 // body -> virtual map in one kernel.  Only the variant whose landmark system is swept in LDS (<= 63 landmarks).
 __global__ __launch_bounds__(kslam::kThreads) void k_step_arrow(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
@@ -185,6 +211,16 @@ void drlgx_launch_step_arrow(const DrlgxState &S, hipStream_t st, LaunchSel sel,
   drlgx_ensure_lds_attr(attr_set, fns, 1, kslam::kLdsBudget);
   hipLaunchKernelGGL(kstep::k_step_arrow, dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, odom, odom_stride, n_measure,
                      kslam::kLdsBudget, chunk);
+}
+
+void drlgx_launch_step_loop(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end) {
+  int chunk = 0;
+  (void)drlgx_map_lds_bytes(S, &chunk, sel.pcap);
+  static bool attr_set[32] = {false};
+  const void *fns[] = {reinterpret_cast<const void *>(&kstep::k_step_loop<kslam::kFastTiles>)};
+  drlgx_ensure_lds_attr(attr_set, fns, 1, kslam::kLdsBudget);
+  hipLaunchKernelGGL((kstep::k_step_loop<kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, odom,
+                     odom_stride, n_measure, kslam::kLdsBudget, chunk, a_end);
 }
 
 void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure) {

@@ -271,9 +271,10 @@ int drlgx_debug_phase_clocks_host(drlgx_engine *e, int arm, int64_t *out /* 64 v
 int drlgx_debug_gemm_tile_rows(int m, int n, int k_slices, int transpose_a);
 
 /* Development aid: picks the form of the stand-alone virtual-map kernel (VirtualMap::updateProbability / updateInformation,
- * VirtualMap.cpp:61-84,256-316) for every later launch of this process: 1 = the two-workgroups-per-CU form, 0 / -1 = the
- * resident form (the default; the environment variable DRLGX_MAP_COMPACT sets the initial value, read once).  Returns the
- * previous value.  Both forms are bit-equal; the parity test switches between them with this call. */
+ * VirtualMap.cpp:61-84,256-316) for every later launch of this process: 1 = the two-workgroups-per-CU form, 0 = the
+ * resident form, -1 (the default; the environment variable DRLGX_MAP_COMPACT sets the initial value, read once) = by launch
+ * size: two per CU when there are more instances than CUs.  Returns the previous value.  Both forms are bit-equal; the
+ * parity test switches between them with this call. */
 int drlgx_debug_map_form(int form);
 
 /* The incremental belief update (csrc/k_inc.hip): between relinearisations of the iSAM2 policy (SLAM2D.cpp:10-12: every
