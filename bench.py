@@ -58,7 +58,7 @@ def make_engine(device_index, seed0, max_poses=41):
     from drl_graph_exploration_amd.engine import Engine
     cfg = default_config(MAP, num_landmarks=NUM_LM, max_poses=max_poses, max_landmarks=100, max_factors=12 * max_poses + 20,
                          max_snapshots=1)
-    eng = Engine(cfg, N_ENVS, 2048, device=device_index)  # 2048 rollout instances for the look-ahead waves
+    eng = Engine(cfg, N_ENVS, 4096, device=device_index)  # rollout instances of the look-ahead (VecExplorationEnv's default: min(n_envs (max_landmarks + 1), 4096))
     ids = np.arange(N_ENVS)
     eng.reset(ids, seed0 + ids, los=seed0 + ids)
     for act in WARM_SCRIPT:

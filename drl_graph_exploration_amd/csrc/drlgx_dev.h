@@ -142,6 +142,9 @@ struct LaunchSel {
   // kernels size their per-pose LDS tables with it, so that a large pose capacity costs short trajectories nothing; an
   // instance that exceeds it raises DRLGX_E_CAPACITY instead of overrunning.
   int pcap = 0;
+  // the fused step kernel leaves the map stage out: the caller launches the stand-alone map kernel behind it (more instances
+  // than CUs: its two-workgroups-per-CU form beats the stage fused into a one-per-CU workgroup)
+  int skip_map = 0;
   __host__ __device__ __forceinline__ int cap(int P_max) const { return pcap > 0 && pcap < P_max ? pcap : P_max; }
   __device__ __forceinline__ bool map_on(int i) const {
     return !(map_last_only && n_act) || act_idx == n_act[i] - 1;
@@ -640,7 +643,9 @@ void drlgx_launch_step_arrow(const DrlgxState &S, hipStream_t st, LaunchSel sel,
 void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure);  // requires drlgx_step_fusable
 // every instance's actions [sel.act_idx, min(a_end, n_act[i])) in ONE launch (requires drlgx_step_fusable for the bound of the LAST action)
 void drlgx_launch_step_loop(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end);
+void drlgx_launch_step_arrow_loop(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end);  // requires drlgx_step_arrow_fusable
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel);  // sel.act_idx == -2: reductions only
+bool drlgx_map_two_per_cu(const DrlgxState &S, int p_bound);
 void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t st, int n, const int32_t *src,
                        const int32_t *dst, int src_off, int dst_off, int skip_mask,  // skip fields with cls & mask
                        const int *cnt = nullptr,  // S.cnt: copy the live part of per-pose / -landmark / -factor fields only

@@ -59,6 +59,7 @@ struct drlgx_engine {
   double t_ms[DRLGX_N_TIMERS] = {0};
   int64_t t_n[DRLGX_N_TIMERS] = {0};
   std::string last_error;
+  int n_cu = 256;       // compute units of the device (drlgx_create)
   bool la_loop = true;  // look-ahead rollouts: one launch for a candidate's whole action list (k_step_loop)
   // FastMarginals2 workspaces (allocated on first use): dense prior covariances, per-candidate scratch
   double *fm2_sig = nullptr, *fm2_scratch = nullptr;
@@ -187,6 +188,8 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   {
     const char *v = getenv("DRLGX_VARIANT_BY_CAPACITY");
     e->by_capacity = v && v[0] == '1';
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cu = prop.multiProcessorCount;
     const char *ll = getenv("DRLGX_LOOKAHEAD_LOOP");  // 0: one launch per action index (the A/B of the look-ahead tests)
     e->la_loop = !(ll && ll[0] == '0');
   }
@@ -532,7 +535,15 @@ int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_de
   if (drlgx_step_fusable(e->S, pb) && !e->per_stage) {
     // one fused kernel per step (timer 5); timing mode 2 launches the stage kernels separately (timers 0-2)
     ScopedTimer t(e, 5);
+    // more envs than CUs: simulator + SLAM fused, the map as its own launch in the two-workgroups-per-CU form (k_map_c) - at one
+    // workgroup per CU the fused map stage cannot overlap anything, two map workgroups per CU cover each other's barriers
+    const bool split = e->S.n_envs > e->n_cu && drlgx_map_two_per_cu(e->S, pb);
+    sel.skip_map = split ? 1 : 0;
     drlgx_launch_step(e->S, e->stream, sel, odom_dev, 3, 2);
+    if (split) {
+      sel.skip_map = 0;
+      drlgx_launch_map(e->S, e->stream, sel);
+    }
   } else if (drlgx_step_arrow_fusable(e->S) && !e->per_stage) {
     ScopedTimer t(e, 5);  // longer trajectories: the same fusion around the pose-chain solver
     drlgx_launch_step_arrow(e->S, e->stream, sel, odom_dev, 3, 2);
@@ -779,6 +790,13 @@ int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env
       sel.pcap = pb_last;
       ScopedTimer t(e, 5);
       drlgx_launch_step_loop(S, e->stream, sel, act, S.A_max * 3, 1, max_n_actions);
+    } else if (e->la_loop && !e->per_stage && drlgx_step_arrow_fusable(S)) {
+      // the same around the pose-chain solver (any trajectory length, <= 63 landmarks): the reference's own worlds
+      LaunchSel sel{roll0, nc, nullptr, na, 0};
+      sel.map_last_only = 1;
+      sel.pcap = pb_last;
+      ScopedTimer t(e, 5);
+      drlgx_launch_step_arrow_loop(S, e->stream, sel, act, S.A_max * 3, 1, max_n_actions);
     } else
     for (int a = 0; a < max_n_actions; ++a) {
       LaunchSel sel{roll0, nc, nullptr, na, a};

@@ -752,6 +752,13 @@ extern "C" int drlgx_debug_map_form(int form) {
   return was;
 }
 
+// true when a rebuild launch of more instances than CUs would run the two-workgroups-per-CU form (the engine then keeps the map
+// stage out of the fused step kernel and launches it separately)
+bool drlgx_map_two_per_cu(const DrlgxState &S, int p_bound) {
+  int cchunk = 0;
+  return map_form() != 0 && map_lds_bytes_compact(S, p_bound, &cchunk) != 0;
+}
+
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
   // sel.act_idx == -2 encodes "reductions only" (used after reset)
   int rebuild = 1;

@@ -84,8 +84,8 @@ constexpr int kSegLog = 3, kSeg = 1 << kSegLog;  // leaf segments of the chain: 
 template <int NTW>
 __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel &sel, int lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int tid = threadIdx.x;
-  const int bi = blockIdx.x;
+  const int tid = drlgx_tid();
+  const int bi = drlgx_bid();
   if (!sel.on(bi)) return;
   if (inc_stage(S, sel, lds_bytes, 0)) return;  // between relinearisations: the rank-k covariance update (k_inc.hip)
   const int inst = sel.base + bi;

@@ -135,7 +135,7 @@ __device__ __forceinline__ void step_once(const DrlgxState &S, const LaunchSel &
   }
   const unsigned char *map_masks = step_smem + kmap::masks_offset(pc, map_chunk);
   if (!handed || reinterpret_cast<const unsigned char *>(lm_lds + 2 * (size_t)S.L_max) > map_masks) lm_lds = nullptr;
-  kmap::map_body<false>(S, sel, 1, map_chunk, handed, lm_lds, lo);
+  if (!sel.skip_map) kmap::map_body<false>(S, sel, 1, map_chunk, handed, lm_lds, lo);
   if (S.prof && tid == 0 && bi < 448) S.prof[129 + 2 * bi] = wall_clock64();
 }
 
@@ -167,10 +167,10 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step_loop(DrlgxState S, Lau
 
 // The same fusion around the pose-chain solver (trajectories beyond the LDS-resident dense solve): simulate -> k_slam_arrow's
 // body -> virtual map in one kernel.  Only the variant whose landmark system is swept in LDS (<= 63 landmarks).
-__global__ __launch_bounds__(kslam::kThreads) void k_step_arrow(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
-                                                                int n_measure, int lds_bytes, int map_chunk) {
+__device__ __forceinline__ void step_arrow_once(const DrlgxState &S, const LaunchSel &sel, const double *odom, int odom_stride, int n_measure,
+                                                int lds_bytes, int map_chunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
-  const int tid = threadIdx.x;
+  const int tid = drlgx_tid();
   if (tid < 64) {
     uint32_t *l0 = reinterpret_cast<uint32_t *>(step_smem);
     uint32_t *l1 = l0 + DRLGX_MT_STRIDE;
@@ -180,7 +180,24 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step_arrow(DrlgxState S, La
   __syncthreads();
   kslam::arrow_body<0>(S, sel, lds_bytes);  // (or, between relinearisations, the incremental update: arrow_body's first lines)
   __syncthreads();
-  kmap::map_body<false>(S, sel, 1, map_chunk);
+  if (!sel.skip_map) kmap::map_body<false>(S, sel, 1, map_chunk);
+}
+__global__ __launch_bounds__(kslam::kThreads) void k_step_arrow(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
+                                                                int n_measure, int lds_bytes, int map_chunk) {
+  step_arrow_once(S, sel, odom, odom_stride, n_measure, lds_bytes, map_chunk);
+}
+// ... and a whole action list per workgroup, as k_step_loop (the look-ahead of trajectories beyond the dense solver's reach)
+__global__ __launch_bounds__(kslam::kThreads) void k_step_arrow_loop(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
+                                                                     int n_measure, int lds_bytes, int map_chunk, int a_end) {
+  const int bi = blockIdx.x;
+  const int n_mine = sel.n_act ? min(a_end, sel.n_act[bi]) : a_end;
+  if (sel.active && !sel.active[bi]) return;
+  for (int a = sel.act_idx; a < n_mine; ++a) {
+    LaunchSel one = sel;
+    one.act_idx = a;
+    step_arrow_once(S, one, odom, odom_stride, n_measure, lds_bytes, map_chunk);
+    __syncthreads();
+  }
 }
 
 }  // namespace kstep
@@ -211,6 +228,16 @@ void drlgx_launch_step_arrow(const DrlgxState &S, hipStream_t st, LaunchSel sel,
   drlgx_ensure_lds_attr(attr_set, fns, 1, kslam::kLdsBudget);
   hipLaunchKernelGGL(kstep::k_step_arrow, dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, odom, odom_stride, n_measure,
                      kslam::kLdsBudget, chunk);
+}
+
+void drlgx_launch_step_arrow_loop(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end) {
+  int chunk = 0;
+  (void)drlgx_map_lds_bytes(S, &chunk, sel.pcap);
+  static bool attr_set[32] = {false};
+  const void *fns[] = {reinterpret_cast<const void *>(&kstep::k_step_arrow_loop)};
+  drlgx_ensure_lds_attr(attr_set, fns, 1, kslam::kLdsBudget);
+  hipLaunchKernelGGL(kstep::k_step_arrow_loop, dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, odom, odom_stride, n_measure,
+                     kslam::kLdsBudget, chunk, a_end);
 }
 
 void drlgx_launch_step_loop(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end) {

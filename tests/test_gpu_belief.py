@@ -816,3 +816,30 @@ def test_incremental_update_equals_the_full_solve_beyond_the_dense_solver_and_wi
     assert inc >= n * (len(script) - len(script) // 10 - 4), (inc, full)  # all but the reset and the 10th updates
     eng.close()
     ref.close()
+
+
+def test_more_envs_than_compute_units_run_the_map_stage_two_per_cu():
+    """With more envs than the device has CUs `drlgx_step` keeps the map stage out of the fused kernel and launches it as the
+    two-workgroups-per-CU kernel (csrc/drlgx_engine.cpp: drlgx_step, k_map_c).  Instances are independent and both map forms
+    are bit-equal, so env i of a 300-env engine must equal, bit for bit, the same env stepped in a small engine."""
+    n_big, pick = 300, [0, 1, 150, 298, 299]
+    big, cfg = make_engine(n_big, num_landmarks=60)
+    small, _ = make_engine(len(pick), num_landmarks=60)
+    assert torch.cuda.get_device_properties(0).multi_processor_count < n_big
+    rng = np.random.RandomState(5)
+    starts = np.stack([rng.uniform(-8, 8, n_big), rng.uniform(-8, 8, n_big), rng.uniform(-3, 3, n_big)], 1)
+    big.reset(np.arange(n_big), np.arange(n_big) + 7, starts=starts)
+    small.reset(np.arange(len(pick)), np.array(pick) + 7, starts=starts[pick])
+    sim = O.OracleSim(O.default_config(MAP, num_landmarks=60), pick[2] + 7, 0, start=tuple(starts[pick[2]]))
+    for s, act in enumerate(SCRIPT + [(2, 0, 0), (0, 0, 0.9), (2, 0, 0)] * 3):
+        big.step(torch.tensor([act] * n_big, dtype=torch.float64, device=big.device))
+        small.step(torch.tensor([act] * len(pick), dtype=torch.float64, device=small.device))
+        sim.simulate(act)
+    assert big.status() == 0 and small.status() == 0
+    for k, i in enumerate(pick):
+        for a, b in zip(big.poses(i) + big.landmarks(i) + big.virtual_map(i), small.poses(k) + small.landmarks(k) + small.virtual_map(k)):
+            np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(big.utility().cpu().numpy()[pick], small.utility().cpu().numpy())
+    compare_state(big, pick[2], sim, "env %d of %d" % (pick[2], n_big))
+    big.close()
+    small.close()
