@@ -603,6 +603,36 @@ int drlgx_step_plan(drlgx_engine *e, const double *actions_dev, const int32_t *n
   return check_launch(e);
 }
 
+// The whole loop `for a in actions: self._sim.simulate(a)` of every env (scripts/envs/exploration_env.py:98-105) in one call: env i
+// executes actions[i][0 .. n_actions[i]); max_n_actions = a host-side bound of the plan lengths.  One launch when the fused
+// step kernel serves every pose count the plans can reach (k_step_loop / k_step_arrow_loop: a workgroup runs its env's whole
+// plan), else one drlgx_step_plan per action index.  Same results as that loop, bit for bit.
+int drlgx_step_plans(drlgx_engine *e, const double *actions_dev, const int32_t *n_actions_dev, int max_n_actions, int map_last_only) {
+  DRLGX_ENTER(e);
+  if (!e || !actions_dev || !n_actions_dev || max_n_actions < 0 || max_n_actions > e->S.A_max) return DRLGX_E_INVALID;
+  if (max_n_actions == 0) return DRLGX_OK;
+  const DrlgxState &S = e->S;
+  const int pb_last = std::min(max_bound(e) + max_n_actions, S.P_max);
+  const bool dense = drlgx_step_fusable(S, pb_last), arrow = !dense && drlgx_step_arrow_fusable(S);
+  if (!e->la_loop || e->per_stage || !(dense || arrow)) {
+    for (int a = 0; a < max_n_actions; ++a) {
+      const int r = drlgx_step_plan(e, actions_dev, n_actions_dev, a, map_last_only);
+      if (r) return r;
+    }
+    return DRLGX_OK;
+  }
+  LaunchSel sel{0, S.n_envs, nullptr, n_actions_dev, 0};
+  sel.map_last_only = map_last_only ? 1 : 0;
+  sel.pcap = pb_last;
+  for (int &v : e->pbound) v = std::min(v + max_n_actions, S.P_max);
+  {
+    ScopedTimer t(e, 5);
+    if (dense) drlgx_launch_step_loop(S, e->stream, sel, actions_dev, S.A_max * 3, 2, max_n_actions);
+    else drlgx_launch_step_arrow_loop(S, e->stream, sel, actions_dev, S.A_max * 3, 2, max_n_actions);
+  }
+  return check_launch(e);
+}
+
 // ---- staged form of the belief step: one call per call of SS2D.__init__ / SS2D.simulate (scripts/envs/pyss2d.py) -------
 int drlgx_stage_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint32_t *seeds, const double *start) {
   DRLGX_ENTER(e);

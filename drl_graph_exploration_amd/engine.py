@@ -95,6 +95,12 @@ class Engine(object):
         i32 on the device; with `map_last_only` the virtual map is rebuilt at each env's last action only."""
         self.use_torch_stream()
         self._chk(self.L.drlgx_step_plan(self.h, _p(actions), _p(n_actions), int(action_index), 1 if map_last_only else 0))
+
+    def step_plans(self, actions, n_actions, max_n_actions, map_last_only=True):
+        """Every env's whole plan (drlgx_step_plans): `for k in range(max_n_actions): step_plan(..., k)` in one call."""
+        self.use_torch_stream()
+        self._chk(self.L.drlgx_step_plans(self.h, _p(actions), _p(n_actions), int(max_n_actions), 1 if map_last_only else 0))
+
     def stage_reset(self, env_ids, seeds, starts):
         env_ids = np.ascontiguousarray(env_ids, dtype=np.int32)
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32)

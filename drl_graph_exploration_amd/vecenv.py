@@ -182,8 +182,7 @@ class VecExplorationEnv(object):
             acts = torch.cat([acts, acts.new_zeros(acts.shape[0], self.cfg.max_actions - acts.shape[1], 3)], dim=1)
         acts = acts.contiguous()
         nact = nact.to(torch.int32).contiguous()
-        for k in range(kmax):
-            self.engine.step_plan(acts, nact, k, map_last_only=not map_every_action)
+        self.engine.step_plans(acts, nact, kmax, map_last_only=not map_every_action)
         live = torch.arange(acts.shape[1], device=self.device)[None, :] < nact[:, None]
         self.dist += (torch.sqrt(acts[:, :, 0] ** 2 + acts[:, :, 1] ** 2) * live).sum(dim=1)
         self.engine.check_status()

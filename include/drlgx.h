@@ -108,6 +108,11 @@ int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_de
  * the state after the plan is the same, intermediate getters of the map see the previous rebuild. */
 int drlgx_step_plan(drlgx_engine *e, const double *actions_dev, const int32_t *n_actions_dev, int action_index,
                     int map_last_only);
+/* The same loop for ALL action indices in one call: env i executes actions[i][0 .. n_actions[i]); max_n_actions: a host-side
+ * bound of the plan lengths (<= max_actions).  One launch - a workgroup runs its env's whole plan - when the fused step
+ * kernel serves every pose count the plans can reach, else one drlgx_step_plan per action index; bit-equal either way. */
+int drlgx_step_plans(drlgx_engine *e, const double *actions_dev, const int32_t *n_actions_dev, int max_n_actions,
+                     int map_last_only);
 
 /* ---- staged form of the belief step -----------------------------------------------------------
  * The reference's pybind classes are driven call by call (scripts/envs/pyss2d.py:102-138 SS2D.__init__, :171-206

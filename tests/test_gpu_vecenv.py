@@ -571,3 +571,40 @@ def test_train_scripts_write_the_reference_artefacts(tmp_path):
     assert tr2.step_t == 32 and len(tr2.buffer) == 32
     sc = tfevents.read_scalars(log)
     assert sc and {t for _, _, t, _ in sc} <= {"Train/avg_reward", "Train/loss"} and any(t == "Train/loss" for _, _, t, _ in sc)
+
+
+def test_whole_plans_in_one_launch_equal_one_launch_per_action(monkeypatch):
+    """Look-ahead rollouts and plan execution run a candidate's / an env's whole action list in ONE launch (csrc/k_step.hip:
+    k_step_loop, k_step_arrow_loop - the fused step once per action inside the workgroup) when the fused kernels serve every
+    pose count the plans can reach; DRLGX_LOOKAHEAD_LOOP=0 keeps one launch per action index.  Same kernels' bodies in the
+    same order: rewards and the state after the plans bit-equal, over decisions that take the trajectories from the dense
+    solver (<= 53 poses) to the pose-chain solver."""
+    from drl_graph_exploration_amd.vecenv import VecExplorationEnv
+    n = 5
+    a = VecExplorationEnv(40, n, env_index=2, test=True, device=0)
+    monkeypatch.setenv("DRLGX_LOOKAHEAD_LOOP", "0")
+    b = VecExplorationEnv(40, n, env_index=2, test=True, device=0)
+    monkeypatch.delenv("DRLGX_LOOKAHEAD_LOOP")
+    for d in range(14):
+        ra = rb = None
+        for e in (a, b):
+            e.graph_matrix()
+            e.actions_all_goals()
+            r = e.rewards_all_goals(return_raw=True)[1]
+            if e is a:
+                ra = r
+            else:
+                rb = r
+        assert torch.equal(ra, rb), "decision %d" % d
+        nfr = a._graph["n_frontier"].long()
+        choice = (torch.arange(n, device=a.device) * 2 + d) % nfr
+        for e in (a, b):
+            e.step(choice)
+        assert torch.equal(a.metrics(), b.metrics())
+    for i in range(n):
+        for x, y in zip(a.engine.poses(i) + a.engine.landmarks(i) + a.engine.virtual_map(i),
+                        b.engine.poses(i) + b.engine.landmarks(i) + b.engine.virtual_map(i)):
+            np.testing.assert_array_equal(x, y)
+    assert max(a.engine.counts(i)["poses"] for i in range(n)) > 54  # both regimes were visited
+    a.close()
+    b.close()
