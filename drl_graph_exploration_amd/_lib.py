@@ -33,7 +33,7 @@ SYMBOLS = [
     "drlgx_create", "drlgx_destroy", "drlgx_set_stream", "drlgx_synchronize", "drlgx_strerror", "drlgx_last_error",
     "drlgx_status_host", "drlgx_reset_host", "drlgx_step", "drlgx_utility", "drlgx_uncertainty_em", "drlgx_explored", "drlgx_metrics", "drlgx_cov_array",
     "drlgx_stage_reset_host", "drlgx_stage_move", "drlgx_stage_measure", "drlgx_stage_add_measurements", "drlgx_stage_optimize",
-    "drlgx_stage_update_map", "drlgx_set_planner_parameter", "drlgx_fm2_update", "drlgx_step_plan", "drlgx_step_plans",
+    "drlgx_stage_update_map", "drlgx_set_planner_parameter", "drlgx_set_fixed_landmarks_host", "drlgx_fm2_update", "drlgx_step_plan", "drlgx_step_plans",
     "drlgx_line_plan", "drlgx_lookahead", "drlgx_lookahead_bounded", "drlgx_graph_capacity", "drlgx_graph", "drlgx_get_counts_host", "drlgx_counts",
     "drlgx_get_poses_host", "drlgx_get_landmarks_host", "drlgx_get_cov_traces_host", "drlgx_vm_shape",
     "drlgx_get_virtual_map_host", "drlgx_get_ground_truth_host", "drlgx_get_adjacency_host", "drlgx_get_factors_host",
@@ -78,6 +78,7 @@ def lib():
     L.drlgx_stage_optimize.argtypes = [vp, vp]
     L.drlgx_stage_update_map.argtypes = [vp, vp, C.c_int]
     L.drlgx_set_planner_parameter.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
+    L.drlgx_set_fixed_landmarks_host.argtypes = [vp, C.c_int, dp]
     L.drlgx_fm2_update.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
     L.drlgx_utility.argtypes = [vp, vp, vp]
     L.drlgx_uncertainty_em.argtypes = [vp, C.c_int, vp]

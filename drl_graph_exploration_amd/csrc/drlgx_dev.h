@@ -54,6 +54,8 @@ struct DrlgxState {
   // --- simulator
   double *gt_pose;    // [n_inst][4] x,y,c,s
   double *gt_lm;      // [n_envs][LG][2]
+  const double *fixed_lm;  // [n_fixed][2] listed landmarks (keys 0 .. n_fixed - 1 of every env; drlgx_set_fixed_landmarks_host) or null
+  int n_fixed;
   int *parent;        // [n_inst] env that owns the ground-truth landmarks
   uint32_t *mt;       // [n_inst][2][MT_STRIDE]  0 = sensor stream, 1 = control stream
   double *nrm_saved;  // [n_inst][2]

@@ -59,6 +59,7 @@ struct drlgx_engine {
   double t_ms[DRLGX_N_TIMERS] = {0};
   int64_t t_n[DRLGX_N_TIMERS] = {0};
   std::string last_error;
+  double *fixed_lm_dev = nullptr;  // drlgx_set_fixed_landmarks_host
   int n_cu = 256;       // compute units of the device (drlgx_create)
   bool la_loop = true;  // look-ahead rollouts: one launch for a candidate's whole action list (k_step_loop)
   // FastMarginals2 workspaces (allocated on first use): dense prior covariances, per-candidate scratch
@@ -715,6 +716,22 @@ int drlgx_fm2_update(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, c
                             e->fm2_sig, e->fm2_sig_stride, e->fm2_scratch, e->fm2_scratch_stride, e->fm2_iscratch, kFm2MaxMeas,
                             cov_out_dev, out_stride_poses, n_out_dev);
   return check_launch(e);
+}
+
+int drlgx_set_fixed_landmarks_host(drlgx_engine *e, int n_fixed, const double *xy) {
+  DRLGX_ENTER(e);
+  if (!e || n_fixed < 0 || n_fixed > e->S.cfg.num_landmarks || (n_fixed > 0 && !xy)) return DRLGX_E_INVALID;
+  if (!e->fixed_lm_dev) {
+    int r = dev_alloc(e, &e->fixed_lm_dev, (size_t)std::max(e->S.cfg.num_landmarks, 1) * 2);
+    if (r) return r;
+  }
+  if (n_fixed > 0) {
+    HIPCHK(e, hipMemcpyAsync(e->fixed_lm_dev, xy, (size_t)n_fixed * 2 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));  // (the host buffer is the caller's)
+  }
+  e->S.fixed_lm = n_fixed > 0 ? e->fixed_lm_dev : nullptr;  // (the state struct travels with every launch: the next reset sees it)
+  e->S.n_fixed = n_fixed;
+  return DRLGX_OK;
 }
 
 int drlgx_set_planner_parameter(drlgx_engine *e, double angle_weight, double distance_weight0, double distance_weight1,

@@ -231,7 +231,9 @@ __global__ __launch_bounds__(64) void k_reset(DrlgxState S, int first_measure, c
   c.veh = make_pose(sp[0], sp[1], sp[2]);
   // Simulator2D::addLandmarks (Simulator2D.cpp:445-464)
   double *gl = S.gt_lm + (size_t)inst * S.LG * 2;
-  for (int i = 0; i < cfg.num_landmarks;) {
+  const int n_fixed = S.fixed_lm ? min(S.n_fixed, cfg.num_landmarks) : 0;  // the listed landmarks come first (keys 0 .. n_fixed - 1)
+  for (int k = lane; k < 2 * n_fixed; k += 64) gl[k] = S.fixed_lm[k];
+  for (int i = n_fixed; i < cfg.num_landmarks;) {
     double x = rng_uniform_real(simrng, cfg.env_min_x, cfg.env_max_x, lane);
     double y = rng_uniform_real(simrng, cfg.env_min_y, cfg.env_max_y, lane);
     double dx = x - c.veh.x, dy = y - c.veh.y;

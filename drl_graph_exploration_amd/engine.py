@@ -135,6 +135,12 @@ class Engine(object):
         self.use_torch_stream()
         self._chk(self.L.drlgx_stage_update_map(self.h, _p(active), int(bool(rebuild))))
 
+    def set_fixed_landmarks(self, xy):
+        """The listed ground-truth landmarks of `Simulator2D.random_landmarks(landmarks, num, params)` (keys 0 .. k - 1 of every
+        env; cfg.num_landmarks is the total): effective at the next reset."""
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        self._chk(self.L.drlgx_set_fixed_landmarks_host(self.h, len(xy), xy.ctypes.data_as(C.POINTER(C.c_double))))
+
     def set_planner_parameter(self, angle_weight, distance_weight0, distance_weight1, occupancy_threshold, max_edge_length, algorithm):
         self._chk(self.L.drlgx_set_planner_parameter(self.h, float(angle_weight), float(distance_weight0), float(distance_weight1),
                                                      float(occupancy_threshold), float(max_edge_length), int(algorithm)))

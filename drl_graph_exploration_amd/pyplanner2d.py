@@ -73,7 +73,11 @@ def config_from_ini(cp, max_poses=256, max_actions=None, max_snapshots=1):
     c.sigma_x0 = cp.getfloat("Simulator", "sigma_x0")
     c.sigma_y0 = cp.getfloat("Simulator", "sigma_y0")
     c.sigma_theta0 = math.radians(cp.getfloat("Simulator", "sigma_theta0"))
-    c.num_landmarks = cp.getint("Simulator", "num")
+    fixed = []
+    if cp.has_section("Landmarks") and cp.has_option("Landmarks", "x") and cp.has_option("Landmarks", "y"):  # pyss2d.py:107-115
+        import ast
+        fixed = list(zip(ast.literal_eval(cp.get("Landmarks", "x")), ast.literal_eval(cp.get("Landmarks", "y"))))
+    c.num_landmarks = cp.getint("Simulator", "num") + len(fixed)
     c.angle_weight, c.distance_weight0, c.distance_weight1 = pp.angle_weight, pp.distance_weight0, pp.distance_weight1
     c.occupancy_threshold, c.max_edge_length, c.algorithm = pp.occupancy_threshold, pp.max_edge_length, int(pp.algorithm)
     c.max_poses = max_poses
@@ -83,7 +87,7 @@ def config_from_ini(cp, max_poses=256, max_actions=None, max_snapshots=1):
         span = max(ep.max_x - ep.min_x, ep.max_y - ep.min_y, (mp.max_x - mp.min_x) / 2, (mp.max_y - mp.min_y) / 2)
         max_actions = int(math.ceil(math.hypot(span, span) / c.max_edge_length)) + 3
     c.max_actions, c.max_snapshots = max_actions, max_snapshots
-    return c, dict(sensor=sp, control=cm, environment=ep, map=mp, virtual_map=vp, planner=pp)
+    return c, dict(sensor=sp, control=cm, environment=ep, map=mp, virtual_map=vp, planner=pp, fixed_landmarks=fixed)
 
 
 class _Map(object):
@@ -213,6 +217,8 @@ class SS2D(object):
         x0, y0, theta0 = start_pose(lo, cfg.map_max_x) if start is None else start
         self.verbose = verbose
         self.engine = Engine(cfg, 1, max(cfg.max_landmarks, 1), device)
+        if prm["fixed_landmarks"]:
+            self.engine.set_fixed_landmarks(prm["fixed_landmarks"])
         self.engine.reset([0], [seed], starts=np.array([[x0, y0, theta0]]))
         self.engine.check_status()
         self._slam, self._virtual_map, self._sim = _Slam(self), _VirtualMap(self), _Sim(self)

@@ -231,6 +231,8 @@ class _Session(object):
         p = prior_state.pose
         if (abs(p.x - sim._start.x), abs(p.y - sim._start.y)) != (0.0, 0.0) or abs(_wrap(p.theta - sim._start.theta)) > 1e-15:
             raise NotImplementedError("the prior pose is the simulator's initial vehicle pose (pyss2d.py:124-133)")
+        if sim._fixed_landmarks:
+            self.engine.set_fixed_landmarks(sim._fixed_landmarks)
         self.engine.stage_reset([0], [sim._seed], np.array([[p.x, p.y, getattr(p, "_theta_in", p.theta)]]))
         self.engine.stage_update_map(rebuild=False)  # sums of the untouched map (a fresh VirtualMap)
         self.engine.check_status()
@@ -321,7 +323,7 @@ class Simulator2D(object):
         self._ses = _Session._latest = _Session()
         self._ses.sim = self
         self._sensor_params, self._control_params, self._seed, self._device = sensor_params, control_params, int(seed), device
-        self._start, self._env_params, self._num_landmarks = Pose2(), None, 0
+        self._start, self._env_params, self._num_landmarks, self._fixed_landmarks = Pose2(), None, 0, []
         self.sensor_model = BearingRangeSensorModel(sensor_params, seed, self._ses)
         self.control_model = SimpleControlModel(control_params, seed, self._ses)
         self.environment = Environment(self._ses, True)
@@ -332,11 +334,11 @@ class Simulator2D(object):
         self._start = pose
 
     def random_landmarks(self, landmarks, num, env_params):
-        """Simulator2D::addLandmarks (Simulator2D.cpp:445-464): `num` landmarks sampled uniformly in the environment box,
-        >= 2 m from the vehicle.  Fixed landmark lists (the ini file's optional [Landmarks] section) are not supported."""
-        if len(landmarks):
-            raise NotImplementedError("explicit landmark lists: the engine samples its ground-truth landmarks on the device")
-        self._num_landmarks, self._env_params = int(num), env_params
+        """Simulator2D::addLandmarks (Simulator2D.cpp:445-464): the listed `landmarks` (Point2; the ini file's optional
+        [Landmarks] section, pyss2d.py:107-115) take the keys 0 .. k - 1, then `num` landmarks are sampled uniformly in the
+        environment box, >= 2 m from the vehicle."""
+        self._fixed_landmarks = [(float(p.x), float(p.y)) for p in landmarks]
+        self._num_landmarks, self._env_params = len(self._fixed_landmarks) + int(num), env_params
         self.environment.parameter = env_params
 
     @property

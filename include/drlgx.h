@@ -150,6 +150,11 @@ int drlgx_stage_update_map(drlgx_engine *e, const uint8_t *active_dev, int rebui
 int drlgx_fm2_update(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *actions_dev, const int32_t *n_actions_dev,
                      double *cov_out_dev, int out_stride_poses, int32_t *n_out_dev);
 
+/* Simulator2D::addLandmarks(landmarks, num_random, params) with a non-empty list (Simulator2D.cpp:445-464; the ini file's
+ * optional [Landmarks] section, scripts/envs/pyss2d.py:107-115): the n_fixed listed points take the ground-truth keys
+ * 0 .. n_fixed - 1 of EVERY env, the remaining cfg.num_landmarks - n_fixed are sampled as before (cfg.num_landmarks is the
+ * total).  HOST array xy [n_fixed][2]; takes effect at the next (staged) reset; n_fixed = 0 restores pure sampling. */
+int drlgx_set_fixed_landmarks_host(drlgx_engine *e, int n_fixed, const double *xy);
 /* EMPlanner2D(parameter, ...) / EMPlanner2D::setParameter (src/Planner2D.cpp:73-77): the planner constants the kernels
  * read (line-plan edge length, utility weights, occupancy threshold, distance angle weight, algorithm) can be replaced
  * after drlgx_create - the reference constructs its planner after the simulator / SLAM objects. */

@@ -232,11 +232,12 @@ struct Simulator {
     vehicle = p;
     trajectory.push_back(p);
   }
-  // Simulator2D::addLandmarks (Simulator2D.cpp:445-464)
-  void addLandmarks(unsigned num) {
+  // Simulator2D::addLandmarks (Simulator2D.cpp:445-464): the listed landmarks take the keys 0 .. n_fixed - 1, the random ones follow
+  void addLandmarks(unsigned num, const double *fixed_xy = nullptr, unsigned n_fixed = 0) {
     landmarks.clear();  // environment_ = Environment(params)  -- NOTE also clears the trajectory
     trajectory.clear();
-    for (unsigned i = 0; i < num;) {
+    for (unsigned i = 0; i < n_fixed; ++i) landmarks.emplace(i, P2{fixed_xy[2 * i], fixed_xy[2 * i + 1]});
+    for (unsigned i = n_fixed; i < num;) {
       double x = rng.uniformReal(cfg.env_min_x, cfg.env_max_x);
       double y = rng.uniformReal(cfg.env_min_y, cfg.env_max_y);
       double dx = x - vehicle.x, dy = y - vehicle.y;
@@ -941,12 +942,13 @@ struct Env {
   int step = 0;
   bool cleared = true;
 
-  Env(const orc_config &c, uint32_t seed, double x0, double y0, double th0) : cfg(c), sim(c, seed) {
+  // fixed_xy / n_fixed: the ini file's optional [Landmarks] list (pyss2d.py:107-115); cfg.num_landmarks counts them too
+  Env(const orc_config &c, uint32_t seed, double x0, double y0, double th0, const double *fixed_xy = nullptr, int n_fixed = 0) : cfg(c), sim(c, seed) {
     slam.cfg = c;
     vm.initialize(c);
     // pyss2d.py:102-138
     sim.initializeVehicle(make_pose(x0, y0, th0));
-    sim.addLandmarks((unsigned)c.num_landmarks);
+    sim.addLandmarks((unsigned)c.num_landmarks, fixed_xy, (unsigned)n_fixed);
     double info[9] = {1.0 / (c.sigma_x0 * c.sigma_x0), 0, 0, 0, 1.0 / (c.sigma_y0 * c.sigma_y0), 0, 0, 0,
                       1.0 / (c.sigma_theta0 * c.sigma_theta0)};
     slam.addPrior(sim.vehicle, info);
@@ -1082,6 +1084,10 @@ extern "C" {
 
 void *orc_create(const orc_config *cfg, uint32_t seed, double x0, double y0, double th0) {
   return new Env(*cfg, seed, x0, y0, th0);
+}
+void *orc_create_fixed(const orc_config *cfg, uint32_t seed, double x0, double y0, double th0, const double *fixed_xy, int n_fixed) {
+  if (n_fixed < 0 || n_fixed > cfg->num_landmarks) return nullptr;
+  return new Env(*cfg, seed, x0, y0, th0, fixed_xy, n_fixed);
 }
 void orc_destroy(void *h) { delete (Env *)h; }
 void *orc_clone(void *h) { return new Env(*(Env *)h); }

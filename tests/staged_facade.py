@@ -25,7 +25,8 @@ class StagedEMExplorer(object):
         self._sim.initialize_vehicle(ss2d.Pose2(x0, y0, theta0))
         self._slam = ss2d.SLAM2D(self._map_params)
         self._virtual_map = ss2d.VirtualMap(prm["virtual_map"], seed)
-        self._sim.random_landmarks([], self._config.getint("Simulator", "num"), self._environment_params)
+        self._sim.random_landmarks([ss2d.Point2(x, y) for x, y in prm["fixed_landmarks"]], self._config.getint("Simulator", "num"),
+                                   self._environment_params)  # pyss2d.py:107-118
         sx0, sy0 = self._config.getfloat("Simulator", "sigma_x0"), self._config.getfloat("Simulator", "sigma_y0")
         st0 = math.radians(self._config.getfloat("Simulator", "sigma_theta0"))
         self._slam.add_prior(ss2d.VehicleBeliefState(self._sim.vehicle, np.diag([1.0 / sx0 ** 2, 1.0 / sy0 ** 2, 1.0 / st0 ** 2])))

@@ -233,3 +233,42 @@ def test_two_simulations_driven_alternately_and_constructed_interleaved():
     with pytest.raises(RuntimeError):
         ss2d.SLAM2D(prm[1]["map"])
     ss2d.SLAM2D(prm[0]["map"], simulator=a)
+
+
+def test_listed_landmarks_of_the_ini_file_through_both_facades():
+    """The ini file's optional [Landmarks] section (pyss2d.py:107-118 -> Simulator2D.random_landmarks(landmarks, num, params),
+    Simulator2D.cpp:445-464): the listed points are the ground-truth landmarks 0 .. k - 1, the sampled ones follow.  The fused
+    facade, the module classes driven in the reference's order and the oracle agree."""
+    from drl_graph_exploration_amd.pyplanner2d import EMExplorer
+    from staged_facade import StagedEMExplorer
+    lo = 4
+    start = tuple(np.array(O.start_pose(lo, MAP / 2 + 20)) + np.array([0.1371, 0.2179, -0.0417]))
+    fixed = [(start[0] + 3.0, start[1] + 1.0), (start[0] - 2.5, start[1] + 2.0), (start[0] + 1.0, start[1] - 4.0), (start[0] + 9.0, start[1] + 9.0)]
+
+    def cfg_with_list():
+        cp = ini(lo, num=6)
+        cp.read_dict({"Landmarks": dict(x=str([float(p[0]) for p in fixed]), y=str([float(p[1]) for p in fixed]))})
+        return cp
+    fused, staged = EMExplorer(cfg_with_list(), start=start), StagedEMExplorer(cfg_with_list(), start=start)
+    ref = O.OracleSim(O.default_config(MAP, num_landmarks=6 + len(fixed)), lo, lo, start=start, fixed_landmarks=fixed)
+    assert fused.engine.cfg.num_landmarks == staged.engine.cfg.num_landmarks == 10
+    for odom in [(1, 1, math.pi / 2)] * 4 + [(2.0, 0.0, 0.0), (0.0, 0.0, 0.8), (2.0, 0.0, 0.0)]:
+        fused.simulate(odom)
+        staged.simulate(odom)
+        ref.simulate(odom)
+    for e in (fused.engine, staged.engine):
+        veh, lms = e.ground_truth(0)
+        oveh, olms, _ = ref.ground_truth()
+        np.testing.assert_array_equal(lms[:4], np.array(fixed))
+        np.testing.assert_array_equal(lms, olms)
+        np.testing.assert_allclose(veh, oveh, atol=1e-12)
+        p, k, b, r = e.factors(0)
+        op, ok, ob, orr = ref.factors()
+        np.testing.assert_array_equal(p, op)
+        np.testing.assert_array_equal(k, ok)
+        np.testing.assert_allclose(b, ob, atol=1e-12)
+        np.testing.assert_allclose(e.poses(0)[0], ref.poses()[0], atol=1e-9)
+        np.testing.assert_allclose(e.virtual_map(0)[1], ref.virtual_map()[1], rtol=1e-7, atol=1e-9)
+    assert fused.engine.counts(0)["landmarks"] >= 3  # the three listed landmarks next to the start are observed
+    for a, b in zip(fused.engine.poses(0) + fused.engine.landmarks(0), staged.engine.poses(0) + staged.engine.landmarks(0)):
+        np.testing.assert_array_equal(a, b)

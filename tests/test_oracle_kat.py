@@ -195,3 +195,19 @@ def test_fm2_restatement_equals_information_form():
     far.simulate((2, 0, 0))
     g2, nm = F.fm2_update(far, [(2.0, 0.0, 0.0)])
     assert nm == [0] and np.trace(g2[-1]) > np.trace(g2[-2])
+
+
+def test_listed_landmarks_take_the_first_keys_and_leave_the_random_stream_alone():
+    """Simulator2D::addLandmarks(landmarks, num_random, params) (Simulator2D.cpp:445-464; pyss2d.py:107-118): the listed points
+    get the keys 0 .. k - 1 unchecked (also closer than 2 m to the vehicle), the sampled ones follow - the same draws, in the
+    same order, as without a list."""
+    k, n_random = 3, 9
+    fixed = [(1.5, -2.25), (-7.0, 3.5), (0.4, 0.3)]  # the last one is < 2 m from the start: kept, the rule is for sampled points
+    start = (0.25, -0.5, 0.3)
+    with_list = O.OracleSim(O.default_config(40, num_landmarks=k + n_random), 11, 0, start=start, fixed_landmarks=fixed)
+    without = O.OracleSim(O.default_config(40, num_landmarks=n_random), 11, 0, start=start)
+    _, gt_a, _ = with_list.ground_truth()
+    _, gt_b, _ = without.ground_truth()
+    np.testing.assert_array_equal(gt_a[:k], np.array(fixed))
+    np.testing.assert_array_equal(gt_a[k:], gt_b)
+    assert len(gt_a) == k + n_random
