@@ -718,6 +718,17 @@ int drlgx_fm2_update(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, c
   return check_launch(e);
 }
 
+int drlgx_stage_set_prior_information_host(drlgx_engine *e, int env, const double *information9) {
+  DRLGX_ENTER(e);
+  if (!e || env < 0 || env >= e->S.n_envs || !information9) return DRLGX_E_INVALID;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < r; ++c)
+      if (information9[3 * r + c] != information9[3 * c + r]) return DRLGX_E_INVALID;  // symmetric, as an information matrix is
+  HIPCHK(e, hipMemcpyAsync(e->S.prior + (size_t)env * DRLGX_PRIOR_STRIDE + 4, information9, 9 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return DRLGX_OK;
+}
+
 int drlgx_set_fixed_landmarks_host(drlgx_engine *e, int n_fixed, const double *xy) {
   DRLGX_ENTER(e);
   if (!e || n_fixed < 0 || n_fixed > e->S.cfg.num_landmarks || (n_fixed > 0 && !xy)) return DRLGX_E_INVALID;

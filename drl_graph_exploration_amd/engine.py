@@ -109,6 +109,11 @@ class Engine(object):
         self._chk(self.L.drlgx_stage_reset_host(self.h, len(env_ids), env_ids.ctypes.data_as(C.POINTER(C.c_int32)),
                                                 seeds.ctypes.data_as(C.POINTER(C.c_uint32)), starts.ctypes.data_as(C.POINTER(C.c_double))))
 
+    def stage_set_prior_information(self, env, information):
+        """A full 3 x 3 prior information for one env (after stage_reset, before the first optimise)."""
+        info = np.ascontiguousarray(information, dtype=np.float64).reshape(9)
+        self._chk(self.L.drlgx_stage_set_prior_information_host(self.h, int(env), info.ctypes.data_as(C.POINTER(C.c_double))))
+
     def stage_move(self, odom, active=None):
         self.use_torch_stream()
         self._chk(self.L.drlgx_stage_move(self.h, _p(odom), _p(active)))

@@ -215,8 +215,9 @@ class _Session(object):
         c.map_min_x, c.map_max_x, c.map_min_y, c.map_max_y = mp.min_x, mp.max_x, mp.min_y, mp.max_y
         c.resolution, c.sigma0, c.num_samples = vp.resolution, vp.sigma0, vp.num_samples
         info = np.asarray(prior_state.information, dtype=np.float64)
-        if np.abs(info - np.diag(np.diag(info))).max() > 0:
-            raise NotImplementedError("the engine's prior is diagonal (sigma_x0, sigma_y0, sigma_theta0 of the ini file)")
+        if info.shape != (3, 3) or np.abs(info - info.T).max() > 0 or not (np.diag(info) > 0).all():
+            raise ValueError("the prior information must be a symmetric 3 x 3 matrix with a positive diagonal")
+        full_prior = np.abs(info - np.diag(np.diag(info))).max() > 0  # (installed after the staged reset, below)
         c.sigma_x0, c.sigma_y0, c.sigma_theta0 = (1.0 / math.sqrt(info[k, k]) for k in range(3))
         c.num_landmarks = sim._num_landmarks
         c.angle_weight, c.distance_weight0, c.distance_weight1 = pp.angle_weight, pp.distance_weight0, pp.distance_weight1
@@ -234,6 +235,8 @@ class _Session(object):
         if sim._fixed_landmarks:
             self.engine.set_fixed_landmarks(sim._fixed_landmarks)
         self.engine.stage_reset([0], [sim._seed], np.array([[p.x, p.y, getattr(p, "_theta_in", p.theta)]]))
+        if full_prior:
+            self.engine.stage_set_prior_information(0, info)
         self.engine.stage_update_map(rebuild=False)  # sums of the untouched map (a fresh VirtualMap)
         self.engine.check_status()
 

@@ -122,6 +122,11 @@ int drlgx_step_plans(drlgx_engine *e, const double *actions_dev, const int32_t *
 /* SS2D.__init__ up to SLAM2D::addPrior (src/SS2D.cpp:173-176 Simulator2D(...), initialize_vehicle, random_landmarks;
  * :191 SLAM2D::add_prior): like drlgx_reset_host but WITHOUT the first measure / optimise / map reductions. */
 int drlgx_stage_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint32_t *seeds, const double *start_xytheta);
+/* SLAM2D::add_prior(VehicleBeliefState(pose, information)) with a FULL information matrix (src/SS2D.cpp:191,
+ * SLAM2D.cpp:44-57: noiseModel::Gaussian::Information): replaces the prior information of one env - the diagonal of the
+ * ini file's sigma_x0 / sigma_y0 / sigma_theta0 that the resets install - after drlgx_stage_reset_host and before the first
+ * optimise.  HOST, row major 3 x 3, symmetric (DRLGX_E_INVALID otherwise). */
+int drlgx_stage_set_prior_information_host(drlgx_engine *e, int env, const double *information9);
 /* Simulator2D::move(odom, true) (src/SS2D.cpp:181) + SLAM2D::add_odometry (:193). odom_dev: double[n_envs*3]. */
 int drlgx_stage_move(drlgx_engine *e, const double *odom_dev, const uint8_t *active_dev);
 /* Simulator2D::measure() (src/SS2D.cpp:182): the noisy (bearing, range) of every ground-truth landmark that passes the

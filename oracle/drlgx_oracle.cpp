@@ -943,7 +943,9 @@ struct Env {
   bool cleared = true;
 
   // fixed_xy / n_fixed: the ini file's optional [Landmarks] list (pyss2d.py:107-115); cfg.num_landmarks counts them too
-  Env(const orc_config &c, uint32_t seed, double x0, double y0, double th0, const double *fixed_xy = nullptr, int n_fixed = 0) : cfg(c), sim(c, seed) {
+  // prior_info: the 3 x 3 information of SLAM2D::addPrior's VehicleBeliefState (row major; null: the ini file's diagonal)
+  Env(const orc_config &c, uint32_t seed, double x0, double y0, double th0, const double *fixed_xy = nullptr, int n_fixed = 0,
+      const double *prior_info = nullptr) : cfg(c), sim(c, seed) {
     slam.cfg = c;
     vm.initialize(c);
     // pyss2d.py:102-138
@@ -951,6 +953,7 @@ struct Env {
     sim.addLandmarks((unsigned)c.num_landmarks, fixed_xy, (unsigned)n_fixed);
     double info[9] = {1.0 / (c.sigma_x0 * c.sigma_x0), 0, 0, 0, 1.0 / (c.sigma_y0 * c.sigma_y0), 0, 0, 0,
                       1.0 / (c.sigma_theta0 * c.sigma_theta0)};
+    if (prior_info) std::memcpy(info, prior_info, sizeof(info));
     slam.addPrior(sim.vehicle, info);
     for (const Measurement &m : sim.measure()) slam.addMeasurement(m.key, m.bearing, m.range);
     slam.optimize();
@@ -1088,6 +1091,9 @@ void *orc_create(const orc_config *cfg, uint32_t seed, double x0, double y0, dou
 void *orc_create_fixed(const orc_config *cfg, uint32_t seed, double x0, double y0, double th0, const double *fixed_xy, int n_fixed) {
   if (n_fixed < 0 || n_fixed > cfg->num_landmarks) return nullptr;
   return new Env(*cfg, seed, x0, y0, th0, fixed_xy, n_fixed);
+}
+void *orc_create_prior(const orc_config *cfg, uint32_t seed, double x0, double y0, double th0, const double *prior_info9) {
+  return new Env(*cfg, seed, x0, y0, th0, nullptr, 0, prior_info9);
 }
 void orc_destroy(void *h) { delete (Env *)h; }
 void *orc_clone(void *h) { return new Env(*(Env *)h); }

@@ -52,6 +52,8 @@ def lib():
         L.orc_create.argtypes = [C.POINTER(OrcConfig), C.c_uint32, C.c_double, C.c_double, C.c_double]
         L.orc_create_fixed.restype = C.c_void_p
         L.orc_create_fixed.argtypes = [C.POINTER(OrcConfig), C.c_uint32, C.c_double, C.c_double, C.c_double, dp, C.c_int]
+        L.orc_create_prior.restype = C.c_void_p
+        L.orc_create_prior.argtypes = [C.POINTER(OrcConfig), C.c_uint32, C.c_double, C.c_double, C.c_double, dp]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_clone.restype = C.c_void_p
         L.orc_clone.argtypes = [C.c_void_p]
@@ -149,14 +151,17 @@ def start_pose(lo, map_max_x):
 class OracleSim(object):
     """EMExplorer / SS2D facade (scripts/envs/pyss2d.py:58-206, pyplanner2d.py:56-81) on the C++ oracle."""
 
-    def __init__(self, cfg, seed, lo, handle=None, start=None, fixed_landmarks=None):
+    def __init__(self, cfg, seed, lo, handle=None, start=None, fixed_landmarks=None, prior_information=None):
         """fixed_landmarks: [(x, y)] of the ini file's optional [Landmarks] section (pyss2d.py:107-115): keys 0 .. k - 1, the
         random landmarks follow; cfg.num_landmarks is the total."""
         self.cfg = cfg
         self.L = lib()
         if handle is None:
             x0, y0, th0 = start_pose(lo, cfg.map_max_x) if start is None else start
-            if fixed_landmarks is not None and len(fixed_landmarks):
+            if prior_information is not None:  # SLAM2D.add_prior(VehicleBeliefState(pose, information)) with a full 3 x 3 matrix
+                info = np.ascontiguousarray(prior_information, dtype=np.float64).reshape(9)
+                self.h = C.c_void_p(self.L.orc_create_prior(C.byref(cfg), seed, x0, y0, th0, info.ctypes.data_as(C.POINTER(C.c_double))))
+            elif fixed_landmarks is not None and len(fixed_landmarks):
                 xy = np.ascontiguousarray(fixed_landmarks, dtype=np.float64).reshape(-1, 2)
                 self.h = C.c_void_p(self.L.orc_create_fixed(C.byref(cfg), seed, x0, y0, th0, xy.ctypes.data_as(C.POINTER(C.c_double)), len(xy)))
             else:

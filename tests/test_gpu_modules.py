@@ -272,3 +272,47 @@ def test_listed_landmarks_of_the_ini_file_through_both_facades():
     assert fused.engine.counts(0)["landmarks"] >= 3  # the three listed landmarks next to the start are observed
     for a, b in zip(fused.engine.poses(0) + fused.engine.landmarks(0), staged.engine.poses(0) + staged.engine.landmarks(0)):
         np.testing.assert_array_equal(a, b)
+
+
+def test_full_prior_information_matrix_through_the_module_classes():
+    """SLAM2D.add_prior(VehicleBeliefState(pose, information)) with a non-diagonal information matrix (src/SS2D.cpp:191,
+    SLAM2D.cpp:44-57): drlgx_stage_set_prior_information_host behind the module classes, against the oracle."""
+    from drl_graph_exploration_amd import ss2d
+    from drl_graph_exploration_amd.pyplanner2d import config_from_ini
+    lo = 2
+    start = tuple(np.array(O.start_pose(lo, MAP / 2 + 20)) + np.array([0.3371, -0.1179, 0.0817]))
+    _, prm = config_from_ini(ini(lo))
+    Lm = np.array([[20.0, 0, 0], [4.0, 18.0, 0], [-2.0, 3.0, 90.0]])
+    info = Lm @ Lm.T  # symmetric positive definite, every off-diagonal entry non-zero
+    sim = ss2d.Simulator2D(prm["sensor"], prm["control"], lo)
+    sim.initialize_vehicle(ss2d.Pose2(*start))
+    slam = ss2d.SLAM2D(prm["map"], simulator=sim)
+    vm = ss2d.VirtualMap(prm["virtual_map"], lo, simulator=sim)
+    sim.random_landmarks([], 8, prm["environment"])
+    slam.add_prior(ss2d.VehicleBeliefState(sim.vehicle, info))
+    ref = O.OracleSim(O.default_config(MAP), lo, lo, start=start, prior_information=info)
+    for key, m in sim.measure():
+        slam.add_measurement(key, m)
+    slam.optimize(update_covariance=True)
+    for odom in [(1, 1, math.pi / 2)] * 4 + [(2.0, 0.0, 0.0), (0.0, 0.0, 0.8)]:
+        _, cs = sim.move(ss2d.Pose2(*odom), True)
+        slam.add_odometry(cs)
+        sim.measure()
+        for key, m in sim.measure():
+            slam.add_measurement(key, m)
+        slam.optimize(update_covariance=True)
+        vm.update_probability(slam, sim.sensor_model)
+        vm.update_information(slam.map, sim.sensor_model)
+        ref.simulate(odom)
+    e = slam._ses.engine
+    xyt, pinfo = e.poses(0)
+    oxyt, opinfo = ref.poses()
+    np.testing.assert_allclose(xyt, oxyt, atol=1e-9)
+    np.testing.assert_allclose(pinfo, opinfo, rtol=1e-7, atol=1e-6)
+    np.testing.assert_allclose(pinfo[0], opinfo[0], rtol=1e-7)
+    assert abs(pinfo[0].reshape(3, 3)[0, 1]) > 1.0  # the coupling of the prior is in the first pose's marginal
+    np.testing.assert_allclose(e.virtual_map(0)[1], ref.virtual_map()[1], rtol=1e-7, atol=1e-9)
+    with pytest.raises(ValueError):
+        s2 = ss2d.Simulator2D(prm["sensor"], prm["control"], lo)
+        s2.random_landmarks([], 8, prm["environment"])
+        ss2d.SLAM2D(prm["map"], simulator=s2).add_prior(ss2d.VehicleBeliefState(s2.vehicle, np.array([[1.0, 2, 0], [0, 1, 0], [0, 0, 1]])))
