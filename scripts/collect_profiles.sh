@@ -25,8 +25,19 @@ ls -la $out
 # the bench line itself, the 2-rank control flow on one device (gloo), and the step-vs-trajectory-length tables
 timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
 DRLGX_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 50 --warmup 5 > $out/bench_2ranks_gloo.json 2> $out/bench_2ranks_gloo.err
-timeout 300 python scripts/bench_vs_poses.py 206 100 phases > $out/vs_poses_100lm.txt 2>&1
+PP_SAMPLE=39,49 timeout 300 python scripts/bench_vs_poses.py 206 100 phases > $out/vs_poses_100lm.txt 2>&1
 timeout 300 python scripts/bench_vs_poses.py 206 8 phases > $out/vs_poses_8lm.txt 2>&1
+# the look-ahead workload: kernel stats and HBM traffic of its kernels (k_step_loop: a candidate's whole action list per launch)
+LA="python scripts/lookahead_workload.py"
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_la -- $LA > $out/lookahead_workload.txt 2> $out/rocprof_la.err
+python scripts/rocpd_summary.py "$(db /tmp/prof_la)" > $out/lookahead_kernel_stats.csv
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_la_fetch -- $LA > /dev/null 2> $out/rocprof_la_fetch.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_la_write -- $LA > /dev/null 2> $out/rocprof_la_write.err
+python scripts/rocpd_pmc.py "$(db /tmp/prof_la_fetch)" "$(db /tmp/prof_la_write)" "\`python scripts/lookahead_workload.py\` (2 633 candidates, 19 475 rollout updates per look-ahead)" > $out/lookahead_pmc_traffic.json
+timeout 200 python scripts/lookahead_breakdown.py > $out/lookahead_breakdown.txt 2>&1
+timeout 200 python scripts/phase_profile_relin.py > $out/relinearising_update_phases.txt 2>&1
+timeout 200 python scripts/phase_profile_blocks.py > $out/step_workgroups.txt 2>&1
+timeout 300 python scripts/full_fill_profile.py > $out/full_fill.json 2> /dev/null
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_gcn -- python $OLDPWD/scripts/profile_gcn.py > /dev/null 2>&1)
 python scripts/rocpd_summary.py "$(db /tmp/prof_gcn)" --by-grid k_ > $out/gcn_kernels_by_grid.csv 2>/dev/null
 ls -la $out

@@ -20,7 +20,8 @@ def per_kernel(path, counter):
 
 
 def short(name):
-    for k in ("k_step", "k_slam_arrow", "k_slam", "k_map", "k_sim_step", "k_copy_instances", "k_reset"):
+    for k in ("k_step_arrow_loop", "k_step_loop", "k_step_arrow", "k_step", "k_slam_arrow", "k_slam", "k_map_c", "k_map", "k_sim_step",
+              "k_copy_instances", "k_reset"):
         if k in name:
             return k
     return name
@@ -37,5 +38,5 @@ for name in fetch:
                         "hbm_read_bytes_corrected": 2.0 * f, "hbm_traffic_bytes_per_launch": 2.0 * f + w}
 import bench  # noqa: E402  (csrc_digest: ties the figures to the kernel sources they were measured on)
 print(json.dumps({"csrc_sha1": bench.csrc_digest(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
-                            "`python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-policy`",
+                            + (sys.argv[3] if len(sys.argv) > 3 else "`python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-policy`"),
                   "correction": "FETCH_SIZE x2 (gfx950), KiB -> bytes", "kernels": out}, indent=1))
