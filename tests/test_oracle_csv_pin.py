@@ -49,11 +49,19 @@ exact_rows = {}  # seed -> rows whose entropy was asserted at 1e-9 (test_entropy
 LONG = [4, 5, 30, 38, 48]
 
 
-@pytest.mark.parametrize("lo", [0, 1, 2, 3, 8, 13, 16, 19, 24, 28, 34, 39] + LONG)
+def _pinned_seeds():
+    """EVERY seed of the fixture with at least one pinned row (44 of the CSV's 50: the same set the GPU replay covers)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "csv_pin.json")) as f:
+        return sorted(int(k) for k, v in json.load(f)["seeds"].items() if len(v["rows"]) > 0)
+
+
+@pytest.mark.parametrize("lo", _pinned_seeds())
 def test_oracle_tracks_reference_csv(pins, dqn_weights, lo):
     pin = pins["seeds"][str(lo)]
     rows_ref = np.array(pin["rows"])
-    assert len(rows_ref) >= 19
+    assert len(rows_ref) >= 1
     env = O.OracleEnv(40, lo)
     st = 0
     agree = n_frontier_choices = n_exact = 0
@@ -91,7 +99,8 @@ def test_oracle_tracks_reference_csv(pins, dqn_weights, lo):
             st += 1
     assert st == len(rows_ref)
     exact_rows[lo] = n_exact
-    assert agree >= 0.85 * n_frontier_choices  # (the oracle's map drifts from the reference's through knife-edge cells)
+    # (the oracle's map drifts from the reference's through knife-edge cells; seeds pinned for only a few decisions are exempt)
+    assert agree >= 0.85 * n_frontier_choices or n_frontier_choices < 8
 
 
 def test_entropy_is_exact_away_from_decision_boundaries():
