@@ -147,6 +147,13 @@ struct LaunchSel {
   // the fused step kernel leaves the map stage out: the caller launches the stand-alone map kernel behind it (more instances
   // than CUs: its two-workgroups-per-CU form beats the stage fused into a one-per-CU workgroup)
   int skip_map = 0;
+  // Rollouts whose simulator was run AHEAD for the whole action list (ksim::k_presim): the log of what every action's move and
+  // measurements appended; wave 0 of the step then replays one entry (ksim::replay_step_body) instead of simulating - the draws
+  // of an action depend on the ground truth and the random streams only, so they need not sit on every update's critical path.
+  // Entry of (instance i, action a) at simlog + i * simlog_roll + a * simlog_act.
+  const unsigned char *simlog = nullptr;
+  size_t simlog_roll = 0;
+  int simlog_act = 0;
   __host__ __device__ __forceinline__ int cap(int P_max) const { return pcap > 0 && pcap < P_max ? pcap : P_max; }
   __device__ __forceinline__ bool map_on(int i) const {
     return !(map_last_only && n_act) || act_idx == n_act[i] - 1;
@@ -632,6 +639,11 @@ void drlgx_launch_sim_stage(const DrlgxState &S, hipStream_t st, LaunchSel sel, 
                             double *br, int32_t *count);
 void drlgx_launch_add_measurements(const DrlgxState &S, hipStream_t st, LaunchSel sel, const int32_t *keys, const double *br,
                                    const int32_t *count);
+// bytes of one action's entry in the look-ahead's simulator log
+size_t drlgx_simlog_entry_bytes(const DrlgxState &S);
+// run the simulator of every selected instance over its WHOLE action list [0, min(a_end, n_act[i])) and log what each action appends
+void drlgx_launch_presim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end,
+                         unsigned char *simlog, size_t simlog_roll, int simlog_act);
 void drlgx_launch_sim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride,
                       int n_measure);
 // p_bound: host-side upper bound of the pose count of every selected instance after this launch (<= P_max); it picks

@@ -60,6 +60,8 @@ struct drlgx_engine {
   int64_t t_n[DRLGX_N_TIMERS] = {0};
   std::string last_error;
   double *fixed_lm_dev = nullptr;  // drlgx_set_fixed_landmarks_host
+  unsigned char *simlog_dev = nullptr;  // the look-ahead's simulator log (k_presim), n_rollouts x max_actions entries
+  bool la_presim = true;
   int n_cu = 256;       // compute units of the device (drlgx_create)
   bool la_loop = true;  // look-ahead rollouts: one launch for a candidate's whole action list (k_step_loop)
   // FastMarginals2 workspaces (allocated on first use): dense prior covariances, per-candidate scratch
@@ -191,6 +193,8 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
     e->by_capacity = v && v[0] == '1';
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cu = prop.multiProcessorCount;
+    const char *lp = getenv("DRLGX_LOOKAHEAD_PRESIM");  // 0: every rollout action simulates inside its belief step (the A/B of the parity test)
+    e->la_presim = !(lp && lp[0] == '0');
     const char *ll = getenv("DRLGX_LOOKAHEAD_LOOP");  // 0: one launch per action index (the A/B of the look-ahead tests)
     e->la_loop = !(ll && ll[0] == '0');
   }
@@ -841,20 +845,32 @@ int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env
       drlgx_launch_fix_rollouts(S, e->stream, nc, ce, roll0);
     }
     const int pb_last = std::min(pbe + max_n_actions, S.P_max);
-    if (e->la_loop && !e->per_stage && drlgx_step_fusable(S, pb_last)) {
-      // every candidate's whole action list in ONE launch (k_step_loop): no per-action tails, candidates dealt to the CUs as they finish
+    const bool loop_dense = e->la_loop && !e->per_stage && drlgx_step_fusable(S, pb_last);
+    const bool loop_arrow = !loop_dense && e->la_loop && !e->per_stage && drlgx_step_arrow_fusable(S);
+    if (loop_dense || loop_arrow) {
+      // every candidate's whole action list in ONE launch (k_step_loop; k_step_arrow_loop around the pose-chain solver: any
+      // trajectory length, <= 63 landmarks): no per-action tails, candidates dealt to the CUs as they finish
       LaunchSel sel{roll0, nc, nullptr, na, 0};
       sel.map_last_only = 1;
       sel.pcap = pb_last;
+      if (e->la_presim) {
+        // the simulator of every rollout for its whole list first (one wave per rollout), its log replayed action by action
+        const size_t entry = drlgx_simlog_entry_bytes(S), roll = entry * (size_t)S.A_max;
+        if (!e->simlog_dev && dev_alloc(e, &e->simlog_dev, roll * (size_t)S.n_roll) != DRLGX_OK) {
+          (void)hipGetLastError();
+          e->last_error.clear();
+          e->la_presim = false;  // (no room for the log: the rollouts simulate inside their steps)
+        } else {
+          ScopedTimer t(e, 0);
+          drlgx_launch_presim(S, e->stream, sel, act, S.A_max * 3, 1, max_n_actions, e->simlog_dev, roll, (int)entry);
+          sel.simlog = e->simlog_dev;
+          sel.simlog_roll = roll;
+          sel.simlog_act = (int)entry;
+        }
+      }
       ScopedTimer t(e, 5);
-      drlgx_launch_step_loop(S, e->stream, sel, act, S.A_max * 3, 1, max_n_actions);
-    } else if (e->la_loop && !e->per_stage && drlgx_step_arrow_fusable(S)) {
-      // the same around the pose-chain solver (any trajectory length, <= 63 landmarks): the reference's own worlds
-      LaunchSel sel{roll0, nc, nullptr, na, 0};
-      sel.map_last_only = 1;
-      sel.pcap = pb_last;
-      ScopedTimer t(e, 5);
-      drlgx_launch_step_arrow_loop(S, e->stream, sel, act, S.A_max * 3, 1, max_n_actions);
+      if (loop_dense) drlgx_launch_step_loop(S, e->stream, sel, act, S.A_max * 3, 1, max_n_actions);
+      else drlgx_launch_step_arrow_loop(S, e->stream, sel, act, S.A_max * 3, 1, max_n_actions);
     } else
     for (int a = 0; a < max_n_actions; ++a) {
       LaunchSel sel{roll0, nc, nullptr, na, a};

@@ -408,6 +408,192 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
   DRLGX_PROF(S, 13);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The simulator run AHEAD over a whole action list, and its replay (look-ahead rollouts: EMPlanner2D::simulations_reward,
+// Planner2D.cpp:1432-1460).  What Simulator2D::move / measure produce for action a - the noisy ground-truth pose, the noisy
+// bearing-range list, which landmarks are first sightings - depends on the ground truth, the two random streams and the
+// earlier actions' sightings only, NOT on the SLAM state.  k_presim therefore runs the simulator of a rollout for all its
+// actions in one go (one wave per rollout, a dozen rollouts per CU at once) and logs per action what it appends; the belief
+// step of action a then REPLAYS that entry (replay_step_body, ~1 us) instead of simulating (8 - 10 us on the critical path of
+// every update).  The two values of the append that do depend on the SLAM state - the new pose's initial guess (last estimate
+// * odometry, SLAM2D.cpp:70-89) and a first sighting's initial estimate (that guess * measurement, Simulator2D.cpp:95-98) - are
+// formed at replay time, with the expressions sim_step_body / measure use.  Same draws in the same order, same expressions:
+// the rollouts' beliefs are bit-equal (test_whole_plans_in_one_launch_equal_one_launch_per_action).
+// Log entry: int32 hdr[8] = {status (0 rejected: odometry out of bounds, 1 appended, 2 pose capacity), P, L, M after the action,
+// new factors, new landmarks, error code, -}, then per new factor {int32 slot, int32 key, double bearing, double range}.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kLogHdr = 32, kLogRec = 24;
+
+__global__ __launch_bounds__(64) void k_presim(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end,
+                                               unsigned char *simlog, size_t simlog_roll, int simlog_act) {
+  __shared__ uint32_t lds[2][DRLGX_MT_STRIDE];
+  extern __shared__ double dyn[];  // nrm[2 * n_measure * LG + 2] doubles, inr[LG] ints, kslot[LG] ints
+  const int lane = threadIdx.x, i = blockIdx.x;
+  if (sel.active && !sel.active[i]) return;
+  const int n_mine = sel.n_act ? min(a_end, sel.n_act[i]) : a_end;
+  if (n_mine <= sel.act_idx) return;
+  const int inst = sel.base + i;
+  const drlgx_config &cfg = S.cfg;
+  double *nrm = dyn;
+  int *inr = reinterpret_cast<int *>(dyn + 2 * n_measure * S.LG + 2);
+  int *kslot = inr + S.LG;
+  const int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
+  SimCtx c{S, inst, lane, {}, {}, {0, 0}, {0, 0}, {}, cnt[C_P], cnt[C_L], cnt[C_M], 0};
+  c.ns_sensor = NormalState{S.nrm_saved[inst * 2 + 0], S.nrm_has[inst * 2 + 0]};
+  c.ns_control = NormalState{S.nrm_saved[inst * 2 + 1], S.nrm_has[inst * 2 + 1]};
+  const double *gp = S.gt_pose + (size_t)inst * 4;
+  c.veh = Pose{gp[0], gp[1], gp[2], gp[3]};
+  mt_load2(lds[0], lds[1], S.mt + (size_t)inst * 2 * DRLGX_MT_STRIDE, lane, c.sensor, c.control);
+  for (int k = lane; k < S.LG; k += 64) kslot[k] = S.key_slot[(size_t)inst * S.LG + k];
+  wave_sync();
+  const double *gl = S.gt_lm + (size_t)S.parent[inst] * S.LG * 2;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int a = sel.act_idx; a < n_mine; ++a) {
+    unsigned char *entry = simlog + (size_t)i * simlog_roll + (size_t)a * simlog_act;
+    int *hdr = reinterpret_cast<int *>(entry);
+    const double *od = odom + (size_t)i * odom_stride + (size_t)a * 3;
+    const double ox = od[0], oy = od[1], oth = od[2];
+    if (!odom_in_bounds(cfg, ox, oy) || c.P >= S.P_max) {
+      if (lane == 0) {
+        hdr[0] = odom_in_bounds(cfg, ox, oy) ? 2 : 0;
+        hdr[1] = c.P; hdr[2] = c.L; hdr[3] = c.M; hdr[4] = 0; hdr[5] = 0; hdr[6] = 0; hdr[7] = 0;
+      }
+      continue;
+    }
+    // SimpleControlModel::evolve (Simulator2D.cpp:161-182): as sim_step_body
+    const Pose odomP = make_pose(ox, oy, oth);
+    draw_normals(c.control, c.ns_control, 3, nrm, lane);
+    const double xn = nrm[0] * cfg.translation_noise + 0.0;
+    const double yn = nrm[1] * cfg.translation_noise + 0.0;
+    const double tn = nrm[2] * cfg.rotation_noise + 0.0;
+    wave_sync();
+    c.veh = compose(compose(c.veh, odomP), make_pose(xn, yn, tn));
+    c.P += 1;
+    int nf = 0, nn = 0, err = 0;
+    if (n_measure > 0) {
+      const int n_in = scan_in_range(c, inr);
+      const int lead = (n_measure - 1) * 2 * n_in;  // SS2D.simulate's first, discarded measure() call: variates drawn and dropped
+      draw_normals(c.sensor, c.ns_sensor, lead + 2 * n_in, nrm, lane, lead);
+      // Simulator2D::measure + SLAM2D::addMeasurement: the expressions of ksim::measure's recording branch
+      for (int base = 0; base < n_in && !err; base += 64) {
+        const int k = base + lane;
+        const bool v = k < n_in;
+        const int key = v ? inr[k] : 0;
+        const P2 lm{gl[2 * key], gl[2 * key + 1]};
+        const double bn = (v ? nrm[2 * k] : 0.0) * cfg.bearing_noise + 0.0;
+        const double rn = (v ? nrm[2 * k + 1] : 0.0) * cfg.range_noise + 0.0;
+        const double bearing = bearing_of<false>(c.veh, lm, nullptr, nullptr) + bn;
+        const double range = range_of<false>(c.veh, lm, nullptr, nullptr) + rn;
+        const bool ok = v && bearing < cfg.max_bearing && bearing > cfg.min_bearing && range < cfg.max_range && range > cfg.min_range;
+        int slot = ok ? kslot[key] : 0;
+        const bool isnew = ok && slot < 0;
+        const unsigned long long okm = __ballot(ok), newm = __ballot(isnew);
+        const int n_ok = __popcll(okm), n_new = __popcll(newm);
+        if (c.L + n_new > S.L_max || c.M + n_ok > S.M_max) {
+          err = DRLGX_E_CAPACITY;
+          break;
+        }
+        if (isnew) {
+          slot = c.L + __popcll(newm & below);
+          kslot[key] = slot;
+        }
+        if (ok) {
+          unsigned char *rec = entry + kLogHdr + (size_t)(nf + __popcll(okm & below)) * kLogRec;
+          reinterpret_cast<int *>(rec)[0] = slot;
+          reinterpret_cast<int *>(rec)[1] = key;
+          reinterpret_cast<double *>(rec + 8)[0] = bearing;
+          reinterpret_cast<double *>(rec + 8)[1] = range;
+        }
+        c.L += n_new;
+        c.M += n_ok;
+        nf += n_ok;
+        nn += n_new;
+        wave_sync();
+      }
+    }
+    if (lane == 0) {
+      hdr[0] = 1; hdr[1] = c.P; hdr[2] = c.L; hdr[3] = c.M; hdr[4] = nf; hdr[5] = nn; hdr[6] = err; hdr[7] = 0;
+    }
+  }
+}
+
+// One logged action of instance blockIdx.x appended to its belief state, by ONE wave: everything sim_step_body + measure write
+// for the SLAM stage (the new pose's initial guess, the odometry factor, the bearing-range factors, first sightings, counters, the
+// travelled distance) - not the ground truth and the random streams, which a rollout never reads again.
+__device__ __forceinline__ void replay_step_body(const DrlgxState &S, const LaunchSel &sel, const double *odom, int odom_stride, int lane,
+                                                 int *mail = nullptr) {
+  const int i = drlgx_bid();
+  if (!sel.on(i)) return;
+  const int inst = sel.base + i;
+  const drlgx_config &cfg = S.cfg;
+  int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
+  const unsigned char *entry = sel.simlog + (size_t)i * sel.simlog_roll + (size_t)sel.act_idx * sel.simlog_act;
+  const int *hdr = reinterpret_cast<const int *>(entry);
+  const int status = hdr[0];
+  if (status != 1) {  // rejected move: nothing appended (sim_step_body's two early returns)
+    if (lane == 0) {
+      cnt[C_FLAG] = 1;
+      if (status == 2) atomicMin(S.status, DRLGX_E_CAPACITY);
+    }
+    return;
+  }
+  const int P0 = cnt[C_P], L0 = cnt[C_L], M0 = cnt[C_M], step0 = cnt[C_STEP];
+  const double *od = odom + (size_t)i * odom_stride + (size_t)sel.act_idx * 3;
+  const double ox = od[0], oy = od[1], oth = od[2];
+  const double *ep = S.est_pose + ((size_t)inst * S.P_max + (P0 - 1)) * 4;
+  const Pose last_est{ep[0], ep[1], ep[2], ep[3]};
+  const double dist0 = S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST];
+  const Pose odomP = make_pose(ox, oy, oth);
+  const Pose p2 = compose(last_est, odomP);  // SLAM2D::addOdometry (SLAM2D.cpp:70-89): initial guess = last estimate * odom
+  if (lane == 0) {
+    double *tp = S.th_pose + ((size_t)inst * S.P_max + P0) * 4;
+    tp[0] = p2.x; tp[1] = p2.y; tp[2] = p2.c; tp[3] = p2.s;
+    double *dp = S.d_pose + ((size_t)inst * S.P_max + P0) * 3;
+    dp[0] = dp[1] = dp[2] = 0;
+    double *oo = S.odo + ((size_t)inst * S.P_max + (P0 - 1)) * 4;
+    oo[0] = odomP.x; oo[1] = odomP.y; oo[2] = odomP.c; oo[3] = odomP.s;
+    cnt[C_NEWP] = P0;
+    cnt[C_NEWL] = L0;
+    cnt[C_FLAG] = 0;
+    cnt[C_STEP] = step0 + 1;
+    const double th = theta_of(odomP);
+    S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST] = dist0 + sqrt(ox * ox + oy * oy + cfg.angle_weight * (th * th));
+  }
+  const int nf = hdr[4];
+  for (int f = lane; f < nf; f += 64) {
+    const unsigned char *rec = entry + kLogHdr + (size_t)f * kLogRec;
+    const int slot = reinterpret_cast<const int *>(rec)[0], key = reinterpret_cast<const int *>(rec)[1];
+    const double bearing = reinterpret_cast<const double *>(rec + 8)[0], range = reinterpret_cast<const double *>(rec + 8)[1];
+    if (slot >= L0) {  // first sighting: origin = initial estimate of the measuring pose (Simulator2D.cpp:95-98)
+      const P2 g = transform_from(p2, P2{range * cos(bearing), range * sin(bearing)});
+      double *tl = S.th_lm + ((size_t)inst * S.L_max + slot) * 2;
+      tl[0] = g.x;
+      tl[1] = g.y;
+      double *dl = S.d_lm + ((size_t)inst * S.L_max + slot) * 2;
+      dl[0] = 0;
+      dl[1] = 0;
+      S.lm_key[(size_t)inst * S.L_max + slot] = key;
+      S.key_slot[(size_t)inst * S.LG + key] = slot;
+    }
+    S.meas_pose[(size_t)inst * S.M_max + M0 + f] = P0;
+    S.meas_lm[(size_t)inst * S.M_max + M0 + f] = slot;
+    double *br = S.meas_br + ((size_t)inst * S.M_max + M0 + f) * 2;
+    br[0] = bearing;
+    br[1] = range;
+  }
+  if (lane == 0) {
+    cnt[C_P] = hdr[1];
+    cnt[C_L] = hdr[2];
+    cnt[C_M] = hdr[3];
+    if (mail) {
+      mail[0] = hdr[1];
+      mail[1] = hdr[2];
+      mail[2] = hdr[3];
+    }
+    if (hdr[6]) atomicMin(S.status, hdr[6]);
+  }
+}
+
 __global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
                                                  int n_measure) {
   __shared__ uint32_t lds[2][DRLGX_MT_STRIDE];
@@ -481,6 +667,12 @@ __global__ void k_add_measurements(DrlgxState S, LaunchSel sel, const int32_t *k
 
 }  // namespace ksim
 
+size_t drlgx_simlog_entry_bytes(const DrlgxState &S) { return ((size_t)ksim::kLogHdr + (size_t)ksim::kLogRec * S.LG + 31) & ~(size_t)31; }
+void drlgx_launch_presim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end,
+                         unsigned char *simlog, size_t simlog_roll, int simlog_act) {
+  const size_t dyn = (size_t)(2 * (n_measure > 0 ? n_measure : 1) * S.LG + 2) * sizeof(double) + (size_t)2 * S.LG * sizeof(int);
+  hipLaunchKernelGGL(ksim::k_presim, dim3(sel.n), dim3(64), dyn, st, S, sel, odom, odom_stride, n_measure, a_end, simlog, simlog_roll, simlog_act);
+}
 void drlgx_launch_sim_stage(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int mode, int32_t *keys,
                             double *br, int32_t *count) {
   const size_t dyn = (size_t)(2 * S.LG + 2) * sizeof(double) + (size_t)S.LG * sizeof(int);

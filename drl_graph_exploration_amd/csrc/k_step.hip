@@ -41,7 +41,7 @@ __device__ __forceinline__ void step_once(const DrlgxState &S, const LaunchSel &
   // what the simulator wave appends, left in LDS for the SLAM stage (ksim::measure)
   double *sim_dyn = reinterpret_cast<double *>(step_smem + 2 * DRLGX_MT_STRIDE * sizeof(uint32_t));
   double *lmbox = reinterpret_cast<double *>(step_smem + sim_bytes - 16 - (size_t)2 * S.LG * 8);
-  const kslam::SimBox box{n_measure == 2 ? sim_dyn : nullptr, reinterpret_cast<const int *>(sim_dyn + 2 * S.LG + 2), lmbox};
+  const kslam::SimBox box{(n_measure == 2 && !sel.simlog) ? sim_dyn : nullptr, reinterpret_cast<const int *>(sim_dyn + 2 * S.LG + 2), lmbox};
   // (the map stage's ladder tables: fetched now, stored to its LDS after the SLAM stage)
   kmap::LadderEntry lo{S.lo_ntab <= kslam::kThreads, 0.0, 0u, -1, 0, 0};
   if (lo.have && tid < S.lo_ntab) {
@@ -78,8 +78,11 @@ __device__ __forceinline__ void step_once(const DrlgxState &S, const LaunchSel &
     uint32_t *l0 = reinterpret_cast<uint32_t *>(step_smem);
     uint32_t *l1 = l0 + DRLGX_MT_STRIDE;
     double *dyn = sim_dyn;  // 5008 B: 16-aligned
-    ksim::sim_step_body(S, sel, odom, odom_stride, n_measure, l0, l1, dyn, tid, nullptr, nullptr, nullptr, true, sub_cnt + 1,
-                        n_measure == 2 ? lmbox : nullptr, sel.on(bi) ? P0 : -1, L0, M0);
+    if (sel.simlog)  // the simulator ran ahead for the whole action list (k_presim): this action's entry is replayed
+      ksim::replay_step_body(S, sel, odom, odom_stride, tid, sub_cnt + 1);
+    else
+      ksim::sim_step_body(S, sel, odom, odom_stride, n_measure, l0, l1, dyn, tid, nullptr, nullptr, nullptr, true, sub_cnt + 1,
+                          n_measure == 2 ? lmbox : nullptr, sel.on(bi) ? P0 : -1, L0, M0);
   } else if (pre) {
     ctx.front<true>(S, tid, P0, L0, M0, P0, L0, isam + 1, false, od3, kslam::SubBarrier{sub_cnt, kslam::kThreads / 64 - 1, 0});
   } else if (inc_try) {
@@ -95,7 +98,7 @@ __device__ __forceinline__ void step_once(const DrlgxState &S, const LaunchSel &
   }
   __syncthreads();
   DRLGX_PROF(S, 32);
-  if (accepted && tid >= 64) {
+  if (accepted && tid >= 64 && !sel.simlog) {
     // the two random streams go back to HBM from their LDS images (the simulator wave left the counters in them): seven
     // waves, in the shadow of the few threads that linearise this step's factors
     uint32_t *g = S.mt + (size_t)(sel.base + bi) * 2 * DRLGX_MT_STRIDE;
@@ -175,7 +178,8 @@ __device__ __forceinline__ void step_arrow_once(const DrlgxState &S, const Launc
     uint32_t *l0 = reinterpret_cast<uint32_t *>(step_smem);
     uint32_t *l1 = l0 + DRLGX_MT_STRIDE;
     double *dyn = reinterpret_cast<double *>(step_smem + 2 * DRLGX_MT_STRIDE * sizeof(uint32_t));
-    ksim::sim_step_body(S, sel, odom, odom_stride, n_measure, l0, l1, dyn, tid);
+    if (sel.simlog) ksim::replay_step_body(S, sel, odom, odom_stride, tid);
+    else ksim::sim_step_body(S, sel, odom, odom_stride, n_measure, l0, l1, dyn, tid);
   }
   __syncthreads();
   kslam::arrow_body<0>(S, sel, lds_bytes);  // (or, between relinearisations, the incremental update: arrow_body's first lines)

@@ -585,26 +585,27 @@ def test_whole_plans_in_one_launch_equal_one_launch_per_action(monkeypatch):
     monkeypatch.setenv("DRLGX_LOOKAHEAD_LOOP", "0")
     b = VecExplorationEnv(40, n, env_index=2, test=True, device=0)
     monkeypatch.delenv("DRLGX_LOOKAHEAD_LOOP")
+    # ... and the rollouts' simulator run ahead for the whole action list and replayed (ksim::k_presim / replay_step_body, the
+    # default) against simulating inside every rollout step (DRLGX_LOOKAHEAD_PRESIM=0): the same draws in the same order
+    monkeypatch.setenv("DRLGX_LOOKAHEAD_PRESIM", "0")
+    c = VecExplorationEnv(40, n, env_index=2, test=True, device=0)
+    monkeypatch.delenv("DRLGX_LOOKAHEAD_PRESIM")
     for d in range(14):
-        ra = rb = None
-        for e in (a, b):
+        raws = []
+        for e in (a, b, c):
             e.graph_matrix()
             e.actions_all_goals()
-            r = e.rewards_all_goals(return_raw=True)[1]
-            if e is a:
-                ra = r
-            else:
-                rb = r
-        assert torch.equal(ra, rb), "decision %d" % d
+            raws.append(e.rewards_all_goals(return_raw=True)[1])
+        assert torch.equal(raws[0], raws[1]) and torch.equal(raws[0], raws[2]), "decision %d" % d
         nfr = a._graph["n_frontier"].long()
         choice = (torch.arange(n, device=a.device) * 2 + d) % nfr
-        for e in (a, b):
+        for e in (a, b, c):
             e.step(choice)
-        assert torch.equal(a.metrics(), b.metrics())
+        assert torch.equal(a.metrics(), b.metrics()) and torch.equal(a.metrics(), c.metrics())
     for i in range(n):
         for x, y in zip(a.engine.poses(i) + a.engine.landmarks(i) + a.engine.virtual_map(i),
                         b.engine.poses(i) + b.engine.landmarks(i) + b.engine.virtual_map(i)):
             np.testing.assert_array_equal(x, y)
     assert max(a.engine.counts(i)["poses"] for i in range(n)) > 54  # both regimes were visited
-    a.close()
-    b.close()
+    for e in (a, b, c):
+        e.close()
