@@ -655,7 +655,8 @@ bool drlgx_step_fusable(const DrlgxState &S, int p_bound);
 bool drlgx_step_arrow_fusable(const DrlgxState &S);
 void drlgx_launch_step_arrow(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure);
 void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure);  // requires drlgx_step_fusable
-// every instance's actions [sel.act_idx, min(a_end, n_act[i])) in ONE launch (requires drlgx_step_fusable for the bound of the LAST action)
+// every instance's actions [sel.act_idx, min(a_end, n_act[i])) in ONE launch; sel.pcap = the pose bound of the FIRST action of the
+// range (action a runs with sel.pcap + a - sel.act_idx); requires drlgx_step_fusable for the bound of the LAST one
 void drlgx_launch_step_loop(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end);
 void drlgx_launch_step_arrow_loop(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end);  // requires drlgx_step_arrow_fusable
 void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel);  // sel.act_idx == -2: reductions only

@@ -617,9 +617,11 @@ int drlgx_step_plans(drlgx_engine *e, const double *actions_dev, const int32_t *
   if (!e || !actions_dev || !n_actions_dev || max_n_actions < 0 || max_n_actions > e->S.A_max) return DRLGX_E_INVALID;
   if (max_n_actions == 0) return DRLGX_OK;
   const DrlgxState &S = e->S;
-  const int pb_last = std::min(max_bound(e) + max_n_actions, S.P_max);
-  const bool dense = drlgx_step_fusable(S, pb_last), arrow = !dense && drlgx_step_arrow_fusable(S);
-  if (!e->la_loop || e->per_stage || !(dense || arrow)) {
+  const int pbe = max_bound(e);
+  int a_sw = 0;  // the leading actions the fused dense-solver step serves (as one drlgx_step_plan per action index would choose)
+  while (a_sw < max_n_actions && drlgx_step_fusable(S, std::min(pbe + a_sw + 1, S.P_max))) ++a_sw;
+  const bool rest_loops = a_sw == max_n_actions || drlgx_step_arrow_fusable(S);
+  if (!e->la_loop || e->per_stage || !rest_loops) {
     for (int a = 0; a < max_n_actions; ++a) {
       const int r = drlgx_step_plan(e, actions_dev, n_actions_dev, a, map_last_only);
       if (r) return r;
@@ -628,12 +630,18 @@ int drlgx_step_plans(drlgx_engine *e, const double *actions_dev, const int32_t *
   }
   LaunchSel sel{0, S.n_envs, nullptr, n_actions_dev, 0};
   sel.map_last_only = map_last_only ? 1 : 0;
-  sel.pcap = pb_last;
   for (int &v : e->pbound) v = std::min(v + max_n_actions, S.P_max);
   {
     ScopedTimer t(e, 5);
-    if (dense) drlgx_launch_step_loop(S, e->stream, sel, actions_dev, S.A_max * 3, 2, max_n_actions);
-    else drlgx_launch_step_arrow_loop(S, e->stream, sel, actions_dev, S.A_max * 3, 2, max_n_actions);
+    if (a_sw > 0) {
+      sel.pcap = std::min(pbe + 1, S.P_max);
+      drlgx_launch_step_loop(S, e->stream, sel, actions_dev, S.A_max * 3, 2, a_sw);
+    }
+    if (a_sw < max_n_actions) {
+      sel.act_idx = a_sw;
+      sel.pcap = std::min(pbe + a_sw + 1, S.P_max);
+      drlgx_launch_step_arrow_loop(S, e->stream, sel, actions_dev, S.A_max * 3, 2, max_n_actions);
+    }
   }
   return check_launch(e);
 }
@@ -844,16 +852,19 @@ int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env
                         &S);  // (with the base solve's covariance panel)
       drlgx_launch_fix_rollouts(S, e->stream, nc, ce, roll0);
     }
-    const int pb_last = std::min(pbe + max_n_actions, S.P_max);
-    const bool loop_dense = e->la_loop && !e->per_stage && drlgx_step_fusable(S, pb_last);
-    const bool loop_arrow = !loop_dense && e->la_loop && !e->per_stage && drlgx_step_arrow_fusable(S);
-    if (loop_dense || loop_arrow) {
-      // every candidate's whole action list in ONE launch (k_step_loop; k_step_arrow_loop around the pose-chain solver: any
-      // trajectory length, <= 63 landmarks): no per-action tails, candidates dealt to the CUs as they finish
+    // Whole action lists per launch (k_step_loop / k_step_arrow_loop).  A launch per action index picks its kernel from the pose
+    // bound of THAT action (the fused dense-solver step while it serves the bound, then the step around the pose-chain solver);
+    // the loop form keeps that choice action by action - the leading actions [0, a_sw) in the dense loop kernel, the rest in the
+    // pose-chain one - because the two solvers round differently and the reference's integer worlds hold cells at exactly
+    // max_range from a pose: one ulp of a pose decides them, and with them O(0.1) of a reward.
+    int a_sw = 0;
+    while (a_sw < max_n_actions && drlgx_step_fusable(S, std::min(pbe + a_sw + 1, S.P_max))) ++a_sw;
+    const bool rest_loops = a_sw == max_n_actions || drlgx_step_arrow_fusable(S);
+    int a_begin = 0;  // first action index still to be launched one by one
+    if (e->la_loop && !e->per_stage && (a_sw > 0 || rest_loops)) {
       LaunchSel sel{roll0, nc, nullptr, na, 0};
       sel.map_last_only = 1;
-      sel.pcap = pb_last;
-      if (e->la_presim) {
+      if (e->la_presim && rest_loops) {  // (only when EVERY action is replayed: a replay leaves the ground truth and the streams behind)
         // the simulator of every rollout for its whole list first (one wave per rollout), its log replayed action by action
         const size_t entry = drlgx_simlog_entry_bytes(S), roll = entry * (size_t)S.A_max;
         if (!e->simlog_dev && dev_alloc(e, &e->simlog_dev, roll * (size_t)S.n_roll) != DRLGX_OK) {
@@ -869,10 +880,20 @@ int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env
         }
       }
       ScopedTimer t(e, 5);
-      if (loop_dense) drlgx_launch_step_loop(S, e->stream, sel, act, S.A_max * 3, 1, max_n_actions);
-      else drlgx_launch_step_arrow_loop(S, e->stream, sel, act, S.A_max * 3, 1, max_n_actions);
-    } else
-    for (int a = 0; a < max_n_actions; ++a) {
+      if (a_sw > 0) {
+        sel.act_idx = 0;
+        sel.pcap = std::min(pbe + 1, S.P_max);
+        drlgx_launch_step_loop(S, e->stream, sel, act, S.A_max * 3, 1, a_sw);
+      }
+      a_begin = a_sw;
+      if (a_sw < max_n_actions && rest_loops) {
+        sel.act_idx = a_sw;
+        sel.pcap = std::min(pbe + a_sw + 1, S.P_max);
+        drlgx_launch_step_arrow_loop(S, e->stream, sel, act, S.A_max * 3, 1, max_n_actions);
+        a_begin = max_n_actions;
+      }
+    }
+    for (int a = a_begin; a < max_n_actions; ++a) {
       LaunchSel sel{roll0, nc, nullptr, na, a};
       sel.map_last_only = 1;
       const int pb = std::min(pbe + a + 1, S.P_max);

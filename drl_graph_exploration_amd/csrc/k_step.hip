@@ -163,6 +163,9 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step_loop(DrlgxState S, Lau
   for (int a = sel.act_idx; a < n_mine; ++a) {
     LaunchSel one = sel;
     one.act_idx = a;
+    // (the pose bound of THIS action, as a launch per action index would pass it: LDS plans - and with them the choice between
+    // equivalent code paths whose roundings differ - then agree with that form bit for bit; sel.pcap = the first action's bound)
+    one.pcap = min(sel.pcap + (a - sel.act_idx), S.P_max);
     step_once<FT>(S, one, odom, odom_stride, n_measure, lds_bytes, map_chunk);
     __syncthreads();  // (also a workgroup-scope fence: the next action reads what this one wrote)
   }
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step_arrow_loop(DrlgxState 
   for (int a = sel.act_idx; a < n_mine; ++a) {
     LaunchSel one = sel;
     one.act_idx = a;
+    one.pcap = min(sel.pcap + (a - sel.act_idx), S.P_max);
     step_arrow_once(S, one, odom, odom_stride, n_measure, lds_bytes, map_chunk);
     __syncthreads();
   }
@@ -236,7 +240,7 @@ void drlgx_launch_step_arrow(const DrlgxState &S, hipStream_t st, LaunchSel sel,
 
 void drlgx_launch_step_arrow_loop(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end) {
   int chunk = 0;
-  (void)drlgx_map_lds_bytes(S, &chunk, sel.pcap);
+  (void)drlgx_map_lds_bytes(S, &chunk, std::min(sel.pcap + (a_end - 1 - sel.act_idx), S.P_max));  // (sized for the range's last action)
   static bool attr_set[32] = {false};
   const void *fns[] = {reinterpret_cast<const void *>(&kstep::k_step_arrow_loop)};
   drlgx_ensure_lds_attr(attr_set, fns, 1, kslam::kLdsBudget);
@@ -246,7 +250,7 @@ void drlgx_launch_step_arrow_loop(const DrlgxState &S, hipStream_t st, LaunchSel
 
 void drlgx_launch_step_loop(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end) {
   int chunk = 0;
-  (void)drlgx_map_lds_bytes(S, &chunk, sel.pcap);
+  (void)drlgx_map_lds_bytes(S, &chunk, std::min(sel.pcap + (a_end - 1 - sel.act_idx), S.P_max));  // (sized for the range's last action)
   static bool attr_set[32] = {false};
   const void *fns[] = {reinterpret_cast<const void *>(&kstep::k_step_loop<kslam::kFastTiles>)};
   drlgx_ensure_lds_attr(attr_set, fns, 1, kslam::kLdsBudget);

@@ -578,9 +578,12 @@ def test_whole_plans_in_one_launch_equal_one_launch_per_action(monkeypatch):
     k_step_loop, k_step_arrow_loop - the fused step once per action inside the workgroup) when the fused kernels serve every
     pose count the plans can reach; DRLGX_LOOKAHEAD_LOOP=0 keeps one launch per action index.  Same kernels' bodies in the
     same order: rewards and the state after the plans bit-equal, over decisions that take the trajectories from the dense
-    solver (<= 53 poses) to the pose-chain solver."""
+    solver (<= 53 poses) to the pose-chain solver.  (The loop form keeps the per-action choice between the two solvers: they
+    round differently, and the integer worlds hold cells at exactly max_range from a pose - with enough candidates some
+    rollout's relinearising update falls where the two forms would otherwise pick different solvers, scripts/ab_lookahead_paths.py
+    found that with 64 envs.)"""
     from drl_graph_exploration_amd.vecenv import VecExplorationEnv
-    n = 5
+    n = 24
     a = VecExplorationEnv(40, n, env_index=2, test=True, device=0)
     monkeypatch.setenv("DRLGX_LOOKAHEAD_LOOP", "0")
     b = VecExplorationEnv(40, n, env_index=2, test=True, device=0)
@@ -590,7 +593,7 @@ def test_whole_plans_in_one_launch_equal_one_launch_per_action(monkeypatch):
     monkeypatch.setenv("DRLGX_LOOKAHEAD_PRESIM", "0")
     c = VecExplorationEnv(40, n, env_index=2, test=True, device=0)
     monkeypatch.delenv("DRLGX_LOOKAHEAD_PRESIM")
-    for d in range(14):
+    for d in range(16):
         raws = []
         for e in (a, b, c):
             e.graph_matrix()
