@@ -208,6 +208,9 @@ class DeepQ(object):
         self.target_window = "reference"  # or "aligned": see td_targets
         # minibatch updates per vector step; None = one per environment step like the reference (n_envs per vector step)
         self.updates_per_vector_step = None
+        # pool-backed updates as two host calls over one arena (drlgx_dqn_prepare / _forward_backward); False: the same launches one
+        # by one from Python (the A/B of scripts/ab_dqn_update_paths.py)
+        self.fused_update = True
 
     @property
     def temp_loss(self):
@@ -508,7 +511,7 @@ class DeepQ(object):
         (`_fused_prepare`, `_fused_forward_backward`) plus the Adam launch; the generic path issues the same launches one by one."""
         fused = type(policy_net) is GCN and isinstance(optimizer, FusedAdam)
         pending = None
-        if fused and prepared is not None and self.target_window in ("reference", "aligned"):
+        if fused and prepared is not None and self.target_window in ("reference", "aligned") and self.__dict__.get("fused_update", True):
             if not policy_net.training:
                 policy_net.train()
             W1, _, _, _, Wf, _ = policy_net.trunk_parameters()
