@@ -109,8 +109,10 @@ int drlgx_step(drlgx_engine *e, const double *odom_dev, const uint8_t *active_de
 int drlgx_step_plan(drlgx_engine *e, const double *actions_dev, const int32_t *n_actions_dev, int action_index,
                     int map_last_only);
 /* The same loop for ALL action indices in one call: env i executes actions[i][0 .. n_actions[i]); max_n_actions: a host-side
- * bound of the plan lengths (<= max_actions).  One launch - a workgroup runs its env's whole plan - when the fused step
- * kernel serves every pose count the plans can reach, else one drlgx_step_plan per action index; bit-equal either way. */
+ * bound of the plan lengths (<= max_actions).  A workgroup runs its env's whole plan inside one launch wherever a fused step
+ * kernel serves the pose counts the plans reach (one launch for the actions the dense-solver step serves, one for the rest
+ * around the pose-chain solver: the same per-action choice as drlgx_step_plan makes), else one drlgx_step_plan per action
+ * index; bit-equal either way. */
 int drlgx_step_plans(drlgx_engine *e, const double *actions_dev, const int32_t *n_actions_dev, int max_n_actions,
                      int map_last_only);
 
@@ -206,7 +208,11 @@ int drlgx_lookahead(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, co
 
 /* drlgx_lookahead with a host-side bound on the plan lengths: max_n_actions >= every n_actions_dev[i] (the caller
  * usually knows it from stepping the chosen plan; 0 < max_n_actions <= max_actions).  Action indices beyond it are
- * not launched at all (drlgx_lookahead launches all max_actions of them and lets the workgroups exit). */
+ * not launched at all (drlgx_lookahead launches all max_actions of them and lets the workgroups exit).  Where the fused
+ * step kernels serve the pose counts the rollouts reach, a candidate's WHOLE action list runs inside one workgroup (two
+ * launches per wave of candidates instead of one per action index) and the rollouts' simulator - whose draws do not depend
+ * on the SLAM state - is run ahead for the whole list and replayed; same rewards bit for bit (DRLGX_LOOKAHEAD_LOOP=0 /
+ * DRLGX_LOOKAHEAD_PRESIM=0 switch the two off for A/B runs). */
 int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env_dev, const double *actions_dev,
                             const int32_t *n_actions_dev, int max_n_actions, double *rewards_dev);
 
