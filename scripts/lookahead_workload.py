@@ -15,8 +15,22 @@ fidx = torch.arange(cand_env.numel(), device=dev) - first[cand_env.long()]
 goals = g["frontier_xy"][cand_env.long(), fidx].contiguous()
 acts, nact = eng.line_plan(cand_env, goals)
 kmax = int(nact.max())
-for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
-    eng.lookahead(cand_env, acts, nact, kmax)
+import time
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+rew = None
+for r in range(reps):
+    if r == 2:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+    rew = eng.lookahead(cand_env, acts, nact, kmax)
 torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / max(1, reps - 2) * 1e3 if reps > 2 else float("nan")
 eng.check_status()
-print("candidates %d, rollout updates %d" % (cand_env.numel(), int(nact.sum())))
+print("candidates %d, rollout updates %d; %.3f ms per look-ahead (host clock, %d repetitions); reward checksum %.17g" %
+      (cand_env.numel(), int(nact.sum()), dt, max(0, reps - 2), float(rew.double().sum())))
+if os.environ.get("LA_SPANS"):
+    eng.timing_enable(True); eng.timing_read()
+    for _ in range(5):
+        eng.lookahead(cand_env, acts, nact, kmax)
+    print("spans (ms, launches) per look-ahead:", {k: (round(v[0] / 5, 3), v[1] // 5) for k, v in eng.timing_read().items() if v[1]})
+    eng.timing_enable(False)
