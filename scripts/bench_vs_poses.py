@@ -52,11 +52,20 @@ for s in range(cap - 3):
             eng.timing_enable(2)
             eng.L.drlgx_debug_phase_clocks_host(eng.h, 1, None)
             eng.restore(0)
+            eng.inc_stats(True)
             eng.step(odoms[(s + 1) % len(loop)])
+            n_inc, n_full = eng.inc_stats(True)
             eng.L.drlgx_debug_phase_clocks_host(eng.h, 0, out)
             eng.timing_enable(False)
             a = np.array(out[:11], dtype=np.float64)[order]
-            extra = " | block 0: " + ", ".join("%s %.1f" % (names[k], (a[k + 1] - a[k]) / 100.0) for k in range(10))
+            d = (a[1:] - a[:-1]) / 100.0
+            # (the stamps are the pose-chain solver's: an update served by the rank-k path leaves them untouched)
+            if n_full and (d >= 0).all() and d.sum() < 1e4:
+                extra = " | full solve (%d of %d envs), block 0: " % (n_full, n_inc + n_full) + ", ".join("%s %.1f" % (names[k], d[k]) for k in range(10))
+            elif n_full:  # (block 0 itself may have been served by the rank-k path: no consistent stamps)
+                extra = " | full solve (%d of %d envs)" % (n_full, n_inc + n_full)
+            else:
+                extra = " | rank-k update (%d of %d envs)" % (n_inc, n_inc + n_full)
         eng.restore(0)
         c = eng.counts_dev().cpu().numpy()
         ov = tm["t7"][0] / tm["t7"][1] * 1e3
