@@ -27,6 +27,9 @@ import os
 import sys
 import time
 
+# (multi-process GPU work on this platform needs dmabuf IPC - RCCL fails with hipIpcGetMemHandle otherwise; set before HIP loads)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 
