@@ -360,11 +360,20 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// ... and the one for LDS traffic INSIDE the wave only (a lane reads what another lane of the same wave wrote to LDS): the
+// wave's LDS operations execute in order, so nothing has to drain - the workgroup-scope fences above also wait for every
+// global load and STORE in flight (vmcnt(0)): in the simulator wave that was a memory round trip per refill of the generator
+// and per commit that followed a global access.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // load a stream from HBM into LDS (64 lanes) and back
 __device__ inline MtStream mt_load(uint32_t *lds, const uint32_t *g, int lane) {
   for (int i = lane; i < DRLGX_MT_STRIDE; i += 64) lds[i] = g[i];
-  wave_sync();
+  wave_lds_sync();
   MtStream s;
   s.st = lds;
   s.gen = lds[DRLGX_MT_N];
@@ -382,18 +391,15 @@ __device__ inline void mt_load2_issue(const uint32_t *g, int lane, uint4 (&v)[5]
   }
 }
 __device__ inline void mt_load2_commit(uint32_t *lds0, uint32_t *lds1, const uint4 (&v)[5], int lane, MtStream &a, MtStream &b) {
+  // (the two images are contiguous in LDS - lds1 == lds0 + DRLGX_MT_STRIDE, 16-byte aligned, every caller - like the two streams
+  // in HBM: 313 whole 16-byte pieces, five stores per lane; word by word with a range test each this was ~80 branches)
+  uint4 *l4 = reinterpret_cast<uint4 *>(lds0);
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
-    const int w = 4 * (lane + 64 * k);
-    const uint32_t e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int idx = w + t;
-      if (idx < DRLGX_MT_STRIDE) lds0[idx] = e[t];
-      else if (idx < 2 * DRLGX_MT_STRIDE) lds1[idx - DRLGX_MT_STRIDE] = e[t];
-    }
+    const int i = lane + 64 * k;
+    if (i < 313) l4[i] = v[k];
   }
-  wave_sync();
+  wave_lds_sync();
   a.st = lds0; a.gen = lds0[DRLGX_MT_N]; a.cons = lds0[DRLGX_MT_N + 1];
   b.st = lds1; b.gen = lds1[DRLGX_MT_N]; b.cons = lds1[DRLGX_MT_N + 1];
 }
@@ -412,7 +418,7 @@ __device__ inline void mt_park(const MtStream &s, int lane) {
   }
 }
 __device__ inline void mt_store(const MtStream &s, uint32_t *g, int lane) {
-  wave_sync();
+  wave_lds_sync();
   for (int i = lane; i < DRLGX_MT_N; i += 64) g[i] = s.st[i];
   if (lane == 0) {
     const uint32_t k = (s.cons / DRLGX_MT_N) * DRLGX_MT_N;  // keep the monotonic counters small (same positions mod 624)
@@ -430,7 +436,7 @@ __device__ inline MtStream mt_seed(uint32_t *lds, uint32_t seed, int lane) {
       lds[i] = x;
     }
   }
-  wave_sync();
+  wave_lds_sync();
   MtStream s;
   s.st = lds;
   s.gen = 0;
@@ -452,12 +458,12 @@ __device__ inline void mt_refill(MtStream &s, int lane) {
     b = s.st[(i + 1) % DRLGX_MT_N];
     c = s.st[(i + 397) % DRLGX_MT_N];
   }
-  wave_sync();
+  wave_lds_sync();
   if ((uint32_t)lane < nvalid) {
     uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
     s.st[i] = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
   }
-  wave_sync();
+  wave_lds_sync();
   s.gen += nvalid;
 }
 // next 32-bit output; wave-uniform
@@ -498,7 +504,7 @@ __device__ inline void mt_refill_wide(MtStream &s, int lane) {
       c[k] = s.st[(i + 397) % DRLGX_MT_N];
     }
   }
-  wave_sync();
+  wave_lds_sync();
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const uint32_t o = (uint32_t)lane + 64u * k, i = p + o;
@@ -507,7 +513,7 @@ __device__ inline void mt_refill_wide(MtStream &s, int lane) {
       s.st[i] = c[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
     }
   }
-  wave_sync();
+  wave_lds_sync();
   s.gen += nvalid;
 }
 // make at least n (<= 256) generated-but-unconsumed words available.  A refill overwrites outputs produced 624 words
@@ -595,7 +601,7 @@ __device__ inline void draw_normals(MtStream &s, NormalState &ns, int count, dou
       have += A;
     }
   }
-  wave_sync();
+  wave_lds_sync();
   if (R & 1) {
     ns.saved = out[count - skip];
     ns.has = 1;

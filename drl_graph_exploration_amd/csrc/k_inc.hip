@@ -42,12 +42,21 @@ __device__ __forceinline__ int *inc_meta(const DrlgxState &S, int inst) { return
 // Can the update that brings instance `inst` to P_after poses be incremental?  Uniform over the workgroup; every thread calls.
 // scratch: one int of LDS nobody else uses at this point (the library's __syncthreads_or brings 256 B of STATIC LDS with it,
 // which on top of the 160 KB of dynamic LDS these kernels request makes the launch fail).
-__device__ __forceinline__ bool inc_precheck(const DrlgxState &S, int inst, int P_after, int tid, int *scratch) {
+// (meta0 / meta1 / isam: the panel's valid flag and pose count and the update counter when the caller has loaded them already -
+// k_step's prelude issues them together with the instance's counts: one round trip to HBM before the simulator wave starts
+// instead of two; meta0 < 0: loaded here)
+__device__ __forceinline__ bool inc_precheck(const DrlgxState &S, int inst, int P_after, int tid, int *scratch, int meta0 = -1, int meta1 = 0,
+                                             int isam = 0) {
   if (!S.jc) return false;
   const int *meta = inc_meta(S, inst);
-  if (meta[0] != 1 || meta[1] + 1 != P_after || P_after < 2) return false;
   const int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
-  const int count = cnt[C_ISAM] + 1;
+  if (meta0 < 0) {
+    meta0 = meta[0];
+    meta1 = meta[1];
+    isam = cnt[C_ISAM];
+  }
+  if (meta0 != 1 || meta1 + 1 != P_after || P_after < 2) return false;
+  const int count = isam + 1;
   if (count % 10 != 0) return true;
   // relinearizeSkip = 10: the variables that existed at the previous update are checked against relinearizeThreshold = 0.1
   const double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
@@ -97,11 +106,15 @@ struct IncCtx {
 // HBM / L2).  The decision is taken for the SAME LDS offset in every kernel (the fused step's: behind the simulator's region),
 // so that the fused kernel and the stage kernels always run the same instantiation.
 // pc: the launch's pose bound (LaunchSel::cap): the fused step's simulator region is sized by it.
-__device__ __forceinline__ bool inc_plan(const DrlgxState &S, int inst, int P, int lds_bytes, size_t smem_off, IncCtx &x, bool &lds_panel, int pc) {
+// L0_known / M0_known (>= 0): the panel's landmark and factor counts as the caller loaded them already (k_step's prelude): the plan
+// is then pure arithmetic - no load from HBM behind the stores the fused step has in flight when it plans the second half.
+__device__ __forceinline__ bool inc_plan(const DrlgxState &S, int inst, int P, int lds_bytes, size_t smem_off, IncCtx &x, bool &lds_panel, int pc,
+                                         int L0_known = -1, int M0_known = -1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int *meta = inc_meta(S, inst);
   x.inst = inst; x.P = P; x.pn = P - 1; x.pp = P - 2;
-  x.L0 = meta[2]; x.M0 = meta[3];
+  x.L0 = L0_known >= 0 ? L0_known : meta[2];
+  x.M0 = L0_known >= 0 ? M0_known : meta[3];
   x.Lcap = min(S.L_max, x.L0 + INEW);
   x.n1 = 3 * P + 2 * x.L0; x.n1p = (x.n1 + 15) & ~15;
   x.a0 = 3 + 2 * x.L0;
@@ -541,15 +554,18 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
         }
 #endif
       };
+      // (straight-line body: every iteration issues the same loads - past the end a repeat of the last unit's tiles, never used -
+      // so that the wait in front of a unit's products can count them.  With the loads under `if (e + 1 < nun)` the compiler
+      // could not, waited for EVERYTHING in flight there, and the next unit's loads never ran under this unit's products.)
+      int e = 0;
       loads(0, aA0, aA1);
-      for (int e = 0; e < nun; e += 2) {
-        if (e + 1 < nun) loads(e + 1, aB0, aB1);
+      for (; e + 1 < nun; e += 2) {
+        loads(e + 1, aB0, aB1);
         unit(e, aA0, aA1);
-        if (e + 1 < nun) {
-          if (e + 2 < nun) loads(e + 2, aA0, aA1);
-          unit(e + 1, aB0, aB1);
-        }
+        loads(min(e + 2, nun - 1), aA0, aA1);
+        unit(e + 1, aB0, aB1);
       }
+      if (e < nun) unit(e, aA0, aA1);  // (an odd count: the last unit's tiles are the ones the loop requested last)
     }
     __syncthreads();
     if (b0 == 0) DRLGX_PROF(S, 38);

@@ -19,6 +19,11 @@ struct SimCtx {
   Pose veh;
   int P, L, M;
   int err;
+  // the initial guess of the newest pose (what SLAM2D::addOdometry inserted, SLAM2D.cpp:70-89) when this wave has just formed it
+  // itself: a first sighting's initial estimate is relative to it (Simulator2D.cpp:95-98), and reading it back from th_pose
+  // would mean waiting for lane 0's store to drain first
+  Pose origin;
+  int has_origin;
 };
 
 // Simulator2D::measure (Simulator2D.cpp:505-527) + SLAM2D::addMeasurement (SLAM2D.cpp:103-124), wave-parallel.
@@ -36,12 +41,6 @@ struct GtPrefetch {
   int key[2];
   double x[2], y[2];
 };
-__device__ inline void gt_prefetch_keys(const SimCtx &c, GtPrefetch &g) {
-  const int n_gt = c.S.cfg.num_landmarks;
-  g.ok = n_gt <= 128;
-#pragma unroll
-  for (int r = 0; r < 2; ++r) g.key[r] = (g.ok && 64 * r + c.lane < n_gt) ? c.S.lm_order[64 * r + c.lane] : 0;
-}
 __device__ inline void gt_prefetch_points(const SimCtx &c, GtPrefetch &g) {
   const double *gl = c.S.gt_lm + (size_t)c.S.parent[c.inst] * c.S.LG * 2;
 #pragma unroll
@@ -67,7 +66,7 @@ __device__ inline int scan_in_range(SimCtx &c, int *inr, const GtPrefetch *pf = 
       if (in) inr[n_in + __popcll(mask & below)] = pf->key[r];
       n_in += __popcll(mask);
     }
-    wave_sync();
+    wave_lds_sync();
     return n_in;
   }
   for (int base = 0; base < n_gt; base += 64) {
@@ -81,7 +80,7 @@ __device__ inline int scan_in_range(SimCtx &c, int *inr, const GtPrefetch *pf = 
     if (in) inr[n_in + __popcll(mask & below)] = key;
     n_in += __popcll(mask);
   }
-  wave_sync();
+  wave_lds_sync();
   return n_in;
 }
 // exp_*: the staged interface (drlgx_stage_measure) exports the valid measurements (key, bearing, range) in order instead
@@ -97,14 +96,32 @@ __device__ inline void measure(SimCtx &c, bool record, double *nrm, const int *i
   const drlgx_config &cfg = S.cfg;
   const double *gl = S.gt_lm + (size_t)S.parent[c.inst] * S.LG * 2;
   const unsigned long long below = (1ull << c.lane) - 1ull;
+  int *key_slot = S.key_slot + (size_t)c.inst * S.LG;
+  // what the lanes need from HBM for their landmarks (ground-truth point, landmark slot) is requested BEFORE the draws: the round
+  // trip then runs under them instead of at the head of the loop below (the first 128 in-range landmarks: two per lane)
+  int pf_key[2] = {0, 0}, pf_slot[2] = {0, 0};
+  double pf_x[2] = {0, 0}, pf_y[2] = {0, 0};
+  if (record || exp_keys) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int k = 64 * r + c.lane;
+      if (k < n_in) {
+        pf_key[r] = inr[k];
+        pf_x[r] = gl[2 * pf_key[r]];
+        pf_y[r] = gl[2 * pf_key[r] + 1];
+        if (record) pf_slot[r] = key_slot[pf_key[r]];
+      }
+    }
+  }
   draw_normals(c.sensor, c.ns_sensor, lead + 2 * n_in, nrm, c.lane, (record || exp_keys) ? lead : lead + 2 * n_in);
   if (exp_keys) {
     int n_out = 0;
     for (int base = 0; base < n_in; base += 64) {
       const int k = base + c.lane;
       const bool v = k < n_in;
-      const int key = v ? inr[k] : 0;
-      const P2 lm{gl[2 * key], gl[2 * key + 1]};
+      const bool pf = base < 128;
+      const int key = pf ? pf_key[base >> 6] : (v ? inr[k] : 0);
+      const P2 lm = pf ? P2{pf_x[base >> 6], pf_y[base >> 6]} : P2{gl[2 * key], gl[2 * key + 1]};
       const double bn = (v ? nrm[2 * k] : 0.0) * cfg.bearing_noise + 0.0;
       const double rn = (v ? nrm[2 * k + 1] : 0.0) * cfg.range_noise + 0.0;
       const double bearing = bearing_of<false>(c.veh, lm, nullptr, nullptr) + bn;
@@ -123,19 +140,19 @@ __device__ inline void measure(SimCtx &c, bool record, double *nrm, const int *i
     return;
   }
   if (!record) return;
-  int *key_slot = S.key_slot + (size_t)c.inst * S.LG;
   const int L_first = c.L, M_first = c.M;
   for (int base = 0; base < n_in; base += 64) {
     const int k = base + c.lane;
     const bool v = k < n_in;
-    const int key = v ? inr[k] : 0;
-    const P2 lm{gl[2 * key], gl[2 * key + 1]};
+    const bool pf = base < 128;
+    const int key = pf ? pf_key[base >> 6] : (v ? inr[k] : 0);
+    const P2 lm = pf ? P2{pf_x[base >> 6], pf_y[base >> 6]} : P2{gl[2 * key], gl[2 * key + 1]};
     const double bn = (v ? nrm[2 * k] : 0.0) * cfg.bearing_noise + 0.0;  // RNG::normal(0, sd) = n01 * sd + 0
     const double rn = (v ? nrm[2 * k + 1] : 0.0) * cfg.range_noise + 0.0;
     const double bearing = bearing_of<false>(c.veh, lm, nullptr, nullptr) + bn;
     const double range = range_of<false>(c.veh, lm, nullptr, nullptr) + rn;
     const bool ok = v && bearing < cfg.max_bearing && bearing > cfg.min_bearing && range < cfg.max_range && range > cfg.min_range;
-    int slot = ok ? key_slot[key] : 0;
+    int slot = ok ? (pf ? pf_slot[base >> 6] : key_slot[key]) : 0;
     const bool isnew = ok && slot < 0;
     const unsigned long long okm = __ballot(ok), newm = __ballot(isnew);
     const int n_ok = __popcll(okm), n_new = __popcll(newm);
@@ -146,8 +163,11 @@ __device__ inline void measure(SimCtx &c, bool record, double *nrm, const int *i
     if (isnew) {
       slot = c.L + __popcll(newm & below);
       // origin = initial estimate of the measuring pose (it is never in result_ yet)
-      const double *tp = S.th_pose + ((size_t)c.inst * S.P_max + (c.P - 1)) * 4;
-      const Pose origin{tp[0], tp[1], tp[2], tp[3]};
+      Pose origin = c.origin;
+      if (!c.has_origin) {
+        const double *tp = S.th_pose + ((size_t)c.inst * S.P_max + (c.P - 1)) * 4;
+        origin = Pose{tp[0], tp[1], tp[2], tp[3]};
+      }
       const P2 g = transform_from(origin, P2{range * cos(bearing), range * sin(bearing)});  // Simulator2D.cpp:95-98
       double *tl = S.th_lm + ((size_t)c.inst * S.L_max + slot) * 2;
       tl[0] = g.x;
@@ -297,6 +317,38 @@ __device__ __forceinline__ bool move_accepted(const DrlgxState &S, double ox, do
   return odom_in_bounds(S.cfg, ox, oy) && P < S.P_max;
 }
 
+// What the simulator wave reads of its instance that does not depend on the pose count, as the caller's own loads left it in
+// registers: k_step's prelude requests it together with the counts, so that the wave starts to draw the moment it is released
+// instead of a round trip to HBM (~2.7 us at the head of a 256-workgroup launch) later.
+struct SimPre {
+  uint4 mt[5];            // the two random streams (mt_load2_issue)
+  double ns_s, ns_c;      // std::normal_distribution's saved variates and flags
+  int nh_s, nh_c;
+  Pose veh;               // ground-truth pose
+  int step0;
+  double dist0;
+  GtPrefetch gt;          // keys of the range scan
+  bool have = false;
+};
+__device__ __forceinline__ void sim_preload(const DrlgxState &S, int inst, int lane, int n_measure, SimPre &p) {
+  p.ns_s = S.nrm_saved[inst * 2 + 0];
+  p.ns_c = S.nrm_saved[inst * 2 + 1];
+  p.nh_s = S.nrm_has[inst * 2 + 0];
+  p.nh_c = S.nrm_has[inst * 2 + 1];
+  const double *gp = S.gt_pose + (size_t)inst * 4;
+  p.veh = Pose{gp[0], gp[1], gp[2], gp[3]};
+  p.step0 = S.cnt[(size_t)inst * DRLGX_CNT_STRIDE + C_STEP];
+  p.dist0 = S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST];
+  mt_load2_issue(S.mt + (size_t)inst * 2 * DRLGX_MT_STRIDE, lane, p.mt);
+  p.gt.ok = false;
+  if (n_measure > 0) {
+    const int n_gt = S.cfg.num_landmarks;
+    p.gt.ok = n_gt <= 128;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) p.gt.key[r] = (p.gt.ok && 64 * r + lane < n_gt) ? S.lm_order[64 * r + lane] : 0;
+  }
+}
+
 // move + addOdometry + measure(s) + addMeasurement for one belief step, executed by ONE wave (lane = 0..63).
 // lds0 / lds1: 626 words each, dyn: (2 LG + 2) doubles + LG ints of LDS scratch.
 // kMove / exp_*: the staged interface runs the move (with addOdometry) and a single exporting measure() as separate
@@ -306,7 +358,7 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
                                               int n_measure, uint32_t *lds0, uint32_t *lds1, double *dyn, int lane,
                                               int32_t *exp_keys = nullptr, double *exp_br = nullptr, int32_t *exp_count = nullptr,
                                               bool park_streams = false, int *mail = nullptr, double *lmbox = nullptr,
-                                              int known_P = -1, int known_L = 0, int known_M = 0) {
+                                              int known_P = -1, int known_L = 0, int known_M = 0, const SimPre &pre_in = SimPre{}) {
   uint32_t *lds[2] = {lds0, lds1};
   double *nrm = dyn;
   int *inr = reinterpret_cast<int *>(dyn + 2 * S.LG + 2);
@@ -336,46 +388,33 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
     return;
   }
   DRLGX_PROF(S, 8);
-  // Loads first, in the order of their first use (vmcnt counts in order): the small ones, the two random streams, the
-  // ground-truth landmarks of the range scan.  The part of the move that needs no random numbers is evaluated while the
-  // streams are on their way from HBM.
-  const double ns_s = S.nrm_saved[inst * 2 + 0], ns_c = S.nrm_saved[inst * 2 + 1];
-  const int nh_s = S.nrm_has[inst * 2 + 0], nh_c = S.nrm_has[inst * 2 + 1];
-  const double *gp = S.gt_pose + (size_t)inst * 4;
-  c.veh = Pose{gp[0], gp[1], gp[2], gp[3]};
+  // Loads first, in the order of their first use (vmcnt counts in order): what does not depend on the pose count (the caller may
+  // have it already: SimPre), then the last pose's estimate.  Nothing is STORED before the simulator's last load has been
+  // consumed: the memory counter is decremented in issue order, so a load requested behind a store is not consumed before that
+  // store has been acknowledged.  Lane 0's stores of the new pose are issued at the end, with the counts (store_ctx); the new
+  // pose's initial guess - formed late, when the estimate it needs has had the draws and the scan to arrive - travels in
+  // registers (SimCtx::origin).
+  SimPre pre = pre_in;
+  if (!pre.have) sim_preload(S, inst, lane, n_measure, pre);
   const double *ep = S.est_pose + ((size_t)inst * S.P_max + (c.P - 1)) * 4;
   const Pose last_est{ep[0], ep[1], ep[2], ep[3]};
-  const int step0 = cnt[C_STEP];
-  const double dist0 = S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST];
-  uint4 mtv[5];
-  mt_load2_issue(S.mt + (size_t)inst * 2 * DRLGX_MT_STRIDE, lane, mtv);
-  GtPrefetch gtp;
-  gtp.ok = false;
-  if (n_measure > 0) gt_prefetch_keys(c, gtp);
-  c.ns_sensor = NormalState{ns_s, nh_s};
-  c.ns_control = NormalState{ns_c, nh_c};
-  Pose odomP{0, 0, 1, 0};
+  c.veh = pre.veh;
+  const int step0 = pre.step0;
+  const double dist0 = pre.dist0;
+  GtPrefetch gtp = pre.gt;
+  c.ns_sensor = NormalState{pre.ns_s, pre.nh_s};
+  c.ns_control = NormalState{pre.ns_c, pre.nh_c};
+  Pose odomP{0, 0, 1, 0}, p2{0, 0, 1, 0};
+  const int P_before = c.P, L_before = c.L;
+  double dist_new = 0.0;
   if constexpr (kMove) {
     odomP = make_pose(ox, oy, oth);
-    // SLAM2D::addOdometry (SLAM2D.cpp:70-89): initial guess = last estimate * odom
-    Pose p2 = compose(last_est, odomP);
-    if (lane == 0) {
-      double *tp = S.th_pose + ((size_t)inst * S.P_max + c.P) * 4;
-      tp[0] = p2.x; tp[1] = p2.y; tp[2] = p2.c; tp[3] = p2.s;
-      double *dp = S.d_pose + ((size_t)inst * S.P_max + c.P) * 3;
-      dp[0] = dp[1] = dp[2] = 0;
-      double *oo = S.odo + ((size_t)inst * S.P_max + (c.P - 1)) * 4;
-      oo[0] = odomP.x; oo[1] = odomP.y; oo[2] = odomP.c; oo[3] = odomP.s;
-      cnt[C_NEWP] = c.P;
-      cnt[C_NEWL] = c.L;
-      cnt[C_FLAG] = 0;
-      cnt[C_STEP] = step0 + 1;
-      // Planner2D.cpp:1440: dist += sqrt(x^2 + y^2 + angle_weight * theta^2), theta = Pose2::theta()
-      double th = theta_of(odomP);
-      S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST] = dist0 + sqrt(ox * ox + oy * oy + cfg.angle_weight * (th * th));
-    }
+    // Planner2D.cpp:1440: dist += sqrt(x^2 + y^2 + angle_weight * theta^2), theta = Pose2::theta() (evaluated here, beside the
+    // loads, by every lane; lane 0 stores it with the rest at the end)
+    const double th = theta_of(odomP);
+    dist_new = dist0 + sqrt(ox * ox + oy * oy + cfg.angle_weight * (th * th));
   }
-  mt_load2_commit(lds[0], lds[1], mtv, lane, c.sensor, c.control);
+  mt_load2_commit(lds[0], lds[1], pre.mt, lane, c.sensor, c.control);
   if (n_measure > 0) gt_prefetch_points(c, gtp);  // (the keys arrived with the streams; the points travel during the move)
   DRLGX_PROF(S, 9);
   if constexpr (kMove) {
@@ -384,11 +423,17 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
   const double xn = nrm[0] * cfg.translation_noise + 0.0;
   const double yn = nrm[1] * cfg.translation_noise + 0.0;
   const double tn = nrm[2] * cfg.rotation_noise + 0.0;
-  wave_sync();  // (also: lane 0's writes above - the initial guess of the new pose - are read by every lane below)
+  wave_lds_sync();  // (the variates in LDS)
   c.veh = compose(compose(c.veh, odomP), make_pose(xn, yn, tn));
   c.P += 1;
   }
   DRLGX_PROF(S, 10);
+  if constexpr (kMove) {
+    // SLAM2D::addOdometry (SLAM2D.cpp:70-89): initial guess = last estimate * odom
+    p2 = compose(last_est, odomP);
+    c.origin = p2;
+    c.has_origin = 1;
+  }
   if (n_measure > 0) {
     const int n_in = scan_in_range(c, inr, &gtp);
     if (n_measure == 2 && !exp_keys) {
@@ -402,6 +447,21 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
         measure(c, m == n_measure - 1 && !exp_keys, nrm, inr, n_in, exp_keys, exp_br, exp_count);
         DRLGX_PROF(S, 11 + m);
       }
+    }
+  }
+  if constexpr (kMove) {
+    if (lane == 0) {
+      double *tp = S.th_pose + ((size_t)inst * S.P_max + P_before) * 4;
+      tp[0] = p2.x; tp[1] = p2.y; tp[2] = p2.c; tp[3] = p2.s;
+      double *dp = S.d_pose + ((size_t)inst * S.P_max + P_before) * 3;
+      dp[0] = dp[1] = dp[2] = 0;
+      double *oo = S.odo + ((size_t)inst * S.P_max + (P_before - 1)) * 4;
+      oo[0] = odomP.x; oo[1] = odomP.y; oo[2] = odomP.c; oo[3] = odomP.s;
+      cnt[C_NEWP] = P_before;
+      cnt[C_NEWL] = L_before;
+      cnt[C_FLAG] = 0;
+      cnt[C_STEP] = step0 + 1;
+      S.red[(size_t)inst * DRLGX_RED_STRIDE + R_DIST] = dist_new;
     }
   }
   store_ctx(c, park_streams, mail);
@@ -426,7 +486,7 @@ constexpr int kLogHdr = 32, kLogRec = 24;
 
 __global__ __launch_bounds__(64) void k_presim(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end,
                                                unsigned char *simlog, size_t simlog_roll, int simlog_act) {
-  __shared__ uint32_t lds[2][DRLGX_MT_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2][DRLGX_MT_STRIDE];
   extern __shared__ double dyn[];  // nrm[2 * n_measure * LG + 2] doubles, inr[LG] ints, kslot[LG] ints
   const int lane = threadIdx.x, i = blockIdx.x;
   if (sel.active && !sel.active[i]) return;
@@ -445,7 +505,7 @@ __global__ __launch_bounds__(64) void k_presim(DrlgxState S, LaunchSel sel, cons
   c.veh = Pose{gp[0], gp[1], gp[2], gp[3]};
   mt_load2(lds[0], lds[1], S.mt + (size_t)inst * 2 * DRLGX_MT_STRIDE, lane, c.sensor, c.control);
   for (int k = lane; k < S.LG; k += 64) kslot[k] = S.key_slot[(size_t)inst * S.LG + k];
-  wave_sync();
+  wave_lds_sync();
   const double *gl = S.gt_lm + (size_t)S.parent[inst] * S.LG * 2;
   const unsigned long long below = (1ull << lane) - 1ull;
   for (int a = sel.act_idx; a < n_mine; ++a) {
@@ -466,7 +526,7 @@ __global__ __launch_bounds__(64) void k_presim(DrlgxState S, LaunchSel sel, cons
     const double xn = nrm[0] * cfg.translation_noise + 0.0;
     const double yn = nrm[1] * cfg.translation_noise + 0.0;
     const double tn = nrm[2] * cfg.rotation_noise + 0.0;
-    wave_sync();
+    wave_lds_sync();
     c.veh = compose(compose(c.veh, odomP), make_pose(xn, yn, tn));
     c.P += 1;
     int nf = 0, nn = 0, err = 0;
@@ -508,7 +568,7 @@ __global__ __launch_bounds__(64) void k_presim(DrlgxState S, LaunchSel sel, cons
         c.M += n_ok;
         nf += n_ok;
         nn += n_new;
-        wave_sync();
+        wave_lds_sync();
       }
     }
     if (lane == 0) {
@@ -596,7 +656,7 @@ __device__ __forceinline__ void replay_step_body(const DrlgxState &S, const Laun
 
 __global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
                                                  int n_measure) {
-  __shared__ uint32_t lds[2][DRLGX_MT_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2][DRLGX_MT_STRIDE];
   extern __shared__ double dyn[];  // nrm[2 LG + 2] doubles, inr[LG] ints
   sim_step_body(S, sel, odom, odom_stride, n_measure, lds[0], lds[1], dyn, threadIdx.x);
 }
@@ -605,7 +665,7 @@ __global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, co
 // Simulator2D::measure whose valid measurements are exported: keys [n][LG], br [n][LG][2], count [n].
 __global__ __launch_bounds__(64) void k_sim_stage(DrlgxState S, LaunchSel sel, const double *odom, int mode, int32_t *keys,
                                                   double *br, int32_t *count) {
-  __shared__ uint32_t lds[2][DRLGX_MT_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2][DRLGX_MT_STRIDE];
   extern __shared__ double dyn[];
   const int i = blockIdx.x;
   if (mode == 0)

@@ -135,11 +135,6 @@ __device__ __forceinline__ void ld4(const double *p, double (&o)[4]) {
   const double2 a = *reinterpret_cast<const double2 *>(p), b = *reinterpret_cast<const double2 *>(p + 2);
   o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
 }
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 __device__ __forceinline__ double readlane_f64(double v, int src) {
   const long long b = __double_as_longlong(v);

@@ -51,17 +51,30 @@ __device__ __forceinline__ void step_once(const DrlgxState &S, const LaunchSel &
   kslam::SlamCtx ctx;
   bool pre = false, accepted = false, inc_try = false;
   double od3[3] = {0, 0, 0};
-  int P0 = 0, L0 = 0, M0 = 0, isam = 0;
+  int P0 = 0, L0 = 0, M0 = 0, isam = 0, pan_L0 = -1, pan_M0 = -1;
+  // (what the simulator wave reads that does not depend on the pose count is requested with the prelude's loads: ksim::SimPre)
+  ksim::SimPre spre;
+  spre.have = tid < 64 && !sel.simlog && sel.on(bi);
   if (sel.on(bi)) {
     const int inst = sel.base + bi;
     const int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
     P0 = cnt[C_P]; L0 = cnt[C_L]; M0 = cnt[C_M]; isam = cnt[C_ISAM];
+    // (the covariance panel's header with the same round trip: what inc_precheck decides on)
+    int meta0 = 0, meta1 = 0;
+    if (S.jc) {
+      const int4 mv = *reinterpret_cast<const int4 *>(kslam::inc_meta(S, inst));  // {valid, poses, landmarks, factors}
+      meta0 = mv.x & 0x7fffffff;
+      meta1 = mv.y;
+      pan_L0 = mv.z;
+      pan_M0 = mv.w;
+    }
     const double *od = odom + (size_t)bi * odom_stride + (size_t)sel.act_idx * 3;
     od3[0] = od[0]; od3[1] = od[1]; od3[2] = od[2];
+    if (spre.have) ksim::sim_preload(S, inst, tid, n_measure, spre);
     // the simulator's own acceptance test (ksim::move_accepted): a rejected move appends nothing - no front end then
     accepted = ksim::move_accepted(S, od3[0], od3[1], P0);
     // between relinearisations the SLAM stage is a rank-k covariance update (k_inc.hip): no front end to run ahead
-    inc_try = accepted && kslam::inc_precheck(S, inst, P0 + 1, tid, sub_cnt);
+    inc_try = accepted && kslam::inc_precheck(S, inst, P0 + 1, tid, sub_cnt, meta0, meta1, isam);
     // room for the landmarks / factors a step may add (more: slam_finish starts over); the front end only runs ahead when
     // the factor records fit the LDS (else slam_finish takes the workspace variant after the simulator)
     const int Lb = min(S.L_max, L0 + 48), Mb = min(S.M_max, M0 + 48);
@@ -82,7 +95,7 @@ __device__ __forceinline__ void step_once(const DrlgxState &S, const LaunchSel &
       ksim::replay_step_body(S, sel, odom, odom_stride, tid, sub_cnt + 1);
     else
       ksim::sim_step_body(S, sel, odom, odom_stride, n_measure, l0, l1, dyn, tid, nullptr, nullptr, nullptr, true, sub_cnt + 1,
-                          n_measure == 2 ? lmbox : nullptr, sel.on(bi) ? P0 : -1, L0, M0);
+                          n_measure == 2 ? lmbox : nullptr, sel.on(bi) ? P0 : -1, L0, M0, spre);
   } else if (pre) {
     ctx.front<true>(S, tid, P0, L0, M0, P0, L0, isam + 1, false, od3, kslam::SubBarrier{sub_cnt, kslam::kThreads / 64 - 1, 0});
   } else if (inc_try) {
@@ -90,7 +103,7 @@ __device__ __forceinline__ void step_once(const DrlgxState &S, const LaunchSel &
     // (the LDS plan is a few scalar operations: evaluated here and again after the simulator rather than kept in registers)
     kslam::IncCtx ix;
     bool inc_lds = false;
-    if (kslam::inc_plan(S, sel.base + bi, P0 + 1, lds_bytes, sim_bytes, ix, inc_lds, pc)) {
+    if (kslam::inc_plan(S, sel.base + bi, P0 + 1, lds_bytes, sim_bytes, ix, inc_lds, pc, pan_L0, pan_M0)) {
       const kslam::SubBarrier sb{sub_cnt, kslam::kThreads / 64 - 1, 0};
       if (inc_lds) kslam::inc_pre<true, true>(S, ix, tid, od3, sb);
       else kslam::inc_pre<false, true>(S, ix, tid, od3, sb);
@@ -118,7 +131,7 @@ __device__ __forceinline__ void step_once(const DrlgxState &S, const LaunchSel &
     // structure check of inc_post would refuse them)
     kslam::IncCtx ix;
     bool inc_lds = false;
-    if (kslam::inc_plan(S, sel.base + bi, P0 + 1, lds_bytes, sim_bytes, ix, inc_lds, pc)) {
+    if (kslam::inc_plan(S, sel.base + bi, P0 + 1, lds_bytes, sim_bytes, ix, inc_lds, pc, pan_L0, pan_M0)) {
       double *hp = hand ? reinterpret_cast<double *>(step_smem) : nullptr;
       inc_done = inc_lds ? kslam::inc_post<true>(S, ix, sub_cnt[2], sub_cnt[3], box, tid, hp, pc)
                          : kslam::inc_post<false>(S, ix, sub_cnt[2], sub_cnt[3], box, tid, hp, pc);

@@ -22,6 +22,10 @@ timeout 400 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ
   --kernel-trace -d /tmp/prof_sq2 -- $BENCH > /dev/null 2> $out/rocprof_sq2.err
 python scripts/pmc_sq_summary.py "$(db /tmp/prof_sq)" "$(db /tmp/prof_sq2)" --json $out/sq_counters.json > $out/sq_counters.txt
 ls -la $out
+# (the counters of THIS tree become the digest-checked files bench.py reads, here on the box too: the bench line below then carries
+# roofline.traffic; scripts/install_profiles.sh does the same in the repository afterwards)
+[ -s $out/pmc_traffic.json ] && cp $out/pmc_traffic.json profiles/pmc_traffic.json
+[ -s $out/sq_counters.json ] && cp $out/sq_counters.json profiles/sq_counters.json
 # the bench line itself, the 2-rank control flow on one device (gloo), and the step-vs-trajectory-length tables
 timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
 DRLGX_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 50 --warmup 5 > $out/bench_2ranks_gloo.json 2> $out/bench_2ranks_gloo.err
