@@ -105,6 +105,11 @@ struct DrlgxState {
   unsigned long long *inc_stats;
   long long *prof;  // [1024] development aid: wall_clock64() stamps of the phases of ONE workgroup (or null)
   int prof_block;   // ... this one
+  // This struct in device memory (the engine keeps it current; null: no copy).  A kernel that takes the struct BY VALUE reads
+  // every member it uses from the kernel-argument segment before its first instruction - for the fused step that is most of the
+  // ~0.8 KB, a dozen cache lines of memory nobody has touched before, and it cost 2.6 us per launch against reading the members
+  // where they are needed from this copy, which stays in L2 from launch to launch (k_step_ref, profiles/r05_ab_state_pointer.txt).
+  const DrlgxState *self_dev;
 };
 
 // phase stamp (100 MHz constant clock) — only block 0 / thread 0, only when profiling is armed

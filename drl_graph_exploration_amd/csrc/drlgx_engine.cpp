@@ -34,6 +34,10 @@ struct drlgx_engine {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::vector<void *> allocs;
+  // the state struct's copy in device memory (DrlgxState::self_dev) and what was uploaded last: every entry point compares and
+  // re-uploads before it launches anything (state_sync), whatever changed the struct
+  DrlgxState *state_dev = nullptr;
+  unsigned char state_shadow[sizeof(DrlgxState)];
   std::vector<DrlgxField> fields;       // per-instance fields (n_inst instances)
   DrlgxField *fields_dev = nullptr;
   std::vector<int> lm_order;
@@ -74,8 +78,14 @@ struct drlgx_engine {
 // every entry point makes the engine's device current (a process may drive several engines on several devices)
 #define DRLGX_ENTER(e)                          \
   do {                                          \
-    if (e) (void)hipSetDevice((e)->device);     \
+    if (e) {                                    \
+      (void)hipSetDevice((e)->device);          \
+      state_sync(e);                            \
+    }                                           \
   } while (0)
+
+struct drlgx_engine;
+static void state_sync(drlgx_engine *e);
 
 namespace {
 
@@ -440,13 +450,32 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   TRY(dev_alloc(e, &e->stage_mask, (size_t)n_envs));
   e->graph_gi_stride = 4 * S.L_max + 8;
   TRY(dev_alloc(e, &e->graph_gi, (size_t)n_envs * e->graph_gi_stride));
+  {
+    const char *sp = getenv("DRLGX_STATE_PTR");  // 0: the fused step takes the struct by value (the A/B of profiles/r05_ab_state_pointer.txt)
+    if (!(sp && sp[0] == '0')) {
+      unsigned char *raw = nullptr;
+      TRY(dev_alloc(e, &raw, sizeof(DrlgxState)));
+      e->state_dev = reinterpret_cast<DrlgxState *>(raw);
+      S.self_dev = e->state_dev;
+    }
+  }
 #undef TRY
   if (hipStreamSynchronize(e->stream) != hipSuccess) {
     drlgx_destroy(e);
     return DRLGX_E_HIP;
   }
+  state_sync(e);
   *out = e;
   return DRLGX_OK;
+}
+
+// The device copy of the state struct follows the host's: compared at every entry point (0.8 KB), uploaded when it differs -
+// after whatever the stream still runs with the old one.
+static void state_sync(drlgx_engine *e) {
+  if (!e->state_dev || memcmp(e->state_shadow, &e->S, sizeof(DrlgxState)) == 0) return;
+  (void)hipStreamSynchronize(e->stream);
+  (void)hipMemcpy(e->state_dev, &e->S, sizeof(DrlgxState), hipMemcpyHostToDevice);
+  memcpy(e->state_shadow, &e->S, sizeof(DrlgxState));
 }
 
 int drlgx_destroy(drlgx_engine *e) {

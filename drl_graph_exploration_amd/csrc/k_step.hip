@@ -161,6 +161,14 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
   step_once<FT>(S, sel, odom, odom_stride, n_measure, lds_bytes, map_chunk);
 }
 
+// The same kernel with the state struct read through a pointer to its device-resident copy (DrlgxState::self_dev): the
+// launch of one workgroup per CU that the headline measures pays for its arguments' first touch in full.
+template <int FT>
+__global__ __launch_bounds__(kslam::kThreads) void k_step_ref(const DrlgxState *__restrict__ Sp, LaunchSel sel, const double *odom, int odom_stride,
+                                                              int n_measure, int lds_bytes, int map_chunk) {
+  step_once<FT>(*Sp, sel, odom, odom_stride, n_measure, lds_bytes, map_chunk);
+}
+
 // A whole action LIST per workgroup (the look-ahead's rollouts, EMPlanner2D::simulations_reward's loop, Planner2D.cpp:1432-1460):
 // instance bi runs its actions [sel.act_idx, min(a_end, n_act[bi])) back to back - the fused step above once per action, the
 // state of one action handed to the next through HBM / L2 exactly as between launches (a workgroup barrier orders them).
@@ -275,8 +283,13 @@ void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const
   int chunk = 0;
   (void)drlgx_map_lds_bytes(S, &chunk, sel.pcap);
   static bool attr_set[32] = {false};
-  const void *fns[] = {reinterpret_cast<const void *>(&kstep::k_step<kslam::kFastTiles>)};
-  drlgx_ensure_lds_attr(attr_set, fns, 1, kslam::kLdsBudget);
-  hipLaunchKernelGGL((kstep::k_step<kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, odom,
-                     odom_stride, n_measure, kslam::kLdsBudget, chunk);
+  const void *fns[] = {reinterpret_cast<const void *>(&kstep::k_step<kslam::kFastTiles>),
+                       reinterpret_cast<const void *>(&kstep::k_step_ref<kslam::kFastTiles>)};
+  drlgx_ensure_lds_attr(attr_set, fns, 2, kslam::kLdsBudget);
+  if (S.self_dev)
+    hipLaunchKernelGGL((kstep::k_step_ref<kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S.self_dev, sel,
+                       odom, odom_stride, n_measure, kslam::kLdsBudget, chunk);
+  else
+    hipLaunchKernelGGL((kstep::k_step<kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, odom,
+                       odom_stride, n_measure, kslam::kLdsBudget, chunk);
 }
