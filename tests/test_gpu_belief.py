@@ -723,6 +723,40 @@ def test_compact_map_kernel_equals_the_resident_one():
     b.close()
 
 
+def test_state_struct_through_a_pointer_equals_by_value(monkeypatch):
+    """The fused step reads the engine's state struct through a pointer to a device-resident copy (csrc/k_step.hip k_step_ref,
+    kept current by drlgx_engine.cpp state_sync) instead of taking it by value in the kernel arguments; DRLGX_STATE_PTR=0 at
+    creation keeps the by-value kernel.  Same code on the same struct: every state bit-equal, step after step - also across a
+    call that CHANGES the struct between steps (the phase-stamp switch), which the copy has to follow."""
+    n = 6
+    monkeypatch.setenv("DRLGX_STATE_PTR", "0")
+    a, cfg = make_engine(n, num_landmarks=60)
+    monkeypatch.delenv("DRLGX_STATE_PTR")
+    b, _ = make_engine(n, num_landmarks=60)
+    starts = generic_starts(n)
+    for e in (a, b):
+        e.reset(np.arange(n), np.arange(n), starts=starts)
+    import ctypes as C
+    for s, act in enumerate(SCRIPT + [(2, 0, 0), (0, 0, 0.9), (2, 0, 0)] * 4):
+        odom = torch.tensor([act] * n, dtype=torch.float64, device=a.device)
+        if s == 5:  # the struct changes (a member is set): the device copy must be re-uploaded before the next launch
+            for e in (a, b):
+                e._chk(e.L.drlgx_debug_phase_clocks_host(e.h, 1, None))
+        if s == 8:
+            out = (C.c_int64 * 64)()
+            for e in (a, b):
+                e._chk(e.L.drlgx_debug_phase_clocks_host(e.h, 0, out))
+        a.step(odom)
+        b.step(odom)
+        assert a.status() == 0 and b.status() == 0
+        for i in range(n):
+            for x, y in zip(a.poses(i) + a.landmarks(i) + a.virtual_map(i), b.poses(i) + b.landmarks(i) + b.virtual_map(i)):
+                np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(a.utility().cpu().numpy(), b.utility().cpu().numpy())
+    a.close()
+    b.close()
+
+
 def _staged_episode(e, seed, start, n_moves):
     """reset; measure + add at pose 0 WITHOUT an optimise there; then moves, each followed by the step's two measure calls,
     add and optimise (the staged C ABI, include/drlgx.h drlgx_stage_*)."""
