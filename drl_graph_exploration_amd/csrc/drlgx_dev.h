@@ -112,6 +112,23 @@ struct DrlgxState {
   const DrlgxState *self_dev;
 };
 
+// The device-resident copy as a kernel parameter: a pointer into the CONSTANT address space.  The members are then read with scalar
+// loads where they are used, and - what matters more - the pointers among them are known to point to global memory: loaded through
+// a plain (flat / global) pointer every access of the kernel became a flat_load / flat_store with a 64-bit address pair per access
+// (256 VGPRs + 108 B of scratch per thread in round 5, and every LDS wait also waited for the memory accesses in flight).
+typedef const __attribute__((address_space(4))) DrlgxState *DrlgxStateConst;
+// How the belief kernels of the unity build receive the state: DRLGX_KS_PARAM in the signature, `const DrlgxState &S = DRLGX_KS_REF;`
+// as the first line, DRLGX_KS_ARG(S) at the launch.  -DDRLGX_STATE_BY_VALUE builds the by-value form (the A/B of profiles/r06_ab_state_const.txt).
+#ifdef DRLGX_STATE_BY_VALUE
+#define DRLGX_KS_PARAM DrlgxState S_
+#define DRLGX_KS_REF S_
+#define DRLGX_KS_ARG(S) (S)
+#else
+#define DRLGX_KS_PARAM DrlgxStateConst S_
+#define DRLGX_KS_REF (*(const DrlgxState *)S_)
+#define DRLGX_KS_ARG(S) ((DrlgxStateConst)(S).self_dev)
+#endif
+
 // phase stamp (100 MHz constant clock) — only block 0 / thread 0, only when profiling is armed
 #define DRLGX_PROF(S, slot)                                                        \
   do {                                                                             \

@@ -451,13 +451,11 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   e->graph_gi_stride = 4 * S.L_max + 8;
   TRY(dev_alloc(e, &e->graph_gi, (size_t)n_envs * e->graph_gi_stride));
   {
-    const char *sp = getenv("DRLGX_STATE_PTR");  // 0: the fused step takes the struct by value (the A/B of profiles/r05_ab_state_pointer.txt)
-    if (!(sp && sp[0] == '0')) {
-      unsigned char *raw = nullptr;
-      TRY(dev_alloc(e, &raw, sizeof(DrlgxState)));
-      e->state_dev = reinterpret_cast<DrlgxState *>(raw);
-      S.self_dev = e->state_dev;
-    }
+    // the struct's device copy: what the belief kernels read their state from (DrlgxStateConst; drlgx_dev.h)
+    unsigned char *raw = nullptr;
+    TRY(dev_alloc(e, &raw, sizeof(DrlgxState)));
+    e->state_dev = reinterpret_cast<DrlgxState *>(raw);
+    S.self_dev = e->state_dev;
   }
 #undef TRY
   if (hipStreamSynchronize(e->stream) != hipSuccess) {

@@ -692,12 +692,14 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
   }
 }
 
-__global__ __launch_bounds__(kThreads) void k_map(DrlgxState S, LaunchSel sel, int rebuild, int chunk) {
+__global__ __launch_bounds__(kThreads) void k_map(DRLGX_KS_PARAM, LaunchSel sel, int rebuild, int chunk) {
+  const DrlgxState &S = DRLGX_KS_REF;
   map_body<false>(S, sel, rebuild, chunk);
 }
 // The multi-resident form: <= 128 VGPRs (four waves per SIMD) and, with the compact carve, <= 80 KB of LDS - two workgroups
 // per CU, each covering the other's dependent chains and barriers.  Launched when there are more instances than CUs.
-__global__ __launch_bounds__(kThreads, KMAPC_WAVES) void k_map_c(DrlgxState S, LaunchSel sel, int rebuild, int chunk) {
+__global__ __launch_bounds__(kThreads, KMAPC_WAVES) void k_map_c(DRLGX_KS_PARAM, LaunchSel sel, int rebuild, int chunk) {
+  const DrlgxState &S = DRLGX_KS_REF;
   map_body<true>(S, sel, rebuild, chunk);
 }
 
@@ -784,7 +786,7 @@ void drlgx_launch_map(const DrlgxState &S, hipStream_t st, LaunchSel sel) {
   // more instances than CUs: the form of which two workgroups share a CU (each covers the other's barriers and dependent chains:
   // 97 against 136 us at 2 048 instances, profiles/r05_ab_machine_licm.txt); up to one instance per CU the resident form
   if (clds && (force == 1 || (force != 0 && sel.n > n_cu)))
-    hipLaunchKernelGGL(kmap::k_map_c, dim3(sel.n), dim3(kmap::kThreads), clds, st, S, sel, rebuild, cchunk);
+    hipLaunchKernelGGL(kmap::k_map_c, dim3(sel.n), dim3(kmap::kThreads), clds, st, DRLGX_KS_ARG(S), sel, rebuild, cchunk);
   else
-    hipLaunchKernelGGL(kmap::k_map, dim3(sel.n), dim3(kmap::kThreads), lds, st, S, sel, rebuild, chunk);
+    hipLaunchKernelGGL(kmap::k_map, dim3(sel.n), dim3(kmap::kThreads), lds, st, DRLGX_KS_ARG(S), sel, rebuild, chunk);
 }

@@ -233,8 +233,9 @@ __device__ inline void store_ctx(SimCtx &c, bool park = false, int *mail = nullp
 }
 
 // SS2D.__init__ (pyss2d.py:102-138): seed, vehicle, landmarks, prior, first measure.
-__global__ __launch_bounds__(64) void k_reset(DrlgxState S, int first_measure, const int32_t *env_ids, const uint32_t *seeds,
+__global__ __launch_bounds__(64) void k_reset(DRLGX_KS_PARAM, int first_measure, const int32_t *env_ids, const uint32_t *seeds,
                                               const double *start) {
+  const DrlgxState &S = DRLGX_KS_REF;
   __shared__ uint32_t lds[3][DRLGX_MT_STRIDE];
   extern __shared__ double dyn[];  // nrm[2 LG + 2] doubles, inr[LG] ints
   double *nrm = dyn;
@@ -484,8 +485,9 @@ __device__ __forceinline__ void sim_step_body(const DrlgxState &S, const LaunchS
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kLogHdr = 32, kLogRec = 24;
 
-__global__ __launch_bounds__(64) void k_presim(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end,
+__global__ __launch_bounds__(64) void k_presim(DRLGX_KS_PARAM, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end,
                                                unsigned char *simlog, size_t simlog_roll, int simlog_act) {
+  const DrlgxState &S = DRLGX_KS_REF;
   __shared__ __attribute__((aligned(16))) uint32_t lds[2][DRLGX_MT_STRIDE];
   extern __shared__ double dyn[];  // nrm[2 * n_measure * LG + 2] doubles, inr[LG] ints, kslot[LG] ints
   const int lane = threadIdx.x, i = blockIdx.x;
@@ -654,8 +656,9 @@ __device__ __forceinline__ void replay_step_body(const DrlgxState &S, const Laun
   }
 }
 
-__global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
+__global__ __launch_bounds__(64) void k_sim_step(DRLGX_KS_PARAM, LaunchSel sel, const double *odom, int odom_stride,
                                                  int n_measure) {
+  const DrlgxState &S = DRLGX_KS_REF;
   __shared__ __attribute__((aligned(16))) uint32_t lds[2][DRLGX_MT_STRIDE];
   extern __shared__ double dyn[];  // nrm[2 LG + 2] doubles, inr[LG] ints
   sim_step_body(S, sel, odom, odom_stride, n_measure, lds[0], lds[1], dyn, threadIdx.x);
@@ -663,8 +666,9 @@ __global__ __launch_bounds__(64) void k_sim_step(DrlgxState S, LaunchSel sel, co
 
 // drlgx_stage_move (mode 0): Simulator2D::move + SLAM2D::addOdometry.  drlgx_stage_measure (mode 1): one
 // Simulator2D::measure whose valid measurements are exported: keys [n][LG], br [n][LG][2], count [n].
-__global__ __launch_bounds__(64) void k_sim_stage(DrlgxState S, LaunchSel sel, const double *odom, int mode, int32_t *keys,
+__global__ __launch_bounds__(64) void k_sim_stage(DRLGX_KS_PARAM, LaunchSel sel, const double *odom, int mode, int32_t *keys,
                                                   double *br, int32_t *count) {
+  const DrlgxState &S = DRLGX_KS_REF;
   __shared__ __attribute__((aligned(16))) uint32_t lds[2][DRLGX_MT_STRIDE];
   extern __shared__ double dyn[];
   const int i = blockIdx.x;
@@ -677,7 +681,8 @@ __global__ __launch_bounds__(64) void k_sim_stage(DrlgxState S, LaunchSel sel, c
 
 // drlgx_stage_add_measurements: SLAM2D::addMeasurement (SLAM2D.cpp:103-124) of every listed (key, bearing, range) at the
 // newest pose, in list order (a key may repeat: the second one is no longer new).  Not a hot path: one lane per instance.
-__global__ void k_add_measurements(DrlgxState S, LaunchSel sel, const int32_t *keys, const double *br, const int32_t *count) {
+__global__ void k_add_measurements(DRLGX_KS_PARAM, LaunchSel sel, const int32_t *keys, const double *br, const int32_t *count) {
+  const DrlgxState &S = DRLGX_KS_REF;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sel.n || !sel.on(i)) return;
   const int inst = sel.base + i;
@@ -731,24 +736,24 @@ size_t drlgx_simlog_entry_bytes(const DrlgxState &S) { return ((size_t)ksim::kLo
 void drlgx_launch_presim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride, int n_measure, int a_end,
                          unsigned char *simlog, size_t simlog_roll, int simlog_act) {
   const size_t dyn = (size_t)(2 * (n_measure > 0 ? n_measure : 1) * S.LG + 2) * sizeof(double) + (size_t)2 * S.LG * sizeof(int);
-  hipLaunchKernelGGL(ksim::k_presim, dim3(sel.n), dim3(64), dyn, st, S, sel, odom, odom_stride, n_measure, a_end, simlog, simlog_roll, simlog_act);
+  hipLaunchKernelGGL(ksim::k_presim, dim3(sel.n), dim3(64), dyn, st, DRLGX_KS_ARG(S), sel, odom, odom_stride, n_measure, a_end, simlog, simlog_roll, simlog_act);
 }
 void drlgx_launch_sim_stage(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int mode, int32_t *keys,
                             double *br, int32_t *count) {
   const size_t dyn = (size_t)(2 * S.LG + 2) * sizeof(double) + (size_t)S.LG * sizeof(int);
-  hipLaunchKernelGGL(ksim::k_sim_stage, dim3(sel.n), dim3(64), dyn, st, S, sel, odom, mode, keys, br, count);
+  hipLaunchKernelGGL(ksim::k_sim_stage, dim3(sel.n), dim3(64), dyn, st, DRLGX_KS_ARG(S), sel, odom, mode, keys, br, count);
 }
 void drlgx_launch_add_measurements(const DrlgxState &S, hipStream_t st, LaunchSel sel, const int32_t *keys, const double *br,
                                    const int32_t *count) {
-  hipLaunchKernelGGL(ksim::k_add_measurements, dim3((sel.n + 63) / 64), dim3(64), 0, st, S, sel, keys, br, count);
+  hipLaunchKernelGGL(ksim::k_add_measurements, dim3((sel.n + 63) / 64), dim3(64), 0, st, DRLGX_KS_ARG(S), sel, keys, br, count);
 }
 void drlgx_launch_reset(const DrlgxState &S, hipStream_t st, int n, const int32_t *env_ids_dev,
                         const uint32_t *seeds_dev, const double *start_dev, int first_measure) {
   const size_t dyn = (size_t)(2 * S.LG + 2) * sizeof(double) + (size_t)S.LG * sizeof(int);
-  hipLaunchKernelGGL(ksim::k_reset, dim3(n), dim3(64), dyn, st, S, first_measure, env_ids_dev, seeds_dev, start_dev);
+  hipLaunchKernelGGL(ksim::k_reset, dim3(n), dim3(64), dyn, st, DRLGX_KS_ARG(S), first_measure, env_ids_dev, seeds_dev, start_dev);
 }
 void drlgx_launch_sim(const DrlgxState &S, hipStream_t st, LaunchSel sel, const double *odom, int odom_stride,
                       int n_measure) {
   const size_t dyn = (size_t)(2 * S.LG + 2) * sizeof(double) + (size_t)S.LG * sizeof(int);
-  hipLaunchKernelGGL(ksim::k_sim_step, dim3(sel.n), dim3(64), dyn, st, S, sel, odom, odom_stride, n_measure);
+  hipLaunchKernelGGL(ksim::k_sim_step, dim3(sel.n), dim3(64), dyn, st, DRLGX_KS_ARG(S), sel, odom, odom_stride, n_measure);
 }

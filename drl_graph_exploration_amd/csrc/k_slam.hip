@@ -1797,7 +1797,8 @@ __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &
 }
 
 template <int FT>
-__global__ __launch_bounds__(kThreads) void k_slam(DrlgxState S, LaunchSel sel, int lds_bytes) {
+__global__ __launch_bounds__(kThreads) void k_slam(DRLGX_KS_PARAM, LaunchSel sel, int lds_bytes) {
+  const DrlgxState &S = DRLGX_KS_REF;
   slam_body<FT>(S, sel, lds_bytes);
 }
 
@@ -1859,10 +1860,10 @@ void drlgx_launch_slam(const DrlgxState &S, hipStream_t st, LaunchSel sel, int p
   const dim3 grid(sel.n), block(kslam::kThreads);
   // (the whole LDS is requested: what the tables and the system leave free holds the factor records and the observation table)
   if (drlgx_slam_in_lds(Pb, S.L_max, S.M_max))
-    hipLaunchKernelGGL((kslam::k_slam<kslam::kFastTiles>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
+    hipLaunchKernelGGL((kslam::k_slam<kslam::kFastTiles>), grid, block, kslam::kLdsBudget, st, DRLGX_KS_ARG(S), sel, kslam::kLdsBudget);
   else if (2 * S.L_max + 1 <= 16 * kslam::kFastTilesArrow)  // landmark system always packed in LDS: no register-tile sweep compiled in
-    hipLaunchKernelGGL((kslam::k_slam_arrow<0>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
+    hipLaunchKernelGGL((kslam::k_slam_arrow<0>), grid, block, kslam::kLdsBudget, st, DRLGX_KS_ARG(S), sel, kslam::kLdsBudget);
   else
-    hipLaunchKernelGGL((kslam::k_slam_arrow<kslam::kArrowRegTiles>), grid, block, kslam::kLdsBudget, st, S, sel, kslam::kLdsBudget);
+    hipLaunchKernelGGL((kslam::k_slam_arrow<kslam::kArrowRegTiles>), grid, block, kslam::kLdsBudget, st, DRLGX_KS_ARG(S), sel, kslam::kLdsBudget);
 }
 #pragma clang fp contract(off)

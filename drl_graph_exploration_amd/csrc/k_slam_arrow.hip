@@ -1057,6 +1057,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
 }
 
 template <int NTW>
-__global__ __launch_bounds__(kThreads) void k_slam_arrow(DrlgxState S, LaunchSel sel, int lds_bytes) {
+__global__ __launch_bounds__(kThreads) void k_slam_arrow(DRLGX_KS_PARAM, LaunchSel sel, int lds_bytes) {
+  const DrlgxState &S = DRLGX_KS_REF;
   arrow_body<NTW>(S, sel, lds_bytes);
 }

@@ -164,9 +164,9 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
 // The same kernel with the state struct read through a pointer to its device-resident copy (DrlgxState::self_dev): the
 // launch of one workgroup per CU that the headline measures pays for its arguments' first touch in full.
 template <int FT>
-__global__ __launch_bounds__(kslam::kThreads) void k_step_ref(const DrlgxState *__restrict__ Sp, LaunchSel sel, const double *odom, int odom_stride,
+__global__ __launch_bounds__(kslam::kThreads) void k_step_ref(DrlgxStateConst Sp, LaunchSel sel, const double *odom, int odom_stride,
                                                               int n_measure, int lds_bytes, int map_chunk) {
-  step_once<FT>(*Sp, sel, odom, odom_stride, n_measure, lds_bytes, map_chunk);
+  step_once<FT>(*(const DrlgxState *)Sp, sel, odom, odom_stride, n_measure, lds_bytes, map_chunk);
 }
 
 // A whole action LIST per workgroup (the look-ahead's rollouts, EMPlanner2D::simulations_reward's loop, Planner2D.cpp:1432-1460):
@@ -176,8 +176,9 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step_ref(const DrlgxState *
 // instance) and lets the hardware deal the candidates to the CUs as they finish: a candidate with few actions makes room
 // for the next one instead of idling through the other candidates' later actions.
 template <int FT>
-__global__ __launch_bounds__(kslam::kThreads) void k_step_loop(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
+__global__ __launch_bounds__(kslam::kThreads) void k_step_loop(DRLGX_KS_PARAM, LaunchSel sel, const double *odom, int odom_stride,
                                                                int n_measure, int lds_bytes, int map_chunk, int a_end) {
+  const DrlgxState &S = DRLGX_KS_REF;
   const int bi = blockIdx.x;
   const int n_mine = sel.n_act ? min(a_end, sel.n_act[bi]) : a_end;
   if (sel.active && !sel.active[bi]) return;
@@ -210,13 +211,15 @@ __device__ __forceinline__ void step_arrow_once(const DrlgxState &S, const Launc
   __syncthreads();
   if (!sel.skip_map) kmap::map_body<false>(S, sel, 1, map_chunk);
 }
-__global__ __launch_bounds__(kslam::kThreads) void k_step_arrow(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
+__global__ __launch_bounds__(kslam::kThreads) void k_step_arrow(DRLGX_KS_PARAM, LaunchSel sel, const double *odom, int odom_stride,
                                                                 int n_measure, int lds_bytes, int map_chunk) {
+  const DrlgxState &S = DRLGX_KS_REF;
   step_arrow_once(S, sel, odom, odom_stride, n_measure, lds_bytes, map_chunk);
 }
 // ... and a whole action list per workgroup, as k_step_loop (the look-ahead of trajectories beyond the dense solver's reach)
-__global__ __launch_bounds__(kslam::kThreads) void k_step_arrow_loop(DrlgxState S, LaunchSel sel, const double *odom, int odom_stride,
+__global__ __launch_bounds__(kslam::kThreads) void k_step_arrow_loop(DRLGX_KS_PARAM, LaunchSel sel, const double *odom, int odom_stride,
                                                                      int n_measure, int lds_bytes, int map_chunk, int a_end) {
+  const DrlgxState &S = DRLGX_KS_REF;
   const int bi = blockIdx.x;
   const int n_mine = sel.n_act ? min(a_end, sel.n_act[bi]) : a_end;
   if (sel.active && !sel.active[bi]) return;
@@ -255,7 +258,7 @@ void drlgx_launch_step_arrow(const DrlgxState &S, hipStream_t st, LaunchSel sel,
   static bool attr_set[32] = {false};
   const void *fns[] = {reinterpret_cast<const void *>(&kstep::k_step_arrow)};
   drlgx_ensure_lds_attr(attr_set, fns, 1, kslam::kLdsBudget);
-  hipLaunchKernelGGL(kstep::k_step_arrow, dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, odom, odom_stride, n_measure,
+  hipLaunchKernelGGL(kstep::k_step_arrow, dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, DRLGX_KS_ARG(S), sel, odom, odom_stride, n_measure,
                      kslam::kLdsBudget, chunk);
 }
 
@@ -265,7 +268,7 @@ void drlgx_launch_step_arrow_loop(const DrlgxState &S, hipStream_t st, LaunchSel
   static bool attr_set[32] = {false};
   const void *fns[] = {reinterpret_cast<const void *>(&kstep::k_step_arrow_loop)};
   drlgx_ensure_lds_attr(attr_set, fns, 1, kslam::kLdsBudget);
-  hipLaunchKernelGGL(kstep::k_step_arrow_loop, dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, odom, odom_stride, n_measure,
+  hipLaunchKernelGGL(kstep::k_step_arrow_loop, dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, DRLGX_KS_ARG(S), sel, odom, odom_stride, n_measure,
                      kslam::kLdsBudget, chunk, a_end);
 }
 
@@ -275,7 +278,7 @@ void drlgx_launch_step_loop(const DrlgxState &S, hipStream_t st, LaunchSel sel, 
   static bool attr_set[32] = {false};
   const void *fns[] = {reinterpret_cast<const void *>(&kstep::k_step_loop<kslam::kFastTiles>)};
   drlgx_ensure_lds_attr(attr_set, fns, 1, kslam::kLdsBudget);
-  hipLaunchKernelGGL((kstep::k_step_loop<kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, odom,
+  hipLaunchKernelGGL((kstep::k_step_loop<kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, DRLGX_KS_ARG(S), sel, odom,
                      odom_stride, n_measure, kslam::kLdsBudget, chunk, a_end);
 }
 
@@ -286,8 +289,10 @@ void drlgx_launch_step(const DrlgxState &S, hipStream_t st, LaunchSel sel, const
   const void *fns[] = {reinterpret_cast<const void *>(&kstep::k_step<kslam::kFastTiles>),
                        reinterpret_cast<const void *>(&kstep::k_step_ref<kslam::kFastTiles>)};
   drlgx_ensure_lds_attr(attr_set, fns, 2, kslam::kLdsBudget);
-  if (S.self_dev)
-    hipLaunchKernelGGL((kstep::k_step_ref<kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S.self_dev, sel,
+  // (DRLGX_STATE_PTR=0: the struct by value, the A/B of profiles/r05_ab_state_pointer.txt / r06_ab_state_const.txt)
+  static const bool by_value = [] { const char *sp = getenv("DRLGX_STATE_PTR"); return sp && sp[0] == '0'; }();
+  if (!by_value)
+    hipLaunchKernelGGL((kstep::k_step_ref<kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, (DrlgxStateConst)S.self_dev, sel,
                        odom, odom_stride, n_measure, kslam::kLdsBudget, chunk);
   else
     hipLaunchKernelGGL((kstep::k_step<kslam::kFastTiles>), dim3(sel.n), dim3(kslam::kThreads), kslam::kLdsBudget, st, S, sel, odom,
