@@ -36,6 +36,13 @@
 
 constexpr int IYS = 18;  // row stride (doubles) of the Y / U' / W' images: 16 columns in ks16 order + 2 pad (144 B)
 constexpr int INF = 64;  // most bearing-range factors one step may add on this path
+#ifndef INC_STREAM_KB
+#define INC_STREAM_KB 512
+#endif
+#ifndef INC_ISNT
+#define INC_ISNT 4
+#endif
+constexpr int ISNT = INC_ISNT;  // the streamed form of the update (panel in HBM / L2): at most 8 ISNT re-observed landmarks per walk over the panel
 
 __device__ __forceinline__ int *inc_meta(const DrlgxState &S, int inst) { return S.jc_meta + (size_t)inst * 4; }
 
@@ -92,6 +99,15 @@ __device__ __forceinline__ double rowgroup_xor(double v) {
   return __longlong_as_double(((long long)w[1] << 32) | w[0]);
 }
 
+// value of the lane kShift (1 or 2) lanes below inside the 16-lane row (row_shr); lanes without such a neighbour read 0
+template <int kShift>
+__device__ __forceinline__ double row_shr_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x110 + kShift, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x110 + kShift, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // LDS carve of one incremental update.  Sizes follow what is known BEFORE the step (the pose count after it, the landmark
 // count L0 of the previous update) plus room for up to INEW landmarks seen for the first time, so that the first half of the
 // update can run beside the simulator wave of the fused step kernel.
@@ -101,6 +117,9 @@ struct IncCtx {
   int *fre, *fnew, *fslot, *ictl;
   double *fq, *recs, *gs, *vvec, *wks, *thp, *thl, *dl, *Dl, *Y, *Yh, *cwl;
   bool wide;  // room for the second half of Y: batches of up to 16 re-observed landmarks
+  // the panel in HBM / L2 (inc_stream_batch): up to 8 snt re-observed landmarks per walk over the panel; LDS images
+  int snt, yrows;
+  double *yt, *wim, *jt, *svv;
 };
 // false: the step cannot take this path (LDS).  lds_panel: the panel is staged in LDS for the step (else updated in place in
 // HBM / L2).  The decision is taken for the SAME LDS offset in every kernel (the fused step's: behind the simulator's region),
@@ -121,6 +140,9 @@ __device__ __forceinline__ bool inc_plan(const DrlgxState &S, int inst, int P, i
   x.ldw = (3 + 2 * x.Lcap + 31) & ~31;  // (whole pairs of 16-column tiles: inc_post, B3)
   const int ncap = max(3 * P + 2 * x.Lcap, x.n1p);
   size_t plan_off = drlgx_sim_lds_bytes(S.LG, pc);
+  // (no fused kernel ever serves this state - more poses than the dense solver takes and more landmarks than k_step_arrow sweeps in
+  // LDS, drlgx_step_arrow_fusable -: nothing to agree with, the simulator's region is not set aside)
+  if ((3 * P + 1 + 15) / 16 > kDenseTiles && 2 * S.L_max + 1 > 16 * 8) plan_off = 0;
   if (smem_off > plan_off) plan_off = smem_off;
   size_t off = (smem_off + 15) & ~(size_t)15;
   const size_t off0 = off;
@@ -147,6 +169,26 @@ __device__ __forceinline__ bool inc_plan(const DrlgxState &S, int inst, int P, i
   const size_t pan = lds_panel ? (size_t)ncap * x.ldw * 8 : 0, yh = (size_t)(x.n1p + 1) * IYS * 8;
   x.Yh = x.cwl + pan / 8;
   x.wide = fixed + pan + yh <= (size_t)lds_bytes;
+  x.snt = 0;
+  // (the dense solver's kernels - k_step, k_slam: <= 53 poses - keep the two-walk form for the panels that miss the LDS: those are a
+  // few hundred KB that stay in L2, and the streamed form's fixed costs - a k x k inverse, the gathers at the head of every row tile -
+  // made the 48-landmark instance of the bench state 6 us slower)
+  if (!lds_panel && (3 * P + 1 + 15) / 16 > kDenseTiles) {
+    // The panel stays in HBM / L2: the update walks it ONCE per batch of up to 8 snt landmarks (inc_stream_batch), and what it
+    // keeps in LDS is indexed by the panel's COLUMNS, not its rows: Y^T of the active variables as snt tiles of 16 factor columns
+    // (rows = the columns of the panel + one row of zeros for the pad columns), the snt x snt operand images of
+    // W' = -T^-1 and the batch's Jacobians in column order - everything from x.Y to the end of the LDS.
+    x.yrows = x.a0 + 1;  // (+ one row of zeros: the operand of the pad columns)
+    const size_t y_off = (size_t)(reinterpret_cast<unsigned char *>(x.Y) - smem_raw);
+    // (sized like everything else in this plan: as if the carve began at plan_off - the fused step and the stage kernels agree)
+    const size_t avail = (size_t)lds_bytes - (((plan_off + 15) & ~(size_t)15) + (y_off - off0));
+    for (int t = ISNT; t >= 1 && !x.snt; --t)
+      if ((size_t)t * x.yrows * IYS * 8 + (size_t)max(0, t * t - 5) * 16 * IYS * 8 + (size_t)16 * t * 8 * 8 + 64 * 8 <= avail) x.snt = t;
+    x.yt = x.Y;
+    x.wim = x.yt + (size_t)x.snt * x.yrows * IYS;  // images 5 .. snt^2 - 1 of W' (the first five: x.wks)
+    x.jt = x.wim + (size_t)max(0, x.snt * x.snt - 5) * 16 * IYS;
+    x.svv = x.jt + (size_t)16 * x.snt * 8;
+  }
   return true;
 }
 
@@ -258,7 +300,7 @@ __device__ __forceinline__ void inc_pre(const DrlgxState &S, const IncCtx &x, in
 // (the HBM panel, if inc_pre already moved it, is marked invalid); uniform over the workgroup.
 // hand (k_step; or null): LDS that receives what the map stage reads next - est_pose [P][4] and, at hand + 4 hand_cap,
 // pose_info [P][6] (as SlamCtx::back leaves them) - and the landmark estimates are left in x.thl for the same reason.
-template <bool kLds>
+template <bool kLds, int kSNT = ISNT>
 __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, int L, int M, const SimBox &box, int tid,
                                          double *hand = nullptr, int hand_cap = 0) {
   const int lane = tid & 63, wave = tid >> 6, lc = lane & 15, lr = lane >> 4;
@@ -570,16 +612,359 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
     __syncthreads();
     if (b0 == 0) DRLGX_PROF(S, 38);
   };
-  for (int b0 = 0; b0 < n_re;) {
-    const int left = n_re - b0;
-    if (left > 8 && x.wide) {
-      const int nb = min(16, left);
-      batch(b0, nb, std::true_type{});
-      b0 += nb;
-    } else {
-      const int nb = min(8, left);
-      batch(b0, nb, std::false_type{});
-      b0 += nb;
+
+  // ---- B'. the panel in HBM / L2: ONE walk over it per batch of up to 8 NT re-observed landmarks (k = 2 nb <= 16 NT columns) ----
+  // In the form above every batch of 8 landmarks reads the panel twice (Y = Sigma A^T, then the tiles) and writes it once; at BASELINE
+  // config 5 (110 poses, 92 landmarks: a 770 KB panel per instance, ~21 factors per step) that is three batches = 1.8 GB per
+  // 256-instance launch, and the update ran at the memory system's speed: 370-420 us.  Here
+  //   S1  Ya = (Sigma A^T) for the ACTIVE rows only (the current pose, the landmarks: 36 % of the rows), kept in LDS indexed by the
+  //       panel's column - it is the B operand of every tile product and all that T = R + A Ya needs;
+  //   S2  one wave: T (k x k, NT x NT tiles in registers, both triangles), W' = -T^-1 by block Gauss-Jordan on the matrix cores
+  //       (pivot tiles by inv16_blk; with both triangles in registers every product is of the form X^T Z that accumulator
+  //       registers feed directly), stored as operand images;
+  //   S3  per row tile, once: the lanes form THEIR entries of Y^T (the B operand of U'^T = W' Y^T) straight from the rows in HBM /
+  //       L2 - lines the tile loads behind them want anyway -, U' on the matrix cores, delta and the pose marginals from the U'
+  //       registers and the neighbouring lanes' Y (DPP), then every column pair C += U' Ya^T as above.
+  // Pose rows are dealt 15 to a tile (five poses: the three rows of a pose never straddle tiles, so the marginal's row products
+  // stay inside the 16-lane rows), landmark rows 16.  One batch of all re-observed landmarks equals the sequence of batches of 8
+  // in exact arithmetic (independent measurement noise).
+  auto sbatch = [&](int b0, int nb, auto nt_tag) {
+    constexpr int NT = decltype(nt_tag)::value;
+    const int k = 2 * nb, npr = (a0 + 31) >> 5, yrows = x.yrows;
+    double *Yt = x.yt, *jt = x.jt, *vv = x.svv;
+    const size_t ytile = (size_t)yrows * IYS;
+    // tile i of the NT x NT images of W' (and, before them, of the register dumps of T): the first five where the LDS form keeps its
+    // W' images, the others behind Ya
+    auto timg = [&](int i) -> double * { return i < 5 ? wks + (size_t)i * 16 * IYS : x.wim + (size_t)(i - 5) * 16 * IYS; };
+    // S0 / S1. the batch's Jacobians in column order (kk = 2 f + u: Jx (3), Jl (2), the landmark's first column); Ya
+    if (tid >= kThreads - 16 * NT) {
+      const int kk = kThreads - 1 - tid, f = kk >> 1, u = kk & 1;
+      double *o = jt + 8 * kk;
+      int cl = 3;
+      double j0 = 0, j1 = 0, j2 = 0, j3 = 0, j4 = 0;
+      if (f < nb) {
+        const int t = fre[b0 + f];
+        const double *rc = recs + (size_t)REC * t;
+        j0 = rc[3 * u]; j1 = rc[3 * u + 1]; j2 = rc[3 * u + 2]; j3 = rc[6 + 2 * u]; j4 = rc[7 + 2 * u];
+        cl = 3 + 2 * fslot[t];
+      }
+      o[0] = j0; o[1] = j1; o[2] = j2; o[3] = j3; o[4] = j4;
+      reinterpret_cast<int *>(o + 5)[0] = cl;
+    }
+    {
+      constexpr int FS = 8 * NT, RS = kThreads / FS;
+      const int f = tid % FS, rr = tid / FS;
+      if (rr < RS) {
+        double j0 = 0, j1 = 0, j2 = 0, j3 = 0, j4 = 0, j5 = 0, l0c = 0, l1c = 0, l2c = 0, l3c = 0;
+        int cl = 3;
+        if (f < nb) {
+          const int t = fre[b0 + f];
+          const double *rc = recs + (size_t)REC * t;
+          j0 = rc[0]; j1 = rc[1]; j2 = rc[2]; j3 = rc[3]; j4 = rc[4]; j5 = rc[5];
+          l0c = rc[6]; l1c = rc[7]; l2c = rc[8]; l3c = rc[9];
+          cl = 3 + 2 * fslot[t];
+        }
+        double *Yf = Yt + (size_t)(f >> 3) * ytile;
+        const int k0 = ks16(2 * (f & 7)), k1 = ks16(2 * (f & 7) + 1);
+        for (int c0 = rr; c0 < a0; c0 += 4 * RS) {
+          double p0[4], p1[4], p2[4], l0[4], l1[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = min(c0 + u * RS, a0 - 1);
+            const double *r = rowp(c < 3 ? 3 * pn + c : 3 * P + c - 3);
+            p0[u] = r[0]; p1[u] = r[1]; p2[u] = r[2]; l0[u] = r[cl]; l1[u] = r[cl + 1];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * RS;
+            if (c < a0) {
+              Yf[(size_t)c * IYS + k0] = p0[u] * j0 + p1[u] * j1 + p2[u] * j2 + l0[u] * l0c + l1[u] * l1c;
+              Yf[(size_t)c * IYS + k1] = p0[u] * j3 + p1[u] * j4 + p2[u] * j5 + l0[u] * l2c + l1[u] * l3c;
+            }
+          }
+        }
+      }
+      for (int e = tid; e < NT * IYS; e += kThreads) {  // the pad columns' zero row
+        const int t = e / IYS, o = e - t * IYS;
+        Yt[(size_t)t * ytile + (size_t)a0 * IYS + o] = 0.0;
+      }
+    }
+    __syncthreads();
+    if (b0 == 0) DRLGX_PROF(S, 36);
+    // S2. T = R + A Ya and v = -e - A delta by everybody (T as the register dumps of its NT x NT tiles, where the images of W' go
+    // afterwards); W' = -T^-1 by one wave.  (Assembled in registers by that wave alone the compiler requested every operand of every
+    // entry at once: 160 loads in flight at NT = 2, and every belief kernel of this translation unit spilled.)
+#ifndef INC_EXP_NO_S2
+    {
+      if (tid < 16 * NT) {
+        double v = 0.0;
+        if (tid < k) {
+          const int t = fre[b0 + (tid >> 1)], u = tid & 1;
+          const double *rc = recs + (size_t)REC * t;
+          const double *dp = dl + 3 * pn, *dq = dl + 3 * P + 2 * fslot[t];
+          v = -rc[10 + u] - (rc[3 * u] * dp[0] + rc[3 * u + 1] * dp[1] + rc[3 * u + 2] * dp[2] + rc[6 + 2 * u] * dq[0] + rc[7 + 2 * u] * dq[1]);
+        }
+        vv[(tid & ~15) + ks16(tid & 15)] = v;
+      }
+#pragma clang loop unroll(disable)
+      for (int e = tid; e < NT * NT * 256; e += kThreads) {
+        const int tile = e >> 8, rg = (e >> 6) & 3, ln = e & 63, ta = tile / NT, tb = tile - NT * ta;
+        const int i = 16 * ta + (ln >> 4) + 4 * rg, j = 16 * tb + (ln & 15), hi = max(i, j), lo = min(i, j);
+        double sv = i == j ? 1.0 : 0.0;
+        if (hi < k) {  // row hi of A (factor hi / 2, bearing or range) against column lo of Ya
+          const double *ji = jt + 8 * hi;
+          const int cl = reinterpret_cast<const int *>(ji + 5)[0];
+          const double *yc = Yt + (size_t)(lo >> 4) * ytile + ks16(lo & 15);
+          sv = ji[0] * yc[0] + ji[1] * yc[IYS] + ji[2] * yc[2 * IYS] + ji[3] * yc[(size_t)cl * IYS] + ji[4] * yc[(size_t)(cl + 1) * IYS];
+          if (hi == lo) sv += (hi & 1) ? Rr : Rb;
+        }
+        timg(tile)[e & 255] = sv;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      v4d T[NT][NT];
+#pragma unroll
+      for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < NT; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) T[ta][tb][r] = timg(ta * NT + tb)[64 * r + lane];
+      wave_lds_sync();  // (the images below overwrite the dumps)
+      // block Gauss-Jordan, E = -D^-1 convention (as the sweep of k_slam.hip): after the last pivot tile T = -T^-1.
+      // mfma4(X registers, Z registers) = X^T Z; T is symmetric, so tile (i, K) is the transpose of tile (K, i).
+#pragma unroll
+      for (int K = 0; K < NT; ++K) {
+        if (16 * K < k) {
+          const int nact = min(16, k - 16 * K);
+          const SweepCtx sx{0, lane, lc, lr, nact, 16, true, true, ictl + 1, nullptr};
+          inv16_blk<true>(sx, nact, T[K][K]);
+          const double e4[4] = {T[K][K][0], T[K][K][1], T[K][K][2], T[K][K][3]};
+          v4d V[NT], Wt[NT];
+#pragma unroll
+          for (int i = 0; i < NT; ++i)
+            if (i != K) {
+              const double tki[4] = {T[K][i][0], T[K][i][1], T[K][i][2], T[K][i][3]};
+              const v4d z = {0.0, 0.0, 0.0, 0.0};
+              V[i] = mfma4(e4, tki, z);   // E T_Ki
+              Wt[i] = mfma4(tki, e4, z);  // T_iK E
+            }
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            if (j != K) {
+              const double tkj[4] = {T[K][j][0], T[K][j][1], T[K][j][2], T[K][j][3]};
+#pragma unroll
+              for (int i = 0; i < NT; ++i)
+                if (i != K) {
+                  const double vi[4] = {V[i][0], V[i][1], V[i][2], V[i][3]};
+                  T[j][i] = mfma4(tkj, vi, T[j][i]);  // T_ji += T_jK E T_Ki
+                }
+            }
+#pragma unroll
+          for (int i = 0; i < NT; ++i)
+            if (i != K) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                T[K][i][r] = -V[i][r];
+                T[i][K][r] = -Wt[i][r];
+              }
+            }
+        }
+      }
+      // operand images: image (mt, t) row lc = W'[16 mt + lc][16 t + lr + 4 r] at ks16 position 4 lr + r = the registers of tile
+      // (t, mt) as they are (W' is symmetric); the inactive part zeroed
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          double *o = timg(mt * NT + t) + lc * IYS + 4 * lr;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (16 * mt + lc < k && 16 * t + lr + 4 * r < k) ? T[t][mt][r] : 0.0;
+        }
+    }
+#endif
+    __syncthreads();
+    if (b0 == 0) DRLGX_PROF(S, 37);
+    // S3. the walk over the panel
+    const int TP = (P + 4) / 5, ntr = TP + ((n1 - 3 * P + 15) >> 4);
+    auto rowq = [&](int I, int j) -> int {  // panel row of tile I's row j, or -1
+      if (I < TP) {
+        const int q = 15 * I + j;
+        return (j < 15 && q < 3 * P) ? q : -1;
+      }
+      const int q = 3 * P + 16 * (I - TP) + j;
+      return q < n1 ? q : -1;
+    };
+#ifndef INC_EXP_NO_S3
+    if (wave < ntr) {
+      const int nun = ((ntr - wave + kWaves - 1) / kWaves) * npr;
+      const int nksl = (k - 16 * (NT - 1) + 3) >> 2;  // K steps with live columns in the last factor tile
+      v4d aA0, aA1, aB0, aB1;
+      double ua[NT][4];
+      // the operands of a row tile's Y^T entries, requested a whole row tile ahead: the first three columns of this lane's row and
+      // its entries in the columns of the batch's landmarks (lines the tile loads behind them want anyway)
+      double gp[3], gl0[NT][4], gl1[NT][4];
+      auto gather = [&](int I) {
+        const double *rw = rowp(max(rowq(I, lc), 0));
+        gp[0] = rw[0]; gp[1] = rw[1]; gp[2] = rw[2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int ss = 0; ss < 4; ++ss) {
+            const int cl = reinterpret_cast<const int *>(jt + 8 * (16 * t + lr + 4 * ss) + 5)[0];
+            gl0[t][ss] = rw[cl];
+            gl1[t][ss] = rw[cl + 1];
+          }
+      };
+      auto loads = [&](int e, v4d &c0, v4d &c1) {
+        const int it = e / npr, pr = e - it * npr, I = wave + kWaves * it;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double *rw = rowp(max(rowq(I, lr + 4 * r), 0)) + 32 * pr + lc;
+          c0[r] = rw[0];
+          c1[r] = rw[16];
+        }
+      };
+      auto unit = [&](int e, v4d &acc0, v4d &acc1) {
+        const int it = e / npr, pr = e - it * npr, I = wave + kWaves * it;
+        if (pr == 0) {
+          // this lane's entries of Y^T: row q = tile row lc, factor columns 16 t + lr + 4 s.  (Requesting these operands a row tile
+          // ahead was built: 35 more doubles live across the tile products, 1.1 KB of scratch per thread in the kernels of the
+          // pose-chain solver - dropped.)
+          const int q = rowq(I, lc);
+          const double *rw = rowp(max(q, 0));
+          const double p0 = rw[0], p1 = rw[1], p2 = rw[2];
+          double yb[NT][4], l0[NT][4], l1[NT][4];
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+              const int cl = reinterpret_cast<const int *>(jt + 8 * (16 * t + lr + 4 * ss) + 5)[0];
+              l0[t][ss] = rw[cl];
+              l1[t][ss] = rw[cl + 1];
+            }
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+              const double *jj = jt + 8 * (16 * t + lr + 4 * ss);
+              yb[t][ss] = p0 * jj[0] + p1 * jj[1] + p2 * jj[2] + l0[t][ss] * jj[3] + l1[t][ss] * jj[4];
+            }
+          // U'^T = W' Y^T: tile mt, register r at lane (lr, lc) = U'[row lc][16 mt + lr + 4 r] - the A operand of the tile products
+#pragma unroll
+          for (int mt = 0; mt < NT; ++mt) {
+            v4d ut = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              double w4[4];
+              ld4(timg(mt * NT + t) + lc * IYS + 4 * lr, w4);
+              ut = mfma4(w4, yb[t], ut);
+            }
+            ua[mt][0] = ut[0]; ua[mt][1] = ut[1]; ua[mt][2] = ut[2]; ua[mt][3] = ut[3];
+          }
+          // delta' = delta - U' v;  pose rows: D_i += U'_i Y_i^T - the Y of the pose's earlier rows sits one / two lanes below
+          double sv = 0.0, so = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+          for (int mt = 0; mt < NT; ++mt) {
+            double v4[4];
+            ld4(vv + 16 * mt + 4 * lr, v4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              sv += ua[mt][r] * v4[r];
+              so += ua[mt][r] * yb[mt][r];
+              s1 += ua[mt][r] * row_shr_f64<1>(yb[mt][r]);
+              s2 += ua[mt][r] * row_shr_f64<2>(yb[mt][r]);
+            }
+          }
+          sv += rowgroup_xor<16>(sv); sv += rowgroup_xor<32>(sv);
+          so += rowgroup_xor<16>(so); so += rowgroup_xor<32>(so);
+          s1 += rowgroup_xor<16>(s1); s1 += rowgroup_xor<32>(s1);
+          s2 += rowgroup_xor<16>(s2); s2 += rowgroup_xor<32>(s2);
+          if (lr == 0 && q >= 0) {
+            dl[q] -= sv;
+            if (q < 3 * pn) {
+              const int pi = q / 3, rp = q - 3 * pi;
+              double *D = Dl + 6 * pi + (rp * (rp + 1)) / 2;
+              D[rp] += so;
+              if (rp >= 1) D[rp - 1] += s1;
+              if (rp >= 2) D[0] += s2;
+            }
+          }
+        }
+        {
+          const int cA = min(32 * pr + lc, a0), cB = min(32 * pr + 16 + lc, a0);  // (pad columns: the zero row)
+#pragma unroll
+          for (int mt = 0; mt < NT; ++mt) {
+            double yJ0[4], yJ1[4];
+            ld4(Yt + (size_t)mt * ytile + (size_t)cA * IYS + 4 * lr, yJ0);
+            ld4(Yt + (size_t)mt * ytile + (size_t)cB * IYS + 4 * lr, yJ1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+              if (mt < NT - 1 || ks < nksl) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[mt][ks], yJ0[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[mt][ks], yJ1[ks], acc1, 0, 0, 0);
+              }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = rowq(I, lr + 4 * r);
+          if (q >= 0) {
+            double *rw = rowp(q) + 32 * pr + lc;
+            rw[0] = acc0[r];
+            rw[16] = acc1[r];
+          }
+        }
+      };
+      int e = 0;
+      loads(0, aA0, aA1);
+      for (; e + 1 < nun; e += 2) {
+        loads(e + 1, aB0, aB1);
+        unit(e, aA0, aA1);
+        loads(min(e + 2, nun - 1), aA0, aA1);
+        unit(e + 1, aB0, aB1);
+      }
+      if (e < nun) unit(e, aA0, aA1);
+    }
+#endif
+    __syncthreads();
+    if (b0 == 0) DRLGX_PROF(S, 38);
+  };
+  // Which form serves this update (the same decision in the fused step and in the stage kernels: plan quantities and list lengths
+  // only): the streamed one where it exists (kSNT > 0: the kernels of the pose-chain solver; x.snt > 0: the panel in HBM / L2) unless
+  // the two-walk form needs a single batch and the panel is small enough for L2 to serve its second walk (measured in the
+  // 100-landmark world, two-walk / streamed: 41 / 53 us at 96 poses and 43 / 53 at 112, where one wide batch does; 74 / 64 at 128 and
+  // 105 / 91 at 204, where the second half of Y no longer fits the LDS; profiles/r06_ab_streamed_update.txt).  One form per update:
+  // Ya lies where the other form keeps Y.
+  bool streamed = false;
+  if constexpr (!kLds && kSNT > 0)
+#ifndef INC_EXP_NOSTREAM
+    streamed = x.snt > 0 && (n_re > (x.wide ? 16 : 8) || (size_t)n1 * a0 * 8 > (size_t)(INC_STREAM_KB << 10));
+#endif
+  // (a loop per form: in one loop the invariants of both forms were hoisted in front of it and lived side by side - 170 B of scratch)
+  if (streamed) {
+    if constexpr (!kLds && kSNT > 0) {
+      for (int b0 = 0; b0 < n_re;) {
+        const int left = n_re - b0, nt = min(x.snt, (left + 7) >> 3), nb = min(8 * nt, left);
+        if (nt >= 4) sbatch(b0, nb, std::integral_constant<int, kSNT >= 4 ? 4 : 1>{});
+        else if (nt == 3) sbatch(b0, nb, std::integral_constant<int, 3>{});
+        else if (nt == 2) sbatch(b0, nb, std::integral_constant<int, 2>{});
+        else sbatch(b0, nb, std::integral_constant<int, 1>{});
+        b0 += nb;
+      }
+    }
+  } else {
+    for (int b0 = 0; b0 < n_re;) {
+      const int left = n_re - b0;
+      if (left > 8 && x.wide) {
+        const int nb = min(16, left);
+        batch(b0, nb, std::true_type{});
+        b0 += nb;
+      } else {
+        const int nb = min(8, left);
+        batch(b0, nb, std::false_type{});
+        b0 += nb;
+      }
     }
   }
   DRLGX_PROF(S, 3);

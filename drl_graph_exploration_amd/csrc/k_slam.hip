@@ -1715,6 +1715,7 @@ struct SlamCtx {
 
 // The incremental update as a stage (k_slam / k_slam_arrow / k_step_arrow, after the simulator): true when it served the
 // instance - the caller then skips its solver.  Every thread of the workgroup calls it.
+template <int kSNT>
 __device__ __forceinline__ bool inc_stage(const DrlgxState &S, const LaunchSel &sel, int lds_bytes, size_t smem_off) {
   const int tid = drlgx_tid(), bi = drlgx_bid();
   if (!S.jc || !sel.on(bi)) return false;
@@ -1732,11 +1733,11 @@ __device__ __forceinline__ bool inc_stage(const DrlgxState &S, const LaunchSel &
   if (lds_panel) {
     inc_pre<true, false>(S, x, tid, nullptr, SubBarrier{nullptr, 0, 0});
     __syncthreads();
-    done = inc_post<true>(S, x, L, M, nobox, tid);
+    done = inc_post<true, kSNT>(S, x, L, M, nobox, tid);
   } else {
     inc_pre<false, false>(S, x, tid, nullptr, SubBarrier{nullptr, 0, 0});
     __syncthreads();
-    done = inc_post<false>(S, x, L, M, nobox, tid);
+    done = inc_post<false, kSNT>(S, x, L, M, nobox, tid);
   }
   if (!done) __syncthreads();  // (the full solve reuses the LDS)
   return done;
@@ -1791,7 +1792,7 @@ __device__ __forceinline__ void slam_finish(const DrlgxState &S, const LaunchSel
 
 template <int FT>
 __device__ __forceinline__ void slam_body(const DrlgxState &S, const LaunchSel &sel, int lds_bytes) {
-  if (inc_stage(S, sel, lds_bytes, 0)) return;
+  if (inc_stage<0>(S, sel, lds_bytes, 0)) return;
   SlamCtx none;
   slam_finish<FT>(S, sel, lds_bytes, 0, none, false);
 }
@@ -1805,6 +1806,7 @@ __global__ __launch_bounds__(kThreads) void k_slam(DRLGX_KS_PARAM, LaunchSel sel
 constexpr int kLdsBudget = 160 * 1024;
 constexpr int kFastTiles = 8;       // fast path: N = 128 (<= 42 poses), system + panels in LDS
 constexpr int kFastTilesArrow = 8;  // arrow path: landmark system of <= 63 landmarks (N <= 128) packed in LDS
+static_assert(kFastTilesArrow == 8, "inc_plan (k_inc.hip) spells the reach of k_step_arrow out as 16 * 8");
 constexpr int kArrowRegTiles = 20;  // ... beyond: up to 20 register tiles per wave (N <= 256, <= 127 landmarks)
 
 #include "k_slam_arrow.hip"

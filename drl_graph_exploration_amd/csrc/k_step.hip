@@ -133,8 +133,8 @@ __device__ __forceinline__ void step_once(const DrlgxState &S, const LaunchSel &
     bool inc_lds = false;
     if (kslam::inc_plan(S, sel.base + bi, P0 + 1, lds_bytes, sim_bytes, ix, inc_lds, pc, pan_L0, pan_M0)) {
       double *hp = hand ? reinterpret_cast<double *>(step_smem) : nullptr;
-      inc_done = inc_lds ? kslam::inc_post<true>(S, ix, sub_cnt[2], sub_cnt[3], box, tid, hp, pc)
-                         : kslam::inc_post<false>(S, ix, sub_cnt[2], sub_cnt[3], box, tid, hp, pc);
+      inc_done = inc_lds ? kslam::inc_post<true, 0>(S, ix, sub_cnt[2], sub_cnt[3], box, tid, hp, pc)
+                         : kslam::inc_post<false, 0>(S, ix, sub_cnt[2], sub_cnt[3], box, tid, hp, pc);
       if (inc_done) lm_lds = ix.thl;  // (the map stage's inputs are in LDS, as after slam_finish)
       else __syncthreads();
     }
