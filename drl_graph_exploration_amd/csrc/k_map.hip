@@ -51,20 +51,12 @@ __device__ __forceinline__ bool in_fov(const DrlgxState &S, const Pose &ps, cons
   return bearing < cfg.max_bearing && bearing > cfg.min_bearing;
 }
 
-// VirtualMap::predictVirtualLandmark (VirtualMap.cpp:213-229). info: symmetric xx xy xt yy yt tt.
-template <bool kCheckFov>
-__device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps, const double *pi, const P2 &pt,
-                                             double &oxx, double &oxy, double &oyy) {
+// The algebra of predictVirtualLandmark behind its decisions: tolerance-only (the values are compared at 1e-7, no decision depends
+// on them), so multiply-adds may contract - which this translation unit otherwise forbids for the decisions' sake.
+__device__ __forceinline__ void predict_info(const DrlgxState &S, const Pose &ps, const double *pi, const P2 &pt, const P2 &d, double d2,
+                                             double gx, double gy, double g2, double &oxx, double &oxy, double &oyy) {
+#pragma clang fp contract(fast)
   const drlgx_config &cfg = S.cfg;
-  // Jacobians of bearing (Pose2::bearing) and range (Pose2::range); the bearing VALUE is only needed for the
-  // FOV check, which in_fov() answers without atan2 for almost every cell
-  const P2 d = transform_to(ps, pt);
-  const double d2 = d.x * d.x + d.y * d.y;
-  const double gx = pt.x - ps.x, gy = pt.y - ps.y;
-  const double g2 = gx * gx + gy * gy;
-  // range < max_range && range > min_range, decided exactly on the squared distance (host-computed thresholds)
-  if (!(g2 < S.r2_max_lt && g2 > S.r2_min_gt)) return false;
-  if (kCheckFov && !in_fov(S, ps, pt)) return false;
   const double rrange = rsqrt_n1(g2);  // 1 / range
   double Hbx[3], Hbl[2], Hrx[3], Hrl[2];
   if (d2 > 1e-10) {  // |d| > 1e-5
@@ -113,28 +105,52 @@ __device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps
   oxx = Hl0 * u0 + Hl2 * v0;
   oxy = Hl0 * u1 + Hl2 * v1;
   oyy = Hl1 * u1 + Hl3 * v1;
+}
+
+
+// VirtualMap::predictVirtualLandmark (VirtualMap.cpp:213-229). info: symmetric xx xy xt yy yt tt.
+template <bool kCheckFov>
+__device__ __forceinline__ bool predict_cell(const DrlgxState &S, const Pose &ps, const double *pi, const P2 &pt,
+                                             double &oxx, double &oxy, double &oyy) {
+  // Jacobians of bearing (Pose2::bearing) and range (Pose2::range); the bearing VALUE is only needed for the
+  // FOV check, which in_fov() answers without atan2 for almost every cell
+  const P2 d = transform_to(ps, pt);
+  const double d2 = d.x * d.x + d.y * d.y;
+  const double gx = pt.x - ps.x, gy = pt.y - ps.y;
+  const double g2 = gx * gx + gy * gy;
+  // range < max_range && range > min_range, decided exactly on the squared distance (host-computed thresholds)
+  if (!(g2 < S.r2_max_lt && g2 > S.r2_min_gt)) return false;
+  if (kCheckFov && !in_fov(S, ps, pt)) return false;
+  predict_info(S, ps, pi, pt, d, d2, gx, gy, g2, oxx, oxy, oyy);
   return true;
 }
 
 // VirtualMap::covarianceIntersection2D (VirtualMap.cpp:364-378), symmetric storage.  The LLT solve is
 // written with two reciprocals instead of eight divisions (fp64 division is ~30 instructions here).
 __device__ __forceinline__ void ci_fuse(double &axx, double &axy, double &ayy, double bxx, double bxy, double byy) {
+  // (tolerance-only algebra: contraction allowed.  The fusion is ONE dependent chain per cell, walked ~30 times for the cells on the
+  // trajectory; its depth is what the cell pass costs: c (3 operations behind the cell's current information), d, the reciprocal with
+  // one Newton step folded into the product with the numerator, the clamps, one multiply-add per component.)
+#pragma clang fp contract(fast)
   const double a = axx * ayy - axy * axy;
   const double b = bxx * byy - bxy * bxy;
   // c = a * m1.llt().solve(m2).trace() = det(m1) trace(m1^-1 m2) = trace(adj(m1) m2): no factorisation needed
-  // (tolerance-only algebra; w is continuous across its clamps)
+  // (w is continuous across its clamps)
   const double c = (ayy * bxx - axy * bxy) + (axx * byy - axy * bxy);
   const double d = a + b - c;
-  double w = 0.5 * (2 * b - c) * rcp_n1(d);
+  const double dxx = axx - bxx, dxy = axy - bxy, dyy = ayy - byy;  // (off the chain)
+  const double r0 = __builtin_amdgcn_rcp(d);
+  double w = ((b - 0.5 * c) * r0) * (2.0 - d * r0);  // 0.5 (2 b - c) / d
   {  // the reference's two clamps, as selects (no branches on the chain)
     const bool lo = w < 0, hi = w > 1, dn = d < 0, dp = d > 0;
     const bool zero = (lo & dn) | (hi & dp), one = (lo & dp) | (hi & dn);
     w = one ? 1.0 : w;
     w = zero ? 0.0 : w;
   }
-  axx = w * axx + (1.0 - w) * bxx;
-  axy = w * axy + (1.0 - w) * bxy;
-  ayy = w * ayy + (1.0 - w) * byy;
+  // w m1 + (1 - w) m2
+  axx = w * dxx + bxx;
+  axy = w * dxy + bxy;
+  ayy = w * dyy + byy;
 }
 
 // Sum over the 64 lanes of a wave, result in lane 63: DPP row shifts within the 16-lane rows, then the two gfx9
@@ -439,7 +455,11 @@ __device__ __forceinline__ void map_body(const DrlgxState &S, const LaunchSel &s
       // while others work until 6.5 us; a tile queue - with the utility terms summed per tile, or parked per cell and summed
       // afterwards, to keep the sums reproducible - and a deal by ranked cost both evened the waves out and both made the
       // kernel slower: ranking costs more than it saves, and with the queue the barrier after the pass completed 1.9 us
-      // after the last wave instead of 0.2 us.)
+      // after the last wave instead of 0.2 us.  Round 6 measured two more forms, both slower: two tiles per wave with their chains
+      // interleaved in one loop (11.9 against 6.9 us: the waves are bound by fp64 issue on their SIMD, not by the chain's latency),
+      // and the cells sorted by chain length - ballots and a prefix, deterministic - with 64 consecutive ones per wave (9.2 us: the
+      // two classification passes and the prefix cost 4.9 us, and the longest chain alone, ~30 fusions of ~140 ns, lasts 4.2 us -
+      // that chain is the floor of this pass; 97 against 89 us at 2 048 instances).)
       const int tiles_c = (cols + 7) >> 3, ntiles = ((rows + 7) >> 3) * tiles_c;
       // the untouched cell (prior information I / sigma0^2, ladder state 0), as the general path computes it
       double pv_prior = 0.0;
