@@ -891,7 +891,7 @@ int drlgx_lookahead_bounded(drlgx_engine *e, int n_cand, const int32_t *cand_env
     if (e->la_loop && !e->per_stage && (a_sw > 0 || rest_loops)) {
       LaunchSel sel{roll0, nc, nullptr, na, 0};
       sel.map_last_only = 1;
-      if (e->la_presim && rest_loops) {  // (only when EVERY action is replayed: a replay leaves the ground truth and the streams behind)
+      if (e->la_presim && rest_loops) {  // (only when EVERY action is replayed: k_presim leaves the ground truth and the streams of the LAST action)
         // the simulator of every rollout for its whole list first (one wave per rollout), its log replayed action by action
         const size_t entry = drlgx_simlog_entry_bytes(S), roll = entry * (size_t)S.A_max;
         if (!e->simlog_dev && dev_alloc(e, &e->simlog_dev, roll * (size_t)S.n_roll) != DRLGX_OK) {

@@ -577,11 +577,25 @@ __global__ __launch_bounds__(64) void k_presim(DRLGX_KS_PARAM, LaunchSel sel, co
       hdr[0] = 1; hdr[1] = c.P; hdr[2] = c.L; hdr[3] = c.M; hdr[4] = nf; hdr[5] = nn; hdr[6] = err; hdr[7] = 0;
     }
   }
+  // What the simulator itself carries - the ground-truth pose, the two random streams, the normal distribution's saved variates -
+  // goes back to the rollout as the steps' own simulator would have left it after the last action: a rollout that is read or
+  // continued after a replayed look-ahead then holds a ground truth that matches its belief.  (The counts are the replay's to
+  // advance, action by action.)
+  mt_store(c.sensor, S.mt + ((size_t)inst * 2 + 0) * DRLGX_MT_STRIDE, lane);
+  mt_store(c.control, S.mt + ((size_t)inst * 2 + 1) * DRLGX_MT_STRIDE, lane);
+  if (lane == 0) {
+    S.nrm_saved[inst * 2 + 0] = c.ns_sensor.saved;
+    S.nrm_has[inst * 2 + 0] = c.ns_sensor.has;
+    S.nrm_saved[inst * 2 + 1] = c.ns_control.saved;
+    S.nrm_has[inst * 2 + 1] = c.ns_control.has;
+    double *gpo = S.gt_pose + (size_t)inst * 4;
+    gpo[0] = c.veh.x; gpo[1] = c.veh.y; gpo[2] = c.veh.c; gpo[3] = c.veh.s;
+  }
 }
 
 // One logged action of instance blockIdx.x appended to its belief state, by ONE wave: everything sim_step_body + measure write
 // for the SLAM stage (the new pose's initial guess, the odometry factor, the bearing-range factors, first sightings, counters, the
-// travelled distance) - not the ground truth and the random streams, which a rollout never reads again.
+// travelled distance) - not the ground truth and the random streams: k_presim left those as they are after the rollout's last action.
 __device__ __forceinline__ void replay_step_body(const DrlgxState &S, const LaunchSel &sel, const double *odom, int odom_stride, int lane,
                                                  int *mail = nullptr) {
   const int i = drlgx_bid();

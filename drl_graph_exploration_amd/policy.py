@@ -152,6 +152,55 @@ class ReplayList(list):
             self._n -= 1
         return t
 
+    # Every other mutation of the list switches the side table off for good (the trainer then takes the generic path, which reads the
+    # transitions themselves): a same-length mutation - buffer[i] = t, sort, reverse, random.shuffle - would otherwise leave rows
+    # that no longer describe the items, and `table()` only compares the first and the last one.
+    def _side_off(self):
+        self._ok = False
+        self._rows = self._rew = None
+
+    def __setitem__(self, i, v):
+        self._side_off()
+        list.__setitem__(self, i, v)
+
+    def __delitem__(self, i):
+        self._side_off()
+        list.__delitem__(self, i)
+
+    def __iadd__(self, items):
+        self.extend(items)
+        return self
+
+    def __imul__(self, k):
+        self._side_off()
+        return list.__imul__(self, k)
+
+    def insert(self, i, v):
+        self._side_off()
+        list.insert(self, i, v)
+
+    def pop(self, i=-1):
+        if i == 0:
+            return self.popleft()
+        self._side_off()
+        return list.pop(self, i)
+
+    def remove(self, v):
+        self._side_off()
+        list.remove(self, v)
+
+    def sort(self, *a, **k):
+        self._side_off()
+        list.sort(self, *a, **k)
+
+    def reverse(self):
+        self._side_off()
+        list.reverse(self)
+
+    def clear(self):
+        list.clear(self)
+        self._reset_side()
+
     def table(self):
         """(pool, rows int64 [len][14], rewards float64 [len]) aligned with the list, or None."""
         if not self.__dict__.get("_ok") or self._rows is None or self._n != len(self) or self._n == 0:
@@ -388,6 +437,10 @@ class DeepQ(object):
         """Collation of s_j, the cached target read-out of s_j1 and the TD targets of one prepared mini-batch: one host call
         (drlgx_dqn_prepare), results in the arena."""
         pool, B = pr["pool"], self.BATCH
+        # (the arena is carved with dims[0] as the feature width - x comes first, every offset behind it follows - and
+        # drlgx_dqn_prepare carves it with the pool's: the two must be one number)
+        if pool.X.shape[1] != dims[0]:
+            raise ValueError("replay pool features are %d wide, the network's first layer takes %d" % (pool.X.shape[1], dims[0]))
         a = self._arena_for(device, B, pr["N"], pr["E"], pr["N1"], dims)
         vp = C.c_void_p
         _lib.check(_lib.lib().drlgx_dqn_prepare(vp(_lib.stream_ptr(device)), B, vp(pr["p_desc_j"]), vp(pr["p_desc_j1"]), vp(pool.X.data_ptr()),

@@ -600,6 +600,13 @@ def test_whole_plans_in_one_launch_equal_one_launch_per_action(monkeypatch):
             e.actions_all_goals()
             raws.append(e.rewards_all_goals(return_raw=True)[1])
         assert torch.equal(raws[0], raws[1]) and torch.equal(raws[0], raws[2]), "decision %d" % d
+        if d in (0, 7):
+            # the rollouts themselves after a look-ahead: the replayed form (k_presim stores the simulator's own state once, behind the
+            # last action) leaves the ground truth where simulating inside every step leaves it
+            roll0 = 2 * n
+            for k in (0, 1, 5, 17):
+                np.testing.assert_array_equal(a.engine.ground_truth(roll0 + k)[0], c.engine.ground_truth(roll0 + k)[0])
+                assert a.engine.counts(roll0 + k) == c.engine.counts(roll0 + k)
         nfr = a._graph["n_frontier"].long()
         choice = (torch.arange(n, device=a.device) * 2 + d) % nfr
         for e in (a, b, c):

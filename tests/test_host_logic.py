@@ -437,13 +437,20 @@ def test_bench_launch_contract():
 
 
 def test_build_alias_resolves_the_reference_import_lines():
-    """`import build.ss2d as ss2d` / `import build.planner2d as planner2d` (scripts/envs/pyss2d.py:7, pyplanner2d.py:6)."""
-    import build.planner2d as planner2d_alias
-    import build.ss2d as ss2d_alias
-    from build import planner2d as p2, ss2d as s2
-    from drl_graph_exploration_amd import planner2d, ss2d
-    assert ss2d_alias is ss2d is s2 and planner2d_alias is planner2d is p2
-    assert hasattr(ss2d_alias, "Simulator2D") and hasattr(planner2d_alias, "EMPlanner2D")
+    """`import build.ss2d as ss2d` / `import build.planner2d as planner2d` (scripts/envs/pyss2d.py:7, pyplanner2d.py:6), in a fresh
+    interpreter: `compat.enable()` puts the alias package on sys.path (it is not at the repository root, where it would shadow
+    the PyPA `build` module)."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import drl_graph_exploration_amd.compat as compat; compat.enable()\n"
+            "import build.planner2d as planner2d_alias\nimport build.ss2d as ss2d_alias\n"
+            "from build import planner2d as p2, ss2d as s2\n"
+            "from drl_graph_exploration_amd import planner2d, ss2d\n"
+            "assert ss2d_alias is ss2d is s2 and planner2d_alias is planner2d is p2\n"
+            "assert hasattr(ss2d_alias, 'Simulator2D') and hasattr(planner2d_alias, 'EMPlanner2D')\n"
+            "print('alias ok')\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert out.returncode == 0 and "alias ok" in out.stdout, out.stderr
 
 
 def test_module_objects_never_join_across_simulations():
