@@ -593,7 +593,7 @@ def test_whole_plans_in_one_launch_equal_one_launch_per_action(monkeypatch):
     monkeypatch.setenv("DRLGX_LOOKAHEAD_PRESIM", "0")
     c = VecExplorationEnv(40, n, env_index=2, test=True, device=0)
     monkeypatch.delenv("DRLGX_LOOKAHEAD_PRESIM")
-    for d in range(16):
+    for d in range(22):
         raws = []
         for e in (a, b, c):
             e.graph_matrix()
@@ -616,6 +616,8 @@ def test_whole_plans_in_one_launch_equal_one_launch_per_action(monkeypatch):
         for x, y in zip(a.engine.poses(i) + a.engine.landmarks(i) + a.engine.virtual_map(i),
                         b.engine.poses(i) + b.engine.landmarks(i) + b.engine.virtual_map(i)):
             np.testing.assert_array_equal(x, y)
-    assert max(a.engine.counts(i)["poses"] for i in range(n)) > 54  # both regimes were visited
+    # both solvers' regimes were visited, and trajectories beyond 64 poses: there the map stage works in pose chunks (one mask bit
+    # per pose), and the loop kernels size the chunk for the range's last action while every action passes its own pose bound
+    assert max(a.engine.counts(i)["poses"] for i in range(n)) > 66
     for e in (a, b, c):
         e.close()
