@@ -303,9 +303,13 @@ def a2c_loop_bench(device_index, n_envs=256, iters=40):
             "reference_published": "~3.8 RL iterations/s (A2C+GCN, authors' PC; BASELINE.md) - other hardware, reported beside"}
 
 
-def config5_bench(device_index, n_envs=256, warm=108, timed=8):
+def config5_bench(device_index, n_envs=256, warm=108, timed=10):
     """BASELINE config 5 scale as a secondary figure: 50 m map, 500 landmarks, graphs grown by a fixed motion loop to
-    ~110 poses / ~95 landmarks (k_slam_arrow with a ~200 x 200 landmark system, k_map in pose chunks); per-stage kernels."""
+    ~110 poses / ~95 landmarks; per-stage kernels (more landmarks than the fused kernels sweep in LDS).  The timed region is one
+    whole cycle of the iSAM2 counter - ten consecutive updates, one of them the relinearising 10th - so that `ms_per_step` is what
+    a trajectory pays on average; a second pass with events gives the stage kernels' rows, incremental and relinearising updates
+    apart (SLAM stage: k_slam_arrow - between relinearisations the rank-k update of k_inc.hip with the covariance panel in HBM / L2,
+    ONE walk over it per batch of up to 32 re-observed landmarks)."""
     from drl_graph_exploration_amd import default_config
     from drl_graph_exploration_amd.engine import Engine
     cfg = default_config(50, num_landmarks=500, max_poses=127, max_landmarks=127, max_factors=3800)
@@ -319,6 +323,7 @@ def config5_bench(device_index, n_envs=256, warm=108, timed=8):
         eng.step(odoms[s % len(loop)])
     eng.synchronize()
     eng.check_status()
+    eng.snapshot(0)
     c = eng.counts_dev().cpu().numpy()
     t0 = time.perf_counter()
     for s in range(timed):
@@ -326,10 +331,45 @@ def config5_bench(device_index, n_envs=256, warm=108, timed=8):
     eng.synchronize()
     dt = (time.perf_counter() - t0) / timed
     eng.check_status()
+    # the same ten updates again from the snapshot, one at a time with events around the stage kernels
+    eng.restore(0)
+    eng.timing_enable(2)
+    rows = {"incremental": {"sim": [], "slam": [], "map": []}, "relinearising": {"sim": [], "slam": [], "map": []}}
+    V = eng.rows * eng.cols
+    for s in range(timed):
+        eng.inc_stats(reset=True)
+        eng.timing_read()
+        eng.step(odoms[(warm + s) % len(loop)])
+        eng.synchronize()
+        tm = eng.timing_read()
+        inc, full = eng.inc_stats(reset=True)
+        ev = tm["t7"][0] / max(tm["t7"][1], 1) * 1e3
+        kind = "incremental" if inc >= full else "relinearising"
+        for k in ("sim", "slam", "map"):
+            if tm[k][1]:
+                rows[kind][k].append(tm[k][0] / tm[k][1] * 1e3 - ev)
+    eng.timing_enable(False)
+    eng.check_status()
     eng.close()
-    return {"workload": "50x50 map (V=2025), 500 landmarks, %d envs" % n_envs, "poses": float(c[:, 0].mean()),
-            "landmarks": float(c[:, 1].mean()), "factors": float(c[:, 2].mean()), "ms_per_step": dt * 1e3,
-            "env_steps_per_sec": n_envs / dt}
+    P, L, M = float(c[:, 0].mean()) + timed / 2.0, float(c[:, 1].mean()), float(c[:, 2].mean())
+    ab = algorithmic_bytes(P, L, M, V)
+    # what the incremental update keeps INSTEAD of recomputing: the covariance panel Sigma[:, active], read and written once per walk
+    panel_bytes = (3 * P + 2 * L) * (3 + 2 * L) * 8
+    kernels = {}
+    for kind, st in rows.items():
+        for k, v in st.items():
+            if not v:
+                continue
+            us = float(np.mean(v))
+            ent = {"avg_us_per_launch": us, "launches": len(v), "algorithmic_bytes_per_launch": ab[k] * n_envs,
+                   "achieved_GBs": ab[k] * n_envs / (us * 1e-6) / 1e9, "frac_hbm_peak": ab[k] * n_envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            if k == "slam" and kind == "incremental":
+                ent["panel_bytes_read_and_written_per_walk"] = 2 * panel_bytes * n_envs
+                ent["panel_traffic_frac_hbm_peak_at_one_walk"] = 2 * panel_bytes * n_envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+            kernels["%s_%s" % (k, kind)] = ent
+    return {"workload": "50x50 map (V=%d), 500 landmarks, %d envs; %d consecutive updates (one relinearising)" % (V, n_envs, timed),
+            "poses": float(c[:, 0].mean()), "landmarks": L, "factors": M, "ms_per_step": dt * 1e3,
+            "env_steps_per_sec": n_envs / dt, "kernels": kernels}
 
 
 def update_cycle_bench(device_index, reps=10, steps=10):
@@ -743,6 +783,27 @@ def main():
                     "source": "profiles/sq_counters.json (rocprofv3 --pmc SQ_*), kernel sources sha1 %s = this tree" % sq["csrc_sha1"][:12]}
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass
+        # ... and the same bound for the kernel the north star sets a target for (the covariance-propagation kernel k_map, stand-alone
+        # form, 256 instances): its VALU instruction count per launch against the issue rate of 1 024 SIMDs
+        roofline_issue_map = None
+        try:
+            if sq.get("csrc_sha1") == csrc_digest() and "k_map" in sq["kernels"] and "map" in kernels:
+                c = sq["kernels"]["k_map"]
+                peak = 256 * 4 * 2.4e9 / 4.0 / 1e9
+                us = kernels["map"]["avg_us_per_launch"]
+                roofline_issue_map = {
+                    "kernel": "k_map", "bound": "valu-issue", "achieved": c["SQ_INSTS_VALU"] / (us * 1e-6) / 1e9, "peak": peak,
+                    "unit": "G wave64 VALU instructions/s", "frac": c["SQ_INSTS_VALU"] / (us * 1e-6) / 1e9 / peak,
+                    "valu_instructions_per_instance": c["SQ_INSTS_VALU"] / N_ENVS,
+                    "us_of_pure_fp64_issue_per_cu": c["SQ_INSTS_VALU"] / N_ENVS / 4.0 * 4.0 / 2.4e3,
+                    "avg_us_per_launch": us, "frac_hbm_peak": kernels["map"]["frac_hbm_peak"],
+                    "wave_cycle_shares": {"issuing_valu": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                                          "parked_on_waitcnt_or_barrier": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]},
+                    "note": "one workgroup (8 waves, 4 SIMDs) per CU: an instance's VALU instructions / 4 SIMDs x 4 cycles is the time its CU "
+                            "needs to ISSUE them if they were all fp64 - the floor of the launch under this instruction count",
+                    "source": "profiles/sq_counters.json, kernel sources sha1 %s = this tree" % sq["csrc_sha1"][:12]}
+        except (NameError, KeyError, ValueError, ZeroDivisionError):
+            pass
         total_steps = args.steps * N_ENVS * world
         out = {
             "metric": "env-steps/sec (256 parallel envs, ~64-node graphs)", "value": total_steps / elapsed,
@@ -753,7 +814,8 @@ def main():
                                    "~%.0f-node graphs (P=%.1f poses, L=%.1f landmarks, M=%.0f factors) from a device snapshot"
                                    % (P + 1 + L, P + 1, L, M),
                        "envs_per_gpu": N_ENVS, "map_size": MAP, "num_landmarks": NUM_LM, "parallelism": "env-sharded x%d" % world},
-            "roofline": roofline, "roofline_issue": roofline_issue, "kernels": kernels, "event_pair_overhead_us": ev_over_us,
+            "roofline": roofline, "roofline_issue": roofline_issue, "roofline_issue_k_map": roofline_issue_map, "kernels": kernels,
+            "event_pair_overhead_us": ev_over_us,
             "slam_path": {"incremental_updates": inc_split[0], "full_solves": inc_split[1],
                           "note": "belief updates served by the rank-k covariance update (csrc/k_inc.hip) / by the full solve since the "
                                   "engine was created (warm-up script included); the timed update is #37 of the iSAM2 counter: "

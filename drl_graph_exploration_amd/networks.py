@@ -509,6 +509,21 @@ class PoolRef(object):
         self.d5 = pool.desc[self.slot][self.env]  # (n0, nn, e0, ne, loc) as the collation kernel reads them
         self.n0, self.nn, self.e0, self.ne, self.loc = self.d5.tolist()
 
+    @classmethod
+    def many(cls, pool, slot, n):
+        """The references of graphs 0 .. n-1 of one pooled export: the descriptor block is converted once (a constructor call per
+        graph cost ~10 us - 2.5 ms per 256-env vector step of the A2C loop, 5 ms of the DQN loop)."""
+        slot = int(slot)
+        D = pool.desc[slot]
+        rows = D[:n].tolist()
+        out = []
+        for i in range(n):
+            r = cls.__new__(cls)
+            r.pool, r.slot, r.env, r.batch, r.d5 = pool, slot, i, None, D[i]
+            r.n0, r.nn, r.e0, r.ne, r.loc = rows[i]
+            out.append(r)
+        return out
+
     @property
     def num_nodes(self):
         return self.nn

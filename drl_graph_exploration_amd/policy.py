@@ -727,9 +727,10 @@ class DeepQ(object):
             g1 = self._host_offsets(env.graph_matrix())
             nfr1 = g1["n_frontier"].cpu().numpy()
             slot_t1 = pool.put(g1)
+            refs_t, refs_t1 = PoolRef.many(pool, slot_t, n_envs), PoolRef.many(pool, slot_t1, n_envs)
+            a_l, r_l, d_l, f_l = a_loc.tolist(), r_h.tolist(), current_done.tolist(), nfr1.tolist()
             for i in range(n_envs):
-                self.buffer.append((PoolRef(pool, slot_t, i), int(a_loc[i]), float(r_h[i]), PoolRef(pool, slot_t1, i),
-                                    bool(current_done[i]), int(nfr1[i])))
+                self.buffer.append((refs_t[i], int(a_l[i]), float(r_l[i]), refs_t1[i], bool(d_l[i]), int(f_l[i])))
                 pool.ref[slot_t] += 1
                 pool.ref[slot_t1] += 1
                 if len(self.buffer) > self.REPLAY_MEMORY:
@@ -956,7 +957,7 @@ class A2C(object):
         slot = pool.put(g)
         pool.ref[slot] = 1
         while temp_i < self.epoch:
-            s_t = [PoolRef(pool, slot, i) for i in range(n_envs)]
+            s_t = PoolRef.many(pool, slot, n_envs)
             env.actions_all_goals()
             rewards = env.rewards_all_goals()
             cand_env, cand_node, cand_first = env.candidates

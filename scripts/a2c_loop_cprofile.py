@@ -1,0 +1,34 @@
+"""Dev tool: cProfile over A2C.running (bench.py's a2c_loop workload): where the host side of a vector step goes.  (NOGC=1: with the
+cyclic garbage collector off - under the profiler the allocation bursts of a step trigger full collections that a plain run does not
+show: a gc-quiet wrapper around the loops measured 12.2-12.6 against 11.6 ms per vector step and was dropped.)"""
+import os, sys, time, tempfile, cProfile, pstats
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import bench
+from drl_graph_exploration_amd.networks import PolicyGCN, ValueGCN
+from drl_graph_exploration_amd.policy import A2C
+from drl_graph_exploration_amd.vecenv import VecExplorationEnv
+n_envs, iters = 256, 40
+dev = torch.device("cuda", 0)
+torch.manual_seed(0); np.random.seed(0)
+with tempfile.TemporaryDirectory() as tmp:
+    a2c = A2C("b/", data_root=tmp)
+    actor, critic = PolicyGCN().to(dev), ValueGCN().to(dev)
+    env = VecExplorationEnv(bench.MAP, n_envs, env_index=0, test=True, device=0)
+    a2c.epoch, a2c.nstep = n_envs * 2, 2
+    a2c.running(actor, critic, test=True, env=env)
+    a2c.nstep = 40
+    a2c.buffer.clear()
+    a2c.epoch = n_envs * iters
+    import gc
+    if os.environ.get("NOGC"): gc.disable()
+    pr = cProfile.Profile()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    pr.enable()
+    a2c.running(actor, critic, test=True, env=env)
+    torch.cuda.synchronize()
+    pr.disable()
+    dt = time.perf_counter() - t0
+    env.close()
+print("%.2f ms per vector step" % (dt / iters * 1e3))
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
