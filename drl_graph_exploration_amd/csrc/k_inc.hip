@@ -785,6 +785,7 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
 #endif
     __syncthreads();
     if (b0 == 0) DRLGX_PROF(S, 37);
+    else DRLGX_PROF(S, 39);  // (a second batch: start of its walk)
     // S3. the walk over the panel
     const int TP = (P + 4) / 5, ntr = TP + ((n1 - 3 * P + 15) >> 4);
     auto rowq = [&](int I, int j) -> int {  // panel row of tile I's row j, or -1
@@ -929,6 +930,7 @@ __device__ __forceinline__ bool inc_post(const DrlgxState &S, const IncCtx &x, i
 #endif
     __syncthreads();
     if (b0 == 0) DRLGX_PROF(S, 38);
+    else DRLGX_PROF(S, 47);  // (... and its end)
   };
   // Which form serves this update (the same decision in the fused step and in the stage kernels: plan quantities and list lengths
   // only): the streamed one where it exists (kSNT > 0: the kernels of the pose-chain solver; x.snt > 0: the panel in HBM / L2) unless

@@ -87,7 +87,11 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   const int tid = drlgx_tid();
   const int bi = drlgx_bid();
   if (!sel.on(bi)) return;
-  if (inc_stage<ISNT>(S, sel, lds_bytes, 0)) return;  // between relinearisations: the rank-k covariance update (k_inc.hip)
+  if (S.prof && tid == 0 && bi < 448) S.prof[128 + 2 * bi] = wall_clock64();  // (dev aid: per-workgroup start / end, as k_step)
+  if (inc_stage<ISNT>(S, sel, lds_bytes, 0)) {  // between relinearisations: the rank-k covariance update (k_inc.hip)
+    if (S.prof && tid == 0 && bi < 448) S.prof[129 + 2 * bi] = wall_clock64();
+    return;
+  }
   const int inst = sel.base + bi;
   int *cnt = S.cnt + (size_t)inst * DRLGX_CNT_STRIDE;
   // (`full` / `refresh`: see slam_body - intermediate look-ahead steps solve for the estimates only.  Not with the

@@ -33,6 +33,6 @@ for s in range(NUP):
     a = np.array(out[:], dtype=np.float64)
     us = lambda i, j: (a[i] - a[j]) / 100.0
     print("update #%d wg %d (P %d L %d, +%d factors, +%d lms; launch mean +%.1f factors): slam %.1f us | loads %.1f, new pose %.1f, lists+lin %.1f, "
-          "B %.1f (first batch: Ya %.1f, T+inverse %.1f, walk %.1f), C %.1f, D %.1f, meta %.1f; total %.1f" % (
+          "B %.1f (first batch: Ya %.1f, T+inverse %.1f, walk %.1f; a second batch: Ya + T + inverse %.1f, walk %.1f), C %.1f, D %.1f, meta %.1f; total %.1f" % (
               c1[0, 4], BLK, c1[BLK, 0], c1[BLK, 1], c1[BLK, 2] - c0[BLK, 2], c1[BLK, 1] - c0[BLK, 1], (c1[:, 2] - c0[:, 2]).mean(), tm["slam"][0] * 1e3,
-              us(1, 0), us(2, 1), us(35, 2), us(3, 35), us(36, 35), us(37, 36), us(38, 37), us(4, 3), us(5, 4), us(7, 5), us(7, 0)))
+              us(1, 0), us(2, 1), us(35, 2), us(3, 35), us(36, 35), us(37, 36), us(38, 37), us(39, 38) if a[39] > a[38] else 0.0, us(47, 39) if a[47] > a[39] else 0.0, us(4, 3), us(5, 4), us(7, 5), us(7, 0)))
