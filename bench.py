@@ -469,7 +469,7 @@ def full_fill_bench(device_index, n_envs=2048, steps=40):
             "k_map_us_per_launch_incl_event_overhead": map_us, "k_map_frac_hbm_peak": ab["map"] * n_envs / (map_us * 1e-6) / 8e12}
 
 
-BELIEF_STEP_SOURCES = ("drlgx_dev.h", "drlgx_fields.h", "k_sim.hip", "k_slam.hip", "k_slam_arrow.hip", "k_map.hip", "k_step.hip",
+BELIEF_STEP_SOURCES = ("drlgx_dev.h", "drlgx_fields.h", "k_sim.hip", "k_slam.hip", "k_slam_arrow.hip", "k_inc.hip", "k_map.hip", "k_step.hip",
                        "drlgx_engine.cpp")
 
 

@@ -42,6 +42,16 @@ timeout 200 python scripts/lookahead_breakdown.py > $out/lookahead_breakdown.txt
 timeout 200 python scripts/phase_profile_relin.py > $out/relinearising_update_phases.txt 2>&1
 timeout 200 python scripts/phase_profile_blocks.py > $out/step_workgroups.txt 2>&1
 timeout 300 python scripts/full_fill_profile.py > $out/full_fill.json 2> /dev/null
+# BASELINE config 5 scale (scripts/bench_config5.py: stage kernels, incremental updates with the panel in HBM / L2): kernel stats and HBM traffic
+C5="python scripts/bench_config5.py 256 110"
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_c5 -- $C5 > $out/config5_bench.txt 2> $out/rocprof_c5.err
+python scripts/rocpd_summary.py "$(db /tmp/prof_c5)" > $out/config5_kernel_stats.csv
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_c5_fetch -- $C5 > /dev/null 2> $out/rocprof_c5_fetch.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_c5_write -- $C5 > /dev/null 2> $out/rocprof_c5_write.err
+python scripts/rocpd_pmc.py "$(db /tmp/prof_c5_fetch)" "$(db /tmp/prof_c5_write)" "\`python scripts/bench_config5.py 256 110\` (50 m map, 500 landmarks, ~110 poses, 256 envs; warm-up included in the averages)" > $out/config5_pmc_traffic.json
+timeout 200 python scripts/phase_profile_config5_blocks.py > $out/config5_workgroups.txt 2>&1
+timeout 200 python scripts/phase_profile_config5.py 123 6 > $out/config5_update_phases.txt 2>&1
+timeout 200 python scripts/config5_updates.py > $out/config5_updates.txt 2>&1
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_gcn -- python $OLDPWD/scripts/profile_gcn.py > /dev/null 2>&1)
 python scripts/rocpd_summary.py "$(db /tmp/prof_gcn)" --by-grid k_ > $out/gcn_kernels_by_grid.csv 2>/dev/null
 ls -la $out

@@ -9,7 +9,8 @@ for f in kernel_stats.csv pmc_traffic.json sq_counters.txt sq_counters.json benc
 done
 cp $src/vs_poses_100lm.txt profiles/${tag}_step_vs_poses_100lm.txt
 cp $src/vs_poses_8lm.txt profiles/${tag}_step_vs_poses_8lm.txt
-for f in lookahead_kernel_stats.csv lookahead_pmc_traffic.json lookahead_breakdown.txt relinearising_update_phases.txt step_workgroups.txt full_fill.json; do
+for f in lookahead_kernel_stats.csv lookahead_pmc_traffic.json lookahead_breakdown.txt relinearising_update_phases.txt step_workgroups.txt full_fill.json \
+         config5_bench.txt config5_kernel_stats.csv config5_pmc_traffic.json config5_workgroups.txt config5_update_phases.txt config5_updates.txt; do
   [ -f $src/$f ] && cp $src/$f profiles/${tag}_$f
 done
 cp $src/pmc_traffic.json profiles/pmc_traffic.json
