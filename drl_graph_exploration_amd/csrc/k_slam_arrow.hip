@@ -810,6 +810,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   double *pan_pose = mk_panel ? S.jc + (size_t)inst * S.jc_stride : nullptr;  // the covariance panel's pose rows (k_inc.hip)
   double *Sc = Sl;  // [3P][3]: rows of X_i (-C^-1) X_i^T   (the Takahashi cross blocks are dead by now)
   double *dz = Sr;  // [3P]:    X_B delta_l
+  bool pn_done = false;  // the panel's columns of the newest pose were formed with the tiles of Z
   if (!full) {
     // estimates only: dz = X_B delta_l, one 16-lane row per row of X
     const int sub = tid & 15, grp = tid >> 4, ngrp = kThreads / 16;
@@ -869,19 +870,70 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
       }
       __syncthreads();
     }
+    DRLGX_PROF(S, 100);
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lc = lane & 15, lr = lane >> 4;
     const int nrows = 3 * P, nrt = (nrows + 15) / 16, nK = (np + 15) / 16;
-    for (int I = wave; I < nrt; I += kWaves) {
-      const int arow = 16 * I + lc;
-      const double *xa = X + (size_t)(arow < nrows ? arow : 0) * ldx;
-      const bool arow_ok = arow < nrows;
-      // the A operand of the whole tile row (its 16 x np panel of X) is loaded once: every load is in flight before the
-      // first matrix instruction (up to 8 column chunks = 127 landmark columns: the LDS-resident systems; beyond that
-      // the chunks are reloaded per column tile)
-      constexpr int kPanel = 8;
-      double pan[kPanel][4];
-      const bool panel = nK <= kPanel;
-      if (panel) {
+    const int pn = P - 1;
+    pn_done = mk_panel;  // (the tile path below also forms the panel's columns of the newest pose)
+    constexpr int kPanel = 8;
+    // epilogue of one 16 x 16 tile of Z (accumulator `acc`, row tile I, column tile J): products with the three X rows of each
+    // accumulator row's pose (sp) and - for the covariance panel - with the three X rows of the newest pose (sq:
+    // Sigma[i][pn] = (T^-1)[i][pn] + X_i C^-1 X_pn^T = X[., np+1..np+3] - Sigma_pl[i] X_pn^T; a separate pass used to form these sums
+    // with one thread per (row, column): 214 dependent trips each, 85 us at BASELINE config 5 scale), and the delta_l column
+    auto epilogue = [&](int I, const v4d &acc, int J, double (&sp)[4][3], double (&sq)[4][3]) {
+      const int c = 16 * J + lc;
+      double xe[4][3], xn[3] = {0.0, 0.0, 0.0};
+      if (mk_panel && c < np) {
+        const double *xb = X + (size_t)(3 * pn) * ldx + c;
+        xn[0] = xb[0]; xn[1] = xb[ldx]; xn[2] = xb[2 * ldx];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + lr + 4 * r;
+        const bool ok = row < nrows && c < np;
+        const double *xb = X + (size_t)(ok ? 3 * (row / 3) : 0) * ldx + (ok ? c : 0);
+        xe[r][0] = ok ? xb[0] : 0.0;
+        xe[r][1] = ok ? xb[ldx] : 0.0;
+        xe[r][2] = ok ? xb[2 * ldx] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + lr + 4 * r;
+        sp[r][0] += acc[r] * xe[r][0];  // (zeros outside the matrix)
+        sp[r][1] += acc[r] * xe[r][1];
+        sp[r][2] += acc[r] * xe[r][2];
+        if (c < np) {
+          sq[r][0] += acc[r] * xn[0];
+          sq[r][1] += acc[r] * xn[1];
+          sq[r][2] += acc[r] * xn[2];
+        }
+        if (row < nrows && c == np) dz[row] = acc[r];
+        if (mk_panel && row < nrows && c < np) pan_pose[(size_t)row * S.jc_ld + 3 + c] = acc[r];  // Sigma_pl = X_B (-C^-1)
+      }
+    };
+    // the sums over the 16 lanes of an accumulator row, in a fixed order: DPP row shifts (1, 2, 4, 8), the row's sum in its lane 15
+    // (butterflies through ds_bpermute cost 8 us per call at BASELINE config 5 scale: 96 LDS round trips)
+    auto rowsum = [&](double (&sv)[4][3]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b3 = 0; b3 < 3; ++b3) {
+          double v = sv[r][b3];
+          v = dpp_add_f64<0x111>(v);
+          v = dpp_add_f64<0x112>(v);
+          v = dpp_add_f64<0x114>(v);
+          v = dpp_add_f64<0x118>(v);
+          sv[r][b3] = v;
+        }
+    };
+    if (nK <= kPanel) {
+      for (int I = wave; I < nrt; I += kWaves) {
+        const int arow = 16 * I + lc;
+        const bool arow_ok = arow < nrows;
+        const double *xa = X + (size_t)(arow_ok ? arow : 0) * ldx;
+        // the A operand of the whole tile row (its 16 x np panel of X) is loaded once: every load is in flight before the
+        // first matrix instruction (up to 8 column chunks = 127 landmark columns: the LDS-resident systems)
+        double pan[kPanel][4];
 #pragma unroll
         for (int K = 0; K < kPanel; ++K)
 #pragma unroll
@@ -889,35 +941,9 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
             const int k = 16 * K + 4 * lr + t;
             pan[K][t] = (k < np && arow_ok) ? xa[k] : 0.0;
           }
-      }
-      double sp[4][3];
+        double sp[4][3], sq[4][3];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sp[r][0] = sp[r][1] = sp[r][2] = 0.0;
-      // epilogue of one 16 x 16 tile of Z (accumulator `acc`, column tile J): products with the three X rows of each
-      // accumulator row's pose, and the delta_l column
-      auto epilogue = [&](const v4d &acc, int J) {
-        const int c = 16 * J + lc;
-        double xe[4][3];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * I + lr + 4 * r;
-          const bool ok = row < nrows && c < np;
-          const double *xb = X + (size_t)(ok ? 3 * (row / 3) : 0) * ldx + (ok ? c : 0);
-          xe[r][0] = ok ? xb[0] : 0.0;
-          xe[r][1] = ok ? xb[ldx] : 0.0;
-          xe[r][2] = ok ? xb[2 * ldx] : 0.0;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * I + lr + 4 * r;
-          sp[r][0] += acc[r] * xe[r][0];  // (zeros outside the matrix)
-          sp[r][1] += acc[r] * xe[r][1];
-          sp[r][2] += acc[r] * xe[r][2];
-          if (row < nrows && c == np) dz[row] = acc[r];
-          if (mk_panel && row < nrows && c < np) pan_pose[(size_t)row * S.jc_ld + 3 + c] = acc[r];  // Sigma_pl = X_B (-C^-1)
-        }
-      };
-      if (panel) {
+        for (int r = 0; r < 4; ++r) sp[r][0] = sp[r][1] = sp[r][2] = sq[r][0] = sq[r][1] = sq[r][2] = 0.0;
         for (int J = 0; J < Tn; ++J) {
           const int c = 16 * J + lc;
           v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -933,75 +959,146 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
               acc = mfma4(pan[K], bv, acc);
             }
           }
-          epilogue(acc, J);
+          epilogue(I, acc, J, sp, sq);
         }
-      } else {
-        // wide systems (workspace variant, mirrored above): four column tiles at a time share the A operand, and the
-        // operands of step K + 1 are loaded before the sixteen matrix instructions of step K
-        auto load_step = [&](int K, int J0, double (&av)[4], double (&bv)[4][4]) {
+        rowsum(sp);
+        if (mk_panel) rowsum(sq);
+        if (lc == 15) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int k = 16 * K + 4 * lr + t;
-            const bool kin = k < np;
-            const int kc = kin ? k : 0;
-            av[t] = (kin && arow_ok) ? xa[kc] : 0.0;
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + lr + 4 * r;
+            if (row < nrows) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int c = 16 * (J0 + g) + lc;
-              const bool cin = c <= np && J0 + g < Tn;
-              const double v = A[c == np ? (size_t)np * N + kc : (size_t)kc * N + (cin ? c : 0)];  // delta_l row / mirrored -C^-1
-              bv[g][t] = (kin && cin) ? v : 0.0;
+              for (int b3 = 0; b3 < 3; ++b3) {
+                Sc[3 * row + b3] = sp[r][b3];
+                if (mk_panel) pan_pose[(size_t)row * S.jc_ld + b3] = X[(size_t)row * ldx + np + 1 + b3] - sq[r][b3];
+              }
             }
           }
-        };
-        for (int J0 = 0; J0 < Tn; J0 += 4) {
-          v4d acc[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) acc[g] = v4d{0.0, 0.0, 0.0, 0.0};
-          double avn[4], bvn[4][4];
-          load_step(0, J0, avn, bvn);
-          for (int K = 0; K < nK; ++K) {
-            double av[4], bv[4][4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              av[t] = avn[t];
-#pragma unroll
-              for (int g = 0; g < 4; ++g) bv[g][t] = bvn[g][t];
-            }
-            if (K + 1 < nK) load_step(K + 1, J0, avn, bvn);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = mfma4(av, bv[g], acc[g]);
-          }
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            if (J0 + g < Tn) epilogue(acc[g], J0 + g);
         }
       }
+    } else {
+      // Wide systems (workspace variant, mirrored above).  Round 6: the B operand - a group of column tiles of [-C^-1 | delta_l], all
+      // K steps - is STAGED IN LDS for the whole workgroup (the sweep's panels are dead by now) as operand images (a lane's four K
+      // entries contiguous: conflict-free 16-byte reads), and every wave walks its row tiles against it with the A operand - 32-byte
+      // rows of X - requested one K step ahead.  Before, every wave fetched BOTH operands from the workspace per (row tile, column
+      // group, K step): the B operand alone 21 row tiles x 385 KB = 8 MB per instance, 2 GB per 256-instance launch out of the
+      // Infinity Cache - this product ran at a quarter of the fp64 matrix rate (470 of the relinearising update's 1 580 us at
+      // BASELINE config 5 scale).  The row sums are accumulated per column group (the same lane adds to the same entries).
+      constexpr int kZG = 3;
+      // as many column tiles per group as the LDS behind the pose tables holds (one tile = nK x 2 KB); none: one tile, staged in
+      // the workspace's sweep panels (dead as well) - the L2 then serves what the LDS would
+      const size_t zavail = (size_t)lds_bytes - (size_t)(reinterpret_cast<unsigned char *>(U) - smem_raw);
+      const int zfit = (int)(zavail / ((size_t)nK * 2048));
+      const int zg = zfit >= 1 ? min(kZG, zfit) : 1;
+      double *Bs = zfit >= 1 ? U : pws;  // [zg][nK][4 lr][16 lc][4 t]
+      // the row sums are accumulated per column group in LDS - the chain factors' tables (9 P doubles each) are dead since the
+      // selected inverse - and go to the workspace / the panel at the end (as read-modify-writes of the workspace they cost 8 us
+      // per (row tile, column group): a round trip to L2 each)
+      double *ScL = Al, *SqL = GL;  // [3P][3]
+      for (int e = tid; e < nrows * 3; e += kThreads) ScL[e] = SqL[e] = 0.0;
+      const bool zprof = S.prof && blockIdx.x == S.prof_block && tid == 0;
+      long long zt_stage = 0, zt_k = 0, zt_epi = 0, zt_sum = 0;
+      for (int J0 = 0; J0 < Tn; J0 += zg) {
+        __syncthreads();  // (the previous group's images are read; the first time: the initialisation above)
+        const long long zt0 = zprof ? wall_clock64() : 0;
+        for (int e0 = tid; e0 < nK * 16 * zg * 16; e0 += 4 * kThreads) {  // (four loads in flight per thread)
+          double v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+          for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * kThreads;
+            const int k = e / (zg * 16), cc = e - k * (zg * 16), g = cc >> 4, c = 16 * J0 + cc;
+            const bool in = e < nK * 16 * zg * 16 && k < np && c <= np && J0 + g < Tn;
+            v[u] = in ? A[c == np ? (size_t)np * N + k : (size_t)k * N + c] : 0.0;  // delta_l row / mirrored -C^-1
+          }
 #pragma unroll
-        for (int b3 = 0; b3 < 3; ++b3) {
-          double v = sp[r][b3];
-          v += __shfl_xor(v, 8, 16);
-          v += __shfl_xor(v, 4, 16);
-          v += __shfl_xor(v, 2, 16);
-          v += __shfl_xor(v, 1, 16);
-          sp[r][b3] = v;
-        }
-      if (lc == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * I + lr + 4 * r;
-          if (row < nrows) {
-            Sc[3 * row] = sp[r][0];
-            Sc[3 * row + 1] = sp[r][1];
-            Sc[3 * row + 2] = sp[r][2];
+          for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * kThreads;
+            const int k = e / (zg * 16), cc = e - k * (zg * 16), g = cc >> 4;
+            if (e < nK * 16 * zg * 16) Bs[((((size_t)g * nK + (k >> 4)) * 4 + ((k >> 2) & 3)) * 16 + (cc & 15)) * 4 + (k & 3)] = v[u];
           }
         }
+        __syncthreads();
+        if (zprof) zt_stage += wall_clock64() - zt0;
+        for (int I = wave; I < nrt; I += kWaves) {
+          const long long zt1 = zprof ? wall_clock64() : 0;
+          const int arow = 16 * I + lc;
+          const bool arow_ok = arow < nrows;
+          const double *xa = X + (size_t)(arow_ok ? arow : 0) * ldx + 4 * lr;
+          double sp[4][3], sq[4][3];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sp[r][0] = sp[r][1] = sp[r][2] = sq[r][0] = sq[r][1] = sq[r][2] = 0.0;
+          v4d acc[kZG];
+#pragma unroll
+          for (int g = 0; g < kZG; ++g) acc[g] = v4d{0.0, 0.0, 0.0, 0.0};
+          // (the A operand comes from L2 / the Infinity Cache, 1-2 us away: requested FOUR K steps ahead - one step's twelve matrix
+          // instructions last 0.3 us)
+          auto load_a4 = [&](int K0, double (&av)[4][4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) av[u][t] = (16 * (K0 + u) + 4 * lr + t < np && arow_ok) ? xa[16 * (K0 + u) + t] : 0.0;
+          };
+          double avn[4][4];
+          load_a4(0, avn);
+          for (int K0 = 0; K0 < nK; K0 += 4) {
+            double av[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) av[u][t] = avn[u][t];
+            if (K0 + 4 < nK) load_a4(K0 + 4, avn);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (K0 + u < nK) {
+#pragma unroll
+                for (int g = 0; g < kZG; ++g)
+                  if (g < zg) {
+                    double bv[4];
+                    ld4(Bs + ((((size_t)g * nK + K0 + u) * 4 + lr) * 16 + lc) * 4, bv);
+                    acc[g] = mfma4(av[u], bv, acc[g]);
+                  }
+              }
+          }
+          const long long zt2 = zprof ? wall_clock64() : 0;
+#pragma unroll
+          for (int g = 0; g < kZG; ++g)
+            if (g < zg && J0 + g < Tn) epilogue(I, acc[g], J0 + g, sp, sq);
+          const long long zt3 = zprof ? wall_clock64() : 0;
+          rowsum(sp);
+          if (mk_panel) rowsum(sq);
+          if (lc == 15) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * I + lr + 4 * r;
+              if (row < nrows) {
+#pragma unroll
+                for (int b3 = 0; b3 < 3; ++b3) {
+                  ScL[3 * row + b3] += sp[r][b3];
+                  if (mk_panel) SqL[3 * row + b3] += sq[r][b3];
+                }
+              }
+            }
+          }
+          if (zprof) {
+            const long long zt4 = wall_clock64();
+            zt_k += zt2 - zt1; zt_epi += zt3 - zt2; zt_sum += zt4 - zt3;
+          }
+        }
+      }
+      if (zprof) {  // (dev aid: wave 0's time in the staging, the K loops, the epilogues, the row sums)
+        S.prof[105] = zt_stage; S.prof[106] = zt_k; S.prof[107] = zt_epi; S.prof[108] = zt_sum;
+      }
+      __syncthreads();
+      for (int e = tid; e < nrows * 3; e += kThreads) {
+        const int row = e / 3, b3 = e - 3 * row;
+        Sc[e] = ScL[e];
+        if (mk_panel) pan_pose[(size_t)row * S.jc_ld + b3] = X[(size_t)row * ldx + np + 1 + b3] - SqL[e];
       }
     }
   }
   __syncthreads();
+  DRLGX_PROF(S, 101);
   for (int i = tid; i < P; i += kThreads) {
     const double dp0 = X[(size_t)(3 * i) * ldx + np] - dz[3 * i], dp1 = X[(size_t)(3 * i + 1) * ldx + np] - dz[3 * i + 1],
                  dp2 = X[(size_t)(3 * i + 2) * ldx + np] - dz[3 * i + 2];
@@ -1026,15 +1123,17 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     // (newest pose pn, landmarks).  Sigma_pl = X_B (-C^-1) was stored by the pose outputs above, Sigma_ll = C^-1; the
     // cross blocks with the newest pose are  Sigma[i][pn] = (T^-1)[i][pn] + X_i C^-1 X_pn^T = X[., np+1..np+3] - Sigma_pl[i] X_pn^T.
     __syncthreads();
+    DRLGX_PROF(S, 102);
     const int pn = P - 1, ldg = S.jc_ld;
     double *pan_lm = pan_pose + (size_t)3 * S.P_max * ldg;
-    for (int e = tid; e < 3 * P * 3; e += kThreads) {
+    for (int e = tid; e < 3 * P * 3 && !pn_done; e += kThreads) {  // (the few-landmark branch above: one thread per entry)
       const int row = e / 3, b = e - 3 * row;
       const double *zr = pan_pose + (size_t)row * ldg + 3, *xp = X + (size_t)(3 * pn + b) * ldx;
       double v = X[(size_t)row * ldx + np + 1 + b];
       for (int c = 0; c < np; ++c) v -= zr[c] * xp[c];
       pan_pose[(size_t)row * ldg + b] = v;
     }
+    DRLGX_PROF(S, 103);
     for (int e = tid; e < np * np; e += kThreads) {
       const int r = e / np, c = e - r * np;
       pan_lm[(size_t)r * ldg + 3 + c] = -A[c_lds ? AT(max(r, c), min(r, c)) : (size_t)max(r, c) * N + min(r, c)];
@@ -1043,6 +1142,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
       const int r = e / 3, b = e - 3 * r;
       pan_lm[(size_t)r * ldg + b] = pan_pose[(size_t)(3 * pn + b) * ldg + 3 + r];  // Sigma[l][pn] = Sigma[pn][l]^T
     }
+    DRLGX_PROF(S, 104);
     if (tid == 0) {
       int *meta = inc_meta(S, inst);
       meta[0] = 1; meta[1] = P; meta[2] = L; meta[3] = M;

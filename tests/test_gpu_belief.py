@@ -800,16 +800,19 @@ def test_staged_reset_never_continues_the_previous_episodes_covariance_panel():
         e.close()
 
 
-@pytest.mark.parametrize("num_landmarks, max_poses, steps", [(100, 64, 52), (8, 64, 48), (8, 41, 30)])
+@pytest.mark.parametrize("num_landmarks, max_poses, steps", [(100, 64, 52), (8, 64, 48), (8, 41, 30), (300, 72, 66)])
 def test_incremental_update_equals_the_full_solve_beyond_the_dense_solver_and_with_the_panel_in_lds(monkeypatch, num_landmarks, max_poses, steps):
     """The incremental path against DRLGX_INCREMENTAL=0 where the explicit 31-step test does not reach: trajectories beyond
     42 poses (the pose-chain solver builds the panel itself: k_slam_arrow.hip, mk_panel) and few-landmark worlds whose panel
     is LDS-resident for the step (k_inc.hip, kLds = true).  Estimates 1e-9, information 1e-7 relative between the engines
-    and against the oracle at the end; `inc_stats` proves which path served the updates."""
+    and against the oracle at the end; `inc_stats` proves which path served the updates.  (300 landmarks in the 40 m world: beyond
+    53 poses every step re-observes 20-40 landmarks with the covariance panel in HBM / L2 - the streamed form of the update,
+    k_inc.hip: sbatch, with two to four factor tiles per walk and second batches.)"""
     from drl_graph_exploration_amd import default_config
     from drl_graph_exploration_amd.engine import Engine
     n = 4
-    cfg = default_config(MAP, num_landmarks=num_landmarks, max_poses=max_poses, max_landmarks=num_landmarks)
+    cfg = default_config(MAP, num_landmarks=num_landmarks, max_poses=max_poses, max_landmarks=min(num_landmarks, 127),
+                         max_factors=None if num_landmarks <= 100 else 45 * max_poses)
     eng = Engine(cfg, n, 0)
     monkeypatch.setenv("DRLGX_INCREMENTAL", "0")
     ref = Engine(cfg, n, 0)
