@@ -173,10 +173,14 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
   auto srow = [&](int j) -> double * { return SB + (size_t)(j >> sshift) * 3 * ldx; };
   // per-factor records: LDS when they fit
   double *rec;
+  // bytes of LDS from U on that are free once the union region's contents are dead (phases 7 and 10 stage operands there): up to
+  // the factor records if those live in LDS, else to the end
+  size_t u_free = (size_t)(smem_raw + off - reinterpret_cast<unsigned char *>(U));
   if (off + (size_t)M * REC * 8 <= (size_t)lds_bytes) {
     rec = reinterpret_cast<double *>(smem_raw + off); off += (size_t)M * REC * 8;
   } else {
     rec = rec_ws;
+    u_free = (size_t)lds_bytes - (size_t)(reinterpret_cast<unsigned char *>(U) - smem_raw);
   }
   double *th_pose = S.th_pose + (size_t)inst * S.P_max * 4;
   double *d_pose = S.d_pose + (size_t)inst * S.P_max * 3;
@@ -689,6 +693,9 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
     int S_ = 1;
     while (S_ < 64 && items * (S_ * 2) <= kThreads) S_ <<= 1;
     const int per_pass = kThreads / S_;
+    // (Round 6 measured X walked in chunks of 32 columns staged in LDS for the wide systems - every row of X is wanted ~22 times at
+    // BASELINE config 5 scale, 13 MB of 32-byte pieces per instance -: 309 against 286 us.  What an item waits for is not X but the
+    // chain obs -> factor record -> its B block, one L2 round trip per four visits; the records (120 KB) do not fit beside a chunk.)
     for (int e0 = 0; e0 < items; e0 += per_pass) {
       const int e = e0 + tid / S_, s = tid & (S_ - 1);
       const int j = e < items ? e / nq : 0, q = e < items ? e - j * nq : 0, c0 = 4 * q;
@@ -988,8 +995,7 @@ __device__ __forceinline__ void arrow_body(const DrlgxState &S, const LaunchSel 
       constexpr int kZG = 3;
       // as many column tiles per group as the LDS behind the pose tables holds (one tile = nK x 2 KB); none: one tile, staged in
       // the workspace's sweep panels (dead as well) - the L2 then serves what the LDS would
-      const size_t zavail = (size_t)lds_bytes - (size_t)(reinterpret_cast<unsigned char *>(U) - smem_raw);
-      const int zfit = (int)(zavail / ((size_t)nK * 2048));
+      const int zfit = (int)(u_free / ((size_t)nK * 2048));
       const int zg = zfit >= 1 ? min(kZG, zfit) : 1;
       double *Bs = zfit >= 1 ? U : pws;  // [zg][nK][4 lr][16 lc][4 t]
       // the row sums are accumulated per column group in LDS - the chain factors' tables (9 P doubles each) are dead since the
