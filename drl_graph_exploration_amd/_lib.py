@@ -32,7 +32,7 @@ def lib_path():
 SYMBOLS = [
     "drlgx_create", "drlgx_destroy", "drlgx_set_stream", "drlgx_synchronize", "drlgx_strerror", "drlgx_last_error",
     "drlgx_status_host", "drlgx_reset_host", "drlgx_step", "drlgx_utility", "drlgx_uncertainty_em", "drlgx_explored", "drlgx_metrics", "drlgx_cov_array",
-    "drlgx_stage_reset_host", "drlgx_stage_set_prior_information_host", "drlgx_stage_move", "drlgx_stage_measure", "drlgx_stage_add_measurements", "drlgx_stage_optimize",
+    "drlgx_stage_reset_host", "drlgx_stage_set_prior_information_host", "drlgx_stage_set_prior_pose_host", "drlgx_stage_move", "drlgx_stage_measure", "drlgx_stage_add_measurements", "drlgx_stage_optimize",
     "drlgx_stage_update_map", "drlgx_set_planner_parameter", "drlgx_set_fixed_landmarks_host", "drlgx_fm2_update", "drlgx_step_plan", "drlgx_step_plans",
     "drlgx_line_plan", "drlgx_lookahead", "drlgx_lookahead_bounded", "drlgx_graph_capacity", "drlgx_graph", "drlgx_get_counts_host", "drlgx_counts",
     "drlgx_get_poses_host", "drlgx_get_landmarks_host", "drlgx_get_cov_traces_host", "drlgx_vm_shape",
@@ -73,6 +73,7 @@ def lib():
     L.drlgx_step_plans.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     L.drlgx_stage_reset_host.argtypes = [vp, C.c_int, ip, C.POINTER(C.c_uint32), dp]
     L.drlgx_stage_set_prior_information_host.argtypes = [vp, C.c_int, dp]
+    L.drlgx_stage_set_prior_pose_host.argtypes = [vp, C.c_int, dp]
     L.drlgx_stage_move.argtypes = [vp, vp, vp]
     L.drlgx_stage_measure.argtypes = [vp, vp, vp, vp, vp]
     L.drlgx_stage_add_measurements.argtypes = [vp, vp, vp, vp, vp]

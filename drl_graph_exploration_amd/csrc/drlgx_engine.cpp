@@ -768,6 +768,23 @@ int drlgx_stage_set_prior_information_host(drlgx_engine *e, int env, const doubl
   return DRLGX_OK;
 }
 
+int drlgx_stage_set_prior_pose_host(drlgx_engine *e, int env, const double *xytheta) {
+  DRLGX_ENTER(e);
+  if (!e || env < 0 || env >= e->S.n_envs || !xytheta) return DRLGX_E_INVALID;
+  const DrlgxState &S = e->S;
+  // (between the staged reset and the first measurement: one pose, no factor)
+  int cnt[DRLGX_CNT_STRIDE];
+  HIPCHK(e, hipMemcpyAsync(cnt, S.cnt + (size_t)env * DRLGX_CNT_STRIDE, sizeof(cnt), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (cnt[C_P] != 1 || cnt[C_M] != 0) return DRLGX_E_INVALID;
+  const double p4[4] = {xytheta[0], xytheta[1], std::cos(xytheta[2]), std::sin(xytheta[2])};
+  HIPCHK(e, hipMemcpyAsync(S.prior + (size_t)env * DRLGX_PRIOR_STRIDE, p4, sizeof(p4), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(S.th_pose + (size_t)env * S.P_max * 4, p4, sizeof(p4), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(S.est_pose + (size_t)env * S.P_max * 4, p4, sizeof(p4), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return DRLGX_OK;
+}
+
 int drlgx_set_fixed_landmarks_host(drlgx_engine *e, int n_fixed, const double *xy) {
   DRLGX_ENTER(e);
   if (!e || n_fixed < 0 || n_fixed > e->S.cfg.num_landmarks || (n_fixed > 0 && !xy)) return DRLGX_E_INVALID;

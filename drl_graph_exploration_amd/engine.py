@@ -114,6 +114,11 @@ class Engine(object):
         info = np.ascontiguousarray(information, dtype=np.float64).reshape(9)
         self._chk(self.L.drlgx_stage_set_prior_information_host(self.h, int(env), info.ctypes.data_as(C.POINTER(C.c_double))))
 
+    def stage_set_prior_pose(self, env, xytheta):
+        """The pose of the prior factor / the initial estimate of x0 for one env (after stage_reset, before the first measurement)."""
+        p = np.ascontiguousarray(xytheta, dtype=np.float64).reshape(3)
+        self._chk(self.L.drlgx_stage_set_prior_pose_host(self.h, int(env), p.ctypes.data_as(C.POINTER(C.c_double))))
+
     def stage_move(self, odom, active=None):
         self.use_torch_stream()
         self._chk(self.L.drlgx_stage_move(self.h, _p(odom), _p(active)))

@@ -229,12 +229,15 @@ class _Session(object):
         c.max_actions = int(math.ceil(math.hypot(span, span) / c.max_edge_length)) + 3
         c.max_snapshots = 1
         self.engine = Engine(c, 1, max(c.max_landmarks, 1), sim._device)
-        p = prior_state.pose
-        if (abs(p.x - sim._start.x), abs(p.y - sim._start.y)) != (0.0, 0.0) or abs(_wrap(p.theta - sim._start.theta)) > 1e-15:
-            raise NotImplementedError("the prior pose is the simulator's initial vehicle pose (pyss2d.py:124-133)")
+        p, v = prior_state.pose, sim._start
+        # (the reference's own caller passes the vehicle's pose, pyss2d.py:124-135; any other pose becomes the prior factor's pose and
+        # the initial estimate of x0, SLAM2D.cpp:44-57, while the simulator keeps its vehicle where it is)
+        own_pose = (abs(p.x - v.x), abs(p.y - v.y)) != (0.0, 0.0) or abs(_wrap(p.theta - v.theta)) > 1e-15
         if sim._fixed_landmarks:
             self.engine.set_fixed_landmarks(sim._fixed_landmarks)
-        self.engine.stage_reset([0], [sim._seed], np.array([[p.x, p.y, getattr(p, "_theta_in", p.theta)]]))
+        self.engine.stage_reset([0], [sim._seed], np.array([[v.x, v.y, getattr(v, "_theta_in", v.theta)]]))
+        if own_pose:
+            self.engine.stage_set_prior_pose(0, (p.x, p.y, getattr(p, "_theta_in", p.theta)))
         if full_prior:
             self.engine.stage_set_prior_information(0, info)
         self.engine.stage_update_map(rebuild=False)  # sums of the untouched map (a fresh VirtualMap)

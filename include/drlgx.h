@@ -129,6 +129,11 @@ int drlgx_stage_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const
  * ini file's sigma_x0 / sigma_y0 / sigma_theta0 that the resets install - after drlgx_stage_reset_host and before the first
  * optimise.  HOST, row major 3 x 3, symmetric (DRLGX_E_INVALID otherwise). */
 int drlgx_stage_set_prior_information_host(drlgx_engine *e, int env, const double *information9);
+/* SLAM2D::add_prior(VehicleBeliefState(pose, information)) with a POSE that is not the simulator's initial vehicle pose
+ * (src/SS2D.cpp:193, SLAM2D.cpp:44-57: the pose of the prior factor AND the initial estimate of x0; the reference's own caller,
+ * pyss2d.py:124-135, passes the vehicle's pose - what the resets install): replaces it for one env, between
+ * drlgx_stage_reset_host and the first measurement (one pose, no factor: DRLGX_E_INVALID otherwise).  HOST, (x, y, theta). */
+int drlgx_stage_set_prior_pose_host(drlgx_engine *e, int env, const double *xytheta);
 /* Simulator2D::move(odom, true) (src/SS2D.cpp:181) + SLAM2D::add_odometry (:193). odom_dev: double[n_envs*3]. */
 int drlgx_stage_move(drlgx_engine *e, const double *odom_dev, const uint8_t *active_dev);
 /* Simulator2D::measure() (src/SS2D.cpp:182): the noisy (bearing, range) of every ground-truth landmark that passes the

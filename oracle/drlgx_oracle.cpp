@@ -944,8 +944,10 @@ struct Env {
 
   // fixed_xy / n_fixed: the ini file's optional [Landmarks] list (pyss2d.py:107-115); cfg.num_landmarks counts them too
   // prior_info: the 3 x 3 information of SLAM2D::addPrior's VehicleBeliefState (row major; null: the ini file's diagonal)
+  // prior_xyth: the pose of SLAM2D::addPrior's VehicleBeliefState when it is not the simulator's initial vehicle pose (SLAM2D.cpp:44-57:
+  // the prior factor's pose AND the initial estimate of x0; null: the vehicle's, as pyss2d.py:124-135 passes it)
   Env(const orc_config &c, uint32_t seed, double x0, double y0, double th0, const double *fixed_xy = nullptr, int n_fixed = 0,
-      const double *prior_info = nullptr) : cfg(c), sim(c, seed) {
+      const double *prior_info = nullptr, const double *prior_xyth = nullptr) : cfg(c), sim(c, seed) {
     slam.cfg = c;
     vm.initialize(c);
     // pyss2d.py:102-138
@@ -954,7 +956,7 @@ struct Env {
     double info[9] = {1.0 / (c.sigma_x0 * c.sigma_x0), 0, 0, 0, 1.0 / (c.sigma_y0 * c.sigma_y0), 0, 0, 0,
                       1.0 / (c.sigma_theta0 * c.sigma_theta0)};
     if (prior_info) std::memcpy(info, prior_info, sizeof(info));
-    slam.addPrior(sim.vehicle, info);
+    slam.addPrior(prior_xyth ? make_pose(prior_xyth[0], prior_xyth[1], prior_xyth[2]) : sim.vehicle, info);
     for (const Measurement &m : sim.measure()) slam.addMeasurement(m.key, m.bearing, m.range);
     slam.optimize();
     step = 1;
@@ -1091,6 +1093,10 @@ void *orc_create(const orc_config *cfg, uint32_t seed, double x0, double y0, dou
 void *orc_create_fixed(const orc_config *cfg, uint32_t seed, double x0, double y0, double th0, const double *fixed_xy, int n_fixed) {
   if (n_fixed < 0 || n_fixed > cfg->num_landmarks) return nullptr;
   return new Env(*cfg, seed, x0, y0, th0, fixed_xy, n_fixed);
+}
+void *orc_create_prior_pose(const orc_config *cfg, uint32_t seed, double x0, double y0, double th0, const double *prior_info9,
+                            const double *prior_xyth) {
+  return new Env(*cfg, seed, x0, y0, th0, nullptr, 0, prior_info9, prior_xyth);
 }
 void *orc_create_prior(const orc_config *cfg, uint32_t seed, double x0, double y0, double th0, const double *prior_info9) {
   return new Env(*cfg, seed, x0, y0, th0, nullptr, 0, prior_info9);

@@ -54,6 +54,8 @@ def lib():
         L.orc_create_fixed.argtypes = [C.POINTER(OrcConfig), C.c_uint32, C.c_double, C.c_double, C.c_double, dp, C.c_int]
         L.orc_create_prior.restype = C.c_void_p
         L.orc_create_prior.argtypes = [C.POINTER(OrcConfig), C.c_uint32, C.c_double, C.c_double, C.c_double, dp]
+        L.orc_create_prior_pose.restype = C.c_void_p
+        L.orc_create_prior_pose.argtypes = [C.POINTER(OrcConfig), C.c_uint32, C.c_double, C.c_double, C.c_double, dp, dp]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_clone.restype = C.c_void_p
         L.orc_clone.argtypes = [C.c_void_p]
@@ -151,14 +153,20 @@ def start_pose(lo, map_max_x):
 class OracleSim(object):
     """EMExplorer / SS2D facade (scripts/envs/pyss2d.py:58-206, pyplanner2d.py:56-81) on the C++ oracle."""
 
-    def __init__(self, cfg, seed, lo, handle=None, start=None, fixed_landmarks=None, prior_information=None):
+    def __init__(self, cfg, seed, lo, handle=None, start=None, fixed_landmarks=None, prior_information=None, prior_pose=None):
         """fixed_landmarks: [(x, y)] of the ini file's optional [Landmarks] section (pyss2d.py:107-115): keys 0 .. k - 1, the
         random landmarks follow; cfg.num_landmarks is the total."""
         self.cfg = cfg
         self.L = lib()
         if handle is None:
             x0, y0, th0 = start_pose(lo, cfg.map_max_x) if start is None else start
-            if prior_information is not None:  # SLAM2D.add_prior(VehicleBeliefState(pose, information)) with a full 3 x 3 matrix
+            if prior_pose is not None:  # SLAM2D.add_prior(VehicleBeliefState(pose, information)) at a pose that is not the vehicle's
+                info = None if prior_information is None else np.ascontiguousarray(prior_information, dtype=np.float64).reshape(9)
+                pp = np.ascontiguousarray(prior_pose, dtype=np.float64).reshape(3)
+                dpp = C.POINTER(C.c_double)
+                self.h = C.c_void_p(self.L.orc_create_prior_pose(C.byref(cfg), seed, x0, y0, th0,
+                                                                 info.ctypes.data_as(dpp) if info is not None else None, pp.ctypes.data_as(dpp)))
+            elif prior_information is not None:  # SLAM2D.add_prior(VehicleBeliefState(pose, information)) with a full 3 x 3 matrix
                 info = np.ascontiguousarray(prior_information, dtype=np.float64).reshape(9)
                 self.h = C.c_void_p(self.L.orc_create_prior(C.byref(cfg), seed, x0, y0, th0, info.ctypes.data_as(C.POINTER(C.c_double))))
             elif fixed_landmarks is not None and len(fixed_landmarks):

@@ -2,6 +2,7 @@
 `planner2d.EMPlanner2D(parameter, sensor_model, control_model)` driven call by call in the order of the reference's
 scripts/envs/pyss2d.py and scripts/envs/exploration_env.py, against the fused engine path (bit-identical: the same
 kernels launched stage by stage) and against the CPU oracle's ExplorationEnv restatement."""
+import ctypes as C
 import math
 from configparser import ConfigParser
 
@@ -316,3 +317,55 @@ def test_full_prior_information_matrix_through_the_module_classes():
         s2 = ss2d.Simulator2D(prm["sensor"], prm["control"], lo)
         s2.random_landmarks([], 8, prm["environment"])
         ss2d.SLAM2D(prm["map"], simulator=s2).add_prior(ss2d.VehicleBeliefState(s2.vehicle, np.array([[1.0, 2, 0], [0, 1, 0], [0, 0, 1]])))
+
+
+@pytest.mark.gpu
+def test_prior_pose_that_is_not_the_vehicles_through_the_module_classes():
+    """SLAM2D.add_prior(VehicleBeliefState(pose, information)) with a pose OTHER than the simulator's initial vehicle pose
+    (src/SS2D.cpp:193, SLAM2D.cpp:44-57: the prior factor's pose and the initial estimate of x0; the simulator keeps its vehicle where
+    it is): drlgx_stage_set_prior_pose_host behind the module classes, against the oracle.  The belief starts 0.4 m / 0.05 rad off
+    the ground truth and the bearing-range measurements are taken from the true pose."""
+    from drl_graph_exploration_amd import ss2d
+    from drl_graph_exploration_amd.pyplanner2d import config_from_ini
+    lo = 3
+    start = tuple(np.array(O.start_pose(lo, MAP / 2 + 20)) + np.array([0.2113, 0.0907, -0.0311]))
+    prior = (start[0] + 0.31, start[1] - 0.25, start[2] + 0.05)
+    _, prm = config_from_ini(ini(lo))
+    sim = ss2d.Simulator2D(prm["sensor"], prm["control"], lo)
+    sim.initialize_vehicle(ss2d.Pose2(*start))
+    slam = ss2d.SLAM2D(prm["map"], simulator=sim)
+    vm = ss2d.VirtualMap(prm["virtual_map"], lo, simulator=sim)
+    sim.random_landmarks([], 8, prm["environment"])
+    ocfg = O.default_config(MAP)
+    info = np.diag([1.0 / ocfg.sigma_x0 ** 2, 1.0 / ocfg.sigma_y0 ** 2, 1.0 / ocfg.sigma_theta0 ** 2])
+    slam.add_prior(ss2d.VehicleBeliefState(ss2d.Pose2(*prior), info))
+    ref = O.OracleSim(ocfg, lo, lo, start=start, prior_pose=prior)
+    gt, _ = slam._ses.engine.ground_truth(0)
+    np.testing.assert_allclose(gt[:2], start[:2], atol=1e-12)  # the vehicle stayed where the simulator put it
+    assert abs(math.remainder(gt[2] - start[2], 2 * math.pi)) < 1e-12
+    for key, m in sim.measure():
+        slam.add_measurement(key, m)
+    slam.optimize(update_covariance=True)
+    for odom in [(1, 1, math.pi / 2)] * 4 + [(2.0, 0.0, 0.0), (0.0, 0.0, 0.8)]:
+        _, cs = sim.move(ss2d.Pose2(*odom), True)
+        slam.add_odometry(cs)
+        sim.measure()
+        for key, m in sim.measure():
+            slam.add_measurement(key, m)
+        slam.optimize(update_covariance=True)
+        vm.update_probability(slam, sim.sensor_model)
+        vm.update_information(slam.map, sim.sensor_model)
+        ref.simulate(odom)
+    e = slam._ses.engine
+    xyt, pinfo = e.poses(0)
+    oxyt, opinfo = ref.poses()
+    assert np.abs(xyt[0, :2] - np.array(start[:2])).max() > 0.05  # the belief really started away from the ground truth
+    np.testing.assert_allclose(xyt, oxyt, atol=1e-9)
+    np.testing.assert_allclose(pinfo, opinfo, rtol=1e-7, atol=1e-6)
+    k, xy, linfo = e.landmarks(0)
+    ok, oxy, olinfo = ref.landmarks()
+    np.testing.assert_array_equal(k, ok)
+    np.testing.assert_allclose(xy, oxy, atol=1e-9)
+    np.testing.assert_allclose(e.virtual_map(0)[1], ref.virtual_map()[1], rtol=1e-7, atol=1e-9)
+    # ... and only between the staged reset and the first measurement
+    assert e.L.drlgx_stage_set_prior_pose_host(e.h, 0, (C.c_double * 3)(0.0, 0.0, 0.0)) == -1
