@@ -395,6 +395,20 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
   TRY(field_alloc(e, &S.red, DRLGX_RED_STRIDE));
   TRY(field_alloc(e, &S.vm_prob, V, 1));
   TRY(field_alloc(e, &S.vm_info, 3 * V, 1));
+#ifndef COPY_EXP_NOSPLIT
+  {
+    // the three planes of the information as three entries of the copy table (same stride, a third of the bytes each): the 38 KB slice
+    // was the copy kernel's longest workgroup by far
+    DrlgxField f = e->fields.back();
+    e->fields.pop_back();
+    for (int k = 0; k < 3; ++k) {
+      DrlgxField g = f;
+      g.base = f.base + (size_t)k * V * sizeof(double);
+      g.pad = (int)(V * sizeof(double));
+      e->fields.push_back(g);
+    }
+  }
+#endif
   TRY(field_alloc(e, &S.vm_upd, (size_t)S.Vu, 1));
   TRY(field_alloc(e, &S.vm_tr, V, 1));
   TRY(field_alloc(e, &S.gt_lm, (size_t)S.LG * 2, 2));  // rollouts read their parent's landmarks
@@ -442,6 +456,10 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
     }
   }
   TRY(dev_alloc(e, &S.status, 1));
+  // (the copy kernel deals a workgroup to every (instance, field): the largest slices first, so that none of them starts last)
+  std::stable_sort(e->fields.begin(), e->fields.end(), [](const DrlgxField &a, const DrlgxField &b) {
+    return (a.pad > 0 ? (size_t)a.pad : a.stride) > (b.pad > 0 ? (size_t)b.pad : b.stride);
+  });
   TRY(dev_alloc(e, &e->fields_dev, e->fields.size()));
   hipMemcpyAsync(e->fields_dev, e->fields.data(), e->fields.size() * sizeof(DrlgxField), hipMemcpyHostToDevice, e->stream);
   TRY(dev_alloc(e, &e->stage_i32, (size_t)n_envs));

@@ -10,5 +10,5 @@ struct DrlgxField {
   // (its counters): the copy moves the live part only, so that a large capacity costs short trajectories nothing
   int unit;
   int unit_bytes;
-  int pad;
+  int pad;        // > 0: bytes of the slice this entry stands for (a sub-slice: base points at it, stride is the whole slice's); 0: all of it
 };

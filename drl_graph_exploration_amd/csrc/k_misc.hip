@@ -46,18 +46,22 @@ __global__ __launch_bounds__(256) void k_copy_instances(const DrlgxField *fields
                                                         DrlgxState S, int panel) {
   // grid = (instances, fields [+ kCopySplit]): every (instance, field) slice is streamed by its own workgroup with
   // 16-byte accesses when the slice is 16-byte aligned (all large fields are)
-  const int i = blockIdx.x, f = blockIdx.y;
+  // (x = field, y = instance: consecutive workgroups stream slices of DIFFERENT arrays - with x = instance the workgroups in flight
+  // all walked the same field at the same offsets of 256 instances: 20.8 against 18.0 us per 78 MB restore, profiles/r06_ab_copy.txt)
+  const int i = blockIdx.y;
+  const int f = blockIdx.x;
   const int s = (src ? src[i] : i) + src_off, d = (dst ? dst[i] : i) + dst_off;
   if (f >= n_fields) {
     if (panel) copy_panel_part(S, s, d, f - n_fields);
     return;
   }
+  // (one workgroup for ALL the fields of a few bytes per instance was measured: 21.4 against 17.8 us - seven dependent round trips)
   if (fields[f].cls & skip_mask) return;
   const size_t stride = fields[f].stride;
   const char *sb = fields[f].base + (size_t)s * stride;
   char *db = fields[f].base + (size_t)d * stride;
   // the live part: per-pose / per-landmark / per-factor arrays end at the source instance's counts
-  size_t live = stride;
+  size_t live = fields[f].pad > 0 ? (size_t)fields[f].pad : stride;  // (pad: a sub-slice of the instance's slice - one plane of the virtual map's information)
   if (fields[f].unit && cnt) {
     const int *c = cnt + (size_t)s * DRLGX_CNT_STRIDE;
     const int k = fields[f].unit == 1 ? c[C_P] : fields[f].unit == 2 ? c[C_L] : c[C_M];
@@ -68,7 +72,12 @@ __global__ __launch_bounds__(256) void k_copy_instances(const DrlgxField *fields
     const uint4 *sp = reinterpret_cast<const uint4 *>(sb);
     uint4 *dp = reinterpret_cast<uint4 *>(db);
     const size_t nq = live / 16;
-    for (size_t k = threadIdx.x; k < nq; k += 256) dp[k] = sp[k];
+    size_t k = threadIdx.x;
+    for (; k + 256 < nq; k += 512) {  // (two loads in flight per thread)
+      const uint4 v0 = sp[k], v1 = sp[k + 256];
+      dp[k] = v0; dp[k + 256] = v1;
+    }
+    if (k < nq) dp[k] = sp[k];
   } else {
     const uint32_t *sp = reinterpret_cast<const uint32_t *>(sb);
     uint32_t *dp = reinterpret_cast<uint32_t *>(db);
@@ -278,7 +287,8 @@ void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t s
                        const int32_t *dst, int src_off, int dst_off, int skip_mask, const int *cnt, const DrlgxState *panel) {
   if (n <= 0) return;
   const bool with_panel = panel && panel->jc;
-  hipLaunchKernelGGL(k_copy_instances, dim3(n, n_fields + (with_panel ? kCopySplit : 0)), dim3(256), 0, st, fields_dev, n_fields, src, dst,
+  const dim3 cgrid(n_fields + (with_panel ? kCopySplit : 0), n);
+  hipLaunchKernelGGL(k_copy_instances, cgrid, dim3(256), 0, st, fields_dev, n_fields, src, dst,
                      src_off, dst_off, skip_mask, cnt, with_panel ? *panel : DrlgxState{}, with_panel ? 1 : 0);
 }
 void drlgx_launch_rebase(const DrlgxState &S, hipStream_t st, int base0, int n) {
