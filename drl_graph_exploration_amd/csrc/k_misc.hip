@@ -48,6 +48,8 @@ __global__ __launch_bounds__(256) void k_copy_instances(const DrlgxField *fields
   // 16-byte accesses when the slice is 16-byte aligned (all large fields are)
   // (x = field, y = instance: consecutive workgroups stream slices of DIFFERENT arrays - with x = instance the workgroups in flight
   // all walked the same field at the same offsets of 256 instances: 20.8 against 18.0 us per 78 MB restore, profiles/r06_ab_copy.txt)
+  // (a 1-D grid dealt so that instance i's slices are copied on XCD i % 8 - where the belief kernels' workgroup of instance i runs
+  // next - changed neither kernel's time)
   const int i = blockIdx.y;
   const int f = blockIdx.x;
   const int s = (src ? src[i] : i) + src_off, d = (dst ? dst[i] : i) + dst_off;
