@@ -117,6 +117,26 @@ struct DrlgxState {
 // a plain (flat / global) pointer every access of the kernel became a flat_load / flat_store with a 64-bit address pair per access
 // (256 VGPRs + 108 B of scratch per thread in round 5, and every LDS wait also waited for the memory accesses in flight).
 typedef const __attribute__((address_space(4))) DrlgxState *DrlgxStateConst;
+// The state struct's cache lines through the scalar cache once, at the head of the fused step (one wave: the cache is the CU's): the
+// members are read where they are used, and every FIRST touch of a line is otherwise an L2 round trip (~0.3 us) somewhere along the
+// workgroup's critical path - a dozen of them between the prelude and the map stage's constants.  One dword per 64-byte line; the wait is
+// the price of naming destination registers.  -0.3 ... -0.7 us per fused step over eight interleaved same-box pairs
+// (profiles/r06_ab_state_const.txt).
+__device__ __forceinline__ void drlgx_warm_state(DrlgxStateConst Sp) {
+  static_assert(sizeof(DrlgxState) <= 14 * 64, "drlgx_warm_state touches fourteen lines");
+  const unsigned long long sp = reinterpret_cast<unsigned long long>(Sp);
+  unsigned int w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13;
+  asm volatile("s_load_dword %0, %14, 0x0\n\ts_load_dword %1, %14, 0x40\n\ts_load_dword %2, %14, 0x80\n\t"
+               "s_load_dword %3, %14, 0xc0\n\ts_load_dword %4, %14, 0x100\n\ts_load_dword %5, %14, 0x140\n\t"
+               "s_load_dword %6, %14, 0x180\n\ts_load_dword %7, %14, 0x1c0\n\ts_load_dword %8, %14, 0x200\n\t"
+               "s_load_dword %9, %14, 0x240\n\ts_load_dword %10, %14, 0x280\n\ts_load_dword %11, %14, 0x2c0\n\t"
+               "s_load_dword %12, %14, 0x300\n\ts_load_dword %13, %14, 0x340\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=s"(w0), "=s"(w1), "=s"(w2), "=s"(w3), "=s"(w4), "=s"(w5), "=s"(w6), "=s"(w7), "=s"(w8), "=s"(w9), "=s"(w10), "=s"(w11),
+                 "=s"(w12), "=s"(w13)
+               : "s"(sp));
+}
+
 // How the belief kernels of the unity build receive the state: DRLGX_KS_PARAM in the signature, `const DrlgxState &S = DRLGX_KS_REF;`
 // as the first line, DRLGX_KS_ARG(S) at the launch.  -DDRLGX_STATE_BY_VALUE builds the by-value form (the A/B of profiles/r06_ab_state_const.txt).
 #ifdef DRLGX_STATE_BY_VALUE

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(kslam::kThreads) void k_step(DrlgxState S, LaunchSe
 template <int FT>
 __global__ __launch_bounds__(kslam::kThreads) void k_step_ref(DrlgxStateConst Sp, LaunchSel sel, const double *odom, int odom_stride,
                                                               int n_measure, int lds_bytes, int map_chunk) {
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) drlgx_warm_state(Sp);
   step_once<FT>(*(const DrlgxState *)Sp, sel, odom, odom_stride, n_measure, lds_bytes, map_chunk);
 }
 
