@@ -31,7 +31,7 @@ def lib_path():
 # every symbol declared in include/drlgx.h
 SYMBOLS = [
     "drlgx_create", "drlgx_destroy", "drlgx_set_stream", "drlgx_synchronize", "drlgx_strerror", "drlgx_last_error",
-    "drlgx_status_host", "drlgx_reset_host", "drlgx_step", "drlgx_utility", "drlgx_uncertainty_em", "drlgx_explored", "drlgx_metrics", "drlgx_cov_array",
+    "drlgx_status_host", "drlgx_status_fetch_host", "drlgx_reset_host", "drlgx_step", "drlgx_utility", "drlgx_uncertainty_em", "drlgx_explored", "drlgx_metrics", "drlgx_cov_array",
     "drlgx_stage_reset_host", "drlgx_stage_set_prior_information_host", "drlgx_stage_set_prior_pose_host", "drlgx_stage_move", "drlgx_stage_measure", "drlgx_stage_add_measurements", "drlgx_stage_optimize",
     "drlgx_stage_update_map", "drlgx_set_planner_parameter", "drlgx_set_fixed_landmarks_host", "drlgx_fm2_update", "drlgx_step_plan", "drlgx_step_plans",
     "drlgx_line_plan", "drlgx_lookahead", "drlgx_lookahead_bounded", "drlgx_graph_capacity", "drlgx_graph", "drlgx_get_counts_host", "drlgx_counts",
@@ -67,6 +67,7 @@ def lib():
     L.drlgx_last_error.restype = C.c_char_p
     L.drlgx_last_error.argtypes = [vp]
     L.drlgx_status_host.argtypes = [vp]
+    L.drlgx_status_fetch_host.argtypes = [vp, vp, C.c_size_t, vp]
     L.drlgx_reset_host.argtypes = [vp, C.c_int, ip, C.POINTER(C.c_uint32), dp]
     L.drlgx_step.argtypes = [vp, vp, vp]
     L.drlgx_step_plan.argtypes = [vp, vp, vp, C.c_int, C.c_int]

@@ -548,6 +548,15 @@ int drlgx_status_host(drlgx_engine *e) {
   return st;
 }
 
+int drlgx_status_fetch_host(drlgx_engine *e, const void *src_dev, size_t bytes, void *dst_host) {
+  DRLGX_ENTER(e);
+  if (!e || (bytes > 0 && (!src_dev || !dst_host))) return DRLGX_E_INVALID;
+  // the caller's bytes ride on the status read's synchronisation (a vector step of a trainer needs a handful of small device
+  // results on the host: every separate read drains the stream again)
+  if (bytes > 0) HIPCHK(e, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, e->stream));
+  return drlgx_status_host(e);
+}
+
 int drlgx_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint32_t *seeds, const double *start) {
   DRLGX_ENTER(e);
   if (!e || n <= 0 || n > e->S.n_envs || !env_ids || !seeds || !start) return DRLGX_E_INVALID;

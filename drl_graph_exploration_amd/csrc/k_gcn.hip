@@ -538,6 +538,13 @@ __global__ __launch_bounds__(256) void k_aggregate(int N, int hidden, const floa
   }
 }
 
+// EPI 3's factor at element `at` of the [M x ldc] matrices: the ReLU gate recovered from G = H2 (k_dz2) times the dropout mask
+__device__ __forceinline__ float gate3(const float *G, const float *mask, size_t at) {
+  float g = G[at] > 0.f ? 1.f : 0.f;
+  if (mask) g *= mask[at];
+  return g;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The same GEMM with the operand tiles loaded global -> LDS directly (global_load_lds_dwordx4, gfx950): no VGPR staging
 // and no ds_write instructions, four LDS stages with three tiles in flight.  Bit-identical to k_gemm (same MFMA order);
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(256) void k_gemm_dl(int M, int N, int K, const floa
   float *Cz = C + (EPI == 0 ? (size_t)blockIdx.z * M * ldc : 0);
   const int col = n0 + wn * 32 + (lane & 31);
   if (col < N) {
-    const float bj = EPI == 1 ? bias[col] : 0.f;
+    const float bj = (EPI == 1 || EPI == 2) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
@@ -663,6 +670,10 @@ __global__ __launch_bounds__(256) void k_gemm_dl(int M, int N, int K, const floa
       if (EPI == 1) {
         v = fmaxf(v + bj, 0.f);
         if (mask) v *= mask[(size_t)row * ldc + col];
+      } else if (EPI == 2) {
+        v += bj;
+      } else if (EPI == 3) {
+        v *= gate3(bias, mask, (size_t)row * ldc + col);
       }
       Cz[(size_t)row * ldc + col] = v;
     }
@@ -683,6 +694,9 @@ __global__ __launch_bounds__(256) void k_gemm_dl(int M, int N, int K, const floa
 //  * workgroup id -> tile mapping keeps the 8 column tiles of one row panel on one XCD (shared A panel in its L2).
 // EPI 0: C = acc (split-K partial when gridDim.z > 1: C += z * M * N)
 // EPI 1: C = relu(acc + bias[col]) * (mask ? mask[row][col] : 1)        (forward layer 2)
+// EPI 2: C = acc + bias[col]                                            (read-out layer with more than 8 outputs: the critic's 100)
+// EPI 3: C = acc * (G[row][col] > 0) * (mask ? mask[row][col] : 1), G = `bias` read as an [M x ldc] matrix
+//        (dZ2 of that read-out layer: G = H2, see k_dz2)
 // ------------------------------------------------------------------------------------------------
 constexpr int BK = 16;
 constexpr int LDK = BK + 4;  // [x][k] tile stride (floats)
@@ -851,7 +865,7 @@ __global__ __launch_bounds__(256) void k_gemm(
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int col = n0 + wn * 32 * NI + j * 32 + (lane & 31);
-      const float bj = EPI == 1 ? bias[col] : 0.f;
+      const float bj = (EPI == 1 || EPI == 2) ? bias[col] : 0.f;
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const size_t at = (size_t)(m0 + wm * 32 * MI + i * 32 + 4 * (lane >> 5)) * ldc + col;
@@ -868,6 +882,10 @@ __global__ __launch_bounds__(256) void k_gemm(
             if (EPI == 1) {
               v = fmaxf(v + bj, 0.f);
               if (mask) v *= mk[r];
+            } else if (EPI == 2) {
+              v += bj;
+            } else if (EPI == 3) {
+              v *= gate3(bias, mask, at + (size_t)(r + 8 * q) * ldc);
             }
             Cz[at + (size_t)(r + 8 * q) * ldc] = v;
           }
@@ -880,7 +898,7 @@ __global__ __launch_bounds__(256) void k_gemm(
   for (int j = 0; j < NI; ++j) {
     const int col = n0 + wn * 32 * NI + j * 32 + (lane & 31);
     if (col >= N) continue;
-    const float bj = EPI == 1 ? bias[col] : 0.f;
+    const float bj = (EPI == 1 || EPI == 2) ? bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -891,6 +909,10 @@ __global__ __launch_bounds__(256) void k_gemm(
         if (EPI == 1) {
           v = fmaxf(v + bj, 0.f);
           if (mask) v *= mask[(size_t)row * ldc + col];
+        } else if (EPI == 2) {
+          v += bj;
+        } else if (EPI == 3) {
+          v *= gate3(bias, mask, (size_t)row * ldc + col);
         }
         Cz[(size_t)row * ldc + col] = v;
       }
@@ -1080,7 +1102,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_wide(int M, int N, int K, cons
   const int n = n0 + 16 * wave + 4 * (lane >> 4);
   if (n < N) {
     float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (EPI == 1) bj = *reinterpret_cast<const float4 *>(bias + n);
+    if (EPI == 1 || EPI == 2) bj = *reinterpret_cast<const float4 *>(bias + n);
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
       const int m = m0 + 16 * i + (lane & 15);
@@ -1093,6 +1115,16 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_wide(int M, int N, int K, cons
           const float4 mk = *reinterpret_cast<const float4 *>(mask + at);
           v = make_float4(v.x * mk.x, v.y * mk.y, v.z * mk.z, v.w * mk.w);
         }
+      } else if (EPI == 2) {
+        v = make_float4(v.x + bj.x, v.y + bj.y, v.z + bj.z, v.w + bj.w);
+      } else if (EPI == 3) {
+        const float4 h = *reinterpret_cast<const float4 *>(bias + at);
+        float4 g = make_float4(h.x > 0.f ? 1.f : 0.f, h.y > 0.f ? 1.f : 0.f, h.z > 0.f ? 1.f : 0.f, h.w > 0.f ? 1.f : 0.f);
+        if (mask) {
+          const float4 mk = *reinterpret_cast<const float4 *>(mask + at);
+          g = make_float4(g.x * mk.x, g.y * mk.y, g.z * mk.z, g.w * mk.w);
+        }
+        v = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
       }
       *reinterpret_cast<float4 *>(Cz + at) = v;
     }
@@ -1263,6 +1295,12 @@ __global__ void k_splitk_reduce(int n, int S, const float *part, float *out) {
   out[i] = s;
 }
 
+// read-out layers of up to this many outputs are served by the one-pass kernels below (k_linear_out, k_dz2_sums / k_dz2: H2 is
+// read once, HBM-bound); wider ones (the critic: 100) by the matrix-core products with the epilogues EPI 2 / 3
+#ifndef DRLGX_THIN_OUT
+#define DRLGX_THIN_OUT 8  // (-DDRLGX_THIN_OUT=128: the one-pass kernels for every width, A/B runs)
+#endif
+constexpr int kThinOut = DRLGX_THIN_OUT;
 // out[n][o] = sum_c H2m[n][c] Wf[o][c] + bf[o]    (Linear 1000 -> out_dim); one wave per (node, o-chunk)
 __global__ __launch_bounds__(256) void k_linear_out(int N, int hidden, int out_dim, const float *H2m, const float *Wf, const float *bf,
                                                     float *out) {
@@ -1475,7 +1513,8 @@ template <bool TA, bool TB, int EPI>
 bool gemm_wide(hipStream_t st, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias,
                const float *mask, int kps) {
   if (!vec_ok(A, lda, TA ? M : K) || !vec_ok(B, ldb, TB ? K : N) || !vec_ok(C, ldc, N)) return false;
-  if ((EPI == 1 && (!vec_ok(bias, 4, 4) || (mask && !vec_ok(mask, ldc, N)))) || (TA ? M : K) < 4 || (TB ? K : N) < 4 || kps < 16) return false;
+  if (((EPI == 1 || EPI == 2) && !vec_ok(bias, 4, 4)) || (EPI == 3 && !vec_ok(bias, ldc, N)) ||
+      ((EPI == 1 || EPI == 3) && mask && !vec_ok(mask, ldc, N)) || (TA ? M : K) < 4 || (TB ? K : N) < 4 || kps < 16) return false;
   const WidePick pick = wide_pick(M, N, (K + kps - 1) / kps, TA);
 #define DRLGX_WIDE(RT, NW)                                                                          \
   case RT:                                                                                          \
@@ -1520,9 +1559,12 @@ void gemm(hipStream_t st, int M, int N, int K, const float *A, int lda, const fl
 }
 
 // weight-gradient GEMM  C[M x N] = A^T B with K = #nodes: split-K (enough splits to fill the chip) + deterministic reduce
-void gemm_tn_splitk(hipStream_t st, const GcnWs &w, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C) {
+// max_splits: 8 for the hidden x hidden gradients (the partials' workspace holds eight of them); the thin read-out gradient
+// (M = out_dim rows: 32 tiles) takes more slices to reach every CU
+void gemm_tn_splitk(hipStream_t st, const GcnWs &w, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,
+                    int max_splits = 8) {
   const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-  int splits = (int)std::min<size_t>(8, w.part_floats / ((size_t)M * N));
+  int splits = (int)std::min<size_t>(max_splits, w.part_floats / ((size_t)M * N));
   splits = std::max(1, std::min({splits, (int)((1024 + tiles - 1) / tiles), (K + 255) / 256}));
   const int kps = ((K + splits - 1) / splits + BK - 1) / BK * BK;
   const int S = (K + kps - 1) / kps;
@@ -1635,7 +1677,10 @@ static int gcn_forward_impl(void *hip_stream, int n_nodes, int n_edges, int in_d
   }
   // H2 = relu(AH1 W2 + b2) * mask   (fp32 MFMA, fused epilogue)
   gemm<false, false, 1>(st, n_nodes, hidden, hidden, w.AH1, hidden, W2, hidden, w.H2, hidden, b2, dropout_mask, 1);
-  hipLaunchKernelGGL(k_linear_out, dim3((n_nodes + 3) / 4), dim3(256), 0, st, n_nodes, hidden, out_dim, w.H2, Wf, bf, out);
+  if (out_dim <= kThinOut)  // one pass over H2 (HBM-bound)
+    hipLaunchKernelGGL(k_linear_out, dim3((n_nodes + 3) / 4), dim3(256), 0, st, n_nodes, hidden, out_dim, w.H2, Wf, bf, out);
+  else  // the critic's 100 outputs: a product for the matrix cores (k_linear_out walked H2's row once per output: 0.85 ms at 12.8 k nodes)
+    gemm<false, true, 2>(st, n_nodes, out_dim, hidden, w.H2, hidden, Wf, hidden, out, out_dim, bf, nullptr, 1);
   return hipGetLastError() == hipSuccess ? DRLGX_OK : DRLGX_E_HIP;
 }
 
@@ -1718,7 +1763,7 @@ int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, i
   // output layer
   const uintptr_t al16 = reinterpret_cast<uintptr_t>(Wf) | reinterpret_cast<uintptr_t>(dropout_mask) | reinterpret_cast<uintptr_t>(w.H2) |
                          reinterpret_cast<uintptr_t>(w.T0);
-  if (out_dim <= 8 && (al16 & 15) == 0) {
+  if (out_dim <= kThinOut && (al16 & 15) == 0) {
     // dWf = dOut^T H2m, dbf = colsum(dOut), T0 = dZ2, db2 = colsum(dZ2): one pass over H2 and one reduce
     int nb = std::min(128, (n_nodes + 7) / 8);
     nb = (int)std::max<size_t>(1, std::min<size_t>(nb, w.part_floats / ((size_t)(out_dim + 1) * hidden)));
@@ -1729,13 +1774,17 @@ int drlgx_gcn_backward(void *hip_stream, int n_nodes, int n_edges, int in_dim, i
     hipLaunchKernelGGL(k_thin_tn_reduce, dim3(((out_dim + 1) * hidden + 63) / 64 + 1), dim3(1024), 0, st, hidden, out_dim, nb, w.part, dWf, out_dim,
                        db2, d_out, out_dim, n_nodes, dbf);
   } else {
-    if (out_dim <= 8) {
+    if (out_dim <= kThinOut) {
       thin_tn(st, w, out_dim, hidden, n_nodes, d_out, out_dim, w.H2, hidden, dWf, out_dim, nullptr, dbf);  // dWf = dOut^T H2m, dbf = colsum(dOut)
     } else {
-      gemm_tn_splitk(st, w, out_dim, hidden, n_nodes, d_out, out_dim, w.H2, hidden, dWf);
+      gemm_tn_splitk(st, w, out_dim, hidden, n_nodes, d_out, out_dim, w.H2, hidden, dWf, 32);
       colsum(st, w, n_nodes, out_dim, d_out, dbf);
     }
-    hipLaunchKernelGGL(k_dz2, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, out_dim, d_out, Wf, dropout_mask, w.H2, w.T0);  // T0 = dZ2
+    // T0 = dZ2 = (dOut Wf) * gate
+    if (out_dim <= kThinOut)
+      hipLaunchKernelGGL(k_dz2, dim3(n_nodes), dim3(256), 0, st, n_nodes, hidden, out_dim, d_out, Wf, dropout_mask, w.H2, w.T0);
+    else
+      gemm<false, false, 3>(st, n_nodes, hidden, out_dim, d_out, out_dim, Wf, hidden, w.T0, hidden, w.H2, dropout_mask, 1);
     colsum(st, w, n_nodes, hidden, w.T0, db2);
   }
   // layer 2

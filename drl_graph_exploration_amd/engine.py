@@ -16,6 +16,10 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_NP_OF = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32, torch.int64: np.int64, torch.uint8: np.uint8,
+          torch.bool: np.bool_, torch.int16: np.int16, torch.int8: np.int8}
+
+
 class Engine(object):
     def __init__(self, cfg, n_envs, n_rollouts=0, device=0):
         if not isinstance(cfg, DrlgxConfig):
@@ -67,6 +71,30 @@ class Engine(object):
         st = self.status()
         if st != 0:
             _lib.check(st, self.h)
+
+    def fetch(self, *tensors):
+        """check_status() with the given device tensors brought to the host under the same synchronisation (one stream drain and
+        one copy instead of a `.cpu()` / `.item()` each): returns one numpy array per tensor, same dtype and shape."""
+        self.use_torch_stream()
+        parts = [t.contiguous().view(-1).view(torch.uint8) for t in tensors]
+        n = sum(p.numel() for p in parts)
+        if n == 0:
+            self.check_status()
+            return [np.empty(tuple(t.shape), dtype=_NP_OF[t.dtype]) for t in tensors]
+        packed = parts[0] if len(parts) == 1 else torch.cat(parts)
+        host = getattr(self, "_fetch_host", None)
+        if host is None or host.numel() < n:
+            host = self._fetch_host = torch.empty(max(2 * n, 1 << 16), dtype=torch.uint8, pin_memory=True)
+        st = self.L.drlgx_status_fetch_host(self.h, _p(packed), n, C.c_void_p(host.data_ptr()))
+        if st != 0:
+            _lib.check(st, self.h)
+        raw = host.numpy()
+        out, off = [], 0
+        for t, p in zip(tensors, parts):
+            k = p.numel()
+            out.append(raw[off:off + k].copy().view(_NP_OF[t.dtype]).reshape(tuple(t.shape)))
+            off += k
+        return out
 
     # ---- life cycle
     def reset(self, env_ids, seeds, starts=None, los=None):
@@ -237,7 +265,8 @@ class Engine(object):
         """Batched ExplorationEnv.graph_matrix + DeepQ.data_process for all envs (one PyG-style batch).
         Returns a dict of CUDA tensors: x [N,5] f32, edge_index [2,E] i64, edge_attr [E] f32, node_off / edge_off
         [n_envs+1] i32, batch [N] i64, n_frontier [n_envs] i32, frontier_xy [n_envs,Fmax,2] f64,
-        nearest_frontier_node [n_envs] i32 (local node id); max_graph_edges = the largest graph's edge count (host int)."""
+        nearest_frontier_node [n_envs] i32 (local node id); max_graph_edges = the largest graph's edge count (host int);
+        node_off_h / edge_off_h / n_frontier_h = host copies (numpy).  Raises on a non-zero status word (check_status)."""
         self.use_torch_stream()
         if not hasattr(self, "_gcap"):
             a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
@@ -254,12 +283,15 @@ class Engine(object):
         fxy = torch.zeros(self.n_envs, mf, 2, dtype=torch.float64, device=dev)
         near = torch.empty(self.n_envs, dtype=torch.int32, device=dev)
         self._chk(self.L.drlgx_graph(self.h, _p(node_off), _p(edge_off), _p(x), _p(ei), _p(ea), _p(nfr), _p(fxy), _p(near)))
-        tot = torch.stack([node_off[-1], edge_off[-1], (edge_off[1:] - edge_off[:-1]).max()]).cpu()
-        N, E = int(tot[0]), int(tot[1])
+        # the batch's boundaries and frontier counts on the host too, with the status word, in ONE synchronisation (keys *_h)
+        node_off_h, edge_off_h, nfr_h = self.fetch(node_off, edge_off, nfr)
+        N, E = int(node_off_h[-1]), int(edge_off_h[-1])
         counts = (node_off[1:] - node_off[:-1]).to(torch.int64)
         batch = torch.repeat_interleave(torch.arange(self.n_envs, device=dev), counts, output_size=N)
         return dict(x=x[:N], edge_index=ei[:2 * E].view(2, E), edge_attr=ea[:E], node_off=node_off, edge_off=edge_off,
-                    batch=batch, n_frontier=nfr, frontier_xy=fxy, nearest_frontier_node=near, max_graph_edges=int(tot[2]))
+                    batch=batch, n_frontier=nfr, frontier_xy=fxy, nearest_frontier_node=near,
+                    max_graph_edges=int(np.diff(edge_off_h).max()) if self.n_envs else 0,
+                    node_off_h=node_off_h, edge_off_h=edge_off_h, n_frontier_h=nfr_h)
 
     def snapshot(self, slot=0):
         self.use_torch_stream()

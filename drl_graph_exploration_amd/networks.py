@@ -254,7 +254,8 @@ class PolicyGCN(torch.nn.Module):
                       self.fully_con1.weight, self.fully_con1.bias, dmask, graph_segments(data))
         segs = graph_segments(data)
         if segs is not None and mask.dtype == torch.bool:  # wavefront segment reductions over the batch's graph boundaries
-            return _SegmentSoftmax.apply(q.view(-1), mask, segs[1], int(mask.sum()))
+            n_masked = getattr(data, "n_masked", None)  # (a caller that knows the count on the host spares the synchronisation)
+            return _SegmentSoftmax.apply(q.view(-1), mask, segs[1], int(mask.sum()) if n_masked is None else int(n_masked))
         q = torch.masked_select(q.view(-1), mask)
         b = torch.masked_select(batch, mask)
         return segment_softmax(q, b, int(batch.max().item()) + 1 if batch.numel() else 0)

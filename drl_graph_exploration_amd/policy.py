@@ -335,8 +335,9 @@ class DeepQ(object):
 
     @staticmethod
     def _host_offsets(g):
-        g["node_off_h"] = g["node_off"].cpu().numpy()
-        g["edge_off_h"] = g["edge_off"].cpu().numpy()
+        if "node_off_h" not in g:  # (Engine.graph brings them along; a hand-made export may not)
+            g["node_off_h"] = g["node_off"].cpu().numpy()
+            g["edge_off_h"] = g["edge_off"].cpu().numpy()
         return g
 
     def cost(self, pred, target, action):
@@ -714,18 +715,16 @@ class DeepQ(object):
             choice = pick - cand_first
             r_t = rewards[pick]
             key_size = (g["node_off"][1:] - g["node_off"][:-1]).long() - nfr
-            a_loc = (key_size + choice).cpu().numpy()
-            _, done, _ = env.step(choice)
-            current_done = (done | env.loop_clo).cpu().numpy()
-            done_h = done.cpu().numpy()
-            r_h = r_t.cpu().numpy()
+            _, done, _ = env.step(choice, check=False)
+            # (the step's results in one synchronisation, with the status check)
+            a_loc, current_done, done_h, r_h, trunc_h = env.engine.fetch(key_size + choice, done | env.loop_clo, done, r_t, env.truncated())
 
             # next state = the graph after the step, BEFORE a finished env is re-created (policy.py:127-133 store s_t1,
             # then `env = ExplorationEnv(...)` at :185-189); envs that ran out of pose capacity are re-created too, but
             # their transition stays non-terminal (VecExplorationEnv.truncated)
-            renew = done_h | env.truncated().cpu().numpy()
+            renew = done_h | trunc_h
             g1 = self._host_offsets(env.graph_matrix())
-            nfr1 = g1["n_frontier"].cpu().numpy()
+            nfr1 = g1["n_frontier_h"] if "n_frontier_h" in g1 else g1["n_frontier"].cpu().numpy()
             slot_t1 = pool.put(g1)
             refs_t, refs_t1 = PoolRef.many(pool, slot_t, n_envs), PoolRef.many(pool, slot_t1, n_envs)
             a_l, r_l, d_l, f_l = a_loc.tolist(), r_h.tolist(), current_done.tolist(), nfr1.tolist()
@@ -870,29 +869,43 @@ class A2C(object):
             for a in range(0, len(items), self.graphs_per_pass):
                 b = min(len(items), a + self.graphs_per_pass)
                 chunks.append((GraphData.collate(items[a:b]), a, b))
+        # a mask that arrives as a host array gives the masked nodes' positions without asking the device: the chunks below then
+        # run without a single synchronisation (torch.masked_select and the actor's softmax size would drain the stream per chunk)
+        mask_h = None if torch.is_tensor(mask) else np.asarray(mask, dtype=bool)
         mask = torch.as_tensor(mask, dtype=torch.bool, device=device)
         y_adv = torch.as_tensor(y_adv, dtype=torch.float32, device=device)
         dis_reward = torch.as_tensor(dis_reward, dtype=torch.float32, device=device)
         action = torch.as_tensor(action, dtype=torch.float32, device=device)
+        sel_all = None if mask_h is None else torch.as_tensor(np.nonzero(mask_h)[0], device=device)
+        csum_h = None if mask_h is None else np.concatenate([[0], np.cumsum(mask_h)])
         optimizer.zero_grad()
         n_graphs = len(items) if items is not None else chunks[0][2]
-        total, entro, node0 = 0.0, 0.0, 0
+        node0 = 0
+        total = torch.zeros((), dtype=torch.float64, device=device)  # (summed like the host's doubles did)
+        entro = torch.zeros((), dtype=torch.float64, device=device)
         for cdata, g0, g1 in chunks:
             cdata = cdata.to(device)
             nn_ = cdata.x.shape[0]
             m = mask[node0:node0 + nn_]
+            if mask_h is not None:
+                cdata.n_masked = int(csum_h[node0 + nn_] - csum_h[node0])
             actor_out = modelA(cdata, m, batch=cdata.batch) + 1e-35
             critic_out = modelC(cdata, m, batch=cdata.batch)
-            actor_loss = self.policy_cost(actor_out, y_adv[node0:node0 + nn_], action[node0:node0 + nn_], m) / n_traj
+            if mask_h is not None:  # policy_cost with its two masked_select as gathers (same elements, same order)
+                sel = sel_all[int(csum_h[node0]):int(csum_h[node0 + nn_])]
+                actor_loss = torch.mul(-torch.mul(actor_out.view(-1).log(), y_adv.index_select(0, sel)),
+                                       action.index_select(0, sel)).sum() / self.nstep / n_traj
+            else:
+                actor_loss = self.policy_cost(actor_out, y_adv[node0:node0 + nn_], action[node0:node0 + nn_], m) / n_traj
             # mse over all graphs of the batch: this chunk's share of the mean
             critic_loss = ((critic_out.view(-1) - dis_reward[g0:g1]) ** 2).sum() / n_graphs
             ent = self.entropy_loss(actor_out) / n_traj
             loss = actor_loss - ent * self.ent_coef + critic_loss * self.vf_coef
             loss.backward()
-            total += float(loss.item())
-            entro += float(ent.item())
+            total += loss.detach().double()
+            entro += ent.detach().double()
             node0 += nn_
-        self.temp_loss, self.entro = total, entro
+        self.temp_loss, self.entro = (float(v) for v in torch.stack([total, entro]).cpu())
         allreduce_gradients(modelA)
         allreduce_gradients(modelC)
         for param in list(modelA.parameters()) + list(modelC.parameters()):
@@ -961,25 +974,22 @@ class A2C(object):
             env.actions_all_goals()
             rewards = env.rewards_all_goals()
             cand_env, cand_node, cand_first = env.candidates
-            nfr = g["n_frontier"].long()
+            # (a vector step synchronises four times: the export's boundaries, the plans' lengths, the actor's read-out and the
+            # step's results - each with everything the host needs at that point in one copy, Engine.fetch)
+            nfr_h = g["n_frontier_h"].astype(np.int64)
             batch_data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"], g["node_off"], g["edge_off"], g["max_graph_edges"])
+            batch_data.n_masked = int(nfr_h.sum())
             mask = frontier_mask(g)
             with torch.no_grad():
                 readout = self.test(batch_data, g["batch"], mask, device, policy_net).view(-1)  # [C], env-major
                 val = self.test(batch_data, g["batch"], mask, device, value_net).view(-1)       # [n_envs]
-            p_h, first_h, nfr_h = readout.cpu().numpy().astype(np.float64), cand_first.cpu().numpy(), nfr.cpu().numpy()
-            choice = sample_frontiers(p_h, nfr_h, rng)
-            choice_t = torch.as_tensor(choice, device=device)
-            r_t = rewards[cand_first + choice_t]
-            key_size = (g["node_off"][1:] - g["node_off"][:-1]).long() - nfr
-            a_loc = (key_size + choice_t).cpu().numpy()
-            _, done, _ = env.step(choice_t)
-            current_done = (done | env.loop_clo).cpu().numpy()
-            done_h = done.cpu().numpy()
-            r_h = r_t.cpu().numpy()
-            val_h = val.cpu().numpy()
+            (p_h,) = env.engine.fetch(readout)
+            choice = sample_frontiers(p_h.astype(np.float64), nfr_h, rng)
+            r_t = rewards[torch.as_tensor(np.cumsum(nfr_h) - nfr_h + choice, device=device)]
+            a_loc = np.diff(g["node_off_h"]).astype(np.int64) - nfr_h + choice  # key_size + choice
+            _, done, _ = env.step(choice, check=False)
             # envs out of pose capacity are re-created like finished ones, but stay non-terminal (VecExplorationEnv.truncated)
-            trunc_h = env.truncated().cpu().numpy()
+            done_h, trunc_h, current_done, r_h, val_h = env.engine.fetch(done, env.truncated(), done | env.loop_clo, r_t, val)
             renew = done_h | trunc_h
             if renew.any():
                 env.reset(np.nonzero(renew)[0])

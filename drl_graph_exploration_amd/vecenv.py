@@ -129,14 +129,17 @@ class VecExplorationEnv(object):
     def graph_matrix(self):
         """All envs' graphs as one batch (see Engine.graph); node order per env = [landmarks (hash order), poses,
         frontiers], edge order = DeepQ.data_process's. Candidate c = (env, frontier) in env-major order."""
-        g = self.engine.graph()
-        self.engine.check_status()
+        g = self.engine.graph()  # (one synchronisation: the status word, the batch's boundaries and the frontier counts)
         nfr = g["n_frontier"].to(torch.int64)
+        nfr_h = g["n_frontier_h"].astype(np.int64)
+        n_cand = int(nfr_h.sum())
         self._graph = g
-        self._cand_env = torch.repeat_interleave(torch.arange(self.n_envs, device=self.device), nfr).to(torch.int32)
+        self._cand_env = torch.repeat_interleave(torch.arange(self.n_envs, device=self.device), nfr, output_size=n_cand).to(torch.int32)
         first = torch.cumsum(nfr, 0) - nfr
         self._cand_first = first
-        fidx = torch.arange(self._cand_env.numel(), device=self.device) - first[self._cand_env.long()]
+        self._cand_first_h = np.cumsum(nfr_h) - nfr_h
+        self._n_act_h = None
+        fidx = torch.arange(n_cand, device=self.device) - first[self._cand_env.long()]
         self._cand_fidx = fidx
         self._goals = g["frontier_xy"][self._cand_env.long(), fidx].contiguous()
         # global node id of every candidate: node_off[e+1] - n_frontier[e] + f
@@ -153,31 +156,44 @@ class VecExplorationEnv(object):
         if self._graph is None:
             self.graph_matrix()
         self._actions, self._n_act = self.engine.line_plan(self._cand_env, self._goals)
+        # the plans' lengths on the host: the look-ahead and the step launch the action indices some plan reaches
+        (self._n_act_h,) = self.engine.fetch(self._n_act)
         return self._actions, self._n_act
 
     def rewards_all_goals(self, all_actions=None, return_raw=False):
         """Look-ahead reward per candidate, normalised per env like exploration_env.py:151-161:
         nearest frontier is the arg-max -> interp to [-1, 0], loop_clo False; else [-1, 1], loop_clo True."""
         actions, n_act = all_actions if all_actions is not None else (self._actions, self._n_act)
-        kmax = max(int(n_act.max().item()), 1) if n_act.numel() else 1  # host bound: unreached action indices are not launched
+        n_act_h = self._n_act_h if all_actions is None else None
+        if n_act_h is not None:
+            kmax = max(int(n_act_h.max()), 1) if n_act_h.size else 1
+        else:
+            kmax = max(int(n_act.max().item()), 1) if n_act.numel() else 1  # host bound: unreached action indices are not launched
         raw = self.engine.lookahead(self._cand_env, actions, n_act, max_n_actions=kmax)
         r, self.loop_clo = normalise_rewards(raw, self._cand_env.long(), self._cand_first, self.n_envs, self._graph["n_frontier"])
         return (r, raw) if return_raw else r
 
     # ------------------------------------------------------------------ step (exploration_env.py:98-105)
-    def step(self, choice):
+    def step(self, choice, check=True):
         """Execute, for every env, the plan of its chosen candidate. `choice` [n_envs] = frontier index within the env
-        (int tensor / array) — `all_actions[key_size + action_index]` of policy.py:120."""
+        (int tensor / array) — `all_actions[key_size + action_index]` of policy.py:120.  A host array costs no synchronisation
+        (the plans' lengths are on the host since actions_all_goals); check=False leaves the status check to the caller's next
+        `engine.fetch` / `engine.check_status` (the trainers read the step's results with one)."""
+        kmax = None
+        if not torch.is_tensor(choice) and self._n_act_h is not None:
+            kmax = int(self._n_act_h[self._cand_first_h + np.asarray(choice, dtype=np.int64)].max())
         choice = torch.as_tensor(choice, device=self.device).long()
         c = self._cand_first + choice
         acts = self._actions[c]  # [n_envs, A, 3]
         nact = self._n_act[c]
-        return self.step_actions(acts, nact)
+        return self.step_actions(acts, nact, kmax=kmax, check=check)
 
-    def step_actions(self, acts, nact, map_every_action=False):
+    def step_actions(self, acts, nact, map_every_action=False, kmax=None, check=True):
         """Execute `nact[i]` actions of `acts[i]` in every env.  The virtual map is a pure function of the SLAM state, so it
-        is rebuilt at each env's last action only unless `map_every_action` (per-step metrics of the map) asks otherwise."""
-        kmax = int(nact.max().item())
+        is rebuilt at each env's last action only unless `map_every_action` (per-step metrics of the map) asks otherwise.
+        kmax: a host bound of nact (None: read from the device)."""
+        if kmax is None:
+            kmax = int(nact.max().item())
         if acts.shape[1] < self.cfg.max_actions:  # drlgx_step_plan strides the plans by the engine's max_actions
             acts = torch.cat([acts, acts.new_zeros(acts.shape[0], self.cfg.max_actions - acts.shape[1], 3)], dim=1)
         acts = acts.contiguous()
@@ -185,7 +201,8 @@ class VecExplorationEnv(object):
         self.engine.step_plans(acts, nact, kmax, map_last_only=not map_every_action)
         live = torch.arange(acts.shape[1], device=self.device)[None, :] < nact[:, None]
         self.dist += (torch.sqrt(acts[:, :, 0] ** 2 + acts[:, :, 1] ** 2) * live).sum(dim=1)
-        self.engine.check_status()
+        if check:
+            self.engine.check_status()
         self._graph = None
         return self._get_obs(), self.done(), {}
 

@@ -83,6 +83,10 @@ const char *drlgx_strerror(int code);
 const char *drlgx_last_error(const drlgx_engine *e);
 /* Device-side status word of the last kernels: 0 or a DRLGX_E_* code (synchronises). */
 int drlgx_status_host(drlgx_engine *e);
+/* The same, with `bytes` of device memory copied to the host under the same synchronisation (bytes = 0: drlgx_status_host).  A batched
+ * trainer needs a handful of small device results per vector step on the host - counts, offsets, the read-out of the policy
+ * (scripts/policy.py:100-127, 392-400 read them one Python attribute at a time); each separate read drains the stream again. */
+int drlgx_status_fetch_host(drlgx_engine *e, const void *src_dev, size_t bytes, void *dst_host);
 
 /* ---- SS2D life cycle (scripts/envs/pyss2d.py:58-206) ----------------------------------------- */
 

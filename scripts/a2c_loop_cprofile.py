@@ -1,4 +1,4 @@
-"""Dev tool: cProfile over A2C.running (bench.py's a2c_loop workload): where the host side of a vector step goes.  (NOGC=1: with the
+"""Dev tool (NOPROF=1: no profiler, for rocprofv3 --kernel-trace --stats around it - the device-busy time of the loop): cProfile over A2C.running (bench.py's a2c_loop workload): where the host side of a vector step goes.  (NOGC=1: with the
 cyclic garbage collector off - under the profiler the allocation bursts of a step trigger full collections that a plain run does not
 show: a gc-quiet wrapper around the loops measured 12.2-12.6 against 11.6 ms per vector step and was dropped.)"""
 import os, sys, time, tempfile, cProfile, pstats
@@ -21,14 +21,23 @@ with tempfile.TemporaryDirectory() as tmp:
     a2c.buffer.clear()
     a2c.epoch = n_envs * iters
     import gc
+    upd = [0.0]
+    _train = a2c.train
+    def timed_train(*a, **k):  # the update's share of the wall clock (drains the stream before and after: SPLIT=1 only)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        _train(*a, **k)
+        torch.cuda.synchronize(); upd[0] += time.perf_counter() - t
+    if os.environ.get("SPLIT"): a2c.train = timed_train
     if os.environ.get("NOGC"): gc.disable()
     pr = cProfile.Profile()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    pr.enable()
+    if not os.environ.get("NOPROF"): pr.enable()
     a2c.running(actor, critic, test=True, env=env)
     torch.cuda.synchronize()
-    pr.disable()
+    if not os.environ.get("NOPROF"): pr.disable()
     dt = time.perf_counter() - t0
     env.close()
 print("%.2f ms per vector step" % (dt / iters * 1e3))
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+if os.environ.get("SPLIT"): print("  of which the update: %.2f ms per vector step (%.1f ms per update); stepping %.2f ms" % (upd[0] / iters * 1e3, upd[0] * 1e3, (dt - upd[0]) / iters * 1e3))
+if not os.environ.get("NOPROF"):
+    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)

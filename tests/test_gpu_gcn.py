@@ -94,7 +94,13 @@ TALL_TILE_NODES = (1101, 1700, 1903, 3050, 3301, 3803, 4342, 4799)
 
 
 @pytest.mark.parametrize("n_graphs,out_dim,with_mask", [(1, 1, False), (7, 1, True), (64, 1, False), (5, 100, True), (9, 3, True), (6, 8, False)] +
-                         [(-n, 1, n % 2 == 0) for n in TALL_TILE_NODES])
+                         [(-n, 1, n % 2 == 0) for n in TALL_TILE_NODES] +
+                         # (seeded instances: about one 12.8 k-node batch in four has a ReLU pre-activation within fp32 round-off of 0 whose
+                         # gate flips in ours or in torch's fp32 evaluation - 1e-4 .. 1e-3 of the gradient norm either way, for every read-out
+                         # width, scripts/gcn_grad_errors.py; 12 807 is one without)
+                         # the critic's 100-wide read-out (and a width that is no multiple of 4: the unvectorised kernels) on the matrix
+                         # cores: 64 x 64 tiles, the 4-wave and the 8-wave tall tiles for its forward / dZ2 products
+                         [(40, 100, True), (-1903, 100, False), (-4799, 100, True), (-12807, 100, True), (-1700, 10, True)])
 def test_gcn_forward_backward_matches_torch_reference(n_graphs, out_dim, with_mask):
     from drl_graph_exploration_amd.networks import gcn_trunk
     dev = torch.device("cuda", 0)
@@ -106,7 +112,7 @@ def test_gcn_forward_backward_matches_torch_reference(n_graphs, out_dim, with_ma
     N = x.shape[0]
     mask = None
     if with_mask:
-        mask = (torch.rand(N, 1000, device=dev) >= 0.5).float() * 2.0
+        mask = (torch.rand(N, 1000, device=dev, generator=torch.Generator(device=dev).manual_seed(11 + N)) >= 0.5).float() * 2.0
     out = gcn_trunk(x, ei, ea, P["conv1.weight"], P["conv1.bias"], P["conv2.weight"], P["conv2.bias"], P["fully_con1.weight"],
                     P["fully_con1.bias"], mask)
     # the same plain-torch reference evaluated in float64 is the ground truth (in float32 a ReLU gate that sits at
@@ -119,7 +125,7 @@ def test_gcn_forward_backward_matches_torch_reference(n_graphs, out_dim, with_ma
         ref32 = gcn_ref.gcn_forward({k: v.detach() for k, v in P.items()}, x, ei, ea, mask)
     assert rel_err(out.detach(), ref32) < 2e-4
     # backward with a DQN-style weighted sum over the node outputs
-    wgt = torch.randn(N, out_dim, device=dev)
+    wgt = torch.randn(N, out_dim, device=dev, generator=torch.Generator(device=dev).manual_seed(3 + N))
     (out * wgt).sum().backward()
     (ref * wgt.double()).sum().backward()
     # the same plain-torch reference in float32, to calibrate what fp32 round-off does to this problem
