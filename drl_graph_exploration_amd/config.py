@@ -5,6 +5,7 @@ scripts/envs/pyplanner2d.py:24-54 (values: scripts/envs/exploration_env.ini) and
 ExplorationEnv.reset applies (scripts/envs/exploration_env.py:399-407).
 """
 import ctypes as C
+import functools
 import math
 
 import numpy as np
@@ -82,18 +83,14 @@ def default_config(map_size=40, num_landmarks=None, algorithm=0, max_poses=41, m
     return c
 
 
+@functools.lru_cache(maxsize=65536)
 def start_pose(lo, map_max_x):
     """Start pose of SS2D.__init__ (pyss2d.py:89-95): legacy numpy global-seed stream, PADDED max_x for
-    both coordinates."""
+    both coordinates.  `np.random.seed(s); np.random.randint(m)` is the first draw of RandomState(s): private
+    streams give the reference's values without touching the caller's global one (and without the two 2.5 KB state copies
+    that saving / restoring it cost per call: 43 us x one call per re-created env)."""
     m = int(map_max_x)
-    st = np.random.get_state()
-    try:
-        np.random.seed(lo + 1)
-        x0 = float(np.random.randint(m) - map_max_x / 2)
-        np.random.seed(lo + 2)
-        y0 = float(np.random.randint(m) - map_max_x / 2)
-        np.random.seed(lo + 3)
-        theta0 = math.radians(float(np.random.randint(360)))
-    finally:
-        np.random.set_state(st)
+    x0 = float(np.random.RandomState(lo + 1).randint(m) - map_max_x / 2)
+    y0 = float(np.random.RandomState(lo + 2).randint(m) - map_max_x / 2)
+    theta0 = math.radians(float(np.random.RandomState(lo + 3).randint(360)))
     return x0, y0, theta0

@@ -11,6 +11,7 @@ target computation as the reference; the differences are the ones the batched ho
   flattened policy gradient over ranks (RCCL over xGMI, one collective per train step) before the clamp + Adam step.
 """
 import csv
+import gc
 import math
 import os
 import random
@@ -85,6 +86,31 @@ def broadcast_parameters(model, src=0, group=None):
         return
     for t in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+
+
+class _QuietGc(object):
+    """Python's cyclic collector held off while a trainer's loop runs.  A vector step allocates a few thousand short-lived
+    containers (one PoolRef / buffer tuple / log row per env); the automatic collections they trigger walk the whole heap of a
+    torch process - 1-2 ms per vector step of a 256-env A2C loop, all of it on the critical path between two launches.  Reference
+    counting frees the loop's objects anyway; `tick()` (once per update) collects the young generations, and everything every
+    64th time, so that cycles cannot pile up over a long training."""
+
+    def __init__(self, full_every=64):
+        self.full_every, self.n, self.was = full_every, 0, False
+
+    def __enter__(self):
+        self.was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def tick(self):
+        self.n += 1
+        gc.collect(1 if self.n % self.full_every else 2)
+
+    def __exit__(self, *exc):
+        if self.was:
+            gc.enable()
+        return False
 
 
 class ReplayList(list):
@@ -691,80 +717,82 @@ class DeepQ(object):
         g = self._host_offsets(env.graph_matrix())
         slot_t = pool.put(g)
         pool.ref[slot_t] += 1  # the current state's export is held until the next one replaces it
-        while temp_i < self.epoch:
-            if self.epsilon > self.FINAL_EPSILON and self.step_t > self.OBSERVE:
-                self.epsilon -= n_envs * (self.INITIAL_EPSILON - self.FINAL_EPSILON) / self.EXPLORE
-            env.actions_all_goals()
-            rewards = env.rewards_all_goals()
-            cand_env, cand_node, cand_first = env.candidates
-            nfr = g["n_frontier"].long()
-            batch_data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"], g["node_off"], g["edge_off"], g["max_graph_edges"])
-            with torch.no_grad():
-                prob = self.epsilon if method == "bayesian" else 0.0
-                readout = self.test(batch_data, prob, device, policy_net).view(-1)
-            q_c = readout[cand_node]
-            e = cand_env.long()
-            best = torch.full((n_envs,), -float("inf"), device=device).scatter_reduce(0, e, q_c, reduce="amax")
-            idx = torch.arange(q_c.numel(), device=device)
-            pick = torch.full((n_envs,), q_c.numel(), dtype=torch.long, device=device).scatter_reduce(
-                0, e[q_c >= best[e]], idx[q_c >= best[e]], reduce="amin")  # np.argmax: first maximum
-            if method == "e-greedy":
-                explore = torch.rand(n_envs, device=device) <= self.epsilon
-                rnd = cand_first + (torch.rand(n_envs, device=device) * nfr).long().clamp(max=nfr - 1)
-                pick = torch.where(explore, rnd, pick)
-            choice = pick - cand_first
-            r_t = rewards[pick]
-            key_size = (g["node_off"][1:] - g["node_off"][:-1]).long() - nfr
-            _, done, _ = env.step(choice, check=False)
-            # (the step's results in one synchronisation, with the status check)
-            a_loc, current_done, done_h, r_h, trunc_h = env.engine.fetch(key_size + choice, done | env.loop_clo, done, r_t, env.truncated())
+        with _QuietGc() as quiet:  # (the cyclic collector runs at the updates, not between two launches)
+            while temp_i < self.epoch:
+                if self.epsilon > self.FINAL_EPSILON and self.step_t > self.OBSERVE:
+                    self.epsilon -= n_envs * (self.INITIAL_EPSILON - self.FINAL_EPSILON) / self.EXPLORE
+                env.actions_all_goals()
+                rewards = env.rewards_all_goals()
+                cand_env, cand_node, cand_first = env.candidates
+                nfr = g["n_frontier"].long()
+                batch_data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"], g["node_off"], g["edge_off"], g["max_graph_edges"])
+                with torch.no_grad():
+                    prob = self.epsilon if method == "bayesian" else 0.0
+                    readout = self.test(batch_data, prob, device, policy_net).view(-1)
+                q_c = readout[cand_node]
+                e = cand_env.long()
+                best = torch.full((n_envs,), -float("inf"), device=device).scatter_reduce(0, e, q_c, reduce="amax")
+                idx = torch.arange(q_c.numel(), device=device)
+                pick = torch.full((n_envs,), q_c.numel(), dtype=torch.long, device=device).scatter_reduce(
+                    0, e[q_c >= best[e]], idx[q_c >= best[e]], reduce="amin")  # np.argmax: first maximum
+                if method == "e-greedy":
+                    explore = torch.rand(n_envs, device=device) <= self.epsilon
+                    rnd = cand_first + (torch.rand(n_envs, device=device) * nfr).long().clamp(max=nfr - 1)
+                    pick = torch.where(explore, rnd, pick)
+                choice = pick - cand_first
+                r_t = rewards[pick]
+                key_size = (g["node_off"][1:] - g["node_off"][:-1]).long() - nfr
+                _, done, _ = env.step(choice, check=False)
+                # (the step's results in one synchronisation, with the status check)
+                a_loc, current_done, done_h, r_h, trunc_h = env.engine.fetch(key_size + choice, done | env.loop_clo, done, r_t, env.truncated())
 
-            # next state = the graph after the step, BEFORE a finished env is re-created (policy.py:127-133 store s_t1,
-            # then `env = ExplorationEnv(...)` at :185-189); envs that ran out of pose capacity are re-created too, but
-            # their transition stays non-terminal (VecExplorationEnv.truncated)
-            renew = done_h | trunc_h
-            g1 = self._host_offsets(env.graph_matrix())
-            nfr1 = g1["n_frontier_h"] if "n_frontier_h" in g1 else g1["n_frontier"].cpu().numpy()
-            slot_t1 = pool.put(g1)
-            refs_t, refs_t1 = PoolRef.many(pool, slot_t, n_envs), PoolRef.many(pool, slot_t1, n_envs)
-            a_l, r_l, d_l, f_l = a_loc.tolist(), r_h.tolist(), current_done.tolist(), nfr1.tolist()
-            for i in range(n_envs):
-                self.buffer.append((refs_t[i], int(a_l[i]), float(r_l[i]), refs_t1[i], bool(d_l[i]), int(f_l[i])))
-                pool.ref[slot_t] += 1
-                pool.ref[slot_t1] += 1
-                if len(self.buffer) > self.REPLAY_MEMORY:
-                    release(self.buffer.popleft())
-            if renew.any():
-                env.reset(np.nonzero(renew)[0])
+                # next state = the graph after the step, BEFORE a finished env is re-created (policy.py:127-133 store s_t1,
+                # then `env = ExplorationEnv(...)` at :185-189); envs that ran out of pose capacity are re-created too, but
+                # their transition stays non-terminal (VecExplorationEnv.truncated)
+                renew = done_h | trunc_h
                 g1 = self._host_offsets(env.graph_matrix())
+                nfr1 = g1["n_frontier_h"] if "n_frontier_h" in g1 else g1["n_frontier"].cpu().numpy()
                 slot_t1 = pool.put(g1)
-            pool.ref[slot_t1] += 1
-            pool.ref[slot_t] -= 1
-            g, slot_t = g1, slot_t1  # the next iteration's s_t
-            self.step_t += n_envs
-            temp_i += n_envs
+                refs_t, refs_t1 = PoolRef.many(pool, slot_t, n_envs), PoolRef.many(pool, slot_t1, n_envs)
+                a_l, r_l, d_l, f_l = a_loc.tolist(), r_h.tolist(), current_done.tolist(), nfr1.tolist()
+                for i in range(n_envs):
+                    self.buffer.append((refs_t[i], int(a_l[i]), float(r_l[i]), refs_t1[i], bool(d_l[i]), int(f_l[i])))
+                    pool.ref[slot_t] += 1
+                    pool.ref[slot_t1] += 1
+                    if len(self.buffer) > self.REPLAY_MEMORY:
+                        release(self.buffer.popleft())
+                if renew.any():
+                    env.reset(np.nonzero(renew)[0])
+                    g1 = self._host_offsets(env.graph_matrix())
+                    slot_t1 = pool.put(g1)
+                pool.ref[slot_t1] += 1
+                pool.ref[slot_t] -= 1
+                g, slot_t = g1, slot_t1  # the next iteration's s_t
+                self.step_t += n_envs
+                temp_i += n_envs
 
-            # the reference trains once per environment step (policy.py:137-178): n_envs mini-batches per vector step
-            # unless `updates_per_vector_step` says otherwise; the target network is refreshed when the env-step counter
-            # passes a multiple of TARGET_UPDATE
-            if self.step_t > self.OBSERVE and len(self.buffer) >= self.BATCH:
-                n_upd = n_envs if self.updates_per_vector_step is None else int(self.updates_per_vector_step)
-                if self.step_t // self.TARGET_UPDATE > (self.step_t - n_envs) // self.TARGET_UPDATE:
-                    target_net.load_state_dict(policy_net.state_dict())
-                    self._target_version = self.__dict__.get("_target_version", 0) + 1  # cached target read-outs are stale
-                prepared, batches = self._prepare_updates(n_upd, device, target_net)
-                self._train_minibatches(device, policy_net, target_net, optimizer, prepared, batches, n_upd)
-                temp_loss_data.append([self.step_t, self.temp_loss])
+                # the reference trains once per environment step (policy.py:137-178): n_envs mini-batches per vector step
+                # unless `updates_per_vector_step` says otherwise; the target network is refreshed when the env-step counter
+                # passes a multiple of TARGET_UPDATE
+                if self.step_t > self.OBSERVE and len(self.buffer) >= self.BATCH:
+                    n_upd = n_envs if self.updates_per_vector_step is None else int(self.updates_per_vector_step)
+                    if self.step_t // self.TARGET_UPDATE > (self.step_t - n_envs) // self.TARGET_UPDATE:
+                        target_net.load_state_dict(policy_net.state_dict())
+                        self._target_version = self.__dict__.get("_target_version", 0) + 1  # cached target read-outs are stale
+                    prepared, batches = self._prepare_updates(n_upd, device, target_net)
+                    self._train_minibatches(device, policy_net, target_net, optimizer, prepared, batches, n_upd)
+                    temp_loss_data.append([self.step_t, self.temp_loss])
+                quiet.tick()  # (every vector step: n_envs mini-batches each)
 
-            if log_every and (self.step_t // n_envs) % log_every == 0:
-                print("TIMESTEP", self.step_t, "/ EPSILON", self.epsilon, "/ Q_MAX %e" % float(readout.max()),
-                      "/ EXPLORED", float(env.status().mean()), "/ REWARD", float(r_h.mean()))
-            rows.extend([self.step_t, float(x)] for x in r_h)
-            recent.extend(float(x) for x in r_h)
-            if self.step_t // 5e4 > (self.step_t - n_envs) // 5e4:  # every 50000 iterations (policy.py:197-199)
-                save_state_dict(policy_net, os.path.join(self.weights_path, "MyModel.pt"))
-            if self.step_t > 1000 and self.step_t // 100 > (self.step_t - n_envs) // 100:  # every 100 (policy.py:200-203)
-                temp_reward_data.append([self.step_t, float(np.average(recent))])
+                if log_every and (self.step_t // n_envs) % log_every == 0:
+                    print("TIMESTEP", self.step_t, "/ EPSILON", self.epsilon, "/ Q_MAX %e" % float(readout.max()),
+                          "/ EXPLORED", float(env.status().mean()), "/ REWARD", float(r_h.mean()))
+                rows.extend([self.step_t, float(x)] for x in r_h)
+                recent.extend(float(x) for x in r_h)
+                if self.step_t // 5e4 > (self.step_t - n_envs) // 5e4:  # every 50000 iterations (policy.py:197-199)
+                    save_state_dict(policy_net, os.path.join(self.weights_path, "MyModel.pt"))
+                if self.step_t > 1000 and self.step_t // 100 > (self.step_t - n_envs) // 100:  # every 100 (policy.py:200-203)
+                    temp_reward_data.append([self.step_t, float(np.average(recent))])
 
         self.total_reward = np.append(self.total_reward, np.array([r[1] for r in rows]))
         if _is_rank0():  # (data-parallel runs: one writer for the shared artefact files; every rank logs its own envs' rewards in memory)
@@ -969,78 +997,80 @@ class A2C(object):
         g = self._host_offsets(env.graph_matrix())
         slot = pool.put(g)
         pool.ref[slot] = 1
-        while temp_i < self.epoch:
-            s_t = PoolRef.many(pool, slot, n_envs)
-            env.actions_all_goals()
-            rewards = env.rewards_all_goals()
-            cand_env, cand_node, cand_first = env.candidates
-            # (a vector step synchronises four times: the export's boundaries, the plans' lengths, the actor's read-out and the
-            # step's results - each with everything the host needs at that point in one copy, Engine.fetch)
-            nfr_h = g["n_frontier_h"].astype(np.int64)
-            batch_data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"], g["node_off"], g["edge_off"], g["max_graph_edges"])
-            batch_data.n_masked = int(nfr_h.sum())
-            mask = frontier_mask(g)
-            with torch.no_grad():
-                readout = self.test(batch_data, g["batch"], mask, device, policy_net).view(-1)  # [C], env-major
-                val = self.test(batch_data, g["batch"], mask, device, value_net).view(-1)       # [n_envs]
-            (p_h,) = env.engine.fetch(readout)
-            choice = sample_frontiers(p_h.astype(np.float64), nfr_h, rng)
-            r_t = rewards[torch.as_tensor(np.cumsum(nfr_h) - nfr_h + choice, device=device)]
-            a_loc = np.diff(g["node_off_h"]).astype(np.int64) - nfr_h + choice  # key_size + choice
-            _, done, _ = env.step(choice, check=False)
-            # envs out of pose capacity are re-created like finished ones, but stay non-terminal (VecExplorationEnv.truncated)
-            done_h, trunc_h, current_done, r_h, val_h = env.engine.fetch(done, env.truncated(), done | env.loop_clo, r_t, val)
-            renew = done_h | trunc_h
-            if renew.any():
-                env.reset(np.nonzero(renew)[0])
-            g1 = self._host_offsets(env.graph_matrix())
-            slot1 = pool.put(g1)
-            pool.ref[slot1] = 1
-            # (a truncated env is re-created, so in the n-step return - and only there - its trajectory ends here: the
-            # bootstrap value and the next state would belong to another episode)
-            self.buffer.append((s_t, a_loc, r_h, current_done | done_h | trunc_h, nfr_h.copy(), val_h))
-            self.step_t += n_envs
-            temp_i += n_envs
-
-            if len(self.buffer) == self.nstep:
+        with _QuietGc() as quiet:  # (the cyclic collector runs at the updates, not between two launches)
+            while temp_i < self.epoch:
+                s_t = PoolRef.many(pool, slot, n_envs)
+                env.actions_all_goals()
+                rewards = env.rewards_all_goals()
+                cand_env, cand_node, cand_first = env.candidates
+                # (a vector step synchronises four times: the export's boundaries, the plans' lengths, the actor's read-out and the
+                # step's results - each with everything the host needs at that point in one copy, Engine.fetch)
+                nfr_h = g["n_frontier_h"].astype(np.int64)
+                batch_data = GraphData(g["x"], g["edge_index"], g["edge_attr"], g["batch"], g["node_off"], g["edge_off"], g["max_graph_edges"])
+                batch_data.n_masked = int(nfr_h.sum())
+                mask = frontier_mask(g)
                 with torch.no_grad():
-                    b1 = GraphData(g1["x"], g1["edge_index"], g1["edge_attr"], g1["batch"], g1["node_off"], g1["edge_off"], g1["max_graph_edges"])
-                    last_value = self.test(b1, g1["batch"], frontier_mask(g1), device, value_net).view(-1).cpu().numpy()
-                T = self.nstep
-                disc = self.discounted_returns(np.stack([b[2] for b in self.buffer]), np.stack([b[3] for b in self.buffer]),
-                                               last_value, self.GAMMA)
-                # trajectory-major (env by env, then time), as the reference's DataLoader over one env's buffer; the per-node
-                # vectors (one-hot action, frontier mask, advantage at the action node) are built for all graphs at once
-                items = [self.buffer[t][0][i] for i in range(n_envs) for t in range(T)]
-                nn_ = np.array([d.num_nodes for d in items], dtype=np.int64)
-                al_ = np.stack([b[1] for b in self.buffer]).T.reshape(-1)       # [env, t] -> flat
-                fro_ = np.stack([b[4] for b in self.buffer]).T.reshape(-1)
-                v_ = np.stack([b[5] for b in self.buffer]).T.reshape(-1)
-                dr_ = disc.T.reshape(-1)
-                off_ = np.cumsum(nn_) - nn_
-                tot_ = int(nn_.sum())
-                a_all = np.zeros(tot_, dtype=np.float32)
-                a_all[off_ + al_] = 1.0
-                y_all = np.zeros(tot_, dtype=np.float32)
-                y_all[off_ + al_] = (dr_ - v_).astype(np.float32)
-                local = np.arange(tot_) - np.repeat(off_, nn_)
-                m_all = local >= np.repeat(nn_ - fro_, nn_)
-                self.train(items, a_all, m_all, dr_, y_all, device, policy_net, value_net, optimizer, n_traj=n_envs)
-                temp_loss_data.append([self.step_t, self.temp_loss])
-                self.buffer.clear()
-                for k in range(pool.n_slots):
-                    pool.ref[k] = 1 if k == slot1 else 0
-            g, slot = g1, slot1
+                    readout = self.test(batch_data, g["batch"], mask, device, policy_net).view(-1)  # [C], env-major
+                    val = self.test(batch_data, g["batch"], mask, device, value_net).view(-1)       # [n_envs]
+                (p_h,) = env.engine.fetch(readout)
+                choice = sample_frontiers(p_h.astype(np.float64), nfr_h, rng)
+                r_t = rewards[torch.as_tensor(np.cumsum(nfr_h) - nfr_h + choice, device=device)]
+                a_loc = np.diff(g["node_off_h"]).astype(np.int64) - nfr_h + choice  # key_size + choice
+                _, done, _ = env.step(choice, check=False)
+                # envs out of pose capacity are re-created like finished ones, but stay non-terminal (VecExplorationEnv.truncated)
+                done_h, trunc_h, current_done, r_h, val_h = env.engine.fetch(done, env.truncated(), done | env.loop_clo, r_t, val)
+                renew = done_h | trunc_h
+                if renew.any():
+                    env.reset(np.nonzero(renew)[0])
+                g1 = self._host_offsets(env.graph_matrix())
+                slot1 = pool.put(g1)
+                pool.ref[slot1] = 1
+                # (a truncated env is re-created, so in the n-step return - and only there - its trajectory ends here: the
+                # bootstrap value and the next state would belong to another episode)
+                self.buffer.append((s_t, a_loc, r_h, current_done | done_h | trunc_h, nfr_h.copy(), val_h))
+                self.step_t += n_envs
+                temp_i += n_envs
 
-            if log_every and (self.step_t // n_envs) % log_every == 0:
-                print("TIMESTEP", self.step_t, "/ Loss", self.temp_loss, "/ Entropy", self.entro,
-                      "/ EXPLORED", float(env.status().mean()), "/ REWARD", float(r_h.mean()))
-            rows.extend([self.step_t, float(x)] for x in r_h)
-            self.total_reward = np.append(self.total_reward, r_h)
-            if self.step_t // 5e4 > (self.step_t - n_envs) // 5e4:
-                save_state_dict(policy_net, os.path.join(self.weights_path, "MyModel.pt"))
-            if self.step_t > 1000 and self.step_t // 100 > (self.step_t - n_envs) // 100:
-                temp_reward_data.append([self.step_t, float(np.average(self.total_reward[-1000:]))])
+                if len(self.buffer) == self.nstep:
+                    with torch.no_grad():
+                        b1 = GraphData(g1["x"], g1["edge_index"], g1["edge_attr"], g1["batch"], g1["node_off"], g1["edge_off"], g1["max_graph_edges"])
+                        last_value = self.test(b1, g1["batch"], frontier_mask(g1), device, value_net).view(-1).cpu().numpy()
+                    T = self.nstep
+                    disc = self.discounted_returns(np.stack([b[2] for b in self.buffer]), np.stack([b[3] for b in self.buffer]),
+                                                   last_value, self.GAMMA)
+                    # trajectory-major (env by env, then time), as the reference's DataLoader over one env's buffer; the per-node
+                    # vectors (one-hot action, frontier mask, advantage at the action node) are built for all graphs at once
+                    items = [self.buffer[t][0][i] for i in range(n_envs) for t in range(T)]
+                    nn_ = np.array([d.num_nodes for d in items], dtype=np.int64)
+                    al_ = np.stack([b[1] for b in self.buffer]).T.reshape(-1)       # [env, t] -> flat
+                    fro_ = np.stack([b[4] for b in self.buffer]).T.reshape(-1)
+                    v_ = np.stack([b[5] for b in self.buffer]).T.reshape(-1)
+                    dr_ = disc.T.reshape(-1)
+                    off_ = np.cumsum(nn_) - nn_
+                    tot_ = int(nn_.sum())
+                    a_all = np.zeros(tot_, dtype=np.float32)
+                    a_all[off_ + al_] = 1.0
+                    y_all = np.zeros(tot_, dtype=np.float32)
+                    y_all[off_ + al_] = (dr_ - v_).astype(np.float32)
+                    local = np.arange(tot_) - np.repeat(off_, nn_)
+                    m_all = local >= np.repeat(nn_ - fro_, nn_)
+                    self.train(items, a_all, m_all, dr_, y_all, device, policy_net, value_net, optimizer, n_traj=n_envs)
+                    temp_loss_data.append([self.step_t, self.temp_loss])
+                    self.buffer.clear()
+                    quiet.tick()
+                    for k in range(pool.n_slots):
+                        pool.ref[k] = 1 if k == slot1 else 0
+                g, slot = g1, slot1
+
+                if log_every and (self.step_t // n_envs) % log_every == 0:
+                    print("TIMESTEP", self.step_t, "/ Loss", self.temp_loss, "/ Entropy", self.entro,
+                          "/ EXPLORED", float(env.status().mean()), "/ REWARD", float(r_h.mean()))
+                rows.extend([self.step_t, float(x)] for x in r_h)
+                self.total_reward = np.append(self.total_reward, r_h)
+                if self.step_t // 5e4 > (self.step_t - n_envs) // 5e4:
+                    save_state_dict(policy_net, os.path.join(self.weights_path, "MyModel.pt"))
+                if self.step_t > 1000 and self.step_t // 100 > (self.step_t - n_envs) // 100:
+                    temp_reward_data.append([self.step_t, float(np.average(self.total_reward[-1000:]))])
 
         if _is_rank0():  # (data-parallel runs: one writer for the shared artefact files; every rank logs its own envs' rewards in memory)
             np.savetxt(os.path.join(self.object_path, "temp_reward.csv"), np.array(temp_reward_data).reshape(-1, 2), delimiter=",")

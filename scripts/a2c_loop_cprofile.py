@@ -40,4 +40,4 @@ with tempfile.TemporaryDirectory() as tmp:
 print("%.2f ms per vector step" % (dt / iters * 1e3))
 if os.environ.get("SPLIT"): print("  of which the update: %.2f ms per vector step (%.1f ms per update); stepping %.2f ms" % (upd[0] / iters * 1e3, upd[0] * 1e3, (dt - upd[0]) / iters * 1e3))
 if not os.environ.get("NOPROF"):
-    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+    st = pstats.Stats(pr); st.sort_stats(os.environ.get("SORT", "tottime")).print_stats(int(os.environ.get("TOP", "28")))
