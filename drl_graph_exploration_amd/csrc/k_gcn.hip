@@ -538,6 +538,23 @@ __global__ __launch_bounds__(256) void k_aggregate(int N, int hidden, const floa
   }
 }
 
+// workgroup id -> (row panel tm, column tile tn) of a launch of tiles_n * roundup8(tiles_m) workgroups (x) per K-slice (z); false: no tile.
+// XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs; XCD x gets the row panels x, x + 8, ... and walks a
+// panel's column tiles on consecutive slots (the panel of A stays in its L2).  With fewer row panels than XCDs - the read-out layer's
+// weight gradient, M = out_dim rows: ONE panel - that order would put the whole launch on tiles_m XCDs (32 CUs each: 357 us for a
+// 4.4 GFLOP product); such launches take the plain order, consecutive tiles on consecutive XCDs.
+__device__ __forceinline__ bool tile_of_block(int tiles_m, int tiles_n, int &tm, int &tn) {
+  if (tiles_m < 8) {
+    tm = blockIdx.x % tiles_m;
+    tn = blockIdx.x / tiles_m;
+    return tn < tiles_n;
+  }
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  tn = slot % tiles_n;
+  tm = (slot / tiles_n) * 8 + xcd;
+  return tm < tiles_m;
+}
+
 // EPI 3's factor at element `at` of the [M x ldc] matrices: the ReLU gate recovered from G = H2 (k_dz2) times the dropout mask
 __device__ __forceinline__ float gate3(const float *G, const float *mask, size_t at) {
   float g = G[at] > 0.f ? 1.f : 0.f;
@@ -601,9 +618,8 @@ __global__ __launch_bounds__(256) void k_gemm_dl(int M, int N, int K, const floa
                                                  const float *__restrict__ mask, int k_per_split, int tiles_m, int tiles_n) {
   __shared__ __attribute__((aligned(16))) float As[DL_ST][64 * 16];
   __shared__ __attribute__((aligned(16))) float Bs[DL_ST][16 * 64];
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tn = slot % tiles_n, tm = (slot / tiles_n) * 8 + xcd;
-  if (tm >= tiles_m) return;
+  int tm, tn;
+  if (!tile_of_block(tiles_m, tiles_n, tm, tn)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = tm * 64, n0 = tn * 64;
@@ -778,9 +794,8 @@ __global__ __launch_bounds__(256) void k_gemm(
   __shared__ __attribute__((aligned(16))) float Bs[3][TileF<NI>::value];
   // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give XCD x the row panels
   // p = x, x + 8, ... and walk a panel's column tiles on consecutive slots of the same XCD
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tn = slot % tiles_n, tm = (slot / tiles_n) * 8 + xcd;
-  if (tm >= tiles_m) return;
+  int tm, tn;
+  if (!tile_of_block(tiles_m, tiles_n, tm, tn)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -989,9 +1004,8 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_wide(int M, int N, int K, cons
   extern __shared__ __attribute__((aligned(16))) float wd_smem[];
   using WT = WideTile<RT, NW>;
   constexpr int TM = 16 * RT, WD_N = 16 * NW;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tn = slot % tiles_n, tm = (slot / tiles_n) * 8 + xcd;
-  if (tm >= tiles_m) return;
+  int tm, tn;
+  if (!tile_of_block(tiles_m, tiles_n, tm, tn)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = tm * TM, n0 = tn * WD_N;
   const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
@@ -1572,7 +1586,12 @@ void gemm_tn_splitk(hipStream_t st, const GcnWs &w, int M, int N, int K, const f
     gemm<true, false, 0>(st, M, N, K, A, lda, B, ldb, C, N, nullptr, nullptr, 1);
     return;
   }
-  gemm<true, false, 0>(st, M, N, K, A, lda, B, ldb, w.part, N, nullptr, nullptr, S);
+#ifndef DRLGX_THIN_TN_WIDE  // (A/B: the tall tile for the thin product too)
+  if (max_splits > 8)  // thin M: 64 x 64 tiles
+    gemm_tile<true, false, 0, 1, 1>(st, M, N, K, A, lda, B, ldb, w.part, N, nullptr, nullptr, kps);
+  else
+#endif
+    gemm<true, false, 0>(st, M, N, K, A, lda, B, ldb, w.part, N, nullptr, nullptr, S);
   hipLaunchKernelGGL(k_splitk_reduce, dim3((M * N + 255) / 256), dim3(256), 0, st, M * N, S, w.part, C);
 }
 
