@@ -714,6 +714,9 @@ void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t s
                        const int *cnt = nullptr,  // S.cnt: copy the live part of per-pose / -landmark / -factor fields only
                        const DrlgxState *panel = nullptr);  // &S: the same launch copies the instances' covariance panels too
 void drlgx_launch_rebase(const DrlgxState &S, hipStream_t st, int base0, int n);
+// head of a packed status read: the status word + n_envs pose counts, rounded up to 16 bytes (k_fetch_pack)
+inline size_t drlgx_fetch_head_bytes(int n_envs) { return ((size_t)(n_envs + 1) * sizeof(int) + 15) & ~(size_t)15; }
+void drlgx_launch_fetch_pack(const DrlgxState &S, hipStream_t st, const void *src, size_t bytes, void *out);
 void drlgx_launch_fix_rollouts(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0);
 void drlgx_launch_rewards(const DrlgxState &S, hipStream_t st, int n_cand, const int32_t *cand_env, int roll0,
                           double *rewards);

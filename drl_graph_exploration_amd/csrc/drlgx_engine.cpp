@@ -66,6 +66,14 @@ struct drlgx_engine {
   double *fixed_lm_dev = nullptr;  // drlgx_set_fixed_landmarks_host
   unsigned char *simlog_dev = nullptr;  // the look-ahead's simulator log (k_presim), n_rollouts x max_actions entries
   bool la_presim = true;
+  // drlgx_status_host / drlgx_status_fetch_host wait by polling an event (DRLGX_SYNC_SPIN=0: hipStreamSynchronize): a trainer's vector
+  // step reads the status word four times, each on the critical path between two launches, and a blocking wait hands the thread
+  // back tens of microseconds after the stream drained
+  bool spin_sync = true;
+  hipEvent_t sync_event = nullptr;
+  // packed status reads (k_fetch_pack): device staging and its pinned host mirror, grown on demand
+  unsigned char *fetch_dev = nullptr, *fetch_host = nullptr;
+  size_t fetch_cap = 0;
   int n_cu = 256;       // compute units of the device (drlgx_create)
   bool la_loop = true;  // look-ahead rollouts: one launch for a candidate's whole action list (k_step_loop)
   // FastMarginals2 workspaces (allocated on first use): dense prior covariances, per-candidate scratch
@@ -203,6 +211,8 @@ int drlgx_create(const drlgx_config *cfg, int n_envs, int n_rollouts, int device
     e->by_capacity = v && v[0] == '1';
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cu = prop.multiProcessorCount;
+    const char *ss = getenv("DRLGX_SYNC_SPIN");
+    e->spin_sync = !(ss && ss[0] == '0');
     const char *lp = getenv("DRLGX_LOOKAHEAD_PRESIM");  // 0: every rollout action simulates inside its belief step (the A/B of the parity test)
     e->la_presim = !(lp && lp[0] == '0');
     const char *ll = getenv("DRLGX_LOOKAHEAD_LOOP");  // 0: one launch per action index (the A/B of the look-ahead tests)
@@ -505,6 +515,9 @@ int drlgx_destroy(drlgx_engine *e) {
     hipEventDestroy(sp.b);
   }
   for (auto ev : e->free_events) hipEventDestroy(ev);
+  if (e->sync_event) hipEventDestroy(e->sync_event);
+  if (e->fetch_dev) hipFree(e->fetch_dev);
+  if (e->fetch_host) hipHostFree(e->fetch_host);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
   delete e;
   return DRLGX_OK;
@@ -534,18 +547,49 @@ static int max_bound(const drlgx_engine *e) {
   return m;
 }
 
+// the stream drained, observed by polling (see drlgx_engine::spin_sync)
+static hipError_t stream_wait(drlgx_engine *e) {
+  if (!e->spin_sync) return hipStreamSynchronize(e->stream);
+  if (!e->sync_event && hipEventCreateWithFlags(&e->sync_event, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    e->spin_sync = false;
+    return hipStreamSynchronize(e->stream);
+  }
+  hipError_t r = hipEventRecord(e->sync_event, e->stream);
+  if (r != hipSuccess) return r;
+  while ((r = hipEventQuery(e->sync_event)) == hipErrorNotReady) {
+  }
+  return r;
+}
+
+// status word + pose counts (+ `bytes` of the caller's device memory -> dst_host) in one launch, one copy and one wait
+static int status_fetch(drlgx_engine *e, const void *src_dev, size_t bytes, void *dst_host) {
+  const size_t head = drlgx_fetch_head_bytes(e->S.n_envs), total = head + ((bytes + 15) & ~(size_t)15);
+  if (total > e->fetch_cap) {
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->fetch_dev) (void)hipFree(e->fetch_dev);
+    if (e->fetch_host) (void)hipHostFree(e->fetch_host);
+    e->fetch_dev = e->fetch_host = nullptr;
+    e->fetch_cap = 0;
+    const size_t cap = std::max<size_t>(2 * total, 1 << 16);
+    HIPCHK(e, hipMalloc(reinterpret_cast<void **>(&e->fetch_dev), cap));
+    HIPCHK(e, hipHostMalloc(reinterpret_cast<void **>(&e->fetch_host), cap, hipHostMallocDefault));
+    e->fetch_cap = cap;
+  }
+  drlgx_launch_fetch_pack(e->S, e->stream, src_dev, bytes, e->fetch_dev);
+  HIPCHK(e, hipMemcpyAsync(e->fetch_host, e->fetch_dev, head + bytes, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, stream_wait(e));
+  const int32_t *h = reinterpret_cast<const int32_t *>(e->fetch_host);
+  // the same synchronisation refreshes the host's pose-count bounds with the exact device values
+  for (int i = 0; i < e->S.n_envs; ++i) e->pbound[i] = std::min(std::max((int)h[1 + i], 1), e->S.P_max);
+  if (bytes) std::memcpy(dst_host, e->fetch_host + head, bytes);
+  return h[0];
+}
+
 int drlgx_status_host(drlgx_engine *e) {
   DRLGX_ENTER(e);
   if (!e) return DRLGX_E_INVALID;
-  int st = 0;
-  // the same synchronisation refreshes the host's pose-count bounds with the exact device values
-  std::vector<int32_t> poses(e->S.n_envs);
-  HIPCHK(e, hipMemcpyAsync(&st, e->S.status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipMemcpy2DAsync(poses.data(), sizeof(int32_t), e->S.cnt + C_P, DRLGX_CNT_STRIDE * sizeof(int32_t), sizeof(int32_t),
-                             e->S.n_envs, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
-  for (int i = 0; i < e->S.n_envs; ++i) e->pbound[i] = std::min(std::max((int)poses[i], 1), e->S.P_max);
-  return st;
+  return status_fetch(e, nullptr, 0, nullptr);
 }
 
 int drlgx_status_fetch_host(drlgx_engine *e, const void *src_dev, size_t bytes, void *dst_host) {
@@ -553,8 +597,7 @@ int drlgx_status_fetch_host(drlgx_engine *e, const void *src_dev, size_t bytes, 
   if (!e || (bytes > 0 && (!src_dev || !dst_host))) return DRLGX_E_INVALID;
   // the caller's bytes ride on the status read's synchronisation (a vector step of a trainer needs a handful of small device
   // results on the host: every separate read drains the stream again)
-  if (bytes > 0) HIPCHK(e, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, e->stream));
-  return drlgx_status_host(e);
+  return status_fetch(e, src_dev, bytes, dst_host);
 }
 
 int drlgx_reset_host(drlgx_engine *e, int n, const int32_t *env_ids, const uint32_t *seeds, const double *start) {

@@ -88,6 +88,24 @@ __global__ __launch_bounds__(256) void k_copy_instances(const DrlgxField *fields
   }
 }
 
+// What a status read brings to the host, packed for ONE copy: [status word, every env's pose count] (head bytes, a multiple of 16),
+// then the caller's bytes (drlgx_status_fetch_host).  Separate copies - a word, a strided column of the counters, the caller's
+// buffer - cost more in submission than this launch: 40 us per read on an idle stream against ~15 for a single copy.
+__global__ __launch_bounds__(256) void k_fetch_pack(const int *status, const int *cnt, int n_envs, int head, const unsigned char *src,
+                                                    size_t bytes, unsigned char *out) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
+  int *h = reinterpret_cast<int *>(out);
+  for (size_t i = t; i < (size_t)n_envs + 1; i += nt) h[i] = i == 0 ? status[0] : cnt[(i - 1) * DRLGX_CNT_STRIDE + C_P];
+  unsigned char *o = out + head;
+  if (((reinterpret_cast<uintptr_t>(src) | bytes) & 15) == 0) {
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+    uint4 *o4 = reinterpret_cast<uint4 *>(o);
+    for (size_t i = t; i < bytes / 16; i += nt) o4[i] = s4[i];
+  } else {
+    for (size_t i = t; i < bytes; i += nt) o[i] = src[i];
+  }
+}
+
 // SLAM2D::set_copy_isam: theta := calculateBestEstimate(), delta := 0, fresh ISAM2 (update count 0)
 __global__ __launch_bounds__(64) void k_rebase(DrlgxState S, int base0, int n) {
   const int inst = base0 + blockIdx.x;
@@ -292,6 +310,12 @@ void drlgx_launch_copy(const DrlgxField *fields_dev, int n_fields, hipStream_t s
   const dim3 cgrid(n_fields + (with_panel ? kCopySplit : 0), n);
   hipLaunchKernelGGL(k_copy_instances, cgrid, dim3(256), 0, st, fields_dev, n_fields, src, dst,
                      src_off, dst_off, skip_mask, cnt, with_panel ? *panel : DrlgxState{}, with_panel ? 1 : 0);
+}
+void drlgx_launch_fetch_pack(const DrlgxState &S, hipStream_t st, const void *src, size_t bytes, void *out) {
+  const size_t head = drlgx_fetch_head_bytes(S.n_envs);
+  const int blocks = (int)std::min<size_t>(256, (head + bytes + 4095) / 4096);
+  hipLaunchKernelGGL(k_fetch_pack, dim3(std::max(blocks, 1)), dim3(256), 0, st, S.status, S.cnt, S.n_envs, (int)head,
+                     reinterpret_cast<const unsigned char *>(src), bytes, reinterpret_cast<unsigned char *>(out));
 }
 void drlgx_launch_rebase(const DrlgxState &S, hipStream_t st, int base0, int n) {
   hipLaunchKernelGGL(k_rebase, dim3(n), dim3(64), 0, st, S, base0, n);

@@ -261,12 +261,15 @@ class Engine(object):
             self._gcap = (a.value, b.value, c.value)
         return self._gcap
 
-    def graph(self):
+    def graph(self, plan=False):
         """Batched ExplorationEnv.graph_matrix + DeepQ.data_process for all envs (one PyG-style batch).
         Returns a dict of CUDA tensors: x [N,5] f32, edge_index [2,E] i64, edge_attr [E] f32, node_off / edge_off
         [n_envs+1] i32, batch [N] i64, n_frontier [n_envs] i32, frontier_xy [n_envs,Fmax,2] f64,
         nearest_frontier_node [n_envs] i32 (local node id); max_graph_edges = the largest graph's edge count (host int);
-        node_off_h / edge_off_h / n_frontier_h = host copies (numpy).  Raises on a non-zero status word (check_status)."""
+        node_off_h / edge_off_h / n_frontier_h = host copies (numpy).  Raises on a non-zero status word (check_status).
+        plan=True: the line plan to EVERY frontier slot rides along (drlgx_line_plan over all n_envs x Fmax slots, the unused ones
+        planned towards the origin and ignored): actions_pad [n_envs, Fmax, max_actions, 3] f64, n_act_pad [n_envs, Fmax] i32 and
+        its host copy n_act_pad_h - the plans' lengths reach the host in the export's own synchronisation."""
         self.use_torch_stream()
         if not hasattr(self, "_gcap"):
             a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
@@ -283,15 +286,25 @@ class Engine(object):
         fxy = torch.zeros(self.n_envs, mf, 2, dtype=torch.float64, device=dev)
         near = torch.empty(self.n_envs, dtype=torch.int32, device=dev)
         self._chk(self.L.drlgx_graph(self.h, _p(node_off), _p(edge_off), _p(x), _p(ei), _p(ea), _p(nfr), _p(fxy), _p(near)))
+        extra = {}
+        if plan:
+            if getattr(self, "_pad_env", None) is None:
+                self._pad_env = torch.arange(self.n_envs, device=dev, dtype=torch.int32).repeat_interleave(mf).contiguous()
+            acts, n_act = self.line_plan(self._pad_env, fxy.view(-1, 2))
+            extra = dict(actions_pad=acts.view(self.n_envs, mf, -1, 3), n_act_pad=n_act.view(self.n_envs, mf))
         # the batch's boundaries and frontier counts on the host too, with the status word, in ONE synchronisation (keys *_h)
-        node_off_h, edge_off_h, nfr_h = self.fetch(node_off, edge_off, nfr)
+        if plan:
+            node_off_h, edge_off_h, nfr_h, n_act_h = self.fetch(node_off, edge_off, nfr, extra["n_act_pad"])
+            extra["n_act_pad_h"] = n_act_h
+        else:
+            node_off_h, edge_off_h, nfr_h = self.fetch(node_off, edge_off, nfr)
         N, E = int(node_off_h[-1]), int(edge_off_h[-1])
         counts = (node_off[1:] - node_off[:-1]).to(torch.int64)
         batch = torch.repeat_interleave(torch.arange(self.n_envs, device=dev), counts, output_size=N)
         return dict(x=x[:N], edge_index=ei[:2 * E].view(2, E), edge_attr=ea[:E], node_off=node_off, edge_off=edge_off,
                     batch=batch, n_frontier=nfr, frontier_xy=fxy, nearest_frontier_node=near,
                     max_graph_edges=int(np.diff(edge_off_h).max()) if self.n_envs else 0,
-                    node_off_h=node_off_h, edge_off_h=edge_off_h, n_frontier_h=nfr_h)
+                    node_off_h=node_off_h, edge_off_h=edge_off_h, n_frontier_h=nfr_h, **extra)
 
     def snapshot(self, slot=0):
         self.use_torch_stream()

@@ -88,6 +88,11 @@ def broadcast_parameters(model, src=0, group=None):
         dist.broadcast(t.data, src=src, group=group)
 
 
+# the trainers' exports plan the line to every frontier in the same call (VecExplorationEnv.graph_matrix(plan=True)); DRLGX_EXPORT_PLAN=0:
+# a separate actions_all_goals() with its own synchronisation (A/B runs)
+_EXPORT_PLAN = os.environ.get("DRLGX_EXPORT_PLAN", "1") != "0"
+
+
 class _QuietGc(object):
     """Python's cyclic collector held off while a trainer's loop runs.  A vector step allocates a few thousand short-lived
     containers (one PoolRef / buffer tuple / log row per env); the automatic collections they trigger walk the whole heap of a
@@ -714,7 +719,7 @@ class DeepQ(object):
         temp_reward_data, temp_loss_data, rows = [], [], []
         recent = deque(self.total_reward[-1000:].tolist(), maxlen=1000)  # average reward window (policy.py:201-203)
 
-        g = self._host_offsets(env.graph_matrix())
+        g = self._host_offsets(env.graph_matrix(plan=_EXPORT_PLAN))
         slot_t = pool.put(g)
         pool.ref[slot_t] += 1  # the current state's export is held until the next one replaces it
         with _QuietGc() as quiet:  # (the cyclic collector runs at the updates, not between two launches)
@@ -750,7 +755,7 @@ class DeepQ(object):
                 # then `env = ExplorationEnv(...)` at :185-189); envs that ran out of pose capacity are re-created too, but
                 # their transition stays non-terminal (VecExplorationEnv.truncated)
                 renew = done_h | trunc_h
-                g1 = self._host_offsets(env.graph_matrix())
+                g1 = self._host_offsets(env.graph_matrix(plan=_EXPORT_PLAN))
                 nfr1 = g1["n_frontier_h"] if "n_frontier_h" in g1 else g1["n_frontier"].cpu().numpy()
                 slot_t1 = pool.put(g1)
                 refs_t, refs_t1 = PoolRef.many(pool, slot_t, n_envs), PoolRef.many(pool, slot_t1, n_envs)
@@ -763,7 +768,7 @@ class DeepQ(object):
                         release(self.buffer.popleft())
                 if renew.any():
                     env.reset(np.nonzero(renew)[0])
-                    g1 = self._host_offsets(env.graph_matrix())
+                    g1 = self._host_offsets(env.graph_matrix(plan=_EXPORT_PLAN))
                     slot_t1 = pool.put(g1)
                 pool.ref[slot_t1] += 1
                 pool.ref[slot_t] -= 1
@@ -994,7 +999,7 @@ class A2C(object):
                     pool.ref[d.slot] = 1
                 else:  # re-loaded from saved_training.pkl (host graphs) or pooled elsewhere: onto this device, once
                     b[0][k] = d.to(device)
-        g = self._host_offsets(env.graph_matrix())
+        g = self._host_offsets(env.graph_matrix(plan=_EXPORT_PLAN))
         slot = pool.put(g)
         pool.ref[slot] = 1
         with _QuietGc() as quiet:  # (the cyclic collector runs at the updates, not between two launches)
@@ -1014,15 +1019,15 @@ class A2C(object):
                     val = self.test(batch_data, g["batch"], mask, device, value_net).view(-1)       # [n_envs]
                 (p_h,) = env.engine.fetch(readout)
                 choice = sample_frontiers(p_h.astype(np.float64), nfr_h, rng)
-                r_t = rewards[torch.as_tensor(np.cumsum(nfr_h) - nfr_h + choice, device=device)]
+                _, done, _ = env.step(choice, check=False)  # (first thing after the read-out: the device waits for this launch)
+                r_t = rewards[env.last_pick]
                 a_loc = np.diff(g["node_off_h"]).astype(np.int64) - nfr_h + choice  # key_size + choice
-                _, done, _ = env.step(choice, check=False)
                 # envs out of pose capacity are re-created like finished ones, but stay non-terminal (VecExplorationEnv.truncated)
                 done_h, trunc_h, current_done, r_h, val_h = env.engine.fetch(done, env.truncated(), done | env.loop_clo, r_t, val)
                 renew = done_h | trunc_h
                 if renew.any():
                     env.reset(np.nonzero(renew)[0])
-                g1 = self._host_offsets(env.graph_matrix())
+                g1 = self._host_offsets(env.graph_matrix(plan=_EXPORT_PLAN))
                 slot1 = pool.put(g1)
                 pool.ref[slot1] = 1
                 # (a truncated env is re-created, so in the n-step return - and only there - its trajectory ends here: the

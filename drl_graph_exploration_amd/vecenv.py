@@ -126,24 +126,35 @@ class VecExplorationEnv(object):
         return self.engine.virtual_map(int(i))[0]
 
     # ------------------------------------------------------------------ graph export
-    def graph_matrix(self):
+    def graph_matrix(self, plan=False):
         """All envs' graphs as one batch (see Engine.graph); node order per env = [landmarks (hash order), poses,
-        frontiers], edge order = DeepQ.data_process's. Candidate c = (env, frontier) in env-major order."""
-        g = self.engine.graph()  # (one synchronisation: the status word, the batch's boundaries and the frontier counts)
-        nfr = g["n_frontier"].to(torch.int64)
+        frontiers], edge order = DeepQ.data_process's. Candidate c = (env, frontier) in env-major order.
+        plan=True (the trainers): the line plans to all frontiers come out of the same call and the same synchronisation
+        (Engine.graph(plan=True)); actions_all_goals() then has nothing left to do."""
+        g = self.engine.graph(plan=plan)  # (one synchronisation: the status word, the batch's boundaries and the frontier counts)
         nfr_h = g["n_frontier_h"].astype(np.int64)
         n_cand = int(nfr_h.sum())
         self._graph = g
-        self._cand_env = torch.repeat_interleave(torch.arange(self.n_envs, device=self.device), nfr, output_size=n_cand).to(torch.int32)
-        first = torch.cumsum(nfr, 0) - nfr
-        self._cand_first = first
-        self._cand_first_h = np.cumsum(nfr_h) - nfr_h
-        self._n_act_h = None
-        fidx = torch.arange(n_cand, device=self.device) - first[self._cand_env.long()]
+        # the candidate arrays are host arithmetic on the frontier counts: one upload instead of a dozen small launches
+        first_h = np.cumsum(nfr_h) - nfr_h
+        env_h = np.repeat(np.arange(self.n_envs, dtype=np.int64), nfr_h)
+        fidx_h = np.arange(n_cand, dtype=np.int64) - first_h[env_h]
+        node_h = g["node_off_h"][1:].astype(np.int64)[env_h] - nfr_h[env_h] + fidx_h  # node_off[e+1] - n_frontier[e] + f
+        mf = g["frontier_xy"].shape[1]
+        up = torch.as_tensor(np.concatenate([env_h, fidx_h, node_h, env_h * mf + fidx_h, first_h]), device=self.device)
+        env_t, fidx, node_t, slot_t, first = (up[:n_cand], up[n_cand:2 * n_cand], up[2 * n_cand:3 * n_cand], up[3 * n_cand:4 * n_cand],
+                                              up[4 * n_cand:])
+        self._cand_env = env_t.to(torch.int32)
+        self._cand_first, self._cand_first_h = first, first_h
         self._cand_fidx = fidx
-        self._goals = g["frontier_xy"][self._cand_env.long(), fidx].contiguous()
-        # global node id of every candidate: node_off[e+1] - n_frontier[e] + f
-        self._cand_node = (g["node_off"][1:].to(torch.int64)[self._cand_env.long()] - nfr[self._cand_env.long()] + fidx)
+        self._cand_node = node_t
+        self._goals = g["frontier_xy"].view(-1, 2)[slot_t].contiguous()
+        self._n_act_h = None
+        self._actions = self._n_act = None
+        if plan:
+            self._actions = g["actions_pad"].view(self.n_envs * mf, -1, 3)[slot_t].contiguous()
+            self._n_act = g["n_act_pad"].view(-1)[slot_t].contiguous()
+            self._n_act_h = g["n_act_pad_h"].reshape(-1)[env_h * mf + fidx_h]
         return g
 
     @property
@@ -155,6 +166,8 @@ class VecExplorationEnv(object):
         """Line plan to every frontier: (actions [C, max_actions, 3] f64, n_actions [C] i32)."""
         if self._graph is None:
             self.graph_matrix()
+        if self._actions is not None:  # (graph_matrix(plan=True) planned already)
+            return self._actions, self._n_act
         self._actions, self._n_act = self.engine.line_plan(self._cand_env, self._goals)
         # the plans' lengths on the host: the look-ahead and the step launch the action indices some plan reaches
         (self._n_act_h,) = self.engine.fetch(self._n_act)
@@ -181,9 +194,12 @@ class VecExplorationEnv(object):
         `engine.fetch` / `engine.check_status` (the trainers read the step's results with one)."""
         kmax = None
         if not torch.is_tensor(choice) and self._n_act_h is not None:
-            kmax = int(self._n_act_h[self._cand_first_h + np.asarray(choice, dtype=np.int64)].max())
-        choice = torch.as_tensor(choice, device=self.device).long()
-        c = self._cand_first + choice
+            c_h = self._cand_first_h + np.asarray(choice, dtype=np.int64)
+            kmax = int(self._n_act_h[c_h].max())
+            c = torch.as_tensor(c_h, device=self.device)
+        else:
+            c = self._cand_first + torch.as_tensor(choice, device=self.device).long()
+        self.last_pick = c  # the chosen candidates' indices (device, int64)
         acts = self._actions[c]  # [n_envs, A, 3]
         nact = self._n_act[c]
         return self.step_actions(acts, nact, kmax=kmax, check=check)

@@ -18,6 +18,7 @@ with tempfile.TemporaryDirectory() as tmp:
     a2c.epoch, a2c.nstep = n_envs * 2, 2
     a2c.running(actor, critic, test=True, env=env)
     a2c.nstep = 40
+    a2c.graphs_per_pass = int(os.environ.get("GPP", a2c.graphs_per_pass))
     a2c.buffer.clear()
     a2c.epoch = n_envs * iters
     import gc
@@ -28,6 +29,7 @@ with tempfile.TemporaryDirectory() as tmp:
         _train(*a, **k)
         torch.cuda.synchronize(); upd[0] += time.perf_counter() - t
     if os.environ.get("SPLIT"): a2c.train = timed_train
+    if os.environ.get("NOUPD"): a2c.train = lambda *a, **k: None  # (stepping only)
     if os.environ.get("NOGC"): gc.disable()
     pr = cProfile.Profile()
     torch.cuda.synchronize(); t0 = time.perf_counter()
