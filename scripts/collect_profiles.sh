@@ -52,6 +52,14 @@ python scripts/rocpd_pmc.py "$(db /tmp/prof_c5_fetch)" "$(db /tmp/prof_c5_write)
 timeout 200 python scripts/phase_profile_config5_blocks.py > $out/config5_workgroups.txt 2>&1
 timeout 200 python scripts/phase_profile_config5.py 123 6 > $out/config5_update_phases.txt 2>&1
 timeout 200 python scripts/config5_updates.py > $out/config5_updates.txt 2>&1
+# the A2C trainer loop (bench.py's a2c_loop workload): wall clock split into stepping and update, the kernels' totals per vector step
+# (42 = 2 warm-up + 40 timed steps), the device's idle gaps by the launches around them, the host's profile
+SPLIT=1 NOPROF=1 timeout 200 python scripts/a2c_loop_cprofile.py > $out/a2c_loop_split.txt 2>&1
+NOPROF=1 timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_a2c -o a2c -- python scripts/a2c_loop_cprofile.py > /dev/null 2> $out/rocprof_a2c.err
+timeout 60 python scripts/rocpd_kernel_summary.py "$(db /tmp/prof_a2c)" 30 42 > $out/a2c_loop_kernels.txt 2>&1 < /dev/null
+timeout 60 python scripts/rocpd_gaps.py "$(db /tmp/prof_a2c)" 15 1500 > $out/a2c_loop_idle_gaps.txt 2>&1 < /dev/null
+NOGC=1 SORT=cumtime TOP=40 timeout 200 python scripts/a2c_loop_cprofile.py > $out/a2c_loop_cprofile.txt 2>&1
+timeout 120 python scripts/fetch_latency.py > $out/status_fetch_latency.txt 2>&1
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_gcn -- python $OLDPWD/scripts/profile_gcn.py > /dev/null 2>&1)
 python scripts/rocpd_summary.py "$(db /tmp/prof_gcn)" --by-grid k_ > $out/gcn_kernels_by_grid.csv 2>/dev/null
 ls -la $out

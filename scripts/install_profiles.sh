@@ -10,7 +10,8 @@ done
 cp $src/vs_poses_100lm.txt profiles/${tag}_step_vs_poses_100lm.txt
 cp $src/vs_poses_8lm.txt profiles/${tag}_step_vs_poses_8lm.txt
 for f in lookahead_kernel_stats.csv lookahead_pmc_traffic.json lookahead_breakdown.txt relinearising_update_phases.txt step_workgroups.txt full_fill.json \
-         config5_bench.txt config5_kernel_stats.csv config5_pmc_traffic.json config5_workgroups.txt config5_update_phases.txt config5_updates.txt; do
+         config5_bench.txt config5_kernel_stats.csv config5_pmc_traffic.json config5_workgroups.txt config5_update_phases.txt config5_updates.txt \
+         a2c_loop_split.txt a2c_loop_kernels.txt a2c_loop_idle_gaps.txt a2c_loop_cprofile.txt status_fetch_latency.txt; do
   [ -f $src/$f ] && cp $src/$f profiles/${tag}_$f
 done
 cp $src/pmc_traffic.json profiles/pmc_traffic.json
