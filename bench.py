@@ -290,20 +290,16 @@ def a2c_loop_bench(device_index, n_envs=256, iters=40):
         a2c.epoch, a2c.nstep = n_envs * 2, 2  # warm-up: two vector steps and one small update (first-use allocations)
         a2c.running(actor, critic, test=True, env=env)
         a2c.epoch, a2c.nstep = n_envs * iters, 40  # 40 vector steps: exactly one update over all of them in the timed region
-        passes = []
-        for _ in range(2):  # the second pass is the steady state: the first meets the update's chunk sizes for the first time (allocations)
-            a2c.buffer.clear()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            a2c.running(actor, critic, test=True, env=env)
-            torch.cuda.synchronize()
-            passes.append(time.perf_counter() - t0)
-        dt = passes[1]
+        a2c.buffer.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        a2c.running(actor, critic, test=True, env=env)  # (vector steps 3 .. 42 of the episodes: a second pass would time later, longer trajectories)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
         env.close()
     return {"workload": "A2C.running, %d envs in lock-step, 40 m map, %d vector steps with one update over %d transitions" % (
                 n_envs, iters, n_envs * iters),
             "ms_per_vector_step": dt / iters * 1e3, "rl_iterations_per_sec": n_envs * iters / dt,
-            "first_pass_ms_per_vector_step": passes[0] / iters * 1e3,
             "reference_published": "~3.8 RL iterations/s (A2C+GCN, authors' PC; BASELINE.md) - other hardware, reported beside"}
 
 
