@@ -571,3 +571,44 @@ def test_explicit_self_loops_keep_their_weight():
     out2 = gcn_trunk(x, torch.cat([ei2, bad], dim=1), torch.cat([ea2, torch.ones(2, device=dev)]), P["conv1.weight"], P["conv1.bias"],
                      P["conv2.weight"], P["conv2.bias"], P["fully_con1.weight"], P["fully_con1.bias"], None)
     assert torch.equal(out2, out)
+
+
+def test_a2c_update_without_synchronisations_equals_the_masked_select_form(tmp_path):
+    """A2C.train with the frontier mask as a HOST array (the trainer's call: masked positions as gathers, losses accumulated on the device,
+    no synchronisation per chunk) against the same update with the mask as a device tensor (policy_cost's masked_select, policy.py:452-458):
+    same parameters after the step, same logged loss / entropy, over chunked passes."""
+    from drl_graph_exploration_amd.networks import PolicyGCN, ValueGCN, GraphData
+    from drl_graph_exploration_amd.policy import A2C
+    dev = torch.device("cuda", 0)
+    items, masks = [], []
+    for k in range(10):
+        x, ei, ea, _ = random_batch(1, 40 + k, dev)
+        items.append(GraphData(x, ei, ea))
+        m = np.zeros(x.shape[0], dtype=bool)
+        m[-(3 + k % 4):] = True
+        masks.append(m)
+    m_all = np.concatenate(masks)
+    nn_ = np.array([d.num_nodes for d in items])
+    off = np.cumsum(nn_) - nn_
+    rng = np.random.RandomState(0)
+    a_loc = np.array([int(np.nonzero(m)[0][rng.randint(m.sum())]) for m in masks])
+    a_all = np.zeros(m_all.size, dtype=np.float32)
+    a_all[off + a_loc] = 1.0
+    y_all = np.zeros(m_all.size, dtype=np.float32)
+    y_all[off + a_loc] = rng.randn(len(items)).astype(np.float32)
+    dr = rng.randn(len(items))
+    results = []
+    for host_mask in (True, False):
+        torch.manual_seed(3)
+        a2c = A2C("t%d/" % host_mask, data_root=str(tmp_path))
+        a2c.nstep, a2c.graphs_per_pass = 5, 4
+        actor, critic = PolicyGCN().to(dev), ValueGCN().to(dev)
+        opt = torch.optim.Adam(list(actor.parameters()) + list(critic.parameters()), lr=1e-3)
+        torch.manual_seed(9)  # (the dropout draws of the passes)
+        mask = m_all if host_mask else torch.as_tensor(m_all, device=dev)
+        a2c.train(list(items), a_all, mask, dr, y_all, dev, actor, critic, opt, n_traj=2)
+        results.append((a2c.temp_loss, a2c.entro, [p.detach().clone() for p in list(actor.parameters()) + list(critic.parameters())]))
+    (l0, e0, p0), (l1, e1, p1) = results
+    assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l1)) and abs(e0 - e1) <= 1e-6 * max(1.0, abs(e1)), (l0, l1, e0, e1)
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)

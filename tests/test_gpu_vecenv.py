@@ -621,3 +621,68 @@ def test_whole_plans_in_one_launch_equal_one_launch_per_action(monkeypatch):
     assert max(a.engine.counts(i)["poses"] for i in range(n)) > 66
     for e in (a, b, c):
         e.close()
+
+
+def test_engine_fetch_brings_tensors_and_the_status_word_in_one_read():
+    """Engine.fetch (drlgx_status_fetch_host): every dtype the trainers read comes back with the values and shapes of `.cpu()`, empty
+    and unaligned pieces included; the same read refreshes the host's pose bounds and raises on a non-zero status word."""
+    from drl_graph_exploration_amd import _lib
+    from drl_graph_exploration_amd.vecenv import VecExplorationEnv
+    env = VecExplorationEnv(MAP, 3, env_index=0, test=True, max_poses=40)
+    eng, dev = env.engine, env.device
+    g = torch.Generator(device=dev).manual_seed(1)
+    ts = [torch.randn(7, 3, device=dev, generator=g), torch.randn(5, device=dev, dtype=torch.float64, generator=g),
+          torch.arange(11, device=dev, dtype=torch.int32), torch.arange(3, device=dev), torch.rand(9, device=dev, generator=g) > 0.5,
+          torch.empty(0, device=dev), (torch.arange(13, device=dev) % 3).to(torch.uint8)[1:]]
+    out = eng.fetch(*ts)
+    assert len(out) == len(ts)
+    for t, h in zip(ts, out):
+        assert h.shape == tuple(t.shape) and np.array_equal(h, t.cpu().numpy())
+    assert eng.fetch() == []  # (a plain status read)
+    big = torch.arange(300000, device=dev, dtype=torch.float32)  # (beyond the first staging buffer: it grows)
+    assert np.array_equal(eng.fetch(big)[0], big.cpu().numpy())
+    # the counts' column of poses is what the engine selects its kernels by: exact after a read
+    assert np.array_equal(eng.fetch(eng.counts_dev())[0][:, 0], np.array([eng.counts(i)["poses"] for i in range(3)]))
+    # a capacity overflow (plans longer than the pose capacity) sets the status word: the next read raises
+    acts = torch.zeros(3, env.cfg.max_actions, 3, dtype=torch.float64, device=dev)
+    acts[:, :, 0] = 0.5
+    nact = torch.full((3,), env.cfg.max_actions, dtype=torch.int32, device=dev)
+    with pytest.raises(_lib.DrlgxError):
+        for _ in range(40):
+            env.step_actions(acts, nact, kmax=env.cfg.max_actions, check=False)
+        eng.fetch(nact)
+    env.close()
+
+
+def test_export_with_plans_equals_the_separate_calls():
+    """graph_matrix(plan=True) - the line plans to every frontier slot computed inside the export's call and synchronisation - gives the
+    candidates, plans, rewards and step of graph_matrix() + actions_all_goals(), bit for bit; a host array as the choice steps like a
+    device tensor."""
+    from drl_graph_exploration_amd.vecenv import VecExplorationEnv
+    n = 6
+    envs = [VecExplorationEnv(MAP, n, env_index=3, test=True, max_poses=80) for _ in range(2)]
+    rng = np.random.RandomState(5)
+    for decision in range(4):
+        ga, gb = envs[0].graph_matrix(plan=True), envs[1].graph_matrix()
+        assert envs[0]._n_act_h is not None and envs[1]._n_act_h is None
+        for k in ("x", "edge_index", "edge_attr", "node_off", "edge_off", "n_frontier", "frontier_xy"):
+            assert torch.equal(ga[k], gb[k]), k
+        aa, na = envs[0].actions_all_goals()
+        ab, nb = envs[1].actions_all_goals()
+        assert torch.equal(na, nb) and np.array_equal(envs[0]._n_act_h, nb.cpu().numpy())
+        live = torch.arange(aa.shape[1], device=aa.device)[None, :] < na[:, None]
+        assert torch.equal(aa[live], ab[live])
+        for x, y in zip(envs[0].candidates, envs[1].candidates):
+            assert torch.equal(x, y)
+        ra, rb = envs[0].rewards_all_goals(), envs[1].rewards_all_goals()
+        assert torch.equal(ra, rb) and torch.equal(envs[0].loop_clo, envs[1].loop_clo)
+        nfr = ga["n_frontier_h"]
+        choice = np.array([rng.randint(0, max(int(f), 1)) for f in nfr], dtype=np.int64)
+        _, da, _ = envs[0].step(choice, check=False)                                   # host choice: no synchronisation inside
+        _, db, _ = envs[1].step(torch.as_tensor(choice, device=envs[1].device))      # device choice
+        da_h, = envs[0].engine.fetch(da)
+        assert np.array_equal(da_h, db.cpu().numpy())
+        assert torch.equal(envs[0].engine.counts_dev(), envs[1].engine.counts_dev())
+        assert torch.equal(envs[0].dist, envs[1].dist)
+    for e in envs:
+        e.close()
