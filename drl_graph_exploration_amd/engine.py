@@ -76,7 +76,10 @@ class Engine(object):
         """check_status() with the given device tensors brought to the host under the same synchronisation (one stream drain and
         one copy instead of a `.cpu()` / `.item()` each): returns one numpy array per tensor, same dtype and shape."""
         self.use_torch_stream()
-        parts = [t.contiguous().view(-1).view(torch.uint8) for t in tensors]
+        for t in tensors:
+            if t.device != self.device:
+                raise ValueError("Engine.fetch reads tensors on the engine's device (%s), not %s" % (self.device, t.device))
+        parts = [t.detach().contiguous().view(-1).view(torch.uint8) for t in tensors]
         n = sum(p.numel() for p in parts)
         if n == 0:
             self.check_status()
