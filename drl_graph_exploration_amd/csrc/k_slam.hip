@@ -97,9 +97,10 @@ __host__ __device__ inline size_t sweep_region_doubles(size_t N) {
 }
 constexpr int kWaves = kThreads / 64;
 // The landmark-first dense solve serves systems of up to kDenseTiles tile rows (N = 160: 53 poses).  Up to eight the sweep gives
-// every wave ONE tile row (sweep_packed_fast); nine and ten rows (43 .. 53 poses) are swept by sweep_regtiles - the lower tiles
-// dealt over seven waves, eight accumulator tiles each - which is slower per block step but keeps such updates off the
-// pose-chain solver (k_slam_arrow.hip: ~230 us at 46 poses against ~65 us for the dense solve at 41).
+// every wave ONE tile row (sweep_packed_fast); with nine and ten rows (43 .. 53 poses) two light rows share a wave (rows 1 + 2, and
+// 3 + 4 with ten) - the same block-step loop with one barrier per step.  (Until round 6 such systems went through sweep_regtiles -
+// the lower tiles dealt over seven waves, three barriers per step: 54-58 us against 26 at eight rows.)  Either keeps such updates off
+// the pose-chain solver (k_slam_arrow.hip: ~230 us at 46 poses against ~65 us for the dense solve at 41).
 constexpr int kDenseTiles = 10;
 
 struct SweepCtx {
@@ -358,33 +359,187 @@ __device__ __forceinline__ int acc_off(int lr, int lc, int r) {
   return (lc >> 3) * 128 + 2 * (16 * (lc & 3) + lr + 4 * r) + ((lc >> 2) & 1);
 }
 
-// The sweep of ONE ROLE: the wave that owns tile row I (I = -1: no tile row) and, with kE, inverts the diagonal tiles.
-// The role is a compile-time constant - every register index except "tile column K" is static and the tile loops have no
-// branches - and the block steps are a runtime loop, so each wave runs ~2-5 KB of code that stays in the instruction cache.
+// ONE TILE ROW of the sweep: the tiles (R, 0 .. R) in accumulator registers and what the block steps do to them.  R is a
+// compile-time constant (R = -1: no row) - every register index except "tile column K" is static and the tile loops have no
+// branches.  A role (below) owns one row or two.
+template <int R>
+struct SweepRow {
+  static constexpr int NT = R >= 0 ? R + 1 : 1;
+  v4d acc[NT];
+  static __device__ __forceinline__ int AT(int i, int j) { return i * (i + 1) / 2 + j; }
+
+  __device__ __forceinline__ void load(const double *A, int N, int lr, int lc) {
+    if constexpr (R >= 0) {
+#pragma unroll
+      for (int u = 0; u <= R; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * R + lr + 4 * r, j = 16 * u + lc;
+          acc[u][r] = (i < N && j < N) ? A[AT(max(i, j), min(i, j))] : 0.0;
+        }
+    }
+  }
+  // the first diagonal tile, for E_0
+  __device__ __forceinline__ void dump_d0(const SwL &L, int lane) {
+    if constexpr (R == 0) st_op(L.dscr(0), lane, acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+  }
+  // ---- P: publish the pivot tile column (masked columns / rows as zeros) ----
+  __device__ __forceinline__ void publish(const SwL &L, int K, int np, bool have_next, int lane, int lr, int lc, const int (&aoff)[4]) {
+    if constexpr (R >= 0) {
+      const int kb = 16 * K;
+      double *pan = L.pan(K & 1);
+      if (K <= R) {
+        const bool colact = kb + lc < np;
+        double *pI = pan + 256 * R;
+#pragma unroll
+        for (int u = 0; u <= R; ++u)  // (a ladder of scalar branches selects the statically indexed tile K)
+          if (u == K) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pI[aoff[r]] = colact ? acc[u][r] : 0.0;
+          }
+        if (K == R) {  // the transposed tiles (R, u < R): accumulator registers = operand image of PAN_u
+#pragma unroll
+          for (int u = 0; u < R; ++u)
+            st_op(pan + 256 * u, lane, (kb + lr < np) ? acc[u][0] : 0.0, (kb + lr + 4 < np) ? acc[u][1] : 0.0,
+                  (kb + lr + 8 < np) ? acc[u][2] : 0.0, (kb + lr + 12 < np) ? acc[u][3] : 0.0);
+        }
+      }
+      if (have_next && K + 1 == R)  // current values of the next diagonal tile, for the look-ahead
+        st_op(L.dscr((K + 1) & 1), lane, acc[NT - 1][0], acc[NT - 1][1], acc[NT - 1][2], acc[NT - 1][3]);
+    }
+  }
+  // ---- deferred from step K - 1: its pivot rows A_{K-1,u} <- -(W_u)^T (all rows active: only the last block is masked) ----
+  __device__ __forceinline__ void deferred(const SwL &L, int K, int lane) {
+    if constexpr (R >= 1) {
+      if (K == R + 1) {
+        const double *wp = L.wt((K - 1) & 1);
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          double t[4];
+          ld_op(wp + 256 * u, lane, t);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[u][r] = -t[r];
+        }
+      }
+    }
+  }
+  // ---- W, U ----
+  __device__ __forceinline__ void update(const SwL &L, int K, int np, int lane, int lr, int lc, const int (&aoff)[4]) {
+    if constexpr (R >= 0) {
+      const int kb = 16 * K, b = K & 1;
+      const bool has_mask = np < kb + 16;  // the last block holds the rhs row / pads: they are not pivots
+      const double *pan = L.pan(b);
+      double aP[4], eB[4];
+      ld_op(pan + 256 * R, lane, aP);
+      ld_op(L.einv(b), lane, eB);
+      v4d wv = {0.0, 0.0, 0.0, 0.0};
+      wv = mfma4(eB, aP, wv);  // image of W_R
+      double *wI = L.wt(b) + 256 * R;
+      st_op(wI, lane, wv[0], wv[1], wv[2], wv[3]);
+      const double aW[4] = {wv[0], wv[1], wv[2], wv[3]};
+      if (K != R || has_mask) {
+        // A_Ru += W_R PAN_u^T (tile column K is replaced below, except in wave K whose masked rows keep the update); the
+        // next tile's operand is loaded while this tile's MFMAs run
+        // two tiles at a time: their MFMA chains are independent, so the matrix pipe is issued back to back (a chain on
+        // ONE accumulator waits ~20 cycles per link for the previous result)
+        double bP[2][2][4];
+        ld_op(pan, lane, bP[0][0]);
+        if (R >= 1) ld_op(pan + 256, lane, bP[0][1]);
+#pragma unroll
+        for (int u = 0; u <= R; u += 2) {
+          constexpr int R1 = R >= 0 ? R : 0;
+          const int h = (u >> 1) & 1, u1 = u + 1 <= R1 ? u + 1 : u;
+          if (u + 2 <= R) ld_op(pan + 256 * (u + 2), lane, bP[h ^ 1][0]);
+          if (u + 3 <= R) ld_op(pan + 256 * (u + 3), lane, bP[h ^ 1][1]);
+          const bool d0 = u != K || K == R, d1 = u + 1 <= R && (u + 1 != K || K == R);
+          if (d0 && d1) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+              acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[s2], bP[h][0][s2], acc[u], 0, 0, 0);
+              acc[u1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[s2], bP[h][1][s2], acc[u1], 0, 0, 0);
+            }
+          } else if (d0) {
+            acc[u] = mfma4(aW, bP[h][0], acc[u]);
+          } else if (d1) {
+            acc[u1] = mfma4(aW, bP[h][1], acc[u1]);
+          }
+        }
+      }
+      if (K <= R) {
+        wave_lds_sync();  // own image -> accumulator layout
+        double w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = wI[aoff[r]];
+        if (K < R) {
+#pragma unroll
+          for (int u = 0; u < R; ++u)
+            if (u == K) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[u][r] = -w[r];  // A_RK <- A_RK D^-1 (masked columns: W = 0)
+            }
+        } else {
+          // pivot block <- E_K; rows >= np (rhs, pads) keep the regular update, their pivot columns take -W like any other
+          // row; the pivot rows of the tiles (K, u < K) follow after the next barrier
+          const bool colact = kb + lc < np;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool rowact = kb + lr + 4 * r < np;
+            acc[NT - 1][r] = rowact ? (colact ? eB[r] : -aW[r]) : (colact ? -w[r] : acc[NT - 1][r]);
+          }
+        }
+      }
+    }
+  }
+  // the pivot rows of the last block (masked: rows >= np keep their regular update)
+  __device__ __forceinline__ void last_rows(const SwL &L, int nK, int np, int lane, int lr) {
+    if constexpr (R >= 1) {
+      if (R == nK - 1) {
+        const int kb = 16 * R;
+        const double *wp = L.wt(R & 1);
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          double t[4];
+          ld_op(wp + 256 * u, lane, t);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[u][r] = (kb + lr + 4 * r < np) ? -t[r] : acc[u][r];
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void store(double *A, int N, int lr, int lc) const {
+    if constexpr (R >= 0) {
+#pragma unroll
+      for (int u = 0; u <= R; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * R + lr + 4 * r, j = 16 * u + lc;
+          if (j <= i && i < N) A[AT(i, j)] = acc[u][r];
+        }
+    }
+  }
+};
+
+// The sweep of ONE ROLE: the wave that owns tile row I (I = -1: none), a second one I2 (the nine- and ten-row systems of 43 .. 53
+// poses: two light rows share a wave, so that every wave still runs ONE block-step loop with ONE barrier per step) and, with kE,
+// inverts the diagonal tiles.  The block steps are a runtime loop, so each wave runs a few KB of code that stays in the
+// instruction cache.
 // A: the packed lower triangle (LDS); the panels alias it once the tiles are in registers.  Every role executes the same
 // sequence of workgroup barriers.
 // have_e0 (kE only): e0 = E_0 = -D_0^-1 as the caller inverted it already (SlamCtx::back does, under the Schur phase); by
 // value - a pointer to it would put it into scratch memory
-template <int I, bool kE>
+template <int I, bool kE, int I2 = -1>
 __device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &x, double *A, int N, bool have_e0 = false,
                                            v4d e0 = v4d{0.0, 0.0, 0.0, 0.0}) {
-  constexpr int NT = I >= 0 ? I + 1 : 1;
-  auto AT = [&](int i, int j) -> int { return i * (i + 1) / 2 + j; };
   const int lane = x.lane, lc = x.lc, lr = x.lr, np = x.np;
   const int nK = (np + 15) >> 4;
-  v4d acc[NT];
-  if constexpr (I >= 0) {
-#pragma unroll
-    for (int u = 0; u <= I; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * I + lr + 4 * r, j = 16 * u + lc;
-        acc[u][r] = (i < N && j < N) ? A[AT(max(i, j), min(i, j))] : 0.0;
-      }
-  }
+  SweepRow<I> r1;
+  SweepRow<I2> r2;
+  r1.load(A, N, lr, lc);
+  r2.load(A, N, lr, lc);
   __syncthreads();  // every tile is in registers: the LDS region of A now holds the sweep panels
   const SwL L{A, 16 * N};
-  if constexpr (I == 0) st_op(L.dscr(0), lane, acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+  r1.dump_d0(L, lane);
+  r2.dump_d0(L, lane);
   __syncthreads();
   if constexpr (kE) {  // E_0
     if (have_e0) {
@@ -401,48 +556,16 @@ __device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &
 #pragma clang loop unroll(disable)
   for (int K = 0; K < nK; ++K) {
     const int kb = 16 * K, b = K & 1;
-    const bool has_mask = np < kb + 16;  // the last block holds the rhs row / pads: they are not pivots
     const bool have_next = kb + 16 < np;
     const bool trg = x.tr && K == 3;
     if (trg) x.tr[0] = clock64();
-    // ---- P: publish the pivot tile column (masked columns / rows as zeros) ----
-    if constexpr (I >= 0) {
-      double *pan = L.pan(b);
-      if (K <= I) {
-        const bool colact = kb + lc < np;
-        double *pI = pan + 256 * I;
-#pragma unroll
-        for (int u = 0; u <= I; ++u)  // (a ladder of scalar branches selects the statically indexed tile K)
-          if (u == K) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pI[aoff[r]] = colact ? acc[u][r] : 0.0;
-          }
-        if (K == I) {  // the transposed tiles (I, u < I): accumulator registers = operand image of PAN_u
-#pragma unroll
-          for (int u = 0; u < I; ++u)
-            st_op(pan + 256 * u, lane, (kb + lr < np) ? acc[u][0] : 0.0, (kb + lr + 4 < np) ? acc[u][1] : 0.0,
-                  (kb + lr + 8 < np) ? acc[u][2] : 0.0, (kb + lr + 12 < np) ? acc[u][3] : 0.0);
-        }
-      }
-      if (have_next && K + 1 == I)  // current values of the next diagonal tile, for the look-ahead
-        st_op(L.dscr((K + 1) & 1), lane, acc[NT - 1][0], acc[NT - 1][1], acc[NT - 1][2], acc[NT - 1][3]);
-    }
+    r1.publish(L, K, np, have_next, lane, lr, lc, aoff);
+    r2.publish(L, K, np, have_next, lane, lr, lc, aoff);
     if (trg) x.tr[1] = clock64();
     __syncthreads();  // panels of step K, E_K, the W images of step K - 1
     const double *pan = L.pan(b);
-    // ---- deferred from step K - 1: its pivot rows A_{K-1,u} <- -(W_u)^T (all rows active: only the last block is masked) ----
-    if constexpr (I >= 1) {
-      if (K == I + 1) {
-        const double *wp = L.wt((K - 1) & 1);
-#pragma unroll
-        for (int u = 0; u < I; ++u) {
-          double t[4];
-          ld_op(wp + 256 * u, lane, t);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[u][r] = -t[r];
-        }
-      }
-    }
+    r1.deferred(L, K, lane);
+    r2.deferred(L, K, lane);
     // ---- look-ahead (critical path): E_{K+1} = -(D_{K+1} + W_{K+1} PAN_{K+1}^T)^-1 ----
     if constexpr (kE) {
       if (have_next) {
@@ -464,95 +587,16 @@ __device__ __forceinline__ void sweep_role(const DrlgxState &S, const SweepCtx &
         if (trg) x.tr[3] = clock64();
       }
     }
-    // ---- W, U ----
-    if constexpr (I >= 0) {
-      double aP[4], eB[4];
-      ld_op(pan + 256 * I, lane, aP);
-      ld_op(L.einv(b), lane, eB);
-      v4d wv = {0.0, 0.0, 0.0, 0.0};
-      wv = mfma4(eB, aP, wv);  // image of W_I
-      double *wI = L.wt(b) + 256 * I;
-      st_op(wI, lane, wv[0], wv[1], wv[2], wv[3]);
-      const double aW[4] = {wv[0], wv[1], wv[2], wv[3]};
-      if (K != I || has_mask) {
-        // A_Iu += W_I PAN_u^T (tile column K is replaced below, except in wave K whose masked rows keep the update); the
-        // next tile's operand is loaded while this tile's MFMAs run
-        // two tiles at a time: their MFMA chains are independent, so the matrix pipe is issued back to back (a chain on
-        // ONE accumulator waits ~20 cycles per link for the previous result)
-        double bP[2][2][4];
-        ld_op(pan, lane, bP[0][0]);
-        if (I >= 1) ld_op(pan + 256, lane, bP[0][1]);
-#pragma unroll
-        for (int u = 0; u <= I; u += 2) {
-          constexpr int I1 = I >= 0 ? I : 0;
-          const int h = (u >> 1) & 1, u1 = u + 1 <= I1 ? u + 1 : u;
-          if (u + 2 <= I) ld_op(pan + 256 * (u + 2), lane, bP[h ^ 1][0]);
-          if (u + 3 <= I) ld_op(pan + 256 * (u + 3), lane, bP[h ^ 1][1]);
-          const bool d0 = u != K || K == I, d1 = u + 1 <= I && (u + 1 != K || K == I);
-          if (d0 && d1) {
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-              acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[s2], bP[h][0][s2], acc[u], 0, 0, 0);
-              acc[u1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[s2], bP[h][1][s2], acc[u1], 0, 0, 0);
-            }
-          } else if (d0) {
-            acc[u] = mfma4(aW, bP[h][0], acc[u]);
-          } else if (d1) {
-            acc[u1] = mfma4(aW, bP[h][1], acc[u1]);
-          }
-        }
-      }
-      if (K <= I) {
-        wave_lds_sync();  // own image -> accumulator layout
-        double w[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = wI[aoff[r]];
-        if (K < I) {
-#pragma unroll
-          for (int u = 0; u < I; ++u)
-            if (u == K) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) acc[u][r] = -w[r];  // A_IK <- A_IK D^-1 (masked columns: W = 0)
-            }
-        } else {
-          // pivot block <- E_K; rows >= np (rhs, pads) keep the regular update, their pivot columns take -W like any other
-          // row; the pivot rows of the tiles (K, u < K) follow after the next barrier
-          const bool colact = kb + lc < np;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool rowact = kb + lr + 4 * r < np;
-            acc[NT - 1][r] = rowact ? (colact ? eB[r] : -aW[r]) : (colact ? -w[r] : acc[NT - 1][r]);
-          }
-        }
-      }
-    }
+    r1.update(L, K, np, lane, lr, lc, aoff);
+    r2.update(L, K, np, lane, lr, lc, aoff);
     if (trg) x.tr[4] = clock64();
   }
   __syncthreads();
-  // the pivot rows of the last block (masked: rows >= np keep their regular update)
-  if constexpr (I >= 1) {
-    if (I == nK - 1) {
-      const int kb = 16 * I;
-      const double *wp = L.wt(I & 1);
-#pragma unroll
-      for (int u = 0; u < I; ++u) {
-        double t[4];
-        ld_op(wp + 256 * u, lane, t);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[u][r] = (kb + lr + 4 * r < np) ? -t[r] : acc[u][r];
-      }
-    }
-  }
+  r1.last_rows(L, nK, np, lane, lr);
+  r2.last_rows(L, nK, np, lane, lr);
   __syncthreads();
-  if constexpr (I >= 0) {
-#pragma unroll
-    for (int u = 0; u <= I; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * I + lr + 4 * r, j = 16 * u + lc;
-        if (j <= i && i < N) A[AT(i, j)] = acc[u][r];
-      }
-  }
+  r1.store(A, N, lr, lc);
+  r2.store(A, N, lr, lc);
 }
 
 // iterate the poses p (ascending) whose bit is set in the W-word mask at `mk`
@@ -772,6 +816,44 @@ __device__ __forceinline__ void sweep_packed_fast(const DrlgxState &S, double *A
   static_assert(FT == 8, "one role per wave of the 512-thread workgroup");
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (Tn > FT) {
+    // Nine or ten tile rows (43 .. 53 poses): the wave of row 0 inverts the diagonal tiles, rows 1 + 2 share a wave (five tiles), with
+    // ten rows 3 + 4 too (nine); waves w and w + 4 share a SIMD - light next to heavy:
+    //   ten rows:  SIMD 0: {E, 0} + {9}   1: {1, 2} + {8}   2: {3, 4} + {5}   3: {6} + {7}      (11 / 14 / 15 / 15 tiles)
+    //   nine rows: SIMD 0: {E, 0} + {8}   1: {1, 2} + {7}   2: {3} + {6}      3: {4} + {5}      (10 / 13 / 11 / 11)
+    const SweepCtx x{0, lane, lane & 15, lane >> 4, np, N, true, wv == 0, bad,
+                     (S.prof && blockIdx.x == S.prof_block && lane == 0) ? S.prof + 64 + 5 * wv : nullptr};
+    const bool ten = Tn == 10;
+    switch (wv) {
+      case 0: sweep_role<0, true>(S, x, A, N); break;
+      case 1: sweep_role<1, false, 2>(S, x, A, N); break;
+      case 2:
+        if (ten) sweep_role<3, false, 4>(S, x, A, N);
+        else sweep_role<3, false>(S, x, A, N);
+        break;
+      case 3:
+        if (ten) sweep_role<6, false>(S, x, A, N);
+        else sweep_role<4, false>(S, x, A, N);
+        break;
+      case 4:
+        if (ten) sweep_role<9, false>(S, x, A, N);
+        else sweep_role<8, false>(S, x, A, N);
+        break;
+      case 5:
+        if (ten) sweep_role<8, false>(S, x, A, N);
+        else sweep_role<7, false>(S, x, A, N);
+        break;
+      case 6:
+        if (ten) sweep_role<5, false>(S, x, A, N);
+        else sweep_role<6, false>(S, x, A, N);
+        break;
+      default:
+        if (ten) sweep_role<7, false>(S, x, A, N);
+        else sweep_role<5, false>(S, x, A, N);
+        break;
+    }
+    return;
+  }
   // tile rows r and FT-1-r share a SIMD (waves w and w+4): lower-triangle MFMA work is balanced across the SIMDs
   int trow = wv < FT / 2 ? wv : (FT - 1) - (wv - FT / 2);
   if (Tn == FT) {
@@ -1536,8 +1618,12 @@ struct SlamCtx {
     __syncthreads();
     DRLGX_PROF(S, 4);
     // ---- 5. sweep: one tile row per wave (sweep_packed_fast); 9 - 10 tile rows: the tiles dealt over seven waves ----
+#ifdef DRLGX_SWEEP_REGTILES  // (A/B: nine and ten tile rows as tiles dealt over seven waves, three barriers per block step)
     if (Tn <= FT) sweep_packed_fast<FT>(S, A, np, N, Tn, bad, tid, pre_e0, e0);
     else sweep_regtiles<true, 8>(A, A, np, N, Tn, Tn * (Tn + 1) / 2, bad, tid);
+#else
+    sweep_packed_fast<FT>(S, A, np, N, Tn, bad, tid, pre_e0, e0);  // (nine / ten rows: two light rows share a wave)
+#endif
     __syncthreads();
     DRLGX_PROF(S, 5);
     for (int k = tid; k < np; k += kThreads) d_pose[k] = A[AT(np, k)];
