@@ -1121,6 +1121,8 @@ __device__ __forceinline__ void panel_from_dense(const DrlgxState &S, const Slam
   // the next cost more than the whole dense solve: 74 us at 40 poses).  Same sums in the same order per output as before.
   // The items are handed out through an LDS counter (c.bad[1], free after the sweep): list lengths are very uneven - landmarks
   // near the start are seen from most poses - and a static deal left some waves with twice the work of others.
+  // (Requesting the next factor's list entry, pose and G block under the current one's products - a hand-made two-stage pipeline of
+  // the four dependent LDS round trips per factor - measured SLOWER: 17.9 -> 21.9 us at 40 poses, 20.6 -> 24.5 at 50.)
   {
     const int lane = tid & 63, ib = (P + 63) >> 6;  // pose blocks of 64 per landmark
     while (true) {
