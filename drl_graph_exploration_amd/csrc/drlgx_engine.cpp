@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -557,7 +558,11 @@ static hipError_t stream_wait(drlgx_engine *e) {
   }
   hipError_t r = hipEventRecord(e->sync_event, e->stream);
   if (r != hipSuccess) return r;
-  while ((r = hipEventQuery(e->sync_event)) == hipErrorNotReady) {
+  // (polling pays for the waits of a vector step - a look-ahead, a plan execution: up to a few milliseconds; behind a longer queue the
+  // thread hands the core back)
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int polls = 0; (r = hipEventQuery(e->sync_event)) == hipErrorNotReady; ++polls) {
+    if ((polls & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(5000)) return hipStreamSynchronize(e->stream);
   }
   return r;
 }
