@@ -111,8 +111,7 @@ class VecExplorationEnv(object):
             active[torch.as_tensor(todo, device=self.device)] = 1
             for _ in range(4):
                 self.engine.step(self._scan, active)
-            self.engine.check_status()
-            n_lm = self.engine.counts_dev()[:, 1].cpu().numpy()
+            (n_lm,) = self.engine.fetch(self.engine.counts_dev()[:, 1])  # (with the status check, one synchronisation)
             empty = np.array([i for i in todo if n_lm[i] < 1], dtype=np.int64)
             self.env_index[empty] += 50  # "regenerate a environment"
             todo = empty

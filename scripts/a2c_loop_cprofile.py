@@ -30,6 +30,14 @@ with tempfile.TemporaryDirectory() as tmp:
         torch.cuda.synchronize(); upd[0] += time.perf_counter() - t
     if os.environ.get("SPLIT"): a2c.train = timed_train
     if os.environ.get("NOUPD"): a2c.train = lambda *a, **k: None  # (stepping only)
+    stamps, resets = [], []
+    if os.environ.get("PERSTEP"):  # wall clock between consecutive graph exports = one vector step each; resets marked
+        _gm, _rs = env.graph_matrix, env.reset
+        def gm(*a, **k):
+            stamps.append(time.perf_counter()); return _gm(*a, **k)
+        def rs(ids=None):
+            resets.append((len(stamps), 0 if ids is None else len(ids))); return _rs(ids)
+        env.graph_matrix, env.reset = gm, rs
     if os.environ.get("NOGC"): gc.disable()
     pr = cProfile.Profile()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -43,3 +51,8 @@ print("%.2f ms per vector step" % (dt / iters * 1e3))
 if os.environ.get("SPLIT"): print("  of which the update: %.2f ms per vector step (%.1f ms per update); stepping %.2f ms" % (upd[0] / iters * 1e3, upd[0] * 1e3, (dt - upd[0]) / iters * 1e3))
 if not os.environ.get("NOPROF"):
     st = pstats.Stats(pr); st.sort_stats(os.environ.get("SORT", "tottime")).print_stats(int(os.environ.get("TOP", "28")))
+
+if os.environ.get("PERSTEP"):
+    d = np.diff(np.array(stamps)) * 1e3
+    marks = dict(resets)
+    print("per-step ms (r = a reset of n envs inside): " + " ".join("%.2f%s" % (v, ("r%d" % marks[i + 1]) if (i + 1) in marks else "") for i, v in enumerate(d)))
