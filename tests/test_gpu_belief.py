@@ -846,6 +846,10 @@ def test_incremental_update_equals_the_full_solve_beyond_the_dense_solver_and_wi
             np.testing.assert_allclose(linfo, rlinfo, rtol=1e-7, atol=1e-6, err_msg=name)
             np.testing.assert_array_equal(eng.virtual_map(i)[3], ref.virtual_map(i)[3])
             np.testing.assert_allclose(eng.virtual_map(i)[1], ref.virtual_map(i)[1], rtol=1e-6, atol=1e-9, err_msg=name)
+            # the engine whose every update is a full solve against the oracle where the dense solver's sweep runs nine (43 .. 47
+            # poses) and ten (48 .. 53) tile rows - two tile rows per wave (k_slam.hip: SweepRow)
+            if s in (41, 47) and max_poses >= 54:
+                compare_state(ref, i, sims[i], "full-solve engine, " + name, check_vm=False)
     for i in range(n):
         compare_state(eng, i, sims[i], "final env %d" % i, check_vm=False)
     inc, full = eng.inc_stats()
